@@ -1,0 +1,256 @@
+/* uir_kernels.h - C ABI of libuir_hip.so: the MI355X (gfx950) kernels behind the
+ * SpectralTransformer train step.
+ *
+ * The reference (KarthikSundar2002/Underwater-Image-Restoration) has no native layer: its
+ * hot path is ATen ops called from src/Models/SpectralTransformer.py, src/Losses/losses.py
+ * and src/ModelTrainer.py:78-90.  Each entry point below names the reference op site(s)
+ * (path:line) whose arithmetic it replaces.  Conventions:
+ *   - every pointer is a DEVICE pointer to fp32 data owned by the caller (PyTorch caching
+ *     allocator tensors); kernels never allocate or free; scratch ("slab") is passed in;
+ *   - activations are HWC rows: a [B,H,W,C] tensor is M = B*H*W rows of C floats with a row
+ *     stride `ld*` (floats); rows must be 16-byte aligned where a field says "float4";
+ *   - `stream` is a hipStream_t (NULL = default stream); every call is asynchronous;
+ *   - return value: 0 = launched, UIR_EINVAL (1) = argument check failed (nothing launched),
+ *     UIR_ELAUNCH (2) = HIP reported a launch error.  No exceptions cross this boundary.
+ */
+#ifndef UIR_KERNELS_H
+#define UIR_KERNELS_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------- uir_gemm */
+enum { UIR_PRO_NONE = 0, UIR_PRO_LN = 1, UIR_PRO_GATE = 2 };
+enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2 };
+enum { UIR_ACT_NONE = 0, UIR_ACT_LEAKY = 1 };
+
+/* Dense channel contraction over HWC rows, 1 or 9 (3x3, pad 1) taps:
+ *   Y[z][m][n] = epi( sum_tap sum_k pro(X[z][nbr(m,tap)][k]) * W[z][n][k][tap] + bias[n] ) + R[z][m][n]
+ * Replaces: nn.Conv2d 1x1 sites SpectralTransformer.py:81,83,86,90,122,125,165-172,206,234-235;
+ * 3x3 dense sites :154,194,219,247,252; their input-gradients (swap w_sn/w_sk, flip=1);
+ * LayerNorm fused as a prologue (:137,139,144-147); GELU gate fused as a prologue (:128-129). */
+typedef struct UirGemmArgs {
+  const float* X;      /* [batches][M][ldx], float4-aligned rows                                */
+  const float* W;      /* weights, element (n,k,tap) at W[z*w_bs + n*w_sn + k*w_sk + tap*w_st]  */
+  float* Y;            /* [batches][M][ldy]                                                      */
+  const float* bias;   /* [real N] or NULL                                                       */
+  const float* R;      /* residual added after epi (PLAIN only), may alias Y; NULL = none        */
+  const float* ln_g;   /* PRO_LN: gamma[K], beta[K] (16-B aligned)                               */
+  const float* ln_b;
+  float* stats;        /* PRO_LN: optional out [batches*M][2] = (mean, rstd) for backward        */
+  const float* G;      /* GATE_BWD: forward gate input g (g1 at col n, g2 at col g_off+n);       */
+                       /* LEAKY_BWD: forward LeakyReLU output                                    */
+  long x_bs, y_bs, r_bs, g_bs, w_bs; /* per-batch strides (floats); w_bs=0: shared weights      */
+  long w_sn, w_sk, w_st;
+  int ldx, ldy, ldr, ldg;
+  int M, N, K;         /* rows per batch; padded output cols; padded contraction length          */
+  int batches;         /* grid z                                                                 */
+  int taps, flip;      /* taps 1|9; flip=1 uses weight tap 8-t (input-gradient of a 3x3 conv)    */
+  int H, Wd;           /* spatial dims (taps==9); M % (H*Wd) == 0                                */
+  int n_grp_real, n_grp_pad; /* output col n -> real weight row: groups of n_grp_pad cols, the   */
+  int k_grp_real, k_grp_pad; /* first n_grp_real real, the rest exact-zero; pad<=0: identity     */
+  int pro, gate_off;   /* prologue; GATE: second operand at column gate_off + k                  */
+  int epi, g_off;
+  int act;             /* applied before epi                                                     */
+  float slope;         /* LeakyReLU negative slope                                               */
+  float ln_eps;
+} UirGemmArgs;
+int uir_gemm(const UirGemmArgs* args, void* stream);
+
+/* ---------------------------------------------------------------- uir_gram */
+enum { UIR_GRAM_PRO_NONE = 0, UIR_GRAM_PRO_LN = 1, UIR_GRAM_PRO_GATE = 2 };
+
+/* Contraction over pixels (weight gradients and the MDTA q.k^T Gram matrix):
+ *   out[z][n][k][tap] = sum_m A[z][m][n] * pro(B[z][nbr(m,tap)][k])
+ * computed as per-chunk partial slabs slab[chunk][...] (deterministic; summed by uir_reduce_slab).
+ * Optional extras per chunk: column sums of squares of A and B (the L2 norms of F.normalize,
+ * SpectralTransformer.py:98) and column sums of A (bias gradients).
+ * Replaces: torch.matmul(q, k^T) (:99) and every conv weight-gradient of autograd's
+ * convolution_backward on the path. */
+typedef struct UirGramArgs {
+  const float* A;      /* [batches][M][lda]                                                      */
+  const float* B;      /* [batches][M][ldb]                                                      */
+  float* slab;         /* [nchunks][slab_stride]                                                 */
+  const float* stats;  /* PRO_LN: [batches*M][2] (mean, rstd) written by uir_gemm                */
+  const float* ln_g;
+  const float* ln_b;
+  long a_bs, b_bs;     /* per-batch strides (floats)                                             */
+  long o_sn, o_sk, o_st, o_bs; /* output strides: real n, real k, tap, batch                     */
+  long slab_stride;    /* floats per chunk                                                       */
+  long sq_a_off, sq_b_off, cs_a_off; /* offsets (floats) inside a chunk slab; <0 = not computed  */
+  int lda, ldb;
+  int M, N, K;         /* rows per batch; padded cols of A; padded cols of B                     */
+  int batches;
+  int n_grp_real, n_grp_pad, k_grp_real, k_grp_pad;
+  int taps, H, Wd;
+  int pro_b, gate_off;
+  int rows_per_chunk;  /* multiple of 8                                                          */
+  int nchunks;
+} UirGramArgs;
+int uir_gram(const UirGramArgs* args, void* stream);
+
+/* out[i] = (accumulate ? out[i] : 0) + scale * sum_c slab[c*stride + i], i < n */
+int uir_reduce_slab(const float* slab, int nchunks, long stride, float* out, long n, int accumulate,
+                    float scale, void* stream);
+
+/* -------------------------------------------------------------- uir_dwconv */
+/* Depthwise 3x3, pad 1, no bias, on HWC rows; C (padded) % 4 == 0.  flip=1 gives the
+ * input-gradient.  Replaces nn.Conv2d(groups=C) sites SpectralTransformer.py:82,89,123-124. */
+typedef struct UirDwArgs {
+  const float* X;      /* [B*H*W][ldx] float4 rows                                               */
+  const float* Wt;     /* native Conv2d layout [Creal][1][3][3]                                  */
+  float* Y;            /* [B*H*W][ldy]                                                           */
+  int ldx, ldy;
+  int B, H, Wd, C;     /* C = padded channel count                                               */
+  int grp_real, grp_pad; /* padded channel -> real weight row (exact-zero pads)                  */
+  int flip;
+} UirDwArgs;
+int uir_dwconv(const UirDwArgs* args, void* stream);
+
+/* weight-gradient partials: slab[block][Creal][9] = sum_pixels dY[p][c] * X[nbr(p,t)][c] */
+typedef struct UirDwWgradArgs {
+  const float* dY; const float* X; float* slab;
+  int ldy, ldx;
+  int B, H, Wd, C;
+  int grp_real, grp_pad;
+  int creal;           /* number of real channels (slab row count)                               */
+  int nblocks;         /* grid size = slab chunk count                                           */
+} UirDwWgradArgs;
+int uir_dwconv_wgrad(const UirDwWgradArgs* args, void* stream);
+
+/* ----------------------------------------------------------- uir_layernorm */
+/* Input-gradient of the channel LayerNorm (+ residual-path gradient) and per-block partials
+ * of dgamma/dbeta: dX = dRes + LN'(dT).  slab[block][2*C] = (dgamma | dbeta).
+ * Replaces layer_norm backward of SpectralTransformer.py:144-147. */
+typedef struct UirLnBwdArgs {
+  const float* dT; const float* X; const float* stats; const float* gamma;
+  const float* dRes;   /* may be NULL                                                            */
+  float* dX; float* slab;
+  int ldt, ldx, ldr, ldo;
+  int M, C;            /* C in {16,32,64,128}                                                    */
+  int nblocks;
+} UirLnBwdArgs;
+int uir_layernorm_bwd(const UirLnBwdArgs* args, void* stream);
+
+/* ---------------------------------------------------------------- uir_attn */
+/* Channel attention of MDTA (SpectralTransformer.py:98-100, 107, 113), algebraically folded:
+ * per batch b the d x d maps attn[b,h] are composed with the 1x1 projections so that
+ *   u   = WA[b] v      with WA[b] = P * blockdiag(attn[b]),   P = W_kv[vf half] * W_project_out
+ *   out = WB[b] vf     with WB[b] = W_project_outf * blockdiag(attn[b])
+ * (`attn @ v`, project_out, kv and `attn @ vf`, project_outf become two per-batch 1x1 GEMMs).
+ * uir_attn_fwd: Gram matrix + squared norms -> attn (softmax(normalize(q) normalize(k)^T * T)),
+ * WA, WB.  One workgroup per batch. */
+typedef struct UirAttnFwdArgs {
+  const float* G;      /* [B][C][C]   sum_p q_i k_j                                              */
+  const float* sq_q;   /* [B][C]      sum_p q_i^2                                                */
+  const float* sq_k;   /* [B][C]                                                                 */
+  const float* temperature; /* [heads]                                                           */
+  const float* P;      /* [C][C]                                                                 */
+  const float* Wof;    /* [C][C] project_outf.weight                                             */
+  float* attn;         /* [B][heads][d][d]                                                       */
+  float* WA;           /* [B][C][C]                                                              */
+  float* WB;           /* [B][C][C]                                                              */
+  int B, C, heads;
+} UirAttnFwdArgs;
+int uir_attn_fwd(const UirAttnFwdArgs* args, void* stream);
+
+/* Backward of the above.  Inputs dWA[b], dWB[b] (per-batch Grams of the two GEMMs); outputs
+ * Mqk[b] ([2C][2C]: d[q;k] = Mqk[b] [q;k]), and per-batch partials dP[b], dWof[b], dT[b]. */
+typedef struct UirAttnBwdArgs {
+  const float* dWA; const float* dWB;       /* [B][C][C]                                         */
+  const float* G; const float* sq_q; const float* sq_k; const float* temperature;
+  const float* attn; const float* P; const float* Wof;
+  float* Mqk;          /* [B][2C][2C]                                                            */
+  float* dP;           /* [B][C][C]                                                              */
+  float* dWof;         /* [B][C][C]                                                              */
+  float* dT;           /* [B][heads]                                                             */
+  int B, C, heads;
+} UirAttnBwdArgs;
+int uir_attn_bwd(const UirAttnBwdArgs* args, void* stream);
+
+/* ------------------------------------------------------------ uir_spectral */
+/* One axis of a 2-D DFT of [B,H,W,C] tensors held as separate re/im planes, as an f32-MFMA
+ * contraction with cos/sin twiddle tables (any length N, no radix restriction):
+ *   out[o][k][i][c] = scale * sum_n e^{sign*2*pi*i*k*n/N} in[o][n][i][c]
+ * element (o,n,i,c) at ((o*N + n)*I + i)*C + c.  in_im NULL = real input; out_im NULL = only the
+ * real part is produced.  Replaces torch.fft.fft2 / ifft2 (SpectralTransformer.py:176, 186) and
+ * their adjoints. */
+typedef struct UirDftArgs {
+  const float* in_re; const float* in_im;
+  float* out_re; float* out_im;
+  const float* cos_t;  /* [N][N] cos(2*pi*k*n/N) (symmetric)                                     */
+  const float* sin_t;  /* [N][N] sin(2*pi*k*n/N)                                                 */
+  int O, N, I, C;
+  float sign;          /* -1 forward, +1 inverse                                                 */
+  float scale;
+} UirDftArgs;
+int uir_dft_axis(const UirDftArgs* args, void* stream);
+
+/* mag = |F|, pha = atan2(im, re) with Im forced to +0 at the self-conjugate bins (what
+ * torch.fft.fft2 of a real tensor yields; tests/golden/fft_zero_sign.npz).  :177-178 */
+int uir_magpha_fwd(const float* re, const float* im, float* mag, float* pha, int B, int H, int Wd, int C, void* stream);
+/* (g_mag, g_pha) -> (g_re, g_im); zero where mag == 0 */
+int uir_magpha_bwd(const float* mag, const float* pha, const float* g_mag, const float* g_pha,
+                   float* g_re, float* g_im, long n, void* stream);
+/* z = Mag * exp(i Pha)  (:183-185) and its adjoint */
+int uir_polar_fwd(const float* mag, const float* pha, float* zr, float* zi, long n, void* stream);
+int uir_polar_bwd(const float* mag, const float* pha, const float* g_zr, const float* g_zi,
+                  float* g_mag, float* g_pha, long n, void* stream);
+/* t = |z| (:187) and adjoint (sgn(0) = 0) */
+int uir_cabs_fwd(const float* zr, const float* zi, float* t, long n, void* stream);
+int uir_cabs_bwd(const float* zr, const float* zi, const float* t, const float* g_t, float* g_zr, float* g_zi, long n, void* stream);
+
+/* ------------------------------------------------------------- uir_shuffle */
+/* dst[b, 2h+dy, 2w+dx, dcol + c] = src[b, h, w, c] at (dy,dx)=(0,0), fill[c] elsewhere:
+ * the zero-interleaved UpSample output after `post` (bias at the 3/4 empty pixels), :188. */
+int uir_scatter_even(const float* src, int lds, const float* fill, float* dst, int ldd, int dcol,
+                     int B, int H, int Wd, int C, void* stream);
+int uir_gather_even(const float* src, int lds, int scol, float* dst, int ldd, int B, int H, int Wd, int C, void* stream);
+/* PixelShuffle(2) / PixelUnshuffle(2) on HWC rows (:155, :195).  shuffle: src [B,H,W,4*C] ->
+ * dst [B,2H,2W,C] (channel c*4 + dy*2 + dx -> pixel (2h+dy, 2w+dx)); unshuffle is the inverse. */
+int uir_pixel_shuffle(const float* src, int lds, float* dst, int ldd, int dcol, int B, int H, int Wd, int C, void* stream);
+int uir_pixel_unshuffle(const float* src, int lds, int scol, float* dst, int ldd, int B, int H, int Wd, int C, void* stream);
+/* dst[m][dcol + c] = src[m][scol + c] (+ dst if accumulate), c < C: torch.cat joins (:209,264-267) */
+int uir_copy_cols(const float* src, int lds, int scol, float* dst, int ldd, int dcol, long M, int C, int accumulate, void* stream);
+/* slab[block][c] = sum over that block's rows of src[m][col + c]: bias gradients of the 1x1
+ * convs with bias (SpectralTransformer.py:165-172) */
+int uir_colsum_partials(const float* src, int ld, int col, long M, int C, float* slab, int nblocks, void* stream);
+/* NCHW [B,3,H,W] <-> HWC rows [B*H*W][4] (4th column zero) at the model boundary */
+int uir_nchw3_to_hwc4(const float* src, float* dst, int B, int H, int Wd, void* stream);
+int uir_hwc4_to_nchw3(const float* src, float* dst, int B, int H, int Wd, void* stream);
+
+/* ---------------------------------------------------------------- uir_loss */
+enum { UIR_LOSS_L1 = 0, UIR_LOSS_L2 = 1, UIR_LOSS_CHARBONNIER = 2, UIR_LOSS_LUMINANCE = 3, UIR_LOSS_L1_COLOR = 4 };
+/* Partial sums over NCHW [B,3,H,W] pred/truth: slab[block][8] =
+ * (sum|d|, sum d^2, sum sqrt(d^2+1e-6), sum lum^2, sum (clamp01(p)-clamp01(t))^2, 0,0,0).
+ * Replaces nn.L1Loss / MSELoss / CharbonnierLoss / ColorLoss / LuminanceLoss
+ * (src/Losses/losses.py:55-57,76-78,190-192,209-212; luminanceLoss.py:16-19) and the PSNR
+ * reduction (src/ModelTrainer.py:17-21). */
+int uir_loss_partials(const float* pred, const float* truth, float* slab, int nblocks, int B, int HW, void* stream);
+/* sums[8] (reduced slab) -> out[0] = loss(kind), out[1] = PSNR */
+int uir_loss_finalize(const float* sums, float* out, int kind, int B, int HW, void* stream);
+/* dpred = dL/dpred * gscale[0]  (gscale = upstream scalar gradient on device) */
+int uir_loss_bwd(const float* pred, const float* truth, const float* gscale, float* dpred, int kind, int B, int HW, void* stream);
+
+/* --------------------------------------------------------------- uir_optim */
+/* slab[block] = partial sum of squares of g[0..n) */
+int uir_sumsq_partials(const float* g, long n, float* slab, int nblocks, void* stream);
+/* clip_grad_norm_(max_norm) + Adam (src/ModelTrainer.py:87-88,199) over one flat buffer.
+ * sumsq[0] = sum of squares of the (unscaled) gradients; gscale multiplies every gradient
+ * first (1/world_size under data parallelism).  norm_out[0] receives the total norm. */
+typedef struct UirAdamArgs {
+  float* p; const float* g; float* m; float* v;
+  const float* sumsq; float* norm_out;
+  long n;
+  float lr, beta1, beta2, eps, bc1, bc2, max_norm, gscale;
+} UirAdamArgs;
+int uir_clip_adam_step(const UirAdamArgs* args, void* stream);
+
+/* library self-description (used by the loader test) */
+const char* uir_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

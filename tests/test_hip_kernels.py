@@ -1,0 +1,568 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI
+(include/uir_kernels.h) via the Recorder, against fp64 PyTorch-CPU restatements of the same
+op.  Tolerance: 1e-5 relative to the tensor's max magnitude unless stated (fp32 arithmetic,
+different summation order)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+if not torch.cuda.is_available():  # pragma: no cover
+    pytest.skip("needs a GPU", allow_module_level=True)
+
+from underwater_image_restoration_amd import _lib as L            # noqa: E402
+from underwater_image_restoration_amd import ops                  # noqa: E402
+from underwater_image_restoration_amd.engine import Recorder, twiddles  # noqa: E402
+
+lib = L.lib
+DEV = "cuda"
+TOL = 2e-5
+
+
+def rel(a, b):
+    a = torch.as_tensor(a).detach().double().cpu()
+    b = torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def dev(t):
+    return t.float().to(DEV).contiguous()
+
+
+def rec():
+    return Recorder(DEV, scratch_floats=8 * 1024 * 1024)
+
+
+def hwc(x):  # [B,C,H,W] -> [B*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def chw(rows, B, H, W):  # [B*H*W, C] -> [B,C,H,W]
+    return rows.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
+
+
+# ------------------------------------------------------------------ uir_gemm
+@pytest.mark.parametrize("M,K,N", [(300, 16, 48), (129, 32, 96), (64, 128, 384), (1000, 64, 16), (257, 44, 32)])
+def test_gemm_plain(M, K, N):
+    x, w = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    r = rec()
+    X, W, Y = dev(x), dev(w), r.alloc(M, N)
+    r.gemm("g", X, W, Y, N=N, K=K, w_sn=K, w_sk=1)
+    r.run(r.fwd)
+    assert rel(Y, x @ w.T) < TOL
+
+
+def test_gemm_bias_leaky_residual_strided():
+    M, K, N = 333, 32, 32
+    x, w, b, res = rnd(M, K, seed=1), rnd(N, K, seed=2), rnd(N, seed=3), rnd(M, N, seed=4)
+    r = rec()
+    big = r.alloc(M, 80, zero=True)           # output written into a column slice of a wider buffer
+    Y = big[:, 16:48]
+    R = dev(res)
+    r.gemm("g", dev(x), dev(w), Y, N=N, K=K, w_sn=K, w_sk=1, bias=dev(b), R=R, act=L.ACT_LEAKY)
+    r.run(r.fwd)
+    want = F.leaky_relu(x @ w.T + b, 0.1) + res
+    assert rel(Y, want) < TOL
+    assert float(big[:, :16].abs().max()) == 0 and float(big[:, 48:].abs().max()) == 0
+
+
+def test_gemm_transposed_weights_and_padgroups():
+    # project_in layout: N = 2*hp padded columns mapping to 2*h real rows; also the transposed use
+    M, C, h, hp = 200, 32, 85, 88
+    x, w = rnd(M, C, seed=1), rnd(2 * h, C, seed=2)
+    r = rec()
+    Y = r.alloc(M, 2 * hp)
+    Y.fill_(7.0)
+    r.gemm("in", dev(x), dev(w), Y, N=2 * hp, K=C, w_sn=C, w_sk=1, n_grp=(h, hp))
+    # input-gradient: dX = dY_pad @ W  (contraction over padded columns)
+    dy = rnd(M, 2 * hp, seed=3)
+    dy[:, h:hp] = 0
+    dy[:, hp + h:] = 0
+    dX = r.alloc(M, C)
+    r.gemm("in.dx", dev(dy), dev(w), dX, N=C, K=2 * hp, w_sn=1, w_sk=C, k_grp=(h, hp))
+    r.run(r.fwd)
+    full = x @ w.T
+    assert rel(Y[:, :h], full[:, :h]) < TOL and rel(Y[:, hp:hp + h], full[:, h:]) < TOL
+    assert float(Y[:, h:hp].abs().max()) == 0 and float(Y[:, hp + h:].abs().max()) == 0
+    dyr = torch.cat([dy[:, :h], dy[:, hp:hp + h]], 1)
+    assert rel(dX, dyr @ w) < TOL
+
+
+def test_gemm_layernorm_prologue():
+    M, C, N = 500, 32, 96
+    x, w, g, b = rnd(M, C, seed=1, scale=3), rnd(N, C, seed=2), 1 + 0.1 * rnd(C, seed=3), 0.1 * rnd(C, seed=4)
+    r = rec()
+    Y, st = r.alloc(M, N), r.alloc(M, 2)
+    r.gemm("ln", dev(x), dev(w), Y, N=N, K=C, w_sn=C, w_sk=1, pro=L.PRO_LN, ln=(dev(g), dev(b)), stats=st)
+    r.run(r.fwd)
+    t = F.layer_norm(x, (C,), g, b, 1e-5)
+    assert rel(Y, t @ w.T) < TOL
+    assert rel(st[:, 0], x.mean(1)) < TOL
+    assert rel(st[:, 1], 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)) < TOL
+
+
+def test_gemm_gate_prologue_and_gate_bwd():
+    M, C, h, hp = 260, 16, 42, 44
+    g = rnd(M, 2 * hp, seed=1, scale=2)
+    g[:, h:hp] = 0
+    g[:, hp + h:] = 0
+    w = rnd(C, h, seed=2)
+    res = rnd(M, C, seed=3)
+    r = rec()
+    Gd = dev(g)
+    Y = r.alloc(M, C)
+    r.gemm("out", Gd, dev(w), Y, N=C, K=h, w_sn=h, w_sk=1, pro=L.PRO_GATE, gate_off=hp, R=dev(res))
+    dy = rnd(M, C, seed=4)
+    dG = r.alloc(M, 2 * hp)
+    r.gemm("dgate", dev(dy), dev(w), dG, N=hp, K=C, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=Gd, g_off=hp)
+    r.run(r.fwd)
+    g1 = g[:, :h].clone().requires_grad_(True)
+    g2 = g[:, hp:hp + h].clone().requires_grad_(True)
+    y = (F.gelu(g1) * g2) @ w.T + res
+    assert rel(Y, y) < TOL
+    d1, d2 = torch.autograd.grad((y * dy).sum(), (g1, g2))
+    assert rel(dG[:, :h], d1) < TOL and rel(dG[:, hp:hp + h], d2) < TOL
+    assert float(dG[:, h:hp].abs().max()) == 0 and float(dG[:, hp + h:].abs().max()) == 0
+
+
+def test_gemm_leaky_bwd_epilogue():
+    M, C = 130, 32
+    pre = rnd(M, C, seed=1)
+    hmid = F.leaky_relu(pre, 0.1)
+    dy, w = rnd(M, C, seed=2), rnd(C, C, seed=3)
+    r = rec()
+    out = r.alloc(M, C)
+    r.gemm("lb", dev(dy), dev(w), out, N=C, K=C, w_sn=1, w_sk=C, epi=L.EPI_LEAKY_BWD, G=dev(hmid))
+    r.run(r.fwd)
+    want = (dy @ w) * torch.where(pre > 0, torch.ones_like(pre), torch.full_like(pre, 0.1))
+    assert rel(out, want) < TOL
+
+
+def test_gemm_per_batch_weights():
+    B, HW, C = 3, 70, 32
+    x, w, res = rnd(B * HW, 3 * C, seed=1), rnd(B, C, C, seed=2), rnd(B * HW, C, seed=3)
+    r = rec()
+    X = dev(x)
+    Y = r.alloc(B * HW, C)
+    r.gemm("pb", X[:, 2 * C:], dev(w.reshape(B, C * C)), Y, N=C, K=C, w_sn=C, w_sk=1, w_bs=C * C, batches=B, R=dev(res))
+    Yt = r.alloc(B * HW, C)
+    r.gemm("pbT", X[:, :C], dev(w.reshape(B, C * C)), Yt, N=C, K=C, w_sn=1, w_sk=C, w_bs=C * C, batches=B)
+    r.run(r.fwd)
+    v = x[:, 2 * C:].reshape(B, HW, C)
+    assert rel(Y, torch.einsum("bpk,bnk->bpn", v, w).reshape(B * HW, C) + res) < TOL
+    q = x[:, :C].reshape(B, HW, C)
+    assert rel(Yt, torch.einsum("bpk,bkn->bpn", q, w).reshape(B * HW, C)) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 5, 7, 8, 12), (1, 8, 8, 16, 8), (2, 6, 4, 32, 64), (1, 9, 5, 128, 40)])
+def test_gemm_conv3x3_fwd_and_input_grad(B, H, W, Cin, Cout):
+    x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=2)
+    y = F.conv2d(x, w, padding=1)
+    dy = rnd(*y.shape, seed=3)
+    (dx,) = torch.autograd.grad((y * dy).sum(), x)
+    r = rec()
+    Wd = dev(w)
+    Y, dX = r.alloc(B * H * W, Cout), r.alloc(B * H * W, Cin)
+    r.gemm("c", dev(hwc(x.detach())), Wd, Y, N=Cout, K=Cin, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=(H, W))
+    r.gemm("c.dx", dev(hwc(dy)), Wd, dX, N=Cin, K=Cout, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=(H, W))
+    r.run(r.fwd)
+    assert rel(chw(Y, B, H, W), y) < TOL
+    assert rel(chw(dX, B, H, W), dx) < TOL
+
+
+def test_gemm_embed_and_output_padding():
+    B, H, W = 2, 6, 5
+    x = rnd(B, 3, H, W, seed=1)
+    w = rnd(16, 3, 3, 3, seed=2)
+    r = rec()
+    x4 = torch.zeros(B * H * W, 4, dtype=torch.float64)
+    x4[:, :3] = hwc(x)
+    Y = r.alloc(B * H * W, 16)
+    r.gemm("embed", dev(x4), dev(w), Y, N=16, K=4, w_sn=27, w_sk=9, w_st=1, taps=9, hw=(H, W), k_grp=(3, 4))
+    # 8 -> 3 output conv written as 4 padded columns
+    y8, w3 = rnd(B, 8, H, W, seed=3), rnd(3, 8, 3, 3, seed=4)
+    Y4 = r.alloc(B * H * W, 4)
+    Y4.fill_(5.0)
+    r.gemm("output", dev(hwc(y8)), dev(w3), Y4, N=4, K=8, w_sn=72, w_sk=9, w_st=1, taps=9, hw=(H, W), n_grp=(3, 4))
+    r.run(r.fwd)
+    assert rel(chw(Y, B, H, W), F.conv2d(x, w, padding=1)) < TOL
+    assert rel(chw(Y4[:, :3], B, H, W), F.conv2d(y8, w3, padding=1)) < TOL
+    assert float(Y4[:, 3].abs().max()) == 0
+
+
+def test_gemm_rejects_bad_arguments():
+    r = rec()
+    X, W, Y = r.alloc(10, 6), r.alloc(8, 6), r.alloc(10, 8)   # ldx = 6 is not a multiple of 4
+    a = L.GemmArgs()
+    a.X, a.W, a.Y = X.data_ptr(), W.data_ptr(), Y.data_ptr()
+    a.ldx, a.ldy, a.M, a.N, a.K, a.batches, a.taps = 6, 8, 10, 8, 6, 1, 1
+    a.w_sn, a.w_sk = 6, 1
+    import ctypes
+    assert lib.uir_gemm(ctypes.byref(a), None) == 1    # UIR_EINVAL, nothing launched
+
+
+# ------------------------------------------------------------------ uir_gram
+@pytest.mark.parametrize("M,N,K", [(1000, 96, 16), (777, 16, 44), (600, 48, 48), (2050, 176, 32), (300, 128, 128)])
+def test_gram_plain(M, N, K):
+    a, b = rnd(M, N, seed=1), rnd(M, K, seed=2)
+    r = rec()
+    out = r.alloc(N, K)
+    r.gram("g", dev(a), dev(b), out, N=N, K=K, o_sn=K, o_sk=1)
+    r.run(r.fwd)
+    assert rel(out, a.T @ b) < TOL
+
+
+def test_gram_ln_and_gate_prologues_and_groups():
+    M, C, h, hp = 900, 32, 85, 88
+    x, g, be = rnd(M, C, seed=1, scale=2), 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    dgp = rnd(M, 2 * hp, seed=4)
+    dgp[:, h:hp] = 0
+    dgp[:, hp + h:] = 0
+    st = torch.stack([x.mean(1), 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)], 1)
+    r = rec()
+    dW = r.alloc(2 * h, C)
+    r.gram("dWin", dev(dgp), dev(x), dW, N=2 * hp, K=C, o_sn=C, o_sk=1, n_grp=(h, hp), pro_b=L.PRO_LN,
+           ln=(dev(g), dev(be)), stats=dev(st))
+    gg = rnd(M, 2 * hp, seed=5, scale=2)
+    gg[:, h:hp] = 0
+    gg[:, hp + h:] = 0
+    dy = rnd(M, C, seed=6)
+    dWo = r.alloc(C, h)
+    r.gram("dWout", dev(dy), dev(gg), dWo, N=C, K=h, o_sn=h, o_sk=1, pro_b=L.PRO_GATE, gate_off=hp)
+    r.run(r.fwd)
+    t = F.layer_norm(x, (C,), g, be, 1e-5)
+    dreal = torch.cat([dgp[:, :h], dgp[:, hp:hp + h]], 1)
+    assert rel(dW, dreal.T @ t) < TOL
+    gate = F.gelu(gg[:, :h]) * gg[:, hp:hp + h]
+    assert rel(dWo, dy.T @ gate) < TOL
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 5, 7, 8, 12), (2, 6, 4, 32, 64), (1, 8, 8, 64, 32)])
+def test_gram_conv3x3_weight_grad(B, H, W, Cin, Cout):
+    x = rnd(B, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, padding=1)
+    dy = rnd(*y.shape, seed=3)
+    (dw,) = torch.autograd.grad((y * dy).sum(), w)
+    r = rec()
+    out = r.alloc(Cout, Cin, 3, 3)
+    r.gram("dW", dev(hwc(dy)), dev(hwc(x)), out, N=Cout, K=Cin, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=(H, W))
+    r.run(r.fwd)
+    assert rel(out, dw) < TOL
+
+
+def test_gram_per_batch_with_norms_and_colsum():
+    B, HW, C = 3, 500, 32
+    qkv = rnd(B * HW, 3 * C, seed=1)
+    r = rec()
+    X = dev(qkv)
+    G, sq, sk, cs = r.alloc(B, C * C), r.alloc(B * C), r.alloc(B * C), r.alloc(B * C)
+    r.gram("qk", X[:, :C], X[:, C:2 * C], G, N=C, K=C, o_sn=C, o_sk=1, o_bs=C * C, batches=B, out_elems=B * C * C,
+           extras={"sq_a": sq, "sq_b": sk, "cs_a": cs})
+    r.run(r.fwd)
+    q = qkv[:, :C].reshape(B, HW, C)
+    k = qkv[:, C:2 * C].reshape(B, HW, C)
+    assert rel(G.reshape(B, C, C), torch.einsum("bpi,bpj->bij", q, k)) < TOL
+    assert rel(sq.reshape(B, C), (q ** 2).sum(1)) < TOL
+    assert rel(sk.reshape(B, C), (k ** 2).sum(1)) < TOL
+    assert rel(cs.reshape(B, C), q.sum(1)) < 1e-4
+
+
+def test_gram_is_deterministic():
+    M, N, K = 5000, 96, 32
+    a, b = dev(rnd(M, N, seed=1)), dev(rnd(M, K, seed=2))
+    r = rec()
+    o1, o2 = r.alloc(N, K), r.alloc(N, K)
+    r.gram("a", a, b, o1, N=N, K=K, o_sn=K, o_sk=1)
+    r.gram("b", a, b, o2, N=N, K=K, o_sn=K, o_sk=1)
+    r.run(r.fwd)
+    assert torch.equal(o1, o2)
+
+
+# ---------------------------------------------------------------- uir_dwconv
+@pytest.mark.parametrize("B,H,W,C", [(2, 5, 7, 16), (1, 8, 8, 48), (2, 3, 9, 96), (1, 4, 4, 384)])
+def test_dwconv_fwd_bwd(B, H, W, C):
+    x = rnd(B, C, H, W, seed=1).requires_grad_(True)
+    w = rnd(C, 1, 3, 3, seed=2).requires_grad_(True)
+    y = F.conv2d(x, w, padding=1, groups=C)
+    dy = rnd(*y.shape, seed=3)
+    dx, dw = torch.autograd.grad((y * dy).sum(), (x, w))
+    r = rec()
+    Wt = dev(w.detach())
+    X, dY = dev(hwc(x.detach())), dev(hwc(dy))
+    Y, dX, dW = r.alloc(B * H * W, C), r.alloc(B * H * W, C), r.alloc(C, 9)
+    r.dwconv("f", X, Wt, Y, C_=C, dims=(B, H, W))
+    r.dwconv("b", dY, Wt, dX, C_=C, dims=(B, H, W), flip=1)
+    r.dwconv_wgrad("w", dY, X, dW, C_=C, creal=C, dims=(B, H, W))
+    r.run(r.fwd)
+    assert rel(chw(Y, B, H, W), y) < TOL
+    assert rel(chw(dX, B, H, W), dx) < TOL
+    assert rel(dW.reshape(C, 1, 3, 3), dw) < TOL
+
+
+def test_dwconv_padded_groups():
+    B, H, W, h, hp = 2, 6, 5, 42, 44
+    xr = rnd(B, 2 * h, H, W, seed=1)
+    w = rnd(2 * h, 1, 3, 3, seed=2)
+    xp = torch.zeros(B * H * W, 2 * hp, dtype=torch.float64)
+    rows = hwc(xr)
+    xp[:, :h], xp[:, hp:hp + h] = rows[:, :h], rows[:, h:]
+    r = rec()
+    Y, dW = r.alloc(B * H * W, 2 * hp), r.alloc(2 * h, 9)
+    Y.fill_(3.0)
+    Xd = dev(xp)
+    r.dwconv("f", Xd, dev(w), Y, C_=2 * hp, dims=(B, H, W), grp=(h, hp))
+    r.dwconv_wgrad("w", Xd, Xd, dW, C_=2 * hp, creal=2 * h, dims=(B, H, W), grp=(h, hp))
+    r.run(r.fwd)
+    y = hwc(F.conv2d(xr, w, padding=1, groups=2 * h))
+    assert rel(Y[:, :h], y[:, :h]) < TOL and rel(Y[:, hp:hp + h], y[:, h:]) < TOL
+    assert float(Y[:, h:hp].abs().max()) == 0 and float(Y[:, hp + h:].abs().max()) == 0
+    wv = torch.zeros(2 * h, 1, 3, 3, dtype=torch.float64, requires_grad=True)
+    (dw,) = torch.autograd.grad((F.conv2d(xr, wv, padding=1, groups=2 * h) * xr).sum(), wv)
+    assert rel(dW.reshape(2 * h, 1, 3, 3), dw) < TOL
+
+
+# ------------------------------------------------------------- uir_layernorm
+@pytest.mark.parametrize("M,C", [(1000, 16), (333, 32), (129, 64), (70, 128)])
+def test_layernorm_bwd(M, C):
+    x = rnd(M, C, seed=1, scale=2).requires_grad_(True)
+    g = (1 + 0.1 * rnd(C, seed=2)).requires_grad_(True)
+    b = (0.1 * rnd(C, seed=3)).requires_grad_(True)
+    t = F.layer_norm(x, (C,), g, b, 1e-5)
+    dt, dres = rnd(M, C, seed=4), rnd(M, C, seed=5)
+    dx, dg, db = torch.autograd.grad((t * dt).sum(), (x, g, b))
+    st = torch.stack([x.detach().mean(1), 1 / torch.sqrt(x.detach().var(1, unbiased=False) + 1e-5)], 1)
+    r = rec()
+    dX, dG, dB = r.alloc(M, C), r.alloc(C), r.alloc(C)
+    r.ln_bwd("ln", dev(dt), dev(x.detach()), dev(st), dev(g.detach()), dev(dres), dX, dG, dB, C_=C)
+    r.run(r.fwd)
+    assert rel(dX, dx + dres) < TOL
+    assert rel(dG, dg) < TOL and rel(dB, db) < TOL
+
+
+# ------------------------------------------------------------------ uir_attn
+def _attn_ref(q, k, T, P, Wof, heads):
+    B, HW, C = q.shape
+    d = C // heads
+    qh = q.permute(0, 2, 1).reshape(B, heads, d, HW)
+    kh = k.permute(0, 2, 1).reshape(B, heads, d, HW)
+    qn, kn = F.normalize(qh, dim=-1), F.normalize(kh, dim=-1)
+    attn = torch.softmax((qn @ kn.transpose(-2, -1)) * T.view(1, heads, 1, 1), dim=-1)
+    A = torch.zeros(B, C, C, dtype=q.dtype)
+    for h in range(heads):
+        A[:, h * d:(h + 1) * d, h * d:(h + 1) * d] = attn[:, h]
+    return attn, P @ A, Wof @ A
+
+
+@pytest.mark.parametrize("C,heads", [(16, 1), (32, 1), (32, 2), (128, 8)])
+def test_attn_fwd_bwd(C, heads):
+    B, HW = 2, 200
+    d = C // heads
+    q = rnd(B, HW, C, seed=1).requires_grad_(True)
+    k = rnd(B, HW, C, seed=2).requires_grad_(True)
+    T = (1 + 0.25 * rnd(heads, seed=3)).requires_grad_(True)
+    P = rnd(C, C, seed=4, scale=0.3).requires_grad_(True)
+    Wof = rnd(C, C, seed=5, scale=0.3).requires_grad_(True)
+    attn, WA, WB = _attn_ref(q, k, T, P, Wof, heads)
+    dWA, dWB = rnd(B, C, C, seed=6), rnd(B, C, C, seed=7)
+    dq, dk, dT, dP, dWof = torch.autograd.grad((WA * dWA).sum() + (WB * dWB).sum(), (q, k, T, P, Wof))
+    qd, kd = q.detach(), k.detach()
+    G = torch.einsum("bpi,bpj->bij", qd, kd)
+    fa = L.AttnFwdArgs()
+    t = {n: dev(v) for n, v in dict(G=G, sq=(qd ** 2).sum(1), sk=(kd ** 2).sum(1), T=T.detach(), P=P.detach(), Wof=Wof.detach(),
+                                    dWA=dWA, dWB=dWB).items()}
+    o = {n: torch.empty(*s, device=DEV) for n, s in dict(attn=(B, heads, d, d), WA=(B, C, C), WB=(B, C, C), Mqk=(B, 2 * C, 2 * C),
+                                                         dP=(B, C, C), dWof=(B, C, C), dT=(B, heads)).items()}
+    fa.G, fa.sq_q, fa.sq_k, fa.temperature, fa.P, fa.Wof = (t["G"].data_ptr(), t["sq"].data_ptr(), t["sk"].data_ptr(),
+                                                            t["T"].data_ptr(), t["P"].data_ptr(), t["Wof"].data_ptr())
+    fa.attn, fa.WA, fa.WB = o["attn"].data_ptr(), o["WA"].data_ptr(), o["WB"].data_ptr()
+    fa.B, fa.C, fa.heads = B, C, heads
+    import ctypes
+    assert lib.uir_attn_fwd(ctypes.byref(fa), None) == 0
+    ba = L.AttnBwdArgs()
+    ba.dWA, ba.dWB, ba.G, ba.sq_q, ba.sq_k, ba.temperature = (t["dWA"].data_ptr(), t["dWB"].data_ptr(), t["G"].data_ptr(),
+                                                               t["sq"].data_ptr(), t["sk"].data_ptr(), t["T"].data_ptr())
+    ba.attn, ba.P, ba.Wof = o["attn"].data_ptr(), t["P"].data_ptr(), t["Wof"].data_ptr()
+    ba.Mqk, ba.dP, ba.dWof, ba.dT = o["Mqk"].data_ptr(), o["dP"].data_ptr(), o["dWof"].data_ptr(), o["dT"].data_ptr()
+    ba.B, ba.C, ba.heads = B, C, heads
+    assert lib.uir_attn_bwd(ctypes.byref(ba), None) == 0
+    torch.cuda.synchronize()
+    assert rel(o["attn"], attn) < TOL and rel(o["WA"], WA) < TOL and rel(o["WB"], WB) < TOL
+    Mqk = o["Mqk"].double().cpu()
+    qk = torch.cat([qd, kd], 2)
+    dqk = torch.einsum("bnk,bpk->bpn", Mqk, qk)
+    assert rel(dqk[..., :C], dq) < 5e-5 and rel(dqk[..., C:], dk) < 5e-5
+    assert rel(o["dP"].sum(0), dP) < TOL and rel(o["dWof"].sum(0), dWof) < TOL and rel(o["dT"].sum(0), dT) < 5e-5
+
+
+# -------------------------------------------------------------- uir_spectral
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 40), (1, 16, 16, 32), (1, 6, 10, 64), (1, 32, 32, 128)])
+def test_dft_matches_fft2_and_adjoint(B, H, W, C):
+    x = rnd(B, C, H, W, seed=1)
+    f = torch.fft.fft2(x)
+    r = rec()
+    X = dev(hwc(x))
+    M = B * H * W
+    ar, ai, fr, fi = (r.alloc(M, C) for _ in range(4))
+    r.dft("w", X, None, ar, ai, O=B * H, N=W, I=1, C_=C, sign=-1.0, scale=1.0)
+    r.dft("h", ar, ai, fr, fi, O=B, N=H, I=W, C_=C, sign=-1.0, scale=1.0)
+    # inverse of an arbitrary complex field
+    z = torch.complex(rnd(B, C, H, W, seed=2), rnd(B, C, H, W, seed=3))
+    cr, ci, tr, ti = (r.alloc(M, C) for _ in range(4))
+    r.dft("ih", dev(hwc(z.real)), dev(hwc(z.imag)), cr, ci, O=B, N=H, I=W, C_=C, sign=1.0, scale=1.0)
+    r.dft("iw", cr, ci, tr, ti, O=B * H, N=W, I=1, C_=C, sign=1.0, scale=1.0 / (H * W))
+    # real-output adjoint of the forward transform: dx = Re(F^H g)
+    dxr = r.alloc(M, C)
+    g = torch.complex(rnd(B, C, H, W, seed=4), rnd(B, C, H, W, seed=5))
+    gr_, gi_ = (r.alloc(M, C) for _ in range(2))
+    r.dft("bh", dev(hwc(g.real)), dev(hwc(g.imag)), gr_, gi_, O=B, N=H, I=W, C_=C, sign=1.0, scale=1.0)
+    r.dft("bw", gr_, gi_, dxr, None, O=B * H, N=W, I=1, C_=C, sign=1.0, scale=1.0)
+    r.run(r.fwd)
+    assert rel(chw(fr, B, H, W), f.real) < TOL and rel(chw(fi, B, H, W), f.imag) < TOL * 5
+    iz = torch.fft.ifft2(z)
+    assert rel(chw(tr, B, H, W), iz.real) < TOL and rel(chw(ti, B, H, W), iz.imag) < TOL
+    xx = x.clone().requires_grad_(True)
+    ff = torch.fft.fft2(xx)
+    (dx,) = torch.autograd.grad((ff.real * g.real).sum() + (ff.imag * g.imag).sum(), xx)
+    assert rel(chw(dxr, B, H, W), dx) < TOL
+
+
+def test_spectral_elementwise_and_adjoints():
+    B, H, W, C = 2, 8, 8, 32
+    x = rnd(B, C, H, W, seed=1)
+    f = torch.fft.fft2(x)
+    fr = f.real.clone().requires_grad_(True)
+    fi = f.imag.clone().requires_grad_(True)
+    mag, pha = torch.abs(torch.complex(fr, fi)), torch.angle(torch.complex(fr, fi))
+    gm, gp = rnd(B, C, H, W, seed=2), rnd(B, C, H, W, seed=3)
+    dre, dim = torch.autograd.grad((mag * gm).sum() + (pha * gp).sum(), (fr, fi))
+    n = B * H * W * C
+    FR, FI = dev(hwc(f.real)), dev(hwc(f.imag))
+    MAG, PHA, GRE, GIM = (torch.empty(B * H * W, C, device=DEV) for _ in range(4))
+    assert lib.uir_magpha_fwd(FR.data_ptr(), FI.data_ptr(), MAG.data_ptr(), PHA.data_ptr(), B, H, W, C, None) == 0
+    assert lib.uir_magpha_bwd(MAG.data_ptr(), PHA.data_ptr(), dev(hwc(gm)).data_ptr(), dev(hwc(gp)).data_ptr(), GRE.data_ptr(),
+                              GIM.data_ptr(), n, None) == 0
+    torch.cuda.synchronize()
+    assert rel(chw(MAG, B, H, W), mag) < TOL
+    assert rel(chw(PHA, B, H, W), pha) < TOL      # includes the +pi convention at self-conjugate bins
+    assert rel(chw(GRE, B, H, W), dre) < 1e-4 and rel(chw(GIM, B, H, W), dim) < 1e-4
+    # polar + cabs
+    m = rnd(n, seed=4).requires_grad_(True)
+    p = (rnd(n, seed=5) * 3).requires_grad_(True)
+    zr, zi = m * torch.cos(p), m * torch.sin(p)
+    t = torch.abs(torch.complex(zr, zi))
+    gz1, gz2, gt = rnd(n, seed=6), rnd(n, seed=7), rnd(n, seed=8)
+    dm, dp = torch.autograd.grad((zr * gz1).sum() + (zi * gz2).sum(), (m, p), retain_graph=True)
+    Md, Pd = dev(m.detach()), dev(p.detach())
+    ZR, ZI, TT, GM, GP, GZR, GZI = (torch.empty(n, device=DEV) for _ in range(7))
+    assert lib.uir_polar_fwd(Md.data_ptr(), Pd.data_ptr(), ZR.data_ptr(), ZI.data_ptr(), n, None) == 0
+    assert lib.uir_polar_bwd(Md.data_ptr(), Pd.data_ptr(), dev(gz1).data_ptr(), dev(gz2).data_ptr(), GM.data_ptr(), GP.data_ptr(), n, None) == 0
+    assert lib.uir_cabs_fwd(ZR.data_ptr(), ZI.data_ptr(), TT.data_ptr(), n, None) == 0
+    assert lib.uir_cabs_bwd(ZR.data_ptr(), ZI.data_ptr(), TT.data_ptr(), dev(gt).data_ptr(), GZR.data_ptr(), GZI.data_ptr(), n, None) == 0
+    torch.cuda.synchronize()
+    assert rel(ZR, zr) < TOL and rel(ZI, zi) < TOL and rel(TT, t) < TOL
+    assert rel(GM, dm) < TOL and rel(GP, dp) < TOL
+    zr2, zi2 = zr.detach().clone().requires_grad_(True), zi.detach().clone().requires_grad_(True)
+    d1, d2 = torch.autograd.grad((torch.abs(torch.complex(zr2, zi2)) * gt).sum(), (zr2, zi2))
+    assert rel(GZR, d1) < TOL and rel(GZI, d2) < TOL
+
+
+# --------------------------------------------------------------- uir_shuffle
+def test_shuffle_family():
+    B, H, W, C = 2, 3, 5, 8
+    x = rnd(B, 4 * C, H, W, seed=1)
+    src = dev(hwc(x))
+    dst = torch.zeros(B * 4 * H * W, 2 * C + 3, device=DEV)
+    assert lib.uir_pixel_shuffle(src.data_ptr(), 4 * C, dst.data_ptr(), 2 * C + 3, C, B, H, W, C, None) == 0
+    back = torch.empty(B * H * W, 4 * C, device=DEV)
+    assert lib.uir_pixel_unshuffle(dst.data_ptr(), 2 * C + 3, C, back.data_ptr(), 4 * C, B, H, W, C, None) == 0
+    torch.cuda.synchronize()
+    ps = F.pixel_shuffle(x, 2)
+    assert rel(chw(dst[:, C:2 * C], B, 2 * H, 2 * W), ps) == 0
+    assert torch.equal(back, src)
+    assert rel(chw(back, B, H, W), F.pixel_unshuffle(ps, 2)) == 0
+    # scatter / gather on the even grid
+    po, fill = rnd(B * H * W, C, seed=2), rnd(C, seed=3)
+    cat = torch.zeros(B * 4 * H * W, 2 * C, device=DEV)
+    assert lib.uir_scatter_even(dev(po).data_ptr(), C, dev(fill).data_ptr(), cat.data_ptr(), 2 * C, 0, B, H, W, C, None) == 0
+    got = torch.empty(B * H * W, C, device=DEV)
+    assert lib.uir_gather_even(cat.data_ptr(), 2 * C, 0, got.data_ptr(), C, B, H, W, C, None) == 0
+    torch.cuda.synchronize()
+    want = fill.view(1, C, 1, 1).expand(B, C, 2 * H, 2 * W).clone()
+    want[:, :, ::2, ::2] = chw(po, B, H, W)
+    assert rel(chw(cat[:, :C], B, 2 * H, 2 * W), want) == 0
+    assert rel(got, po) == 0
+    # copy_cols (+accumulate), colsum, nchw<->hwc4
+    a = dev(rnd(50, 12, seed=4))
+    d = torch.ones(50, 20, device=DEV)
+    assert lib.uir_copy_cols(a.data_ptr(), 12, 2, d.data_ptr(), 20, 5, 50, 8, 1, None) == 0
+    torch.cuda.synchronize()
+    assert rel(d[:, 5:13], a[:, 2:10] + 1) == 0 and float(d[:, :5].min()) == 1 and float(d[:, 13:].max()) == 1
+    r = rec()
+    big = dev(rnd(4000, 40, seed=5))
+    cs = r.alloc(32)
+    r.colsum("cs", big, 4, 32, cs)
+    r.run(r.fwd)
+    assert rel(cs, big[:, 4:36].double().sum(0)) < 1e-5
+    img = dev(rnd(B, 3, H, W, seed=6))
+    h4 = torch.empty(B * H * W, 4, device=DEV)
+    rt = torch.empty(B, 3, H, W, device=DEV)
+    assert lib.uir_nchw3_to_hwc4(img.data_ptr(), h4.data_ptr(), B, H, W, None) == 0
+    assert lib.uir_hwc4_to_nchw3(h4.data_ptr(), rt.data_ptr(), B, H, W, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(rt, img) and float(h4[:, 3].abs().max()) == 0
+    assert rel(h4[:, :3], hwc(img.cpu())) == 0
+
+
+# ------------------------------------------------------------ loss and optim
+@pytest.mark.parametrize("name", ["L1", "L2", "charbonnier", "Luminance", "L1withColor"])
+def test_losses_and_psnr(name):
+    from oracle import cpu_ref as O
+    p = rnd(3, 3, 20, 24, seed=1).requires_grad_(True)
+    t = rnd(3, 3, 20, 24, seed=2)
+    want = O.loss_by_name(name, p, t)
+    (gw,) = torch.autograd.grad(want * 1.7, p)
+    out = ops.loss_sums(dev(p.detach()), dev(t), L.LOSS_KINDS[name])
+    g = ops.loss_grad(dev(p.detach()), dev(t), torch.tensor([1.7], device=DEV), L.LOSS_KINDS[name])
+    assert abs(float(out[0]) - float(want)) < 1e-6 * max(1.0, abs(float(want)))
+    assert abs(float(out[1]) - float(O.psnr(t, p.detach()))) < 1e-3
+    assert rel(g, gw) < TOL
+
+
+def test_charbonnier_known_answer_on_gpu():
+    x = dev(rnd(2, 3, 16, 16, seed=3))
+    assert abs(float(ops.loss_sums(x, x, L.LOSS_KINDS["charbonnier"])[0]) - 1e-3) < 1e-8   # src/Loss.ipynb:45
+    for n in ("L1", "L2", "Luminance", "L1withColor"):
+        assert float(ops.loss_sums(x, x, L.LOSS_KINDS[n])[0]) == 0.0
+
+
+@pytest.mark.parametrize("gnorm_scale", [0.01, 5.0])
+def test_clip_adam_matches_oracle(gnorm_scale):
+    from oracle import cpu_ref as O
+    from underwater_image_restoration_amd.engine import FlatParams
+    shapes = {"embed_conv_rgb.weight": (16, 3, 3, 3), "outputl.weight": (8, 32, 3, 3), "encoders.0.0.norm1.weight": (16,)}
+    fp = FlatParams(shapes, DEV)
+    P = {n: rnd(*s, seed=i).float() for i, (n, s) in enumerate(shapes.items())}
+    for n in shapes:
+        fp.view(n).copy_(P[n])
+    opt = ops.FusedClipAdam(fp, lr=1e-2)
+    st = O.AdamClipState(P)
+    for it in range(3):
+        grads = {n: (rnd(*s, seed=10 * it + i) * gnorm_scale).float() for i, (n, s) in enumerate(shapes.items())}
+        for n in shapes:
+            fp.gview(n).copy_(grads[n])
+        norm = opt.step()
+        want = st.step(P, grads, 1e-2)
+        assert abs(float(norm) - want) < 1e-5 * want
+        for n in shapes:
+            assert rel(fp.view(n), P[n]) < 1e-6

@@ -1,0 +1,23 @@
+"""Model factory with the reference's surface (src/Models/__init__.py:10-30): ``init_model``,
+``get_names``.  Only ``SpectralTransformer`` is built here (the MI355X hot path); the other
+reference architectures are outside this build's scope and raise with a clear message."""
+from .SpectralTransformer import SpectralTransformer
+
+__model_factory = {
+    "SpectralTransformer": SpectralTransformer,
+}
+_REFERENCE_ONLY = ("NewModel", "NewBigModel", "NewBigFRFNModel", "AST")
+
+
+def get_names():
+    return list(__model_factory.keys()) + list(_REFERENCE_ONLY)
+
+
+def init_model(name, *args, **kwargs):
+    print("modelCreated")
+    if name in _REFERENCE_ONLY:
+        raise NotImplementedError(f"{name}: not part of the MI355X hot-path build (see DESIGN.md, out of scope)")
+    if name not in __model_factory:
+        raise KeyError(f"Unknown model: {name}")
+    kwargs.pop("use_dwt", None)   # the reference drops it for every arch but NewModel (__init__.py:25-29)
+    return __model_factory[name](*args, **kwargs)

@@ -1,0 +1,150 @@
+"""ctypes binding of libuir_hip.so (C ABI: include/uir_kernels.h).
+
+There is NO fallback: if the shared library is missing or a symbol does not resolve, importing
+this module raises.  The product path never routes through PyTorch eager ops or the oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libuir_hip.so")
+
+fp = C.c_void_p  # device pointers travel as integers
+
+# enums (mirror include/uir_kernels.h)
+PRO_NONE, PRO_LN, PRO_GATE = 0, 1, 2
+EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD = 0, 1, 2
+ACT_NONE, ACT_LEAKY = 0, 1
+LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4}
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("X", fp), ("W", fp), ("Y", fp), ("bias", fp), ("R", fp), ("ln_g", fp), ("ln_b", fp),
+                ("stats", fp), ("G", fp),
+                ("x_bs", C.c_long), ("y_bs", C.c_long), ("r_bs", C.c_long), ("g_bs", C.c_long), ("w_bs", C.c_long),
+                ("w_sn", C.c_long), ("w_sk", C.c_long), ("w_st", C.c_long),
+                ("ldx", C.c_int), ("ldy", C.c_int), ("ldr", C.c_int), ("ldg", C.c_int),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int), ("batches", C.c_int),
+                ("taps", C.c_int), ("flip", C.c_int), ("H", C.c_int), ("Wd", C.c_int),
+                ("n_grp_real", C.c_int), ("n_grp_pad", C.c_int), ("k_grp_real", C.c_int), ("k_grp_pad", C.c_int),
+                ("pro", C.c_int), ("gate_off", C.c_int), ("epi", C.c_int), ("g_off", C.c_int), ("act", C.c_int),
+                ("slope", C.c_float), ("ln_eps", C.c_float)]
+
+
+class GramArgs(C.Structure):
+    _fields_ = [("A", fp), ("B", fp), ("slab", fp), ("stats", fp), ("ln_g", fp), ("ln_b", fp),
+                ("a_bs", C.c_long), ("b_bs", C.c_long),
+                ("o_sn", C.c_long), ("o_sk", C.c_long), ("o_st", C.c_long), ("o_bs", C.c_long),
+                ("slab_stride", C.c_long),
+                ("sq_a_off", C.c_long), ("sq_b_off", C.c_long), ("cs_a_off", C.c_long),
+                ("lda", C.c_int), ("ldb", C.c_int), ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("batches", C.c_int),
+                ("n_grp_real", C.c_int), ("n_grp_pad", C.c_int), ("k_grp_real", C.c_int), ("k_grp_pad", C.c_int),
+                ("taps", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("pro_b", C.c_int), ("gate_off", C.c_int),
+                ("rows_per_chunk", C.c_int), ("nchunks", C.c_int)]
+
+
+class DwArgs(C.Structure):
+    _fields_ = [("X", fp), ("Wt", fp), ("Y", fp), ("ldx", C.c_int), ("ldy", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
+                ("grp_real", C.c_int), ("grp_pad", C.c_int), ("flip", C.c_int)]
+
+
+class DwWgradArgs(C.Structure):
+    _fields_ = [("dY", fp), ("X", fp), ("slab", fp), ("ldy", C.c_int), ("ldx", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
+                ("grp_real", C.c_int), ("grp_pad", C.c_int), ("creal", C.c_int), ("nblocks", C.c_int)]
+
+
+class LnBwdArgs(C.Structure):
+    _fields_ = [("dT", fp), ("X", fp), ("stats", fp), ("gamma", fp), ("dRes", fp), ("dX", fp), ("slab", fp),
+                ("ldt", C.c_int), ("ldx", C.c_int), ("ldr", C.c_int), ("ldo", C.c_int),
+                ("M", C.c_int), ("C", C.c_int), ("nblocks", C.c_int)]
+
+
+class AttnFwdArgs(C.Structure):
+    _fields_ = [("G", fp), ("sq_q", fp), ("sq_k", fp), ("temperature", fp), ("P", fp), ("Wof", fp),
+                ("attn", fp), ("WA", fp), ("WB", fp), ("B", C.c_int), ("C", C.c_int), ("heads", C.c_int)]
+
+
+class AttnBwdArgs(C.Structure):
+    _fields_ = [("dWA", fp), ("dWB", fp), ("G", fp), ("sq_q", fp), ("sq_k", fp), ("temperature", fp),
+                ("attn", fp), ("P", fp), ("Wof", fp), ("Mqk", fp), ("dP", fp), ("dWof", fp), ("dT", fp),
+                ("B", C.c_int), ("C", C.c_int), ("heads", C.c_int)]
+
+
+class DftArgs(C.Structure):
+    _fields_ = [("in_re", fp), ("in_im", fp), ("out_re", fp), ("out_im", fp), ("cos_t", fp), ("sin_t", fp),
+                ("O", C.c_int), ("N", C.c_int), ("I", C.c_int), ("C", C.c_int),
+                ("sign", C.c_float), ("scale", C.c_float)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("sumsq", fp), ("norm_out", fp), ("n", C.c_long),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("bc1", C.c_float), ("bc2", C.c_float), ("max_norm", C.c_float), ("gscale", C.c_float)]
+
+
+i32, i64, f32 = C.c_int, C.c_long, C.c_float
+
+# name -> argtypes (every symbol include/uir_kernels.h declares)
+SIGNATURES = {
+    "uir_gemm": [C.POINTER(GemmArgs), fp],
+    "uir_gram": [C.POINTER(GramArgs), fp],
+    "uir_reduce_slab": [fp, i32, i64, fp, i64, i32, f32, fp],
+    "uir_dwconv": [C.POINTER(DwArgs), fp],
+    "uir_dwconv_wgrad": [C.POINTER(DwWgradArgs), fp],
+    "uir_layernorm_bwd": [C.POINTER(LnBwdArgs), fp],
+    "uir_attn_fwd": [C.POINTER(AttnFwdArgs), fp],
+    "uir_attn_bwd": [C.POINTER(AttnBwdArgs), fp],
+    "uir_dft_axis": [C.POINTER(DftArgs), fp],
+    "uir_magpha_fwd": [fp, fp, fp, fp, i32, i32, i32, i32, fp],
+    "uir_magpha_bwd": [fp, fp, fp, fp, fp, fp, i64, fp],
+    "uir_polar_fwd": [fp, fp, fp, fp, i64, fp],
+    "uir_polar_bwd": [fp, fp, fp, fp, fp, fp, i64, fp],
+    "uir_cabs_fwd": [fp, fp, fp, i64, fp],
+    "uir_cabs_bwd": [fp, fp, fp, fp, fp, fp, i64, fp],
+    "uir_scatter_even": [fp, i32, fp, fp, i32, i32, i32, i32, i32, i32, fp],
+    "uir_gather_even": [fp, i32, i32, fp, i32, i32, i32, i32, i32, fp],
+    "uir_pixel_shuffle": [fp, i32, fp, i32, i32, i32, i32, i32, i32, fp],
+    "uir_pixel_unshuffle": [fp, i32, i32, fp, i32, i32, i32, i32, i32, fp],
+    "uir_copy_cols": [fp, i32, i32, fp, i32, i32, i64, i32, i32, fp],
+    "uir_colsum_partials": [fp, i32, i32, i64, i32, fp, i32, fp],
+    "uir_nchw3_to_hwc4": [fp, fp, i32, i32, i32, fp],
+    "uir_hwc4_to_nchw3": [fp, fp, i32, i32, i32, fp],
+    "uir_loss_partials": [fp, fp, fp, i32, i32, i32, fp],
+    "uir_loss_finalize": [fp, fp, i32, i32, i32, fp],
+    "uir_loss_bwd": [fp, fp, fp, fp, i32, i32, i32, fp],
+    "uir_sumsq_partials": [fp, i64, fp, i32, fp],
+    "uir_clip_adam_step": [C.POINTER(AdamArgs), fp],
+}
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m underwater_image_restoration_amd.build` "
+            "(or __graft_entry__.build()).  The HIP library is mandatory; there is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.uir_version.restype = C.c_char_p
+    lib.uir_version.argtypes = []
+    return lib
+
+
+lib = _load()
+
+
+class UirError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        kind = {1: "argument check failed (UIR_EINVAL)", 2: "HIP launch error (UIR_ELAUNCH)"}.get(status, str(status))
+        raise UirError(f"{what}: {kind}")

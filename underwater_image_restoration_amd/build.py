@@ -1,0 +1,58 @@
+"""Build libuir_hip.so (all HIP kernels + the C ABI of include/uir_kernels.h) for gfx950.
+
+In-tree build: objects under csrc/_build/, the shared library next to this file, so the
+library travels with the source tree to the GPU box.  hipcc cross-compiles without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, "_build")
+LIB = os.path.join(HERE, "libuir_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
+SOURCES = ["gemm", "gram", "dwconv", "layernorm", "attn", "spectral", "shuffle", "colsum", "loss", "optim"]
+
+
+def _deps():
+    return [os.path.join(CSRC, "uir_common.h"), os.path.join(HERE, "..", "include", "uir_kernels.h")]
+
+
+def _stale(target, srcs):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in srcs)
+
+
+def _compile(name):
+    src = os.path.join(CSRC, name + ".hip")
+    obj = os.path.join(OBJ, name + ".o")
+    if _stale(obj, [src] + _deps()):
+        subprocess.run([HIPCC, *FLAGS, "-c", src, "-o", obj], check=True)
+    return obj
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    if force:
+        for n in SOURCES:
+            p = os.path.join(OBJ, n + ".o")
+            if os.path.exists(p):
+                os.remove(p)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        objs = list(ex.map(_compile, SOURCES))
+    if force or _stale(LIB, objs):
+        subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs], check=True)
+    if verbose:
+        print("built", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)

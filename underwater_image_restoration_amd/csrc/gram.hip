@@ -1,0 +1,219 @@
+// uir_gram: contraction over pixels on the f32 matrix cores -
+//   out[z][n][k][tap] = sum_m A[z][m][n] * pro(B[z][nbr(m,tap)][k])
+// i.e. every convolution weight-gradient of the path and the MDTA q.k^T Gram matrix.
+// MFMA 32x32x2: two pixels per instruction; A's channel on the MFMA row, B's channel on the
+// lane, so both operand loads are 128-B contiguous channel runs of one pixel (HWC rows).
+// Each workgroup (4 waves) owns one chunk of rows x one (tap, n-group, k-group) tile set, sums
+// its 4 waves through LDS and writes ONE partial slab; uir_reduce_slab sums the chunks in a
+// fixed order (bitwise reproducible, no float atomics).
+#include "uir_common.h"
+#include "../../include/uir_kernels.h"
+
+namespace {
+
+template <int TN, int TK>
+__global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int gn, int gk) {
+  __shared__ float red[TN * TK * 16 * 64];
+  __shared__ float redv[4 * 32 * (2 * TN + TK)];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h2 = lane >> 5;
+  const int z = blockIdx.z;
+  const int ngroups = a.taps * gn * gk;
+  const int tg = blockIdx.x % ngroups, chunk = blockIdx.x / ngroups;
+  const int tap = tg / (gn * gk);
+  const int rem = tg - tap * (gn * gk);
+  const int ng = rem / gk, kg = rem - ng * gk;
+  const int n0 = ng * 32 * TN, k0 = kg * 32 * TK;
+  const float* __restrict__ A = a.A + (long)z * a.a_bs;
+  const float* __restrict__ B = a.B + (long)z * a.b_bs;
+  const int row_begin = chunk * a.rows_per_chunk;
+  const int row_end = min(a.M, row_begin + a.rows_per_chunk);
+  int dy = 0, dx = 0;
+  if (a.taps > 1) { dy = tap / 3 - 1; dx = tap - (tap / 3) * 3 - 1; }
+
+  bool acol_ok[TN], bcol_ok[TK];
+  float lng[TK], lnb[TK];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) acol_ok[t] = (n0 + 32 * t + r) < a.N;
+#pragma unroll
+  for (int t = 0; t < TK; ++t) {
+    int k = k0 + 32 * t + r;
+    bcol_ok[t] = k < a.K;
+    lng[t] = 1.f; lnb[t] = 0.f;
+    if (a.pro_b == UIR_GRAM_PRO_LN && bcol_ok[t]) { lng[t] = a.ln_g[k]; lnb[t] = a.ln_b[k]; }
+  }
+
+  f32x16 acc[TN][TK];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+  float sqa[TN], csa[TN], sqb[TK];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) { sqa[t] = 0.f; csa[t] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < TK; ++t) sqb[t] = 0.f;
+
+  for (int base = row_begin + 2 * wave; base < row_end; base += 8) {
+    const int m = base + h2;
+    const bool mok = m < row_end;
+    float av[TN], bv[TK];
+#pragma unroll
+    for (int t = 0; t < TN; ++t) av[t] = (mok && acol_ok[t]) ? A[(long)m * a.lda + n0 + 32 * t + r] : 0.f;
+    bool bok = mok;
+    long mb = m;
+    if (a.taps > 1) {
+      int hw = m % (a.H * a.Wd);
+      int ph = hw / a.Wd, pw = hw - ph * a.Wd;
+      int hh = ph + dy, ww = pw + dx;
+      bok = bok && hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
+      mb = (long)m + dy * a.Wd + dx;
+    }
+    float mean = 0.f, rstd = 0.f;
+    if (a.pro_b == UIR_GRAM_PRO_LN && bok) {
+      const float* st = a.stats + ((long)z * a.M + mb) * 2;
+      mean = st[0]; rstd = st[1];
+    }
+#pragma unroll
+    for (int t = 0; t < TK; ++t) {
+      float v = 0.f;
+      if (bok && bcol_ok[t]) {
+        const float* bp = B + mb * a.ldb + k0 + 32 * t + r;
+        v = bp[0];
+        if (a.pro_b == UIR_GRAM_PRO_LN) v = (v - mean) * rstd * lng[t] + lnb[t];
+        else if (a.pro_b == UIR_GRAM_PRO_GATE) v = uir_gelu(v) * bp[a.gate_off];
+      }
+      bv[t] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TK; ++j) acc[i][j] = uir_mfma(av[i], bv[j], acc[i][j]);
+#pragma unroll
+    for (int t = 0; t < TN; ++t) { sqa[t] += av[t] * av[t]; csa[t] += av[t]; }
+#pragma unroll
+    for (int t = 0; t < TK; ++t) sqb[t] += bv[t] * bv[t];
+  }
+
+  // ---- sum the 4 waves through LDS (fixed order), wave 0 stores ----
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            float* p = &red[((i * TK + j) * 16 + q) * 64 + lane];
+            *p = (w == 0) ? acc[i][j][q] : (*p + acc[i][j][q]);
+          }
+    }
+    __syncthreads();
+  }
+  float* slab = a.slab + (long)chunk * a.slab_stride;
+  {
+    const int per_thread = TN * TK * 16 * 64 / 256;
+    for (int e = 0; e < per_thread; ++e) {
+      const int idx = e * 256 + threadIdx.x;
+      const int ln = idx & 63;
+      const int q = (idx >> 6) & 15;
+      const int tile = idx >> 10;
+      const int i = tile / TK, j = tile - i * TK;
+      const int n = n0 + 32 * i + uir_mfma_row(q, ln >> 5);
+      const int k = k0 + 32 * j + (ln & 31);
+      if (n < a.N && k < a.K) {
+        const int nr = uir_colmap(n, a.n_grp_real, a.n_grp_pad);
+        const int kr = uir_colmap(k, a.k_grp_real, a.k_grp_pad);
+        if (nr >= 0 && kr >= 0)
+          slab[(long)z * a.o_bs + (long)nr * a.o_sn + (long)kr * a.o_sk + (long)tap * a.o_st] = red[idx];
+      }
+    }
+  }
+  // ---- column extras: sum of squares of A / B columns, column sums of A ----
+  const bool want_a = (a.sq_a_off >= 0 || a.cs_a_off >= 0) && kg == 0 && tap == 0;
+  const bool want_b = a.sq_b_off >= 0 && ng == 0 && tap == 0;
+  if (want_a || want_b) {
+    constexpr int NV = 2 * TN + TK;
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      float s = sqa[t] + __shfl_xor(sqa[t], 32);
+      float c = csa[t] + __shfl_xor(csa[t], 32);
+      if (h2 == 0) { redv[(wave * NV + t) * 32 + r] = s; redv[(wave * NV + TN + t) * 32 + r] = c; }
+    }
+#pragma unroll
+    for (int t = 0; t < TK; ++t) {
+      float s = sqb[t] + __shfl_xor(sqb[t], 32);
+      if (h2 == 0) redv[(wave * NV + 2 * TN + t) * 32 + r] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32 * NV) {
+      const int v = threadIdx.x / 32, c = threadIdx.x & 31;
+      float s = 0.f;
+      for (int w = 0; w < 4; ++w) s += redv[(w * NV + v) * 32 + c];
+      if (v < TN) {
+        const int n = n0 + 32 * v + c;
+        if (want_a && a.sq_a_off >= 0 && n < a.N) slab[a.sq_a_off + (long)z * a.N + n] = s;
+      } else if (v < 2 * TN) {
+        const int n = n0 + 32 * (v - TN) + c;
+        if (want_a && a.cs_a_off >= 0 && n < a.N) slab[a.cs_a_off + (long)z * a.N + n] = s;
+      } else {
+        const int k = k0 + 32 * (v - 2 * TN) + c;
+        if (want_b && k < a.K) slab[a.sq_b_off + (long)z * a.K + k] = s;
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void uir_reduce_slab_kernel(const float* __restrict__ slab, int nchunks, long stride,
+                                                              float* __restrict__ out, long n, int accumulate, float scale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += slab[(long)c * stride + i];
+    s *= scale;
+    out[i] = accumulate ? out[i] + s : s;
+  }
+}
+
+}  // namespace
+
+extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
+  const UirGramArgs& a = *p;
+  UIR_REQUIRE(a.A && a.B && a.slab);
+  UIR_REQUIRE(a.M > 0 && a.N > 0 && a.K > 0 && a.batches > 0 && a.nchunks > 0);
+  UIR_REQUIRE(a.taps == 1 || a.taps == 9);
+  UIR_REQUIRE(a.taps == 1 || (a.H > 0 && a.Wd > 0 && a.M % (a.H * a.Wd) == 0));
+  UIR_REQUIRE(a.rows_per_chunk > 0 && (a.rows_per_chunk & 7) == 0);
+  UIR_REQUIRE((long)a.rows_per_chunk * a.nchunks >= a.M);
+  UIR_REQUIRE(a.lda >= a.N && a.ldb >= a.K);
+  if (a.pro_b == UIR_GRAM_PRO_LN) UIR_REQUIRE(a.stats && a.ln_g && a.ln_b && a.taps == 1);
+  if (a.pro_b == UIR_GRAM_PRO_GATE) UIR_REQUIRE(a.ldb >= a.gate_off + a.K);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 block(256);
+  const int tn_tiles = (a.N + 31) / 32, tk_tiles = (a.K + 31) / 32;
+  if (tk_tiles == 1) {
+    const int gn = (tn_tiles + 3) / 4, gk = 1;
+    dim3 grid(a.taps * gn * gk * a.nchunks, 1, a.batches);
+    hipLaunchKernelGGL((uir_gram_kernel<4, 1>), grid, block, 0, st, a, gn, gk);
+  } else if (tn_tiles == 1) {
+    const int gn = 1, gk = (tk_tiles + 3) / 4;
+    dim3 grid(a.taps * gn * gk * a.nchunks, 1, a.batches);
+    hipLaunchKernelGGL((uir_gram_kernel<1, 4>), grid, block, 0, st, a, gn, gk);
+  } else {
+    const int gn = (tn_tiles + 1) / 2, gk = (tk_tiles + 1) / 2;
+    dim3 grid(a.taps * gn * gk * a.nchunks, 1, a.batches);
+    hipLaunchKernelGGL((uir_gram_kernel<2, 2>), grid, block, 0, st, a, gn, gk);
+  }
+  return uir_launch_status();
+}
+
+extern "C" int uir_reduce_slab(const float* slab, int nchunks, long stride, float* out, long n, int accumulate,
+                               float scale, void* stream) {
+  UIR_REQUIRE(slab && out && nchunks > 0 && n > 0);
+  long blocks = (n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(uir_reduce_slab_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     slab, nchunks, stride, out, n, accumulate, scale);
+  return uir_launch_status();
+}

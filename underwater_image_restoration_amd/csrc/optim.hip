@@ -1,0 +1,64 @@
+// Step tail of the reference trainer (src/ModelTrainer.py:87-88, :199): global-norm gradient
+// clipping (clip_grad_norm_(params, 1.0)) and torch.optim.Adam defaults, fused over ONE flat
+// fp32 buffer that holds every live parameter (and, under data parallelism, is the single RCCL
+// all-reduce bucket).  The clip coefficient is computed on the device from the reduced sum of
+// squares: no host synchronisation in the step.
+#include "uir_common.h"
+#include "../../include/uir_kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __restrict__ g, long n, float* __restrict__ slab) {
+  __shared__ float red[4];
+  float s = 0.f;
+  const long n4 = n >> 2;
+  const float4* g4 = reinterpret_cast<const float4*>(g);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    const float4 v = g4[i];
+    s += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long i = n4 << 2; i < n; ++i) s += g[i] * g[i];
+  s = uir_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) slab[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void clip_adam_kernel(const UirAdamArgs a) {
+  const float total = sqrtf(a.sumsq[0]) * a.gscale;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) a.norm_out[0] = total;
+  float coef = a.max_norm / (total + 1e-6f);
+  coef = (a.max_norm > 0.f) ? fminf(coef, 1.0f) : 1.0f;
+  const float gmul = a.gscale * coef;
+  const float step = a.lr / a.bc1;
+  const float rs2 = rsqrtf(a.bc2);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
+    const float g = a.g[i] * gmul;
+    const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
+    const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
+    a.m[i] = m;
+    a.v[i] = v;
+    a.p[i] -= step * m / (sqrtf(v) * rs2 + a.eps);
+  }
+}
+
+}  // namespace
+
+extern "C" int uir_sumsq_partials(const float* g, long n, float* slab, int nblocks, void* stream) {
+  UIR_REQUIRE(g && slab && n > 0 && nblocks > 0 && uir_aligned16(g));
+  hipLaunchKernelGGL(sumsq_partials_kernel, dim3(nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), g, n, slab);
+  return uir_launch_status();
+}
+
+extern "C" int uir_clip_adam_step(const UirAdamArgs* p, void* stream) {
+  const UirAdamArgs& a = *p;
+  UIR_REQUIRE(a.p && a.g && a.m && a.v && a.sumsq && a.n > 0);
+  UIR_REQUIRE(a.bc1 > 0.f && a.bc2 > 0.f);
+  long blocks = (a.n + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return uir_launch_status();
+}
+
+extern "C" const char* uir_version(void) { return "uir_hip 0.1 gfx950"; }

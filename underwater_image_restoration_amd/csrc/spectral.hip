@@ -1,0 +1,201 @@
+// Spectral up-sampler pieces (reference UpSample, SpectralTransformer.py:174-188):
+//  * uir_dft_axis: one axis of the 2-D DFT of an HWC tensor as an f32-MFMA contraction with
+//    cos/sin twiddle tables - any length N, channels on the MFMA lane so every operand load and
+//    result store is a 128-B contiguous HWC channel run, no bit reversal, no LDS.
+//  * magnitude/phase, polar -> complex, |z| and their adjoints (element-wise, HBM-bound, tiny).
+// The reference's ifft2 of the 2x2-tiled spectrum on 2H x 2W equals ifft2 on H x W written to the
+// even grid (zeros elsewhere), so only H x W transforms are ever computed here.
+#include "uir_common.h"
+#include "../../include/uir_kernels.h"
+
+namespace {
+
+constexpr int KT = 2;  // 32-frequency tiles per wave
+
+__global__ __launch_bounds__(256) void uir_dft_kernel(const UirDftArgs a, int ctiles, int kgroups, long items) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h2 = lane >> 5;
+  const long item = (long)blockIdx.x * 4 + wave;
+  if (item >= items) return;
+  const int kg = (int)(item % kgroups);
+  long t = item / kgroups;
+  const int ct = (int)(t % ctiles);
+  t /= ctiles;
+  const int i = (int)(t % a.I);
+  const long o = t / a.I;
+  const int c = ct * 32 + r;
+  const bool cok = c < a.C;
+  const int k0 = kg * 32 * KT;
+  const bool has_im = a.in_im != nullptr;
+  const bool want_im = a.out_im != nullptr;
+
+  f32x16 are[KT], aim[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { are[kt][q] = 0.f; aim[kt][q] = 0.f; }
+
+  const long line = (o * a.N * a.I + i) * a.C;  // element (o, n=0, i, c=0)
+  const long nstride = (long)a.I * a.C;
+  for (int n = 0; n < a.N; n += 2) {
+    const int nn = n + h2;
+    const bool nok = nn < a.N;
+    float bre = 0.f, bim = 0.f;
+    if (nok && cok) {
+      bre = a.in_re[line + nn * nstride + c];
+      if (has_im) bim = a.in_im[line + nn * nstride + c];
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+      const int k = k0 + 32 * kt + r;
+      float cv = 0.f, sv = 0.f;
+      if (nok && k < a.N) {
+        cv = a.cos_t[(long)nn * a.N + k];
+        sv = a.sign * a.sin_t[(long)nn * a.N + k];
+      }
+      // e^{i s th}(re + i im) = (cos re - s sin im) + i (cos im + s sin re)
+      are[kt] = uir_mfma(cv, bre, are[kt]);
+      if (has_im) are[kt] = uir_mfma(-sv, bim, are[kt]);
+      if (want_im) {
+        aim[kt] = uir_mfma(sv, bre, aim[kt]);
+        if (has_im) aim[kt] = uir_mfma(cv, bim, aim[kt]);
+      }
+    }
+  }
+  if (!cok) return;
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int k = k0 + 32 * kt + uir_mfma_row(q, h2);
+      if (k < a.N) {
+        a.out_re[line + k * nstride + c] = are[kt][q] * a.scale;
+        if (want_im) a.out_im[line + k * nstride + c] = aim[kt][q] * a.scale;
+      }
+    }
+}
+
+__global__ void uir_magpha_fwd_kernel(const float* __restrict__ re, const float* __restrict__ im, float* __restrict__ mag,
+                                      float* __restrict__ pha, int H, int Wd, int C, long n) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const long pix = idx / C;
+    const int w = (int)(pix % Wd);
+    const int h = (int)((pix / Wd) % H);
+    float x = re[idx], y = im[idx];
+    const bool hs = (h == 0) || (((H & 1) == 0) && h == H / 2);
+    const bool ws = (w == 0) || (((Wd & 1) == 0) && w == Wd / 2);
+    if (hs && ws) y = 0.0f;  // self-conjugate bin of a real signal: Im is exactly +0
+    mag[idx] = sqrtf(x * x + y * y);
+    pha[idx] = atan2f(y, x);
+  }
+}
+
+__global__ void uir_magpha_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ pha, const float* __restrict__ gm,
+                                      const float* __restrict__ gp, float* __restrict__ gre, float* __restrict__ gim, long n) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const float m = mag[idx];
+    float s, c;
+    sincosf(pha[idx], &s, &c);
+    float a = 0.f, b = 0.f;
+    if (m > 0.f) {
+      const float q = gp[idx] / m;
+      a = gm[idx] * c - q * s;   // d|z|/dre = re/|z|,  dangle/dre = -im/|z|^2
+      b = gm[idx] * s + q * c;   // d|z|/dim = im/|z|,  dangle/dim =  re/|z|^2
+    }
+    gre[idx] = a;
+    gim[idx] = b;
+  }
+}
+
+__global__ void uir_polar_fwd_kernel(const float* __restrict__ mag, const float* __restrict__ pha, float* __restrict__ zr,
+                                     float* __restrict__ zi, long n) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    float s, c;
+    sincosf(pha[idx], &s, &c);
+    const float m = mag[idx];
+    zr[idx] = m * c;
+    zi[idx] = m * s;
+  }
+}
+
+__global__ void uir_polar_bwd_kernel(const float* __restrict__ mag, const float* __restrict__ pha, const float* __restrict__ gzr,
+                                     const float* __restrict__ gzi, float* __restrict__ gm, float* __restrict__ gp, long n) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    float s, c;
+    sincosf(pha[idx], &s, &c);
+    const float m = mag[idx];
+    gm[idx] = gzr[idx] * c + gzi[idx] * s;
+    gp[idx] = m * (gzi[idx] * c - gzr[idx] * s);
+  }
+}
+
+__global__ void uir_cabs_fwd_kernel(const float* __restrict__ zr, const float* __restrict__ zi, float* __restrict__ t, long n) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const float x = zr[idx], y = zi[idx];
+    t[idx] = sqrtf(x * x + y * y);
+  }
+}
+
+__global__ void uir_cabs_bwd_kernel(const float* __restrict__ zr, const float* __restrict__ zi, const float* __restrict__ t,
+                                    const float* __restrict__ gt, float* __restrict__ gzr, float* __restrict__ gzi, long n) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const float m = t[idx];
+    const float q = m > 0.f ? gt[idx] / m : 0.f;
+    gzr[idx] = q * zr[idx];
+    gzi[idx] = q * zi[idx];
+  }
+}
+
+inline dim3 ew_grid(long n) {
+  long b = (n + 255) / 256;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b);
+}
+
+}  // namespace
+
+extern "C" int uir_dft_axis(const UirDftArgs* p, void* stream) {
+  const UirDftArgs& a = *p;
+  UIR_REQUIRE(a.in_re && a.out_re && a.cos_t && a.sin_t);
+  UIR_REQUIRE(a.O > 0 && a.N > 0 && a.I > 0 && a.C > 0);
+  const int ctiles = (a.C + 31) / 32;
+  const int kgroups = (a.N + 32 * KT - 1) / (32 * KT);
+  const long items = (long)a.O * a.I * ctiles * kgroups;
+  const long blocks = (items + 3) / 4;
+  UIR_REQUIRE(blocks < (1L << 31));
+  hipLaunchKernelGGL(uir_dft_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a, ctiles, kgroups, items);
+  return uir_launch_status();
+}
+
+extern "C" int uir_magpha_fwd(const float* re, const float* im, float* mag, float* pha, int B, int H, int Wd, int C, void* stream) {
+  UIR_REQUIRE(re && im && mag && pha && B > 0 && H > 0 && Wd > 0 && C > 0);
+  const long n = (long)B * H * Wd * C;
+  hipLaunchKernelGGL(uir_magpha_fwd_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), re, im, mag, pha, H, Wd, C, n);
+  return uir_launch_status();
+}
+extern "C" int uir_magpha_bwd(const float* mag, const float* pha, const float* g_mag, const float* g_pha, float* g_re, float* g_im, long n, void* stream) {
+  UIR_REQUIRE(mag && pha && g_mag && g_pha && g_re && g_im && n > 0);
+  hipLaunchKernelGGL(uir_magpha_bwd_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), mag, pha, g_mag, g_pha, g_re, g_im, n);
+  return uir_launch_status();
+}
+extern "C" int uir_polar_fwd(const float* mag, const float* pha, float* zr, float* zi, long n, void* stream) {
+  UIR_REQUIRE(mag && pha && zr && zi && n > 0);
+  hipLaunchKernelGGL(uir_polar_fwd_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), mag, pha, zr, zi, n);
+  return uir_launch_status();
+}
+extern "C" int uir_polar_bwd(const float* mag, const float* pha, const float* g_zr, const float* g_zi, float* g_mag, float* g_pha, long n, void* stream) {
+  UIR_REQUIRE(mag && pha && g_zr && g_zi && g_mag && g_pha && n > 0);
+  hipLaunchKernelGGL(uir_polar_bwd_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), mag, pha, g_zr, g_zi, g_mag, g_pha, n);
+  return uir_launch_status();
+}
+extern "C" int uir_cabs_fwd(const float* zr, const float* zi, float* t, long n, void* stream) {
+  UIR_REQUIRE(zr && zi && t && n > 0);
+  hipLaunchKernelGGL(uir_cabs_fwd_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), zr, zi, t, n);
+  return uir_launch_status();
+}
+extern "C" int uir_cabs_bwd(const float* zr, const float* zi, const float* t, const float* g_t, float* g_zr, float* g_zi, long n, void* stream) {
+  UIR_REQUIRE(zr && zi && t && g_t && g_zr && g_zi && n > 0);
+  hipLaunchKernelGGL(uir_cabs_bwd_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), zr, zi, t, g_t, g_zr, g_zi, n);
+  return uir_launch_status();
+}

@@ -1,0 +1,53 @@
+// Shared device/host helpers for the gfx950 (MI355X, CDNA4) kernels.
+// wave = 64 lanes; f32 MFMA (v_mfma_f32_32x32x2_f32) for every channel contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define UIR_OK 0
+#define UIR_EINVAL 1
+#define UIR_ELAUNCH 2
+
+#define UIR_REQUIRE(cond) do { if (!(cond)) return UIR_EINVAL; } while (0)
+
+static inline int uir_launch_status() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? UIR_OK : UIR_ELAUNCH;
+}
+
+static inline bool uir_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// padded column -> real index (or -1 for an exact-zero pad column).
+// Columns come in groups of grp_pad, of which the first grp_real are real.
+__device__ __forceinline__ int uir_colmap(int c, int grp_real, int grp_pad) {
+  if (grp_pad <= 0) return c;
+  int g = c / grp_pad;
+  int r = c - g * grp_pad;
+  return r < grp_real ? g * grp_real + r : -1;
+}
+
+// exact-erf GELU (torch F.gelu default) and its derivative
+__device__ __forceinline__ float uir_gelu(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float uir_gelu_grad(float x) {
+  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+  float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+// row index held by accumulator register `reg` of a 32x32 f32 MFMA tile for lane half h2
+__device__ __forceinline__ int uir_mfma_row(int reg, int h2) { return (reg & 3) + 8 * (reg >> 2) + 4 * h2; }
+
+__device__ __forceinline__ f32x16 uir_mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float uir_wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}

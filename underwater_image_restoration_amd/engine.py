@@ -1,0 +1,651 @@
+"""Static launch plan for the SpectralTransformer train step on one MI355X.
+
+The network (reference: src/Models/SpectralTransformer.py:213-270) is compiled ONCE per input
+shape into two flat lists of kernel launches - forward and hand-written backward - over
+buffers that live for the lifetime of the plan (288 GB of HBM3E makes activation
+re-materialisation pointless at B=16, 256x256).  Executing a step is walking the lists and
+calling the C ABI of include/uir_kernels.h with pre-built argument structs on the current HIP
+stream: no tracing compiler, no per-step allocation, no host synchronisation.
+
+Layout: activations are HWC rows, `[B*H*W, C]` fp32, NCHW only at the model boundary.
+Parameters live in ONE flat fp32 buffer (live tensors first) with a parallel flat gradient
+buffer: the gradient buffer is the single RCCL all-reduce bucket and the operand of the fused
+clip+Adam kernel; `nn.Parameter`s of the host module are views into it.
+
+Algebra used (exact): MDTA's `attn @ v -> project_out -> kv` and
+`attn @ vf -> project_outf` are folded into two per-batch 1x1 GEMMs with composed weights
+(uir_attn_fwd); the GDFN gate and LayerNorm are GEMM prologues; ifft2 of the 2x2-tiled spectrum
+is evaluated on the H x W grid and zero-interleaved.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Callable, Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+lib = L.lib
+
+NUM_BLOCKS = (2, 3, 3, 4)
+NUM_HEADS = (1, 2, 4, 8)
+CHANNELS = (16, 32, 64, 128)
+NUM_REFINEMENT = 4
+EXPANSION = 2.66
+LN_EPS = 1e-5
+SCRATCH_FLOATS = 96 * 1024 * 1024  # 384 MB of slab scratch shared by every reduction
+
+
+def hidden_of(c: int) -> int:
+    return int(c * EXPANSION)
+
+
+def pad4(n: int) -> int:
+    return (n + 3) & ~3
+
+
+def is_dead_param(name: str) -> bool:
+    """Parameters the reference never uses on the live path (grad stays None):
+    SpectralTransformer.py:103-106,112 (q1X1_*) and :231,233,248,250."""
+    if ".attn.q1X1_" in name:
+        return True
+    return name.startswith(("ups_4.", "ups1.", "ups2.", "output1."))
+
+
+class FlatParams:
+    """All parameters in one flat fp32 buffer (live first, 16-byte aligned slots) plus a
+    parallel gradient buffer.  `view(name)` / `gview(name)` are tensor views."""
+
+    def __init__(self, shapes: "Dict[str, Tuple[int, ...]]", device):
+        names = [n for n in shapes if not is_dead_param(n)] + [n for n in shapes if is_dead_param(n)]
+        self.shapes = dict(shapes)
+        self.slots: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        self.n_live = 0
+        for n in names:
+            numel = int(np.prod(shapes[n]))
+            self.slots[n] = (off, numel)
+            off += pad4(numel)
+            if not is_dead_param(n):
+                self.n_live = off
+        self.total = off
+        self.device = torch.device(device)
+        self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.live_names = [n for n in names if not is_dead_param(n)]
+
+    def view(self, name: str) -> torch.Tensor:
+        o, n = self.slots[name]
+        return self.flat[o:o + n].view(self.shapes[name])
+
+    def gview(self, name: str) -> torch.Tensor:
+        o, n = self.slots[name]
+        return self.grad[o:o + n].view(self.shapes[name])
+
+
+_TWIDDLE_CACHE: Dict[Tuple[int, str], Tuple[torch.Tensor, torch.Tensor]] = {}
+
+
+def twiddles(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """cos/sin(2*pi*k*j/n) tables [n][n], evaluated in float64 on exact residues k*j mod n."""
+    key = (n, str(device))
+    if key not in _TWIDDLE_CACHE:
+        kj = (np.arange(n, dtype=np.int64)[:, None] * np.arange(n, dtype=np.int64)[None, :]) % n
+        ang = 2.0 * np.pi * kj.astype(np.float64) / n
+        c, s = np.cos(ang), np.sin(ang)
+        # exact zeros / ones where the angle is a multiple of pi/2
+        q = (4 * kj) % n == 0
+        c[q] = np.round(c[q]); s[q] = np.round(s[q])
+        _TWIDDLE_CACHE[key] = (torch.from_numpy(c.astype(np.float32)).to(device),
+                               torch.from_numpy(s.astype(np.float32)).to(device))
+    return _TWIDDLE_CACHE[key]
+
+
+def _ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+def _ld(t: torch.Tensor) -> int:
+    assert t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1), (t.shape, t.stride())
+    return t.stride(0)
+
+
+class Recorder:
+    """Kernel-level recorder: buffers + an ordered list of C-ABI launches with pre-built
+    argument structs.  `Plan` (below) records the whole network with it; the GPU unit tests
+    drive single kernels through the same methods."""
+
+    def __init__(self, device, fp: "FlatParams | None" = None, scratch_floats: int = SCRATCH_FLOATS):
+        self.fp = fp
+        self.dev = torch.device(device)
+        self.fwd: List[tuple] = []
+        self.bwd: List[tuple] = []
+        self.cur = self.fwd
+        self.keep: List[object] = []  # ctypes structs / tensors referenced by raw pointer
+        self.bytes = 0
+        self.scratch = self.alloc(scratch_floats)
+
+    # ------------------------------------------------------------------ memory
+    def alloc(self, *shape, zero: bool = False) -> torch.Tensor:
+        t = (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=self.dev)
+        self.bytes += t.numel() * 4
+        self.keep.append(t)
+        return t
+
+    def P(self, name):
+        return self.fp.view(name)
+
+    def Gr(self, name):
+        return self.fp.gview(name)
+
+    # --------------------------------------------------------------- recording
+    def _op(self, name: str, fn, *args):
+        self.cur.append((fn, args, name))
+
+    def run(self, ops: Sequence[tuple]) -> None:
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if self.dev.type == "cuda" else C.c_void_p(0)
+        for fn, args, name in ops:
+            rc = fn(*args, st)
+            if rc:
+                L.check(rc, name)
+
+    # ---------------------------------------------------------------- kernels
+    def gemm(self, name, X, W, Y, *, N, K, w_sn, w_sk, w_st=0, w_bs=0, batches=1, bias=None, R=None,
+             taps=1, flip=0, hw=None, n_grp=(0, 0), k_grp=(0, 0), pro=L.PRO_NONE, gate_off=0, ln=None, stats=None,
+             epi=L.EPI_PLAIN, G=None, g_off=0, act=L.ACT_NONE):
+        M_total = X.shape[0]
+        assert M_total % batches == 0 and Y.shape[0] == M_total
+        M = M_total // batches
+        a = L.GemmArgs()
+        a.X, a.W, a.Y = _ptr(X), _ptr(W), _ptr(Y)
+        a.bias, a.R = _ptr(bias), _ptr(R)
+        a.ldx, a.ldy = _ld(X), _ld(Y)
+        a.ldr = _ld(R) if R is not None else 0
+        a.x_bs, a.y_bs = M * a.ldx, M * a.ldy
+        a.r_bs = M * a.ldr
+        a.w_bs, a.w_sn, a.w_sk, a.w_st = w_bs, w_sn, w_sk, w_st
+        a.M, a.N, a.K, a.batches = M, N, K, batches
+        a.taps, a.flip = taps, flip
+        if taps == 9:
+            a.H, a.Wd = hw
+            assert M % (hw[0] * hw[1]) == 0
+        a.n_grp_real, a.n_grp_pad = n_grp
+        a.k_grp_real, a.k_grp_pad = k_grp
+        a.pro, a.gate_off = pro, gate_off
+        if pro == L.PRO_LN:
+            a.ln_g, a.ln_b = _ptr(ln[0]), _ptr(ln[1])
+            a.stats = _ptr(stats)
+        a.epi, a.g_off, a.act = epi, g_off, act
+        if G is not None:
+            a.G, a.ldg = _ptr(G), _ld(G)
+            a.g_bs = M * a.ldg
+        a.slope, a.ln_eps = 0.1, LN_EPS
+        assert a.ldx % 4 == 0 and a.ldx >= pad4(K) and a.ldy >= N, (name, a.ldx, K, a.ldy, N)
+        assert Y.shape[1] >= N or epi == L.EPI_GATE_BWD, (name, Y.shape, N)
+        self.keep.append(a)
+        self._op(name, lib.uir_gemm, C.byref(a))
+
+    def _chunks(self, M, ngroups, batches):
+        nch = max(1, min(M // 256, 2048 // max(1, ngroups * batches)))
+        rpc = ((M + nch - 1) // nch + 7) & ~7
+        nch = (M + rpc - 1) // rpc
+        return nch, rpc
+
+    def gram(self, name, A, Bm, out, *, N, K, o_sn, o_sk, o_st=0, o_bs=0, batches=1, taps=1, hw=None,
+             n_grp=(0, 0), k_grp=(0, 0), pro_b=0, gate_off=0, ln=None, stats=None, out_elems=None,
+             extras: "Dict[str, torch.Tensor] | None" = None):
+        """out[...] = sum_m A[m][n] * pro(B[nbr(m)][k]); `out` is a flat view of out_elems floats.
+        extras: {'sq_a': tensor[batches*N], 'sq_b': tensor[batches*K], 'cs_a': tensor[batches*N]}."""
+        M_total = A.shape[0]
+        M = M_total // batches
+        tn, tk = (N + 31) // 32, (K + 31) // 32
+        if tk == 1:
+            groups = (tn + 3) // 4
+        elif tn == 1:
+            groups = (tk + 3) // 4
+        else:
+            groups = ((tn + 1) // 2) * ((tk + 1) // 2)
+        nch, rpc = self._chunks(M, taps * groups, batches)
+        if out_elems is None:
+            out_elems = out.numel()
+        a = L.GramArgs()
+        a.A, a.B, a.slab = _ptr(A), _ptr(Bm), _ptr(self.scratch)
+        a.lda, a.ldb = _ld(A), _ld(Bm)
+        a.a_bs, a.b_bs = M * a.lda, M * a.ldb
+        a.o_sn, a.o_sk, a.o_st, a.o_bs = o_sn, o_sk, o_st, o_bs
+        stride = out_elems
+        a.sq_a_off = a.sq_b_off = a.cs_a_off = -1
+        extras = extras or {}
+        if "sq_a" in extras:
+            a.sq_a_off = stride; stride += batches * N
+        if "sq_b" in extras:
+            a.sq_b_off = stride; stride += batches * K
+        if "cs_a" in extras:
+            a.cs_a_off = stride; stride += batches * N
+        a.slab_stride = stride
+        assert nch * stride <= self.scratch.numel(), (name, nch, stride)
+        a.M, a.N, a.K, a.batches = M, N, K, batches
+        a.n_grp_real, a.n_grp_pad = n_grp
+        a.k_grp_real, a.k_grp_pad = k_grp
+        a.taps = taps
+        if taps == 9:
+            a.H, a.Wd = hw
+        a.pro_b, a.gate_off = pro_b, gate_off
+        if pro_b == L.PRO_LN:
+            a.stats, a.ln_g, a.ln_b = _ptr(stats), _ptr(ln[0]), _ptr(ln[1])
+        a.rows_per_chunk, a.nchunks = rpc, nch
+        assert a.lda >= N and a.ldb >= K
+        self.keep.append(a)
+        self._op(name, lib.uir_gram, C.byref(a))
+        sp = self.scratch.data_ptr()
+        self._op(name + ".red", lib.uir_reduce_slab, sp, nch, stride, _ptr(out), out_elems, 0, 1.0)
+        for key, off in (("sq_a", a.sq_a_off), ("sq_b", a.sq_b_off), ("cs_a", a.cs_a_off)):
+            if key in extras:
+                t = extras[key]
+                self._op(name + ".red." + key, lib.uir_reduce_slab, sp + 4 * off, nch, stride, _ptr(t), t.numel(), 0, 1.0)
+
+    def dwconv(self, name, X, Wt, Y, *, C_, dims, grp=(0, 0), flip=0):
+        a = L.DwArgs()
+        a.X, a.Wt, a.Y = _ptr(X), _ptr(Wt), _ptr(Y)
+        a.ldx, a.ldy = _ld(X), _ld(Y)
+        a.B, a.H, a.Wd = dims
+        a.C = C_
+        a.grp_real, a.grp_pad = grp
+        a.flip = flip
+        assert C_ % 4 == 0 and a.ldx >= C_ and a.ldy >= C_ and X.shape[0] == dims[0] * dims[1] * dims[2]
+        self.keep.append(a)
+        self._op(name, lib.uir_dwconv, C.byref(a))
+
+    def dwconv_wgrad(self, name, dY, X, out, *, C_, creal, dims, grp=(0, 0)):
+        a = L.DwWgradArgs()
+        a.dY, a.X, a.slab = _ptr(dY), _ptr(X), _ptr(self.scratch)
+        a.ldy, a.ldx = _ld(dY), _ld(X)
+        a.B, a.H, a.Wd = dims
+        a.C, a.creal = C_, creal
+        a.grp_real, a.grp_pad = grp
+        items = dims[0] * dims[1] * ((dims[2] + 3) // 4)
+        ny = 256 // (C_ // 4)
+        a.nblocks = max(1, min(1024, items // max(1, ny * 4)))
+        assert a.nblocks * creal * 9 <= self.scratch.numel()
+        self.keep.append(a)
+        self._op(name, lib.uir_dwconv_wgrad, C.byref(a))
+        self._op(name + ".red", lib.uir_reduce_slab, _ptr(self.scratch), a.nblocks, creal * 9, _ptr(out), creal * 9, 0, 1.0)
+
+    def ln_bwd(self, name, dT, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_):
+        a = L.LnBwdArgs()
+        a.dT, a.X, a.stats, a.gamma, a.dRes, a.dX, a.slab = (_ptr(dT), _ptr(X), _ptr(stats), _ptr(gamma), _ptr(dRes),
+                                                            _ptr(dX), _ptr(self.scratch))
+        a.ldt, a.ldx, a.ldo = _ld(dT), _ld(X), _ld(dX)
+        a.ldr = _ld(dRes) if dRes is not None else 0
+        a.M, a.C = X.shape[0], C_
+        rows_per_block = 256 // (C_ // 4)
+        a.nblocks = max(1, min(1024, (a.M + rows_per_block * 4 - 1) // (rows_per_block * 4)))
+        self.keep.append(a)
+        self._op(name, lib.uir_layernorm_bwd, C.byref(a))
+        sp = self.scratch.data_ptr()
+        self._op(name + ".dg", lib.uir_reduce_slab, sp, a.nblocks, 2 * C_, _ptr(dgamma), C_, 0, 1.0)
+        self._op(name + ".db", lib.uir_reduce_slab, sp + 4 * C_, a.nblocks, 2 * C_, _ptr(dbeta), C_, 0, 1.0)
+
+    def colsum(self, name, src, col, C_, out):
+        M = src.shape[0]
+        slots = 256 // C_
+        nb = max(1, min(512, M // max(1, slots * 8)))
+        self._op(name, lib.uir_colsum_partials, _ptr(src), _ld(src), col, M, C_, _ptr(self.scratch), nb)
+        self._op(name + ".red", lib.uir_reduce_slab, _ptr(self.scratch), nb, C_, _ptr(out), C_, 0, 1.0)
+
+    def copy_cols(self, name, src, scol, dst, dcol, C_, accumulate=0):
+        self._op(name, lib.uir_copy_cols, _ptr(src), _ld(src), scol, _ptr(dst), _ld(dst), dcol, src.shape[0], C_, accumulate)
+
+    def dft(self, name, in_re, in_im, out_re, out_im, *, O, N, I, C_, sign, scale):
+        a = L.DftArgs()
+        a.in_re, a.in_im, a.out_re, a.out_im = _ptr(in_re), _ptr(in_im), _ptr(out_re), _ptr(out_im)
+        ct, st = twiddles(N, self.dev)
+        self.keep += [ct, st]
+        a.cos_t, a.sin_t = _ptr(ct), _ptr(st)
+        a.O, a.N, a.I, a.C = O, N, I, C_
+        a.sign, a.scale = sign, scale
+        self.keep.append(a)
+        self._op(name, lib.uir_dft_axis, C.byref(a))
+
+
+
+class Plan(Recorder):
+    """Launch lists + buffers of the whole network for one (B, H, W)."""
+
+    def __init__(self, fp: FlatParams, B: int, H: int, W: int, want_backward: bool = True):
+        assert H % 8 == 0 and W % 8 == 0, "H and W must be divisible by 8 (three 2x down-samplings)"
+        super().__init__(fp.device, fp)
+        self.B, self.H, self.W = B, H, W
+        self.want_backward = want_backward
+        self._build()
+
+    @classmethod
+    def bare(cls, fp: FlatParams, scratch_floats: int = SCRATCH_FLOATS) -> "Plan":
+        """A Plan with no network recorded: tests use it to record single sub-graphs."""
+        self = cls.__new__(cls)
+        Recorder.__init__(self, fp.device, fp, scratch_floats)
+        return self
+
+    # ------------------------------------------------------------ sub-graphs
+    def _block(self, pfx: str, x: torch.Tensor, C_: int, heads: int, dims) -> Tuple[torch.Tensor, Callable]:
+        """TransformerBlock (SpectralTransformer.py:142-148) on HWC rows x [M, C]."""
+        B, H, W = dims
+        M, HW = B * H * W, H * W
+        h, hp = hidden_of(C_), pad4(hidden_of(C_))
+        P, Gr = self.P, self.Gr
+        a = f"{pfx}.attn"
+        Wqkv, Wdw = P(f"{a}.qkv.weight"), P(f"{a}.qkv_conv.weight")
+        Wo, Wkv, Wkvdw, Wof = (P(f"{a}.project_out.weight"), P(f"{a}.kv.weight"), P(f"{a}.kv_conv.weight"),
+                               P(f"{a}.project_outf.weight"))
+        Wkvf = Wkv.view(2 * C_, C_)[C_:]                 # vf half of kv (SpectralTransformer.py:107)
+        Wkvdw_f = Wkvdw.view(2 * C_, 9)[C_:]
+        temp = P(f"{a}.temperature")
+        g1, b1 = P(f"{pfx}.norm1.weight"), P(f"{pfx}.norm1.bias")
+        g2, b2 = P(f"{pfx}.norm2.weight"), P(f"{pfx}.norm2.bias")
+        Win, Wffdw, Wout = P(f"{pfx}.ffn.project_in.weight"), P(f"{pfx}.ffn.conv.weight"), P(f"{pfx}.ffn.project_out.weight")
+
+        stats1, stats2 = self.alloc(M, 2), self.alloc(M, 2)
+        qkv_pre, qkv = self.alloc(M, 3 * C_), self.alloc(M, 3 * C_)
+        gbuf = self.alloc(B * C_ * C_ + 2 * B * C_)
+        Gm, sqq, sqk = gbuf[:B * C_ * C_], gbuf[B * C_ * C_:B * C_ * C_ + B * C_], gbuf[B * C_ * C_ + B * C_:]
+        Pm = self.alloc(C_, C_)
+        attn, WA, WB = self.alloc(B * C_ * (C_ // heads)), self.alloc(B, C_ * C_), self.alloc(B, C_ * C_)
+        u, vf, x1 = self.alloc(M, C_), self.alloc(M, C_), self.alloc(M, C_)
+        gpre, g = self.alloc(M, 2 * hp), self.alloc(M, 2 * hp)
+        y = self.alloc(M, C_)
+        q_, k_, v_ = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
+
+        n = pfx
+        # ---- MDTA (live path of :93-100,107,110,113) ----
+        self.gemm(n + ".qkv", x, Wqkv, qkv_pre, N=3 * C_, K=C_, w_sn=C_, w_sk=1, pro=L.PRO_LN, ln=(g1, b1), stats=stats1)
+        self.dwconv(n + ".qkv_conv", qkv_pre, Wdw, qkv, C_=3 * C_, dims=dims)
+        self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
+                  out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk})
+        self.gemm(n + ".P", Wkvf, Wo, Pm, N=C_, K=C_, w_sn=1, w_sk=C_)
+        fa = L.AttnFwdArgs()
+        fa.G, fa.sq_q, fa.sq_k, fa.temperature, fa.P, fa.Wof = _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp), _ptr(Pm), _ptr(Wof)
+        fa.attn, fa.WA, fa.WB = _ptr(attn), _ptr(WA), _ptr(WB)
+        fa.B, fa.C, fa.heads = B, C_, heads
+        self.keep.append(fa)
+        self._op(n + ".attn_fwd", lib.uir_attn_fwd, C.byref(fa))
+        self.gemm(n + ".WA", v_, WA, u, N=C_, K=C_, w_sn=C_, w_sk=1, w_bs=C_ * C_, batches=B)
+        self.dwconv(n + ".kv_conv", u, Wkvdw_f, vf, C_=C_, dims=dims)
+        self.gemm(n + ".WB", vf, WB, x1, N=C_, K=C_, w_sn=C_, w_sk=1, w_bs=C_ * C_, batches=B, R=x)
+        # ---- GDFN (:127-130) ----
+        self.gemm(n + ".ffn_in", x1, Win, gpre, N=2 * hp, K=C_, w_sn=C_, w_sk=1, n_grp=(h, hp), pro=L.PRO_LN, ln=(g2, b2), stats=stats2)
+        self.dwconv(n + ".ffn_conv", gpre, Wffdw, g, C_=2 * hp, dims=dims, grp=(h, hp))
+        self.gemm(n + ".ffn_out", g, Wout, y, N=C_, K=h, w_sn=h, w_sk=1, pro=L.PRO_GATE, gate_off=hp, R=x1)
+
+        def backward(dy: torch.Tensor) -> torch.Tensor:
+            dg, dgpre = self.alloc(M, 2 * hp), self.alloc(M, 2 * hp)
+            dt = self.alloc(M, C_)
+            dx1 = self.alloc(M, C_)
+            dWB, dWA = self.alloc(B, C_ * C_), self.alloc(B, C_ * C_)
+            dvf, du = self.alloc(M, C_), self.alloc(M, C_)
+            dqkv, dqkv_pre = self.alloc(M, 3 * C_), self.alloc(M, 3 * C_)
+            Mqk = self.alloc(B, 4 * C_ * C_)
+            dPb, dWofb, dTb, dPsum = self.alloc(B, C_ * C_), self.alloc(B, C_ * C_), self.alloc(B, heads), self.alloc(C_, C_)
+            dx = self.alloc(M, C_)
+            # GDFN
+            self.gram(n + ".dWout", dy, g, Gr(f"{pfx}.ffn.project_out.weight"), N=C_, K=h, o_sn=h, o_sk=1,
+                      pro_b=L.PRO_GATE, gate_off=hp)
+            self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g, g_off=hp)
+            self.dwconv_wgrad(n + ".dWffdw", dg, gpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h, dims=dims, grp=(h, hp))
+            self.dwconv(n + ".dgpre", dg, Wffdw, dgpre, C_=2 * hp, dims=dims, grp=(h, hp), flip=1)
+            self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
+                      n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
+            self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
+            self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
+            # MDTA
+            self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
+            self.gemm(n + ".dvf", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
+            self.dwconv_wgrad(n + ".dWkvdw", dvf, u, Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, creal=C_, dims=dims)
+            self.dwconv(n + ".du", dvf, Wkvdw_f, du, C_=C_, dims=dims, flip=1)
+            self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
+            self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
+            ba = L.AttnBwdArgs()
+            ba.dWA, ba.dWB, ba.G, ba.sq_q, ba.sq_k, ba.temperature = _ptr(dWA), _ptr(dWB), _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp)
+            ba.attn, ba.P, ba.Wof = _ptr(attn), _ptr(Pm), _ptr(Wof)
+            ba.Mqk, ba.dP, ba.dWof, ba.dT = _ptr(Mqk), _ptr(dPb), _ptr(dWofb), _ptr(dTb)
+            ba.B, ba.C, ba.heads = B, C_, heads
+            self.keep.append(ba)
+            self._op(n + ".attn_bwd", lib.uir_attn_bwd, C.byref(ba))
+            self._op(n + ".dWof", lib.uir_reduce_slab, _ptr(dWofb), B, C_ * C_, _ptr(Gr(f"{a}.project_outf.weight")), C_ * C_, 0, 1.0)
+            self._op(n + ".dPsum", lib.uir_reduce_slab, _ptr(dPb), B, C_ * C_, _ptr(dPsum), C_ * C_, 0, 1.0)
+            self._op(n + ".dT", lib.uir_reduce_slab, _ptr(dTb), B, heads, _ptr(Gr(f"{a}.temperature")), heads, 0, 1.0)
+            # P = Wkvf @ Wo  ->  dWkvf = dP Wo^T ; dWo = Wkvf^T dP
+            self.gemm(n + ".dWkvf", dPsum, Wo, Gr(f"{a}.kv.weight").view(2 * C_, C_)[C_:], N=C_, K=C_, w_sn=C_, w_sk=1)
+            self.gram(n + ".dWo", Wkvf, dPsum, Gr(f"{a}.project_out.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
+            self.gemm(n + ".dqk", qkv[:, :2 * C_], Mqk, dqkv[:, :2 * C_], N=2 * C_, K=2 * C_, w_sn=2 * C_, w_sk=1,
+                      w_bs=4 * C_ * C_, batches=B)
+            self.dwconv_wgrad(n + ".dWqkvdw", dqkv, qkv_pre, Gr(f"{a}.qkv_conv.weight"), C_=3 * C_, creal=3 * C_, dims=dims)
+            self.dwconv(n + ".dqkv_pre", dqkv, Wdw, dqkv_pre, C_=3 * C_, dims=dims, flip=1)
+            self.gram(n + ".dWqkv", dqkv_pre, x, Gr(f"{a}.qkv.weight"), N=3 * C_, K=C_, o_sn=C_, o_sk=1,
+                      pro_b=L.PRO_LN, ln=(g1, b1), stats=stats1)
+            self.gemm(n + ".dt1", dqkv_pre, Wqkv, dt, N=C_, K=3 * C_, w_sn=1, w_sk=C_)
+            self.ln_bwd(n + ".ln1_bwd", dt, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_)
+            return dx
+
+        return y, backward
+
+    def _stack(self, pfx, x, nb, C_, heads, dims):
+        bws = []
+        for j in range(nb):
+            x, bw = self._block(f"{pfx}.{j}", x, C_, heads, dims)
+            bws.append(bw)
+
+        def backward(dy):
+            for bw in reversed(bws):
+                dy = bw(dy)
+            return dy
+        return x, backward
+
+    def _conv3(self, name, x, Wname, Cin, Cout, dims, y=None, k_grp=(0, 0), n_grp=(0, 0), Kp=None, Np=None):
+        """dense 3x3 conv, pad 1, no bias (native weight [Cout][Cin][3][3])."""
+        M = x.shape[0]
+        Kp = Kp or Cin
+        Np = Np or Cout
+        Wt = self.P(Wname)
+        if y is None:
+            y = self.alloc(M, Np)
+        self.gemm(name, x, Wt, y, N=Np, K=Kp, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=dims[1:], k_grp=k_grp, n_grp=n_grp)
+
+        def backward(dy, need_dx=True):
+            self.gram(name + ".dW", dy, x, self.Gr(Wname), N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:],
+                      n_grp=n_grp, k_grp=k_grp)
+            if not need_dx:
+                return None
+            dx = self.alloc(M, Kp)
+            self.gemm(name + ".dX", dy, Wt, dx, N=Kp, K=Np, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=dims[1:],
+                      n_grp=k_grp, k_grp=n_grp)
+            return dx
+        return y, backward
+
+    def _down(self, pfx, x, C_, dims):
+        """DownSample (:154-158): conv3x3 C->C/2 + PixelUnshuffle(2)."""
+        B, H, W = dims
+        t, conv_bw = self._conv3(pfx + ".conv", x, f"{pfx}.body.0.weight", C_, C_ // 2, dims)
+        y = self.alloc(B * (H // 2) * (W // 2), 2 * C_)
+        self._op(pfx + ".unshuffle", lib.uir_pixel_unshuffle, _ptr(t), _ld(t), 0, _ptr(y), _ld(y), B, H // 2, W // 2, C_ // 2)
+
+        def backward(dy):
+            dt = self.alloc(B * H * W, C_ // 2)
+            self._op(pfx + ".unshuffle_bwd", lib.uir_pixel_shuffle, _ptr(dy), _ld(dy), _ptr(dt), _ld(dt), 0, B, H // 2, W // 2, C_ // 2)
+            return conv_bw(dt)
+        return y, backward
+
+    def _fuse(self, pfx, x, C_):
+        """conv1x1+bias -> LeakyReLU(0.1) -> conv1x1+bias (:165-168)."""
+        M = x.shape[0]
+        W0, b0, W2, b2 = (self.P(f"{pfx}.0.weight"), self.P(f"{pfx}.0.bias"), self.P(f"{pfx}.2.weight"), self.P(f"{pfx}.2.bias"))
+        hmid, out = self.alloc(M, C_), self.alloc(M, C_)
+        self.gemm(pfx + ".0", x, W0, hmid, N=C_, K=C_, w_sn=C_, w_sk=1, bias=b0, act=L.ACT_LEAKY)
+        self.gemm(pfx + ".2", hmid, W2, out, N=C_, K=C_, w_sn=C_, w_sk=1, bias=b2)
+
+        def backward(dout):
+            dh, dx = self.alloc(M, C_), self.alloc(M, C_)
+            self.gram(pfx + ".2.dW", dout, hmid, self.Gr(f"{pfx}.2.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
+            self.colsum(pfx + ".2.db", dout, 0, C_, self.Gr(f"{pfx}.2.bias"))
+            self.gemm(pfx + ".2.dX", dout, W2, dh, N=C_, K=C_, w_sn=1, w_sk=C_, epi=L.EPI_LEAKY_BWD, G=hmid)
+            self.gram(pfx + ".0.dW", dh, x, self.Gr(f"{pfx}.0.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
+            self.colsum(pfx + ".0.db", dh, 0, C_, self.Gr(f"{pfx}.0.bias"))
+            self.gemm(pfx + ".0.dX", dh, W0, dx, N=C_, K=C_, w_sn=1, w_sk=C_)
+            return dx
+        return out, backward
+
+    def _ups(self, pfx, x, C_, dims, y_out: torch.Tensor):
+        """UpS (:201-210) = reduce(cat[UpSample(x) (FFT, :174-188), UpSample1(x) (:194-198)]).
+        Writes its [4M, C/2] result into y_out (a column slice of the decoder's concat buffer)."""
+        B, H, W = dims
+        M = B * H * W
+        Ch = C_ // 2
+        f = f"{pfx}.Fups"
+        ar, ai, fr, fi = (self.alloc(M, C_) for _ in range(4))
+        mag, pha = self.alloc(M, C_), self.alloc(M, C_)
+        self.dft(f + ".dftW", x, None, ar, ai, O=B * H, N=W, I=1, C_=C_, sign=-1.0, scale=1.0)
+        self.dft(f + ".dftH", ar, ai, fr, fi, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0)
+        self._op(f + ".magpha", lib.uir_magpha_fwd, _ptr(fr), _ptr(fi), _ptr(mag), _ptr(pha), B, H, W, C_)
+        Mag, amp_bw = self._fuse(f + ".amp_fuse", mag, C_)
+        Pha, pha_bw = self._fuse(f + ".pha_fuse", pha, C_)
+        zr, zi, cr, ci, tr, ti = (self.alloc(M, C_) for _ in range(6))
+        t = self.alloc(M, C_)
+        self._op(f + ".polar", lib.uir_polar_fwd, _ptr(Mag), _ptr(Pha), _ptr(zr), _ptr(zi), M * C_)
+        self.dft(f + ".idftH", zr, zi, cr, ci, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0)
+        self.dft(f + ".idftW", cr, ci, tr, ti, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0 / (H * W))
+        self._op(f + ".cabs", lib.uir_cabs_fwd, _ptr(tr), _ptr(ti), _ptr(t), M * C_)
+        Wpost, bpost = self.P(f + ".post.weight"), self.P(f + ".post.bias")
+        po = self.alloc(M, Ch)
+        self.gemm(f + ".post", t, Wpost, po, N=Ch, K=C_, w_sn=C_, w_sk=1, bias=bpost)
+        cat = self.alloc(4 * M, C_)
+        self._op(f + ".scatter", lib.uir_scatter_even, _ptr(po), _ld(po), _ptr(bpost), _ptr(cat), _ld(cat), 0, B, H, W, Ch)
+        s, sups_bw = self._conv3(pfx + ".Sups", x, f"{pfx}.Sups.body.0.weight", C_, 2 * C_, dims)
+        self._op(pfx + ".Sups.shuffle", lib.uir_pixel_shuffle, _ptr(s), _ld(s), _ptr(cat), _ld(cat), Ch, B, H, W, Ch)
+        Wred = self.P(f"{pfx}.reduce.weight")
+        self.gemm(pfx + ".reduce", cat, Wred, y_out, N=Ch, K=C_, w_sn=C_, w_sk=1)
+
+        def backward(dy: torch.Tensor) -> torch.Tensor:
+            dcat = self.alloc(4 * M, C_)
+            self.gram(pfx + ".reduce.dW", dy, cat, self.Gr(f"{pfx}.reduce.weight"), N=Ch, K=C_, o_sn=C_, o_sk=1)
+            self.gemm(pfx + ".reduce.dX", dy, Wred, dcat, N=C_, K=Ch, w_sn=1, w_sk=C_)
+            # shuffle branch
+            ds = self.alloc(M, 2 * C_)
+            self._op(pfx + ".Sups.shuffle_bwd", lib.uir_pixel_unshuffle, _ptr(dcat), _ld(dcat), Ch, _ptr(ds), _ld(ds), B, H, W, Ch)
+            dx = sups_bw(ds)
+            # spectral branch
+            self.colsum(f + ".post.db", dcat, 0, Ch, self.Gr(f + ".post.bias"))
+            dpo = self.alloc(M, Ch)
+            self._op(f + ".gather", lib.uir_gather_even, _ptr(dcat), _ld(dcat), 0, _ptr(dpo), _ld(dpo), B, H, W, Ch)
+            self.gram(f + ".post.dW", dpo, t, self.Gr(f + ".post.weight"), N=Ch, K=C_, o_sn=C_, o_sk=1)
+            dtt = self.alloc(M, C_)
+            self.gemm(f + ".post.dX", dpo, Wpost, dtt, N=C_, K=Ch, w_sn=1, w_sk=C_)
+            gtr, gti, gcr, gci, gzr, gzi = (self.alloc(M, C_) for _ in range(6))
+            self._op(f + ".cabs_bwd", lib.uir_cabs_bwd, _ptr(tr), _ptr(ti), _ptr(t), _ptr(dtt), _ptr(gtr), _ptr(gti), M * C_)
+            self.dft(f + ".idftW_bwd", gtr, gti, gcr, gci, O=B * H, N=W, I=1, C_=C_, sign=-1.0, scale=1.0 / (H * W))
+            self.dft(f + ".idftH_bwd", gcr, gci, gzr, gzi, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0)
+            gMag, gPha = self.alloc(M, C_), self.alloc(M, C_)
+            self._op(f + ".polar_bwd", lib.uir_polar_bwd, _ptr(Mag), _ptr(Pha), _ptr(gzr), _ptr(gzi), _ptr(gMag), _ptr(gPha), M * C_)
+            gmag = amp_bw(gMag)
+            gpha = pha_bw(gPha)
+            gfr, gfi, gar, gai = (self.alloc(M, C_) for _ in range(4))
+            self._op(f + ".magpha_bwd", lib.uir_magpha_bwd, _ptr(mag), _ptr(pha), _ptr(gmag), _ptr(gpha), _ptr(gfr), _ptr(gfi), M * C_)
+            self.dft(f + ".dftH_bwd", gfr, gfi, gar, gai, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0)
+            dxf = self.alloc(M, C_)
+            self.dft(f + ".dftW_bwd", gar, gai, dxf, None, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0)
+            self.copy_cols(pfx + ".dx_sum", dxf, 0, dx, 0, C_, accumulate=1)
+            return dx
+        return backward
+
+    # ----------------------------------------------------------------- model
+    def _build(self):
+        B, H, W = self.B, self.H, self.W
+        P = self.P
+        d0, d1, d2, d3 = (B, H, W), (B, H // 2, W // 2), (B, H // 4, W // 4), (B, H // 8, W // 8)
+        M0, M1, M2 = B * H * W, B * H * W // 4, B * H * W // 16
+        self.in_nchw = self.alloc(B, 3, H, W)
+        self.out_nchw = self.alloc(B, 3, H, W)
+        self.dout_nchw = self.alloc(B, 3, H, W)
+        x4 = self.alloc(M0, 4)
+        self.cur = self.fwd
+        self._op("in.to_hwc", lib.uir_nchw3_to_hwc4, _ptr(self.in_nchw), _ptr(x4), B, H, W)
+        f0, embed_bw = self._conv3("embed", x4, "embed_conv_rgb.weight", 3, 16, d0, k_grp=(3, 4), Kp=4)
+        e1, enc1_bw = self._stack("encoders.0", f0, 2, 16, 1, d0)
+        t1, down1_bw = self._down("down1", e1, 16, d0)
+        e2, enc2_bw = self._stack("encoders.1", t1, 3, 32, 2, d1)
+        t2, down2_bw = self._down("down2", e2, 32, d1)
+        e3, enc3_bw = self._stack("encoders.2", t2, 3, 64, 4, d2)
+        t3, down3_bw = self._down("down3", e3, 64, d2)
+        e4, enc4_bw = self._stack("encoders.3", t3, 4, 128, 8, d3)
+        # decoder level 3: cat[ups_1(e4), e3] -> reduces1 (SpectralTransformer.py:263-264)
+        cat3 = self.alloc(M2, 128)
+        ups1_bw = self._ups("ups_1", e4, 128, d3, cat3[:, :64])
+        self.copy_cols("cat3.skip", e3, 0, cat3, 64, 64)
+        r3 = self.alloc(M2, 64)
+        self.gemm("reduces1", cat3, P("reduces1.weight"), r3, N=64, K=128, w_sn=128, w_sk=1)
+        dd3, dec3_bw = self._stack("decoders.0", r3, 3, 64, 4, d2)
+        cat2 = self.alloc(M1, 64)
+        ups2_bw = self._ups("ups_2", dd3, 64, d2, cat2[:, :32])
+        self.copy_cols("cat2.skip", e2, 0, cat2, 32, 32)
+        r2 = self.alloc(M1, 32)
+        self.gemm("reduces2", cat2, P("reduces2.weight"), r2, N=32, K=64, w_sn=64, w_sk=1)
+        dd2, dec2_bw = self._stack("decoders.1", r2, 3, 32, 2, d1)
+        cat1 = self.alloc(M0, 32)
+        ups3_bw = self._ups("ups_3", dd2, 32, d1, cat1[:, :16])
+        self.copy_cols("cat1.skip", e1, 0, cat1, 16, 16)
+        fd, dec1_bw = self._stack("decoders.2", cat1, 2, 32, 1, d0)
+        fr, ref_bw = self._stack("refinement", fd, 4, 32, 1, d0)
+        y8, outl_bw = self._conv3("outputl", fr, "outputl.weight", 32, 8, d0)
+        y4, out_bw = self._conv3("output", y8, "output.weight", 8, 3, d0, n_grp=(3, 4), Np=4)
+        self._op("out.to_nchw", lib.uir_hwc4_to_nchw3, _ptr(y4), _ptr(self.out_nchw), B, H, W)
+        if not self.want_backward:
+            return
+        # ------------------------------ backward ------------------------------
+        self.cur = self.bwd
+        dy4 = self.alloc(M0, 4)
+        self._op("dout.to_hwc", lib.uir_nchw3_to_hwc4, _ptr(self.dout_nchw), _ptr(dy4), B, H, W)
+        dy8 = out_bw(dy4)
+        dfr = outl_bw(dy8)
+        dfd = ref_bw(dfr)
+        dcat1 = dec1_bw(dfd)
+        de1 = self.alloc(M0, 16)
+        self.copy_cols("cat1.skip_bwd", dcat1, 16, de1, 0, 16)
+        ddd2 = ups3_bw(dcat1[:, :16])
+        dr2 = dec2_bw(ddd2)
+        dcat2 = self.alloc(M1, 64)
+        self.gram("reduces2.dW", dr2, cat2, self.Gr("reduces2.weight"), N=32, K=64, o_sn=64, o_sk=1)
+        self.gemm("reduces2.dX", dr2, P("reduces2.weight"), dcat2, N=64, K=32, w_sn=1, w_sk=64)
+        de2 = self.alloc(M1, 32)
+        self.copy_cols("cat2.skip_bwd", dcat2, 32, de2, 0, 32)
+        ddd3 = ups2_bw(dcat2[:, :32])
+        dr3 = dec3_bw(ddd3)
+        dcat3 = self.alloc(M2, 128)
+        self.gram("reduces1.dW", dr3, cat3, self.Gr("reduces1.weight"), N=64, K=128, o_sn=128, o_sk=1)
+        self.gemm("reduces1.dX", dr3, P("reduces1.weight"), dcat3, N=128, K=64, w_sn=1, w_sk=128)
+        de3 = self.alloc(M2, 64)
+        self.copy_cols("cat3.skip_bwd", dcat3, 64, de3, 0, 64)
+        de4 = ups1_bw(dcat3[:, :64])
+        dt3 = enc4_bw(de4)
+        d_e3 = down3_bw(dt3)
+        self.copy_cols("e3.grad_sum", d_e3, 0, de3, 0, 64, accumulate=1)
+        dt2 = enc3_bw(de3)
+        d_e2 = down2_bw(dt2)
+        self.copy_cols("e2.grad_sum", d_e2, 0, de2, 0, 32, accumulate=1)
+        dt1 = enc2_bw(de2)
+        d_e1 = down1_bw(dt1)
+        self.copy_cols("e1.grad_sum", d_e1, 0, de1, 0, 16, accumulate=1)
+        df0 = enc1_bw(de1)
+        embed_bw(df0, need_dx=False)
+        self.cur = self.fwd
+
+    # ------------------------------------------------------------------- run
+    def forward(self, x_nchw: torch.Tensor) -> torch.Tensor:
+        self.in_nchw.copy_(x_nchw)
+        self.run(self.fwd)
+        return self.out_nchw
+
+    def backward(self, dout_nchw: torch.Tensor) -> None:
+        """Fills fp.grad (every live parameter's slot is overwritten, not accumulated)."""
+        self.dout_nchw.copy_(dout_nchw)
+        self.run(self.bwd)
