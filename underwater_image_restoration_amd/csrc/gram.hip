@@ -148,8 +148,8 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
       if (h2 == 0) redv[(wave * NV + 2 * TN + t) * 32 + r] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 32 * NV) {
-      const int v = threadIdx.x / 32, c = threadIdx.x & 31;
+    for (int e = threadIdx.x; e < 32 * NV; e += 256) {
+      const int v = e / 32, c = e & 31;
       float s = 0.f;
       for (int w = 0; w < 4; ++w) s += redv[(w * NV + v) * 32 + c];
       if (v < TN) {

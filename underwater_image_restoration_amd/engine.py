@@ -145,6 +145,16 @@ class Recorder:
     def _op(self, name: str, fn, *args):
         self.cur.append((fn, args, name))
 
+    def _hold(self, *tensors):
+        """Raw pointers are recorded: keep every operand alive for the lifetime of the plan."""
+        for t in tensors:
+            if isinstance(t, dict):
+                self.keep.extend(t.values())
+            elif isinstance(t, (tuple, list)):
+                self.keep.extend(x for x in t if x is not None)
+            elif t is not None:
+                self.keep.append(t)
+
     def run(self, ops: Sequence[tuple]) -> None:
         st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if self.dev.type == "cuda" else C.c_void_p(0)
         for fn, args, name in ops:
@@ -159,6 +169,7 @@ class Recorder:
         M_total = X.shape[0]
         assert M_total % batches == 0 and Y.shape[0] == M_total
         M = M_total // batches
+        self._hold(X, W, Y, bias, R, ln, stats, G)
         a = L.GemmArgs()
         a.X, a.W, a.Y = _ptr(X), _ptr(W), _ptr(Y)
         a.bias, a.R = _ptr(bias), _ptr(R)
@@ -201,6 +212,7 @@ class Recorder:
         extras: {'sq_a': tensor[batches*N], 'sq_b': tensor[batches*K], 'cs_a': tensor[batches*N]}."""
         M_total = A.shape[0]
         M = M_total // batches
+        self._hold(A, Bm, out, ln, stats, extras)
         tn, tk = (N + 31) // 32, (K + 31) // 32
         if tk == 1:
             groups = (tn + 3) // 4
@@ -248,6 +260,7 @@ class Recorder:
                 self._op(name + ".red." + key, lib.uir_reduce_slab, sp + 4 * off, nch, stride, _ptr(t), t.numel(), 0, 1.0)
 
     def dwconv(self, name, X, Wt, Y, *, C_, dims, grp=(0, 0), flip=0):
+        self._hold(X, Wt, Y)
         a = L.DwArgs()
         a.X, a.Wt, a.Y = _ptr(X), _ptr(Wt), _ptr(Y)
         a.ldx, a.ldy = _ld(X), _ld(Y)
@@ -260,6 +273,7 @@ class Recorder:
         self._op(name, lib.uir_dwconv, C.byref(a))
 
     def dwconv_wgrad(self, name, dY, X, out, *, C_, creal, dims, grp=(0, 0)):
+        self._hold(dY, X, out)
         a = L.DwWgradArgs()
         a.dY, a.X, a.slab = _ptr(dY), _ptr(X), _ptr(self.scratch)
         a.ldy, a.ldx = _ld(dY), _ld(X)
@@ -275,6 +289,7 @@ class Recorder:
         self._op(name + ".red", lib.uir_reduce_slab, _ptr(self.scratch), a.nblocks, creal * 9, _ptr(out), creal * 9, 0, 1.0)
 
     def ln_bwd(self, name, dT, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_):
+        self._hold(dT, X, stats, gamma, dRes, dX, dgamma, dbeta)
         a = L.LnBwdArgs()
         a.dT, a.X, a.stats, a.gamma, a.dRes, a.dX, a.slab = (_ptr(dT), _ptr(X), _ptr(stats), _ptr(gamma), _ptr(dRes),
                                                             _ptr(dX), _ptr(self.scratch))
@@ -290,6 +305,7 @@ class Recorder:
         self._op(name + ".db", lib.uir_reduce_slab, sp + 4 * C_, a.nblocks, 2 * C_, _ptr(dbeta), C_, 0, 1.0)
 
     def colsum(self, name, src, col, C_, out):
+        self._hold(src, out)
         M = src.shape[0]
         slots = 256 // C_
         nb = max(1, min(512, M // max(1, slots * 8)))
@@ -297,9 +313,11 @@ class Recorder:
         self._op(name + ".red", lib.uir_reduce_slab, _ptr(self.scratch), nb, C_, _ptr(out), C_, 0, 1.0)
 
     def copy_cols(self, name, src, scol, dst, dcol, C_, accumulate=0):
+        self._hold(src, dst)
         self._op(name, lib.uir_copy_cols, _ptr(src), _ld(src), scol, _ptr(dst), _ld(dst), dcol, src.shape[0], C_, accumulate)
 
     def dft(self, name, in_re, in_im, out_re, out_im, *, O, N, I, C_, sign, scale):
+        self._hold(in_re, in_im, out_re, out_im)
         a = L.DftArgs()
         a.in_re, a.in_im, a.out_re, a.out_im = _ptr(in_re), _ptr(in_im), _ptr(out_re), _ptr(out_im)
         ct, st = twiddles(N, self.dev)
