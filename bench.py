@@ -1,0 +1,181 @@
+"""bench.py - train images/s of the SpectralTransformer hot path on N MI355X (one process per GPU).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one full train step of the reference loop (src/ModelTrainer.py:78-90) - forward, loss,
+backward, (all-reduce), clip_grad_norm_(1.0), Adam - on one device-resident synthetic batch of
+16 raw/ref pairs of 256x256x3 per GPU (BASELINE.json metric), fp32, random-init weights.
+Prints ONE JSON line on rank 0 (contract in the task description) with two extra objects:
+  roofline     whole-step algorithmic HBM bytes (10.0625 GB/image) / measured
+               step time vs the 8 TB/s HBM peak, plus the dominant kernel (per-launch HIP-event
+               timing of one extra, untimed, instrumented step)
+  cpu_baseline the CPU oracle (pure PyTorch restatement of the reference path, fixture-verified)
+               timed on this box's host cores on a bounded sample of the same workload
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALG_BYTES_PER_IMAGE_256 = 10.0625e9     # SURVEY.md 8(d) / BASELINE.md section 3 (train step, 256x256)
+ALG_FLOPS_PER_IMAGE_256 = 90.14e9
+HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(image_size: int, budget_s: float = 25.0):
+    """The oracle's train step (fwd + L1 + bwd + clip + Adam) on the host cores: bounded sample."""
+    from oracle import cpu_ref as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    P = O.closed_form_state()
+    st = O.AdamClipState(P)
+    B = 1
+    g = torch.Generator().manual_seed(1000)
+    raw = torch.rand(B, 3, image_size, image_size, generator=g) * 2 - 1
+    ref = torch.rand(B, 3, image_size, image_size, generator=g) * 2 - 1
+
+    def one():
+        _, _, grads = O.loss_and_grads(P, raw, ref, "L1")
+        st.step(P, grads, 3e-4)
+    t0 = time.time()
+    one()                                   # warm-up (also sizes the sample)
+    warm = time.time() - t0
+    n = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
+    t0 = time.time()
+    for _ in range(n):
+        one()
+    dt = (time.time() - t0) / n
+    return {"value": B / dt, "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} timed train steps (after 1 warm-up) of B={B} at {image_size}x{image_size}, fp32, torch CPU, {cores} threads",
+            "s_per_step": dt}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--loss", default="L1withColor")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-breakdown", action="store_true")
+    ap.add_argument("--breakdown-file", default="")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the HIP path)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
+
+    from underwater_image_restoration_amd import init_model
+    from underwater_image_restoration_amd.trainer import TrainStep
+
+    torch.manual_seed(1234)                               # same random init on every rank (replicated weights)
+    model = init_model("SpectralTransformer").to(dev)
+    step = TrainStep(model, args.loss, lr=3e-4)
+    g = torch.Generator(device="cpu").manual_seed(1000 + rank)
+    B, S = args.batch, args.size
+    raw = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
+    ref = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(raw, ref)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, norm = step(raw, ref)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms = dt / args.steps * 1e3
+    imgs_per_s = world * B * args.steps / dt
+    loss_v, norm_v = float(loss), float(norm)
+
+    out = None
+    if rank == 0:
+        scale = (S * S) / (256.0 * 256.0)
+        alg_bytes_step = ALG_BYTES_PER_IMAGE_256 * scale * B          # per GPU per step
+        achieved = alg_bytes_step / (ms * 1e-3)
+        roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK, "traffic": None,
+                "algorithmic_bytes_per_step": alg_bytes_step,
+                "launch": "one train step = forward+backward launch lists + loss + clip/Adam",
+                "mfma_frac_fp32": (ALG_FLOPS_PER_IMAGE_256 * scale * B / (ms * 1e-3)) / 157.3e12}
+        if not args.no_kernel_breakdown:
+            plan = model._plan_for(raw)
+            rows = plan.run_timed(plan.fwd) + plan.run_timed(plan.bwd)
+            agg = {}
+            for name, sym, nb, fl, t_ms in rows:
+                a = agg.setdefault(sym, [0, 0.0, 0, 0])
+                a[0] += 1; a[1] += t_ms; a[2] += nb; a[3] += fl
+            top = max(agg.items(), key=lambda kv: kv[1][1])
+            sym, (cnt, tms, nb, fl) = top
+            roof["dominant_kernel"] = {"symbol": sym, "launches_per_step": cnt, "ms_per_step": tms,
+                                       "avg_launch_ms": tms / cnt, "algorithmic_bytes_per_step": nb,
+                                       "achieved_GBps": nb / (tms * 1e-3) / 1e9, "frac_of_peak": nb / (tms * 1e-3) / HBM_PEAK,
+                                       "achieved_TFLOPs": fl / (tms * 1e-3) / 1e12}
+            roof["instrumented_step_ms"] = sum(r[4] for r in rows)
+            if args.breakdown_file:
+                with open(args.breakdown_file, "w") as f:
+                    f.write("symbol,launches,ms_per_step,alg_GB,alg_GBps,TFLOPs\n")
+                    for sym, (cnt, tms, nb, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                        f.write(f"{sym},{cnt},{tms:.4f},{nb / 1e9:.3f},{nb / max(tms, 1e-9) / 1e6:.1f},{fl / max(tms, 1e-9) / 1e9:.2f}\n")
+                    f.write("\nop,symbol,ms,alg_MB\n")
+                    for name, sym, nb, fl, t_ms in sorted(rows, key=lambda r: -r[4])[:60]:
+                        f.write(f"{name},{sym},{t_ms:.4f},{nb / 1e6:.2f}\n")
+        out = {"metric": "train images/sec at 256x256 bs=16/GPU (SpectralTransformer full train step)",
+               "value": imgs_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"SpectralTransformer {S}x{S} bs={B}/GPU, {args.loss} loss, clip 1.0 + Adam 3e-4, "
+                                      f"full HIP path (BASELINE configs[1]/[2])",
+                          "global_batch": B * world, "image_size": S, "parallelism": f"dp{world}",
+                          "params": 2430709, "final_loss": loss_v, "grad_norm": norm_v},
+               "roofline": roof}
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(S)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

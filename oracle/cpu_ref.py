@@ -179,6 +179,14 @@ def closed_form_images(b: int, s: int, salt: int, dtype=torch.float32) -> torch.
     return torch.from_numpy((img - 0.5) / 0.5).to(dtype)
 
 
+def module_input(cin: int, hw: int, salt: int, dtype=torch.float32) -> torch.Tensor:
+    """Generic [2, cin, hw, hw] module-test input: pure hash noise in [-1, 1).  (Structured
+    inputs - e.g. the sinusoids of closed_form_images - put many spectral bins exactly on the
+    real axis, where torch.angle()'s branch cut makes even fp32-vs-fp64 runs of the REFERENCE
+    differ by ~1e-3; noise inputs keep module fixtures well-conditioned.)"""
+    return torch.from_numpy(_hash_uniform(2 * cin * hw * hw, 5000 + salt).reshape(2, cin, hw, hw)).to(dtype)
+
+
 # ---------------------------------------------------------------------------
 # Live modules
 # ---------------------------------------------------------------------------

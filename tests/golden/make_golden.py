@@ -70,8 +70,7 @@ def main():
     mods = {}
 
     def run_module(tag, module, cin, hw=16, salt=11):
-        x = (O.closed_form_images(2 * ((cin + 2) // 3), hw, salt).reshape(-1)[: 2 * cin * hw * hw]
-             .reshape(2, cin, hw, hw).clone().requires_grad_(True))
+        x = O.module_input(cin, hw, salt).requires_grad_(True)
         y = module(x)
         # fixed pseudo-random cotangent
         g = torch.from_numpy(O._hash_uniform(y.numel(), 777 + salt).reshape(y.shape)).float()
@@ -90,6 +89,7 @@ def main():
     run_module("ups_3.Sups", net.ups_3.Sups, 32, salt=19)
     run_module("ups_3", net.ups_3, 32, salt=20)
     run_module("ups_1", net.ups_1, 128, hw=8, salt=21)
+    run_module("ups_2", net.ups_2, 64, hw=12, salt=33)       # non-power-of-two spectrum
     np.savez_compressed(os.path.join(HERE, "st_modules.npz"), **mods)
 
     # ---------------- full model 2x3x64x64 ----------------------------------

@@ -45,8 +45,7 @@ def flat_from_state(P):
 
 
 def module_input(cin, hw, salt, dtype=torch.float64):
-    return (O.closed_form_images(2 * ((cin + 2) // 3), hw, salt, dtype).reshape(-1)[: 2 * cin * hw * hw]
-            .reshape(2, cin, hw, hw).clone())
+    return O.module_input(cin, hw, salt, dtype)
 
 
 BLOCKS = [("encoders.0.0", 16, 1, 16, 11), ("encoders.1.0", 32, 2, 16, 12), ("refinement.0", 32, 1, 16, 13),
@@ -122,7 +121,7 @@ def test_ups_vs_oracle(pfx, C, hw, salt):
     e_y, e_x = rel(chw(Yb[:, :C // 2], B, 2 * H, 2 * W), y), rel(chw(dX, B, H, W), grads[0])
     print(f"{pfx}: fwd {e_y:.2e} dx {e_x:.2e}")
     assert e_y < 5e-5 and e_x < 5e-4
-    if pfx in ("ups_3", "ups_1"):
+    if pfx in ("ups_3", "ups_1", "ups_2"):
         g = np.load(os.path.join(GOLDEN, "st_modules.npz"))
         assert rel(chw(Yb[:, :C // 2], B, 2 * H, 2 * W), g[f"{pfx}.y"]) < 1e-4
         assert rel(chw(dX, B, H, W), g[f"{pfx}.gx"]) < 1e-3
@@ -172,7 +171,14 @@ def test_full_model_vs_golden_and_oracle():
     P64 = O.closed_form_state(torch.float64)
     _, out64, grads64 = O.loss_and_grads(P64, raw.double(), ref.double(), "L1")
     assert rel(out, out64) < 1e-3
-    bad = [(n, rel(fp.gview(n), gw)) for n, gw in grads64.items() if rel(fp.gview(n), gw) > 2e-3]
+    # element-wise, with an absolute floor: a few gradients are mathematically ZERO (e.g.
+    # pha_fuse.2.bias - a per-channel global phase cancels in |ifft2|) and are pure rounding noise
+    gmax = max(float(gw.abs().max()) for gw in grads64.values())
+    bad = []
+    for n, gw in grads64.items():
+        err = float((fp.gview(n).double().cpu() - gw).abs().max())
+        if err > 2e-3 * float(gw.abs().max()) + 1e-6 * gmax:
+            bad.append((n, err, float(gw.abs().max())))
     assert not bad, bad[:5]
 
 

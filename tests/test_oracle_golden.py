@@ -32,8 +32,7 @@ def test_manifest_matches_reference_state_dict(golden_dir):
 
 
 def _module_input(cin, hw, salt):
-    return (O.closed_form_images(2 * ((cin + 2) // 3), hw, salt).reshape(-1)[: 2 * cin * hw * hw]
-            .reshape(2, cin, hw, hw).clone())
+    return O.module_input(cin, hw, salt)
 
 
 MODULES = [
@@ -48,6 +47,7 @@ MODULES = [
     ("ups_3.Sups", 32, 16, 19, lambda x, P: O.shuffle_upsample(x, P, "ups_3.Sups")),
     ("ups_3", 32, 16, 20, lambda x, P: O.ups(x, P, "ups_3")),
     ("ups_1", 128, 8, 21, lambda x, P: O.ups(x, P, "ups_1")),
+    ("ups_2", 64, 12, 33, lambda x, P: O.ups(x, P, "ups_2")),
 ]
 
 

@@ -126,6 +126,7 @@ class Recorder:
         self.cur = self.fwd
         self.keep: List[object] = []  # ctypes structs / tensors referenced by raw pointer
         self.bytes = 0
+        self.meta: Dict[int, list] = {id(self.fwd): [], id(self.bwd): []}
         self.scratch = self.alloc(scratch_floats)
 
     # ------------------------------------------------------------------ memory
@@ -142,8 +143,11 @@ class Recorder:
         return self.fp.gview(name)
 
     # --------------------------------------------------------------- recording
-    def _op(self, name: str, fn, *args):
+    def _op(self, name: str, fn, *args, nbytes: int = 0, flops: int = 0):
+        """Record one launch.  nbytes/flops = ALGORITHMIC HBM bytes / flops of that launch
+        (each operand counted once; used by the roofline report, never by the launch)."""
         self.cur.append((fn, args, name))
+        self.meta[id(self.cur)].append((name, fn.__name__, nbytes, flops))
 
     def _hold(self, *tensors):
         """Raw pointers are recorded: keep every operand alive for the lifetime of the plan."""
@@ -161,6 +165,22 @@ class Recorder:
             rc = fn(*args, st)
             if rc:
                 L.check(rc, name)
+
+    def run_timed(self, ops: Sequence[tuple]) -> "List[Tuple[str, str, int, int, float]]":
+        """Run a launch list with a HIP event pair around EVERY launch (on the stream the kernels
+        are launched on).  Returns [(op name, C symbol, algorithmic bytes, flops, milliseconds)].
+        Diagnostic only: the event pairs serialise the list."""
+        st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 1)]
+        evs[0].record()
+        for i, (fn, args, name) in enumerate(ops):
+            rc = fn(*args, st)
+            if rc:
+                L.check(rc, name)
+            evs[i + 1].record()
+        torch.cuda.synchronize()
+        meta = self.meta[id(ops)]
+        return [(m[0], m[1], m[2], m[3], evs[i].elapsed_time(evs[i + 1])) for i, m in enumerate(meta)]
 
     # ---------------------------------------------------------------- kernels
     def gemm(self, name, X, W, Y, *, N, K, w_sn, w_sk, w_st=0, w_bs=0, batches=1, bias=None, R=None,
@@ -197,7 +217,12 @@ class Recorder:
         assert a.ldx % 4 == 0 and a.ldx >= pad4(K) and a.ldy >= N, (name, a.ldx, K, a.ldy, N)
         assert Y.shape[1] >= N or epi == L.EPI_GATE_BWD, (name, Y.shape, N)
         self.keep.append(a)
-        self._op(name, lib.uir_gemm, C.byref(a))
+        rows = M * batches
+        kreal = k_grp[0] * (K // k_grp[1]) if k_grp[1] else K
+        nreal = n_grp[0] * (N // n_grp[1]) if n_grp[1] else N
+        nb = 4 * rows * (K * (2 if pro == L.PRO_GATE else 1) + N * (2 if epi == L.EPI_GATE_BWD else 1)
+                         + (N if R is not None else 0) + (N * (2 if epi == L.EPI_GATE_BWD else 1) if G is not None else 0))
+        self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps)
 
     def _chunks(self, M, ngroups, batches):
         nch = max(1, min(M // 256, 2048 // max(1, ngroups * batches)))
@@ -251,7 +276,9 @@ class Recorder:
         a.rows_per_chunk, a.nchunks = rpc, nch
         assert a.lda >= N and a.ldb >= K
         self.keep.append(a)
-        self._op(name, lib.uir_gram, C.byref(a))
+        rows = M * batches
+        self._op(name, lib.uir_gram, C.byref(a), nbytes=4 * rows * (N + K * (2 if pro_b == L.PRO_GATE else 1)),
+                 flops=2 * rows * N * K * taps)
         sp = self.scratch.data_ptr()
         self._op(name + ".red", lib.uir_reduce_slab, sp, nch, stride, _ptr(out), out_elems, 0, 1.0)
         for key, off in (("sq_a", a.sq_a_off), ("sq_b", a.sq_b_off), ("cs_a", a.cs_a_off)):
@@ -270,7 +297,8 @@ class Recorder:
         a.flip = flip
         assert C_ % 4 == 0 and a.ldx >= C_ and a.ldy >= C_ and X.shape[0] == dims[0] * dims[1] * dims[2]
         self.keep.append(a)
-        self._op(name, lib.uir_dwconv, C.byref(a))
+        rows = dims[0] * dims[1] * dims[2]
+        self._op(name, lib.uir_dwconv, C.byref(a), nbytes=8 * rows * C_, flops=18 * rows * C_)
 
     def dwconv_wgrad(self, name, dY, X, out, *, C_, creal, dims, grp=(0, 0)):
         self._hold(dY, X, out)
@@ -285,7 +313,8 @@ class Recorder:
         a.nblocks = max(1, min(1024, items // max(1, ny * 4)))
         assert a.nblocks * creal * 9 <= self.scratch.numel()
         self.keep.append(a)
-        self._op(name, lib.uir_dwconv_wgrad, C.byref(a))
+        rows = dims[0] * dims[1] * dims[2]
+        self._op(name, lib.uir_dwconv_wgrad, C.byref(a), nbytes=8 * rows * C_, flops=18 * rows * C_)
         self._op(name + ".red", lib.uir_reduce_slab, _ptr(self.scratch), a.nblocks, creal * 9, _ptr(out), creal * 9, 0, 1.0)
 
     def ln_bwd(self, name, dT, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_):
@@ -299,7 +328,7 @@ class Recorder:
         rows_per_block = 256 // (C_ // 4)
         a.nblocks = max(1, min(1024, (a.M + rows_per_block * 4 - 1) // (rows_per_block * 4)))
         self.keep.append(a)
-        self._op(name, lib.uir_layernorm_bwd, C.byref(a))
+        self._op(name, lib.uir_layernorm_bwd, C.byref(a), nbytes=4 * a.M * C_ * (4 if dRes is not None else 3), flops=16 * a.M * C_)
         sp = self.scratch.data_ptr()
         self._op(name + ".dg", lib.uir_reduce_slab, sp, a.nblocks, 2 * C_, _ptr(dgamma), C_, 0, 1.0)
         self._op(name + ".db", lib.uir_reduce_slab, sp + 4 * C_, a.nblocks, 2 * C_, _ptr(dbeta), C_, 0, 1.0)
@@ -309,12 +338,13 @@ class Recorder:
         M = src.shape[0]
         slots = 256 // C_
         nb = max(1, min(512, M // max(1, slots * 8)))
-        self._op(name, lib.uir_colsum_partials, _ptr(src), _ld(src), col, M, C_, _ptr(self.scratch), nb)
+        self._op(name, lib.uir_colsum_partials, _ptr(src), _ld(src), col, M, C_, _ptr(self.scratch), nb, nbytes=4 * M * C_)
         self._op(name + ".red", lib.uir_reduce_slab, _ptr(self.scratch), nb, C_, _ptr(out), C_, 0, 1.0)
 
     def copy_cols(self, name, src, scol, dst, dcol, C_, accumulate=0):
         self._hold(src, dst)
-        self._op(name, lib.uir_copy_cols, _ptr(src), _ld(src), scol, _ptr(dst), _ld(dst), dcol, src.shape[0], C_, accumulate)
+        self._op(name, lib.uir_copy_cols, _ptr(src), _ld(src), scol, _ptr(dst), _ld(dst), dcol, src.shape[0], C_, accumulate,
+                 nbytes=4 * src.shape[0] * C_ * (3 if accumulate else 2))
 
     def dft(self, name, in_re, in_im, out_re, out_im, *, O, N, I, C_, sign, scale):
         self._hold(in_re, in_im, out_re, out_im)
@@ -326,7 +356,10 @@ class Recorder:
         a.O, a.N, a.I, a.C = O, N, I, C_
         a.sign, a.scale = sign, scale
         self.keep.append(a)
-        self._op(name, lib.uir_dft_axis, C.byref(a))
+        elems = O * N * I * C_
+        planes = (1 if in_im is None else 2) + (1 if out_im is None else 2)
+        self._op(name, lib.uir_dft_axis, C.byref(a), nbytes=4 * elems * planes,
+                 flops=2 * elems * N * (1 if in_im is None else 2) * (1 if out_im is None else 2))
 
 
 
