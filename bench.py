@@ -42,7 +42,9 @@ def cpu_baseline(image_size: int, budget_s: float = 25.0):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    cores = max(1, min(cores, int(os.environ.get("UIR_CPU_THREADS", "16"))))   # the box's CPU share for one GPU
     torch.set_num_threads(cores)
+    print(f"[bench] cpu_baseline: oracle train step on {cores} host threads ...", file=sys.stderr, flush=True)
     P = O.closed_form_state()
     st = O.AdamClipState(P)
     B = 1
@@ -56,6 +58,7 @@ def cpu_baseline(image_size: int, budget_s: float = 25.0):
     t0 = time.time()
     one()                                   # warm-up (also sizes the sample)
     warm = time.time() - t0
+    print(f"[bench] cpu_baseline: warm-up step {warm:.1f} s", file=sys.stderr, flush=True)
     n = max(1, min(5, int(budget_s / max(warm, 1e-3)) - 1))
     t0 = time.time()
     for _ in range(n):
@@ -168,6 +171,7 @@ def main():
     if world > 1:
         dist.barrier()
     if rank == 0:
+        print("[bench] gpu: " + json.dumps({k: out[k] for k in ("value", "ms_per_step")}), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(S)
         else:

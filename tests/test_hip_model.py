@@ -125,9 +125,12 @@ def test_ups_vs_oracle(pfx, C, hw, salt):
         g = np.load(os.path.join(GOLDEN, "st_modules.npz"))
         assert rel(chw(Yb[:, :C // 2], B, 2 * H, 2 * W), g[f"{pfx}.y"]) < 1e-4
         assert rel(chw(dX, B, H, W), g[f"{pfx}.gx"]) < 1e-3
+    # absolute floor: pha_fuse.2.bias has a mathematically ZERO gradient (a per-channel global
+    # phase cancels in |ifft2|); what is left on either side is rounding noise
+    gmax = max(float(gw.abs().max()) for gw in grads[1:])
     for n, gw in zip(names, grads[1:]):
-        e = rel(fp.gview(n), gw)
-        assert e < 5e-4, (n, e)
+        err = float((fp.gview(n).double().cpu() - gw).abs().max())
+        assert err < 5e-4 * float(gw.abs().max()) + 1e-6 * gmax, (n, err)
 
 
 def test_full_model_vs_golden_and_oracle():
