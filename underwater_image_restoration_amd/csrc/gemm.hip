@@ -21,7 +21,39 @@
 namespace {
 
 template <int NT>
-__global__ __launch_bounds__(256) void uir_gemm_kernel(const UirGemmArgs a) {
+__device__ __forceinline__ void uir_gemm_epilogue(const UirGemmArgs& a, const f32x16 (&acc)[NT], int z, int m0, int n0, int r, int h2) {
+  // lane = output channel, 16 accumulator registers = 16 pixels
+  float* __restrict__ Y = a.Y + (long)z * a.y_bs;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + 32 * nt + r;
+    if (n >= a.N) continue;
+    const int nr = uir_colmap(n, a.n_grp_real, a.n_grp_pad);
+    const float bias = (a.bias && nr >= 0) ? a.bias[nr] : 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int mm = m0 + uir_mfma_row(reg, h2);
+      if (mm >= a.M) continue;
+      float v = acc[nt][reg] + bias;
+      if (a.act == UIR_ACT_LEAKY) v = v > 0.f ? v : v * a.slope;
+      if (a.epi == UIR_EPI_PLAIN) {
+        if (a.R) v += a.R[(long)z * a.r_bs + (long)mm * a.ldr + n];
+        Y[(long)mm * a.ldy + n] = v;
+      } else if (a.epi == UIR_EPI_GATE_BWD) {
+        const float* gp = a.G + (long)z * a.g_bs + (long)mm * a.ldg + n;
+        const float g1 = gp[0], g2 = gp[a.g_off];
+        Y[(long)mm * a.ldy + n] = v * g2 * uir_gelu_grad(g1);
+        Y[(long)mm * a.ldy + a.g_off + n] = v * uir_gelu(g1);
+      } else {  // UIR_EPI_LEAKY_BWD: G holds the forward LeakyReLU output
+        const float o = a.G[(long)z * a.g_bs + (long)mm * a.ldg + n];
+        Y[(long)mm * a.ldy + n] = o > 0.f ? v : v * a.slope;
+      }
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void uir_gemm_kernel(const UirGemmArgs a, const int vecw) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h2 = lane >> 5;
   const int z = blockIdx.z;
@@ -116,6 +148,17 @@ __global__ __launch_bounds__(256) void uir_gemm_kernel(const UirGemmArgs a) {
       }
     }
     av[0] = v.x; av[1] = v.y; av[2] = v.z; av[3] = v.w;
+    if (vecw) {  // k-contiguous weight rows (w_sk == 1, K % 4 == 0): one 16-B load per column tile
+      const bool kok = kc < a.K;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        float4 w = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (kok && wrow[nt] >= 0) w = *reinterpret_cast<const float4*>(W + wrow[nt] + kc);
+        bv[nt][0] = w.x; bv[nt][1] = w.y; bv[nt][2] = w.z; bv[nt][3] = w.w;
+      }
+      if (++ld_ks == ksteps) { ld_ks = 0; ++ld_tap; }
+      return;
+    }
     const int wt = a.flip ? (a.taps - 1 - tap) : tap;
     long koff[4];
 #pragma unroll
@@ -151,32 +194,217 @@ __global__ __launch_bounds__(256) void uir_gemm_kernel(const UirGemmArgs a) {
     }
   }
 
-  // ---- epilogue: lane = output channel, 16 accumulator registers = 16 pixels ----
+  uir_gemm_epilogue<NT>(a, acc, z, m0, n0, r, h2);
+}
+
+// ---------------------------------------------------------------------------------------
+// uir_gemm1x1_kernel: the hot 1x1 path (persistent workgroups).
+//  * the (32*NT) x K weight panel (+ LayerNorm gamma/beta) is staged ONCE per workgroup into LDS
+//    as [col][Kp] with Kp/4 odd: the per-step ds_read_b128 of a column's 4 consecutive k is
+//    bank-conflict free, and LDS reads retire on lgkmcnt, not vmcnt;
+//  * A is read from HBM one 32-wide K chunk at a time (4 float4 per lane) and the NEXT unit
+//    (next chunk, or chunk 0 of the wave's next row tile) is issued BEFORE this unit's MFMAs
+//    and epilogue stores: vmcnt retires in issue order on CDNA4, so the wait for the prefetched
+//    loads never waits for the younger stores (measured: 64 % of wave cycles were s_waitcnt);
+//  * the epilogue is specialised at compile time (no per-element scalar branches).
+template <int NT, int EPI, bool HAS_R>
+__device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f32x16 (&acc)[NT], const float (&biasv)[NT], int z,
+                                                  int m0, int n0, int r, int h2) {
   float* __restrict__ Y = a.Y + (long)z * a.y_bs;
+  const float slope = (a.act == UIR_ACT_LEAKY) ? a.slope : 1.0f;
+  const bool full = (m0 + 32 <= a.M);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + 32 * nt + r;
     if (n >= a.N) continue;
-    const int nr = uir_colmap(n, a.n_grp_real, a.n_grp_pad);
-    const float bias = (a.bias && nr >= 0) ? a.bias[nr] : 0.f;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int mm = m0 + uir_mfma_row(reg, h2);
-      if (mm >= a.M) continue;
+    const float bias = biasv[nt];
+    const long row0 = (long)m0 + 4 * h2;
+    float* yp = Y + row0 * a.ldy + n;
+    const float* rp = HAS_R ? a.R + (long)z * a.r_bs + row0 * a.ldr + n : nullptr;
+    const float* gp = (EPI != UIR_EPI_PLAIN) ? a.G + (long)z * a.g_bs + row0 * a.ldg + n : nullptr;
+    auto put = [&](int reg) {
+      const int dr = (reg & 3) + 8 * (reg >> 2);   // row offset inside the tile (compile-time)
       float v = acc[nt][reg] + bias;
-      if (a.act == UIR_ACT_LEAKY) v = v > 0.f ? v : v * a.slope;
-      if (a.epi == UIR_EPI_PLAIN) {
-        if (a.R) v += a.R[(long)z * a.r_bs + (long)mm * a.ldr + n];
-        Y[(long)mm * a.ldy + n] = v;
-      } else if (a.epi == UIR_EPI_GATE_BWD) {
-        const float* gp = a.G + (long)z * a.g_bs + (long)mm * a.ldg + n;
-        const float g1 = gp[0], g2 = gp[a.g_off];
-        Y[(long)mm * a.ldy + n] = v * g2 * uir_gelu_grad(g1);
-        Y[(long)mm * a.ldy + a.g_off + n] = v * uir_gelu(g1);
-      } else {  // UIR_EPI_LEAKY_BWD: G holds the forward LeakyReLU output
-        const float o = a.G[(long)z * a.g_bs + (long)mm * a.ldg + n];
-        Y[(long)mm * a.ldy + n] = o > 0.f ? v : v * a.slope;
+      v = v > 0.f ? v : v * slope;
+      if constexpr (EPI == UIR_EPI_PLAIN) {
+        if constexpr (HAS_R) v += rp[(long)dr * a.ldr];
+        yp[(long)dr * a.ldy] = v;
+      } else if constexpr (EPI == UIR_EPI_GATE_BWD) {
+        const float g1 = gp[(long)dr * a.ldg], g2 = gp[(long)dr * a.ldg + a.g_off];
+        yp[(long)dr * a.ldy] = v * g2 * uir_gelu_grad(g1);
+        yp[(long)dr * a.ldy + a.g_off] = v * uir_gelu(g1);
+      } else {
+        const float o = gp[(long)dr * a.ldg];
+        yp[(long)dr * a.ldy] = o > 0.f ? v : v * a.slope;
       }
+    };
+    if (full) {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) put(reg);
+    } else {
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg)
+        if (m0 + 4 * h2 + (reg & 3) + 8 * (reg >> 2) < a.M) put(reg);
+    }
+  }
+}
+
+template <int NT, int PRO, int EPI, bool HAS_R>
+__global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, const int Kp, const int tiles) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h2 = lane >> 5;
+  const int z = blockIdx.z;
+  const int n0 = blockIdx.y * (32 * NT);
+  const float* __restrict__ X = a.X + (long)z * a.x_bs;
+  const float* __restrict__ W = a.W + (long)z * a.w_bs;
+  const int K8 = (a.K + 7) & ~7;
+  constexpr int NC = 32 * NT;
+  for (int idx = threadIdx.x; idx < NC * K8; idx += 256) {
+    int nl, k;
+    if (a.w_sk == 1) { nl = idx / K8; k = idx - nl * K8; } else { k = idx / NC; nl = idx - k * NC; }
+    const int n = n0 + nl;
+    const int nr = (n < a.N) ? uir_colmap(n, a.n_grp_real, a.n_grp_pad) : -1;
+    const int kr = (k < a.K) ? uir_colmap(k, a.k_grp_real, a.k_grp_pad) : -1;
+    wl[nl * Kp + k] = (nr >= 0 && kr >= 0) ? W[(long)nr * a.w_sn + (long)kr * a.w_sk] : 0.f;
+  }
+  float* lng = wl + NC * Kp;   // gamma[K8], beta[K8]
+  if constexpr (PRO == UIR_PRO_LN) {
+    for (int k = threadIdx.x; k < K8; k += 256) {
+      lng[k] = k < a.K ? a.ln_g[k] : 0.f;
+      lng[K8 + k] = k < a.K ? a.ln_b[k] : 0.f;
+    }
+  }
+  __syncthreads();
+  const int nchunks = (K8 + 31) >> 5;
+  const float* wbase = wl + r * Kp + 4 * h2;
+  float bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + 32 * nt + r;
+    const int nr = (n < a.N) ? uir_colmap(n, a.n_grp_real, a.n_grp_pad) : -1;
+    bias[nt] = (a.bias && nr >= 0) ? a.bias[nr] : 0.f;
+  }
+
+  // Branch-free loads (a predicated load costs a branch + a full vmcnt(0) drain in hipcc's
+  // codegen): rows past M are clamped to the last row (their results are never stored) and k
+  // past K to column 0 (they meet exact-zero weights staged in LDS), so every address is valid.
+  // Two statically named register panels (P0/P1) alternate between "being consumed" and
+  // "being filled": the loop is unrolled by two so no register copies (and no vmcnt(0) at the
+  // back-edge, behind the epilogue stores) are ever needed.
+  constexpr int NU = (PRO == UIR_PRO_GATE) ? 4 : 1;
+  float4 P0[4], P1[4], U0[NU], U1[NU];
+  const int kmax = (a.K + 3) & ~3;
+  auto load_unit = [&](float4 (&an)[4], float4 (&un)[NU], int tile_, int c_) {
+    const int mm = min(tile_ * 128 + wave * 32 + r, a.M - 1);
+    const float* xr = X + (long)mm * a.ldx;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      int kc = 32 * c_ + 8 * s + 4 * h2;
+      kc = (kc < kmax) ? kc : 0;
+      an[s] = *reinterpret_cast<const float4*>(xr + kc);
+      if constexpr (PRO == UIR_PRO_GATE) un[s] = *reinterpret_cast<const float4*>(xr + a.gate_off + kc);
+    }
+  };
+
+  int tile = blockIdx.x, c = 0;
+  float mean = 0.f, rstd = 0.f;
+  f32x16 acc[NT];
+
+  auto step = [&](float4 (&an)[4], float4 (&un)[NU], float4 (&nx)[4], float4 (&nu)[NU]) -> bool {
+    const int m0 = tile * 128 + wave * 32;
+    const int m = m0 + r;
+    if (c == 0) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+      if constexpr (PRO == UIR_PRO_LN) {
+        float s = 0.f, q = 0.f;
+        if (nchunks == 1) {  // the whole row is already in registers
+#pragma unroll
+          for (int t = 0; t < 4; ++t) s += (8 * t + 4 * h2 < a.K) ? (an[t].x + an[t].y) + (an[t].z + an[t].w) : 0.f;
+          s += __shfl_xor(s, 32);
+          mean = s / (float)a.K;
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const float d0 = an[t].x - mean, d1 = an[t].y - mean, d2 = an[t].z - mean, d3 = an[t].w - mean;
+            q += (8 * t + 4 * h2 < a.K) ? (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) : 0.f;
+          }
+        } else {
+          const float* xr = X + (long)min(m, a.M - 1) * a.ldx;
+          for (int kc = 4 * h2; kc < a.K; kc += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + kc);
+            s += (v.x + v.y) + (v.z + v.w);
+          }
+          s += __shfl_xor(s, 32);
+          mean = s / (float)a.K;
+          for (int kc = 4 * h2; kc < a.K; kc += 8) {
+            const float4 v = *reinterpret_cast<const float4*>(xr + kc);
+            const float d0 = v.x - mean, d1 = v.y - mean, d2 = v.z - mean, d3 = v.w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+          }
+        }
+        q += __shfl_xor(q, 32);
+        rstd = rsqrtf(q / (float)a.K + a.ln_eps);
+        if (a.stats && blockIdx.y == 0 && h2 == 0 && m < a.M)
+          *reinterpret_cast<float2*>(a.stats + ((long)z * a.M + m) * 2) = make_float2(mean, rstd);
+      }
+    }
+    float4 ac[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      float4 v = an[s];
+      const int kc = 32 * c + 8 * s + 4 * h2;
+      if constexpr (PRO == UIR_PRO_LN) {
+        const int kq = (kc < K8) ? kc : 0;
+        const float4 g = *reinterpret_cast<const float4*>(lng + kq);
+        const float4 b = *reinterpret_cast<const float4*>(lng + K8 + kq);
+        v.x = (v.x - mean) * rstd * g.x + b.x;
+        v.y = (v.y - mean) * rstd * g.y + b.y;
+        v.z = (v.z - mean) * rstd * g.z + b.z;
+        v.w = (v.w - mean) * rstd * g.w + b.w;
+      } else if constexpr (PRO == UIR_PRO_GATE) {
+        const float4 u = un[s];
+        v.x = uir_gelu(v.x) * u.x;
+        v.y = uir_gelu(v.y) * u.y;
+        v.z = uir_gelu(v.z) * u.z;
+        v.w = uir_gelu(v.w) * u.w;
+      }
+      ac[s] = v;
+    }
+    // next unit in flight before this unit's MFMAs (and, for the last chunk, before the stores)
+    const bool last = (c + 1 == nchunks);
+    const int tn = last ? tile + (int)gridDim.x : tile;
+    const int cn = last ? 0 : c + 1;
+    load_unit(nx, nu, tn, cn);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int k0 = 32 * c + 8 * s;
+      if (k0 < K8) {
+        float4 b[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(wbase + nt * 32 * Kp + k0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          acc[nt] = uir_mfma(ac[s].x, b[nt].x, acc[nt]);
+          acc[nt] = uir_mfma(ac[s].y, b[nt].y, acc[nt]);
+          acc[nt] = uir_mfma(ac[s].z, b[nt].z, acc[nt]);
+          acc[nt] = uir_mfma(ac[s].w, b[nt].w, acc[nt]);
+        }
+      }
+    }
+    if (last && m0 < a.M) uir_gemm1x1_store<NT, EPI, HAS_R>(a, acc, bias, z, m0, n0, r, h2);
+    tile = tn;
+    c = cn;
+    return tile < tiles;
+  };
+
+  if (tile < tiles) {
+    load_unit(P0, U0, tile, 0);
+    while (true) {
+      if (!step(P0, U0, P1, U1)) break;
+      if (!step(P1, U1, P0, U0)) break;
     }
   }
 }
@@ -198,15 +426,59 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   if (a.epi == UIR_EPI_LEAKY_BWD) UIR_REQUIRE(a.G && a.ldg >= a.N && !a.R);
   if (a.R) UIR_REQUIRE(a.ldr >= a.N);
   const int tiles = (a.N + 31) / 32;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a.taps == 1) {
+    // LDS-resident weight panel: pick the widest column group (<= 4 tiles... 3 keeps 4 waves/SIMD) that fits 64 KB
+    const int K8 = (a.K + 7) & ~7;
+    const int Kp = ((K8 >> 2) & 1) ? K8 : K8 + 4;
+    int groups1 = (tiles + 2) / 3;
+    int nt1 = (tiles + groups1 - 1) / groups1;
+    while (nt1 > 1 && (size_t)nt1 * 32 * Kp * 4 > 64 * 1024) { --nt1; }
+    groups1 = (tiles + nt1 - 1) / nt1;
+    const size_t lds = (size_t)nt1 * 32 * Kp * 4 + (a.pro == UIR_PRO_LN ? (size_t)2 * K8 * 4 : 0);
+    const bool combo_ok = (a.pro == UIR_PRO_NONE) || (a.epi == UIR_EPI_PLAIN && !(a.pro == UIR_PRO_LN && a.R));
+    if (lds <= 96 * 1024 && combo_ok) {
+      const int rtiles = (a.M + 127) / 128;
+      int gx = 1536 / (groups1 * a.batches);
+      if (gx < 1) gx = 1;
+      if (gx > rtiles) gx = rtiles;
+      dim3 grid1(gx, groups1, a.batches);
+#define UIR_L1(NTV, PROV, EPIV, RV) \
+  hipLaunchKernelGGL((uir_gemm1x1_kernel<NTV, PROV, EPIV, RV>), grid1, dim3(256), lds, st, a, Kp, rtiles)
+#define UIR_L1E(NTV, PROV)                                                          \
+  do {                                                                              \
+    if (a.epi == UIR_EPI_GATE_BWD) UIR_L1(NTV, PROV, UIR_EPI_GATE_BWD, false);      \
+    else if (a.epi == UIR_EPI_LEAKY_BWD) UIR_L1(NTV, PROV, UIR_EPI_LEAKY_BWD, false); \
+    else if (a.R) UIR_L1(NTV, PROV, UIR_EPI_PLAIN, true);                           \
+    else UIR_L1(NTV, PROV, UIR_EPI_PLAIN, false);                                   \
+  } while (0)
+#define UIR_L1P(NTV)                                                                \
+  do {                                                                              \
+    if (a.pro == UIR_PRO_LN) UIR_L1(NTV, UIR_PRO_LN, UIR_EPI_PLAIN, false);         \
+    else if (a.pro == UIR_PRO_GATE) { if (a.R) UIR_L1(NTV, UIR_PRO_GATE, UIR_EPI_PLAIN, true); else UIR_L1(NTV, UIR_PRO_GATE, UIR_EPI_PLAIN, false); } \
+    else UIR_L1E(NTV, UIR_PRO_NONE);                                                \
+  } while (0)
+      switch (nt1) {
+        case 1: UIR_L1P(1); break;
+        case 2: UIR_L1P(2); break;
+        default: UIR_L1P(3); break;
+      }
+#undef UIR_L1P
+#undef UIR_L1E
+#undef UIR_L1
+      return uir_launch_status();
+    }
+  }
   const int groups = (tiles + 3) / 4;
   const int nt = (tiles + groups - 1) / groups;
   dim3 grid((a.M + 127) / 128, groups, a.batches), block(256);
-  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int vecw = (a.w_sk == 1 && a.taps == 1 && (a.K & 3) == 0 && a.k_grp_pad <= 0 && (a.w_sn & 3) == 0 &&
+                    (a.w_bs & 3) == 0 && uir_aligned16(a.W)) ? 1 : 0;
   switch (nt) {
-    case 1: hipLaunchKernelGGL(uir_gemm_kernel<1>, grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL(uir_gemm_kernel<2>, grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL(uir_gemm_kernel<3>, grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL(uir_gemm_kernel<4>, grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL(uir_gemm_kernel<1>, grid, block, 0, st, a, vecw); break;
+    case 2: hipLaunchKernelGGL(uir_gemm_kernel<2>, grid, block, 0, st, a, vecw); break;
+    case 3: hipLaunchKernelGGL(uir_gemm_kernel<3>, grid, block, 0, st, a, vecw); break;
+    default: hipLaunchKernelGGL(uir_gemm_kernel<4>, grid, block, 0, st, a, vecw); break;
   }
   return uir_launch_status();
 }

@@ -56,45 +56,53 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
 #pragma unroll
   for (int t = 0; t < TK; ++t) sqb[t] = 0.f;
 
-  for (int base = row_begin + 2 * wave; base < row_end; base += 8) {
-    const int m = base + h2;
-    const bool mok = m < row_end;
-    float av[TN], bv[TK];
+  // U row-pairs per trip: every load of the trip is issued before the first MFMA consumes one
+  constexpr int U = 4;
+  for (int base = row_begin + 2 * wave; base < row_end; base += 8 * U) {
+    float av[U][TN], bv[U][TK];
 #pragma unroll
-    for (int t = 0; t < TN; ++t) av[t] = (mok && acol_ok[t]) ? A[(long)m * a.lda + n0 + 32 * t + r] : 0.f;
-    bool bok = mok;
-    long mb = m;
-    if (a.taps > 1) {
-      int hw = m % (a.H * a.Wd);
-      int ph = hw / a.Wd, pw = hw - ph * a.Wd;
-      int hh = ph + dy, ww = pw + dx;
-      bok = bok && hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
-      mb = (long)m + dy * a.Wd + dx;
-    }
-    float mean = 0.f, rstd = 0.f;
-    if (a.pro_b == UIR_GRAM_PRO_LN && bok) {
-      const float* st = a.stats + ((long)z * a.M + mb) * 2;
-      mean = st[0]; rstd = st[1];
-    }
+    for (int u = 0; u < U; ++u) {
+      const int m = base + 8 * u + h2;
+      const bool mok = m < row_end;
 #pragma unroll
-    for (int t = 0; t < TK; ++t) {
-      float v = 0.f;
-      if (bok && bcol_ok[t]) {
-        const float* bp = B + mb * a.ldb + k0 + 32 * t + r;
-        v = bp[0];
-        if (a.pro_b == UIR_GRAM_PRO_LN) v = (v - mean) * rstd * lng[t] + lnb[t];
-        else if (a.pro_b == UIR_GRAM_PRO_GATE) v = uir_gelu(v) * bp[a.gate_off];
+      for (int t = 0; t < TN; ++t) av[u][t] = (mok && acol_ok[t]) ? A[(long)m * a.lda + n0 + 32 * t + r] : 0.f;
+      bool bok = mok;
+      long mb = m;
+      if (a.taps > 1) {
+        int hw = m % (a.H * a.Wd);
+        int ph = hw / a.Wd, pw = hw - ph * a.Wd;
+        int hh = ph + dy, ww = pw + dx;
+        bok = bok && hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
+        mb = (long)m + dy * a.Wd + dx;
       }
-      bv[t] = v;
+      float mean = 0.f, rstd = 0.f;
+      if (a.pro_b == UIR_GRAM_PRO_LN && bok) {
+        const float2 st = *reinterpret_cast<const float2*>(a.stats + ((long)z * a.M + mb) * 2);
+        mean = st.x; rstd = st.y;
+      }
+#pragma unroll
+      for (int t = 0; t < TK; ++t) {
+        float v = 0.f;
+        if (bok && bcol_ok[t]) {
+          const float* bp = B + mb * a.ldb + k0 + 32 * t + r;
+          v = bp[0];
+          if (a.pro_b == UIR_GRAM_PRO_LN) v = (v - mean) * rstd * lng[t] + lnb[t];
+          else if (a.pro_b == UIR_GRAM_PRO_GATE) v = uir_gelu(v) * bp[a.gate_off];
+        }
+        bv[u][t] = v;
+      }
     }
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
-      for (int j = 0; j < TK; ++j) acc[i][j] = uir_mfma(av[i], bv[j], acc[i][j]);
+      for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int t = 0; t < TN; ++t) { sqa[t] += av[t] * av[t]; csa[t] += av[t]; }
+        for (int j = 0; j < TK; ++j) acc[i][j] = uir_mfma(av[u][i], bv[u][j], acc[i][j]);
 #pragma unroll
-    for (int t = 0; t < TK; ++t) sqb[t] += bv[t] * bv[t];
+      for (int t = 0; t < TN; ++t) { sqa[t] += av[u][t] * av[u][t]; csa[t] += av[u][t]; }
+#pragma unroll
+      for (int t = 0; t < TK; ++t) sqb[t] += bv[u][t] * bv[u][t];
+    }
   }
 
   // ---- sum the 4 waves through LDS (fixed order), wave 0 stores ----
