@@ -40,15 +40,22 @@ __global__ __launch_bounds__(256) void uir_dwconv_kernel(const UirDwArgs a) {
     for (int j = 0; j < R; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int dy = -1; dy <= 1; ++dy) {
+      // branch-free: clamp the neighbour coordinates, zero the out-of-image taps by select
       const int hh = h + dy;
-      if (hh < 0 || hh >= a.H) continue;
-      const float* rowp = a.X + ((long)(b * a.H + hh) * a.Wd) * a.ldx + c4 * 4;
+      const bool hok = hh >= 0 && hh < a.H;
+      const int hc = min(max(hh, 0), a.H - 1);
+      const float* rowp = a.X + ((long)(b * a.H + hc) * a.Wd) * a.ldx + c4 * 4;
       float4 v[R + 2];
 #pragma unroll
       for (int j = 0; j < R + 2; ++j) {
         const int ww = w0 - 1 + j;
-        v[j] = (ww >= 0 && ww < a.Wd) ? *reinterpret_cast<const float4*>(rowp + (long)ww * a.ldx)
-                                     : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int wc = min(max(ww, 0), a.Wd - 1);
+        v[j] = *reinterpret_cast<const float4*>(rowp + (long)wc * a.ldx);
+      }
+#pragma unroll
+      for (int j = 0; j < R + 2; ++j) {
+        const int ww = w0 - 1 + j;
+        if (!(hok && ww >= 0 && ww < a.Wd)) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
       }
 #pragma unroll
       for (int dx = 0; dx < 3; ++dx) {
@@ -84,20 +91,26 @@ __global__ __launch_bounds__(256) void uir_dwconv_wgrad_kernel(const UirDwWgradA
       float4 g[R];
       const float* gp = a.dY + ((long)(b * a.H + h) * a.Wd) * a.ldy + c4 * 4;
 #pragma unroll
+      for (int j = 0; j < R; ++j) g[j] = *reinterpret_cast<const float4*>(gp + (long)min(w0 + j, a.Wd - 1) * a.ldy);
+#pragma unroll
       for (int j = 0; j < R; ++j)
-        g[j] = (w0 + j < a.Wd) ? *reinterpret_cast<const float4*>(gp + (long)(w0 + j) * a.ldy)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+        if (w0 + j >= a.Wd) g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
       for (int dy = -1; dy <= 1; ++dy) {
         const int hh = h + dy;
-        if (hh < 0 || hh >= a.H) continue;
-        const float* rowp = a.X + ((long)(b * a.H + hh) * a.Wd) * a.ldx + c4 * 4;
+        const bool hok = hh >= 0 && hh < a.H;
+        const int hc = min(max(hh, 0), a.H - 1);
+        const float* rowp = a.X + ((long)(b * a.H + hc) * a.Wd) * a.ldx + c4 * 4;
         float4 v[R + 2];
 #pragma unroll
         for (int j = 0; j < R + 2; ++j) {
+          const int wc = min(max(w0 - 1 + j, 0), a.Wd - 1);
+          v[j] = *reinterpret_cast<const float4*>(rowp + (long)wc * a.ldx);
+        }
+#pragma unroll
+        for (int j = 0; j < R + 2; ++j) {
           const int ww = w0 - 1 + j;
-          v[j] = (ww >= 0 && ww < a.Wd) ? *reinterpret_cast<const float4*>(rowp + (long)ww * a.ldx)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+          if (!(hok && ww >= 0 && ww < a.Wd)) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)

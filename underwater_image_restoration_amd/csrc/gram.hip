@@ -56,44 +56,57 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
 #pragma unroll
   for (int t = 0; t < TK; ++t) sqb[t] = 0.f;
 
-  // U row-pairs per trip: every load of the trip is issued before the first MFMA consumes one
+  // U row-pairs per trip: every load of the trip is issued before the first MFMA consumes one.
+  // Loads are branch-free (clamped addresses + select): a predicated load costs a branch and a
+  // vmcnt(0) drain in hipcc's codegen, which serialises the whole trip.
   constexpr int U = 4;
+  int acol[TN], bcol[TK];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) acol[t] = min(n0 + 32 * t + r, a.N - 1);
+#pragma unroll
+  for (int t = 0; t < TK; ++t) bcol[t] = min(k0 + 32 * t + r, a.K - 1);
+  const int last_row = row_end - 1;
   for (int base = row_begin + 2 * wave; base < row_end; base += 8 * U) {
-    float av[U][TN], bv[U][TK];
+    float av[U][TN], bv[U][TK], bg[U][TK];
+    float2 st[U];
+    bool aok[U], bok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int m = base + 8 * u + h2;
-      const bool mok = m < row_end;
+      aok[u] = m < row_end;
+      const int mc = min(m, last_row);
+      const float* ap = A + (long)mc * a.lda;
 #pragma unroll
-      for (int t = 0; t < TN; ++t) av[u][t] = (mok && acol_ok[t]) ? A[(long)m * a.lda + n0 + 32 * t + r] : 0.f;
-      bool bok = mok;
-      long mb = m;
+      for (int t = 0; t < TN; ++t) av[u][t] = ap[acol[t]];
+      bok[u] = aok[u];
+      long mb = mc;
       if (a.taps > 1) {
-        int hw = m % (a.H * a.Wd);
-        int ph = hw / a.Wd, pw = hw - ph * a.Wd;
-        int hh = ph + dy, ww = pw + dx;
-        bok = bok && hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
-        mb = (long)m + dy * a.Wd + dx;
+        const int hw = mc % (a.H * a.Wd);
+        const int ph = hw / a.Wd, pw = hw - ph * a.Wd;
+        const int hh = ph + dy, ww = pw + dx;
+        const bool in = hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
+        bok[u] = bok[u] && in;
+        mb = in ? (long)mc + dy * a.Wd + dx : (long)mc;
       }
-      float mean = 0.f, rstd = 0.f;
-      if (a.pro_b == UIR_GRAM_PRO_LN && bok) {
-        const float2 st = *reinterpret_cast<const float2*>(a.stats + ((long)z * a.M + mb) * 2);
-        mean = st.x; rstd = st.y;
-      }
+      if (a.pro_b == UIR_GRAM_PRO_LN) st[u] = *reinterpret_cast<const float2*>(a.stats + ((long)z * a.M + mb) * 2);
+      const float* bp = B + mb * a.ldb;
 #pragma unroll
       for (int t = 0; t < TK; ++t) {
-        float v = 0.f;
-        if (bok && bcol_ok[t]) {
-          const float* bp = B + mb * a.ldb + k0 + 32 * t + r;
-          v = bp[0];
-          if (a.pro_b == UIR_GRAM_PRO_LN) v = (v - mean) * rstd * lng[t] + lnb[t];
-          else if (a.pro_b == UIR_GRAM_PRO_GATE) v = uir_gelu(v) * bp[a.gate_off];
-        }
-        bv[u][t] = v;
+        bv[u][t] = bp[bcol[t]];
+        if (a.pro_b == UIR_GRAM_PRO_GATE) bg[u][t] = bp[a.gate_off + bcol[t]];
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+#pragma unroll
+      for (int t = 0; t < TN; ++t) av[u][t] = (aok[u] && acol_ok[t]) ? av[u][t] : 0.f;
+#pragma unroll
+      for (int t = 0; t < TK; ++t) {
+        float v = bv[u][t];
+        if (a.pro_b == UIR_GRAM_PRO_LN) v = (v - st[u].x) * st[u].y * lng[t] + lnb[t];
+        else if (a.pro_b == UIR_GRAM_PRO_GATE) v = uir_gelu(v) * bg[u][t];
+        bv[u][t] = (bok[u] && bcol_ok[t]) ? v : 0.f;
+      }
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
