@@ -157,7 +157,7 @@ def main():
                     for sym, (cnt, tms, nb, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                         f.write(f"{sym},{cnt},{tms:.4f},{nb / 1e9:.3f},{nb / max(tms, 1e-9) / 1e6:.1f},{fl / max(tms, 1e-9) / 1e9:.2f}\n")
                     f.write("\nop,symbol,ms,alg_MB\n")
-                    for name, sym, nb, fl, t_ms in sorted(rows, key=lambda r: -r[4])[:60]:
+                    for name, sym, nb, fl, t_ms in sorted(rows, key=lambda r: -r[4]):
                         f.write(f"{name},{sym},{t_ms:.4f},{nb / 1e6:.2f}\n")
         out = {"metric": "train images/sec at 256x256 bs=16/GPU (SpectralTransformer full train step)",
                "value": imgs_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -186,5 +186,16 @@ def main():
     print("fft zero signs:", {k: bool(v) for k, v in signs.items()})
 
 
+def init_checksums():
+    """st_init_seed1234.npz: per-tensor sums of the REFERENCE module's default initialisation under
+    torch.manual_seed(1234) - pins that the HIP module consumes the RNG stream identically."""
+    ST = _load(f"{REF}/src/Models/SpectralTransformer.py", "ref_spectral_transformer_init")
+    torch.manual_seed(1234)
+    sd = ST.SpectralTransformer().state_dict()
+    np.savez(os.path.join(HERE, "st_init_seed1234.npz"), names=np.array(list(sd.keys())),
+             sums=np.array([float(v.double().sum()) for v in sd.values()]))
+
+
 if __name__ == "__main__":
     main()
+    init_checksums()

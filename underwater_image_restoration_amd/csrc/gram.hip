@@ -187,29 +187,32 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
   }
 }
 
-// out[i] = sum_c slab[c][i]: 64 outputs per workgroup, the chunks split over the 4 waves with 4
+// out[i] = sum_c slab[c][i]: 64 outputs per workgroup, the chunks split over 16 waves with 4
 // independent accumulators each (memory-level parallelism), combined in a fixed order.
-__global__ __launch_bounds__(256) void uir_reduce_slab_kernel(const float* __restrict__ slab, int nchunks, long stride,
-                                                              float* __restrict__ out, long n, int accumulate, float scale) {
-  __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void uir_reduce_slab_kernel(const float* __restrict__ slab, int nchunks, long stride,
+                                                               float* __restrict__ out, long n, int accumulate, float scale) {
+  __shared__ float red[16][64];
   const int lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 64 + lane;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
   if (i < n) {
     const float* p = slab + i;
     int c = cl;
-    for (; c + 12 < nchunks; c += 16) {
+    for (; c + 48 < nchunks; c += 64) {
       s0 += p[(long)c * stride];
-      s1 += p[(long)(c + 4) * stride];
-      s2 += p[(long)(c + 8) * stride];
-      s3 += p[(long)(c + 12) * stride];
+      s1 += p[(long)(c + 16) * stride];
+      s2 += p[(long)(c + 32) * stride];
+      s3 += p[(long)(c + 48) * stride];
     }
-    for (; c < nchunks; c += 4) s0 += p[(long)c * stride];
+    for (; c < nchunks; c += 16) s0 += p[(long)c * stride];
   }
   red[cl][lane] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (cl == 0 && i < n) {
-    const float s = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale;
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) s += red[w][lane];
+    s *= scale;
     out[i] = accumulate ? out[i] + s : s;
   }
 }
@@ -251,7 +254,7 @@ extern "C" int uir_reduce_slab(const float* slab, int nchunks, long stride, floa
   UIR_REQUIRE(slab && out && nchunks > 0 && n > 0);
   const long blocks = (n + 63) / 64;
   UIR_REQUIRE(blocks < (1L << 31));
-  hipLaunchKernelGGL(uir_reduce_slab_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(uir_reduce_slab_kernel, dim3((unsigned)blocks), dim3(1024), 0, static_cast<hipStream_t>(stream),
                      slab, nchunks, stride, out, n, accumulate, scale);
   return uir_launch_status();
 }

@@ -225,7 +225,7 @@ class Recorder:
         self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps)
 
     def _chunks(self, M, ngroups, batches):
-        nch = max(1, min(M // 256, 2048 // max(1, ngroups * batches)))
+        nch = max(1, min(M // 256, 1024 // max(1, ngroups * batches)))
         rpc = ((M + nch - 1) // nch + 7) & ~7
         nch = (M + rpc - 1) // rpc
         return nch, rpc
@@ -310,7 +310,7 @@ class Recorder:
         a.grp_real, a.grp_pad = grp
         items = dims[0] * dims[1] * ((dims[2] + 3) // 4)
         ny = 256 // (C_ // 4)
-        a.nblocks = max(1, min(4096, items // max(1, ny * 4)))
+        a.nblocks = max(1, min(2048, items // max(1, ny * 4)))
         assert a.nblocks * creal * 9 <= self.scratch.numel()
         self.keep.append(a)
         rows = dims[0] * dims[1] * dims[2]

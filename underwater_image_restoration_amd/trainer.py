@@ -10,6 +10,7 @@ import torch.distributed as dist
 
 from . import _lib as L
 from . import ops
+from . import parallel
 
 
 class TrainStep:
@@ -21,7 +22,9 @@ class TrainStep:
         self.flat = model.flat_params()
         self.opt = ops.FusedClipAdam(self.flat, lr=lr, max_norm=max_norm)
         self.pg = process_group
-        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.world = parallel.world_size(process_group)
+        if self.world > 1:
+            parallel.broadcast_flat_params(self.flat.flat, process_group)
         self._one = torch.ones(1, dtype=torch.float32, device=self.flat.device)
 
     def __call__(self, raw: torch.Tensor, ref: torch.Tensor, lr: float | None = None):
@@ -33,11 +36,8 @@ class TrainStep:
         dout = ops.loss_grad(out, ref, self._one, self.kind)
         plan.backward(dout)
         self.model._fwd_serial += 1
-        scale = 1.0
-        if self.world > 1:
-            # single flat bucket of the live gradients (8.8 MB): one ring all-reduce over xGMI
-            dist.all_reduce(self.flat.grad[: self.flat.n_live], op=dist.ReduceOp.SUM, group=self.pg)
-            scale = 1.0 / self.world
+        # single flat bucket of the live gradients (8.8 MB): one all-reduce over xGMI
+        scale = parallel.allreduce_flat_grads(self.flat.grad, self.flat.n_live, self.pg)
         norm = self.opt.step(lr=lr, grad_scale=scale)
         return res[0], norm[0]
 
