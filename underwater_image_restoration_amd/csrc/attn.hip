@@ -3,7 +3,7 @@
 // what is left per batch is O(C^2 d) arithmetic on [C x C] matrices (C <= 128, d = C/heads):
 // normalise + temperature + softmax, compose the attention maps with the projections
 // (forward), and the chain rule back to the Gram matrix, the norms, the temperature and the
-// projection weights (backward).  One 256-thread workgroup per batch sample, LDS-resident.
+// projection weights (backward).  One workgroup (256-1024 threads) per batch sample, LDS-resident.
 #include "uir_common.h"
 #include "../../include/uir_kernels.h"
 
@@ -12,7 +12,7 @@ namespace {
 constexpr int MAXCD = 2048;  // C*d: 128*16 or 32*32
 constexpr float NORM_EPS = 1e-12f;  // F.normalize eps (SpectralTransformer.py:98)
 
-__global__ __launch_bounds__(256) void uir_attn_fwd_kernel(const UirAttnFwdArgs a) {
+__global__ __launch_bounds__(512) void uir_attn_fwd_kernel(const UirAttnFwdArgs a) {
   __shared__ float at[MAXCD];
   const int b = blockIdx.x, C = a.C, d = C / a.heads;
   const float* G = a.G + (long)b * C * C;
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void uir_attn_fwd_kernel(const UirAttnFwdArgs 
   }
 }
 
-__global__ __launch_bounds__(256) void uir_attn_bwd_kernel(const UirAttnBwdArgs a) {
+__global__ __launch_bounds__(1024) void uir_attn_bwd_kernel(const UirAttnBwdArgs a) {
   __shared__ float at[MAXCD], dA[MAXCD], S[MAXCD], dS[MAXCD];
   __shared__ float acoef[128], bcoef[128], rowdT[128], nqs[128], nks[128];
   const int b = blockIdx.x, C = a.C, d = C / a.heads;
@@ -151,7 +151,7 @@ extern "C" int uir_attn_fwd(const UirAttnFwdArgs* p, void* stream) {
   UIR_REQUIRE(a.G && a.sq_q && a.sq_k && a.temperature && a.P && a.Wof && a.attn && a.WA && a.WB);
   UIR_REQUIRE(a.B > 0 && a.C > 0 && a.heads > 0 && a.C % a.heads == 0 && a.C <= 128);
   UIR_REQUIRE(a.C * (a.C / a.heads) <= MAXCD);
-  hipLaunchKernelGGL(uir_attn_fwd_kernel, dim3(a.B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(uir_attn_fwd_kernel, dim3(a.B), dim3(a.C >= 64 ? 512 : 256), 0, static_cast<hipStream_t>(stream), a);
   return uir_launch_status();
 }
 
@@ -161,6 +161,6 @@ extern "C" int uir_attn_bwd(const UirAttnBwdArgs* p, void* stream) {
   UIR_REQUIRE(a.Mqk && a.dP && a.dWof && a.dT);
   UIR_REQUIRE(a.B > 0 && a.C > 0 && a.heads > 0 && a.C % a.heads == 0 && a.C <= 128);
   UIR_REQUIRE(a.C * (a.C / a.heads) <= MAXCD);
-  hipLaunchKernelGGL(uir_attn_bwd_kernel, dim3(a.B), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(uir_attn_bwd_kernel, dim3(a.B), dim3(a.C >= 64 ? 1024 : 256), 0, static_cast<hipStream_t>(stream), a);
   return uir_launch_status();
 }

@@ -1,9 +1,10 @@
 // uir_dwconv: depthwise 3x3 (pad 1, no bias) on HWC rows, HBM-bound.
-// A thread owns 4 consecutive channels (one float4) of a run of R=4 pixels along W and slides
-// a 3 x (R+2) window over them, so each input float4 is loaded 3*(R+2)/R = 4.5 times (from
-// L1/L2) instead of 9; lanes of a wave cover consecutive channels of one pixel, i.e. every
-// wave-level load/store is a contiguous C*4-byte HWC row segment.  Weights are staged once per
-// workgroup into LDS, transposed to [tap][channel] (and tap-flipped for the input-gradient).
+// A thread owns 4 consecutive channels (one float4) of a run of R=4 pixels along W and walks a
+// vertical strip of HS rows with a rolling 3 x (R+2) register window: each input float4 is
+// loaded (R+2)/R = 1.5 times per strip instead of 9; lanes of a wave cover consecutive channels
+// of one pixel, i.e. every wave-level load/store is a contiguous C*4-byte HWC row segment.
+// Weights are staged once per workgroup into LDS, transposed to [tap][channel] (tap-flipped for
+// the input-gradient) and then held in registers for the whole strip.
 #include "uir_common.h"
 #include "../../include/uir_kernels.h"
 
@@ -15,6 +16,29 @@ __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
 
+constexpr int HS = 16;  // rows per vertical strip
+
+// one HWC row segment of R+2 float4 (pixels w0-1 .. w0+R), branch-free: clamped address + select
+__device__ __forceinline__ void load_row(float4 (&v)[R + 2], const float* base, long ld, int b, int hh, int w0, int H, int Wd) {
+  const bool hok = hh >= 0 && hh < H;
+  const int hc = min(max(hh, 0), H - 1);
+  const float* rowp = base + ((long)(b * H + hc) * Wd) * ld;
+#pragma unroll
+  for (int j = 0; j < R + 2; ++j) {
+    const int wc = min(max(w0 - 1 + j, 0), Wd - 1);
+    v[j] = *reinterpret_cast<const float4*>(rowp + (long)wc * ld);
+  }
+#pragma unroll
+  for (int j = 0; j < R + 2; ++j) {
+    const int ww = w0 - 1 + j;
+    if (!(hok && ww >= 0 && ww < Wd)) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// Forward / input-gradient.  A thread owns 4 channels x a run of R pixels along W x a strip of HS
+// rows: it keeps a rolling 3-row register window and loads each input row ONCE per strip (1.5
+// float4 loads per output instead of 4.5), so the rows above/below are not re-fetched by
+// workgroups on other XCDs (whose L2s are private).
 __global__ __launch_bounds__(256) void uir_dwconv_kernel(const UirDwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][C]
   for (int i = threadIdx.x; i < 9 * a.C; i += blockDim.x) {
@@ -26,96 +50,87 @@ __global__ __launch_bounds__(256) void uir_dwconv_kernel(const UirDwArgs a) {
   __syncthreads();
   const int c4n = a.C >> 2;
   const int runs = (a.Wd + R - 1) / R;
-  const long total = (long)a.B * a.H * runs * c4n;
+  const int strips = (a.H + HS - 1) / HS;
+  const long total = (long)a.B * strips * runs * c4n;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
     const int c4 = (int)(idx % c4n);
     long t = idx / c4n;
     const int run = (int)(t % runs);
     t /= runs;
-    const int h = (int)(t % a.H);
-    const int b = (int)(t / a.H);
-    const int w0 = run * R;
-    float4 acc[R];
+    const int sp = (int)(t % strips);
+    const int b = (int)(t / strips);
+    const int w0 = run * R, h0 = sp * HS;
+    const int hend = min(h0 + HS, a.H);
+    float4 wv[9];
 #pragma unroll
-    for (int j = 0; j < R; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int q = 0; q < 9; ++q) wv[q] = *reinterpret_cast<const float4*>(&wl[q * a.C + c4 * 4]);
+    const float* xb = a.X + c4 * 4;
+    float4 r0[R + 2], r1[R + 2], r2[R + 2];
+    load_row(r0, xb, a.ldx, b, h0 - 1, w0, a.H, a.Wd);
+    load_row(r1, xb, a.ldx, b, h0, w0, a.H, a.Wd);
+    for (int h = h0; h < hend; ++h) {
+      load_row(r2, xb, a.ldx, b, h + 1, w0, a.H, a.Wd);
+      float* yp = a.Y + ((long)(b * a.H + h) * a.Wd) * a.ldy + c4 * 4;
 #pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-      // branch-free: clamp the neighbour coordinates, zero the out-of-image taps by select
-      const int hh = h + dy;
-      const bool hok = hh >= 0 && hh < a.H;
-      const int hc = min(max(hh, 0), a.H - 1);
-      const float* rowp = a.X + ((long)(b * a.H + hc) * a.Wd) * a.ldx + c4 * 4;
-      float4 v[R + 2];
+      for (int j = 0; j < R; ++j) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-      for (int j = 0; j < R + 2; ++j) {
-        const int ww = w0 - 1 + j;
-        const int wc = min(max(ww, 0), a.Wd - 1);
-        v[j] = *reinterpret_cast<const float4*>(rowp + (long)wc * a.ldx);
+        for (int dx = 0; dx < 3; ++dx) {
+          acc = f4_fma(r0[j + dx], wv[dx], acc);
+          acc = f4_fma(r1[j + dx], wv[3 + dx], acc);
+          acc = f4_fma(r2[j + dx], wv[6 + dx], acc);
+        }
+        if (w0 + j < a.Wd) *reinterpret_cast<float4*>(yp + (long)(w0 + j) * a.ldy) = acc;
       }
 #pragma unroll
-      for (int j = 0; j < R + 2; ++j) {
-        const int ww = w0 - 1 + j;
-        if (!(hok && ww >= 0 && ww < a.Wd)) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-#pragma unroll
-      for (int dx = 0; dx < 3; ++dx) {
-        const float4 wv = *reinterpret_cast<const float4*>(&wl[((dy + 1) * 3 + dx) * a.C + c4 * 4]);
-#pragma unroll
-        for (int j = 0; j < R; ++j) acc[j] = f4_fma(v[j + dx], wv, acc[j]);
-      }
+      for (int j = 0; j < R + 2; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
     }
-    float* yp = a.Y + ((long)(b * a.H + h) * a.Wd) * a.ldy + c4 * 4;
-#pragma unroll
-    for (int j = 0; j < R; ++j)
-      if (w0 + j < a.Wd) *reinterpret_cast<float4*>(yp + (long)(w0 + j) * a.ldy) = acc[j];
   }
 }
 
-// weight-gradient: thread (c4 = threadIdx.x, py = threadIdx.y) accumulates 9 float4 over its runs
+// weight-gradient: thread (c4 = threadIdx.x, py = threadIdx.y) walks (strip, run) items with the same
+// rolling window and accumulates 9 float4; per-workgroup partial slab.
 __global__ __launch_bounds__(256) void uir_dwconv_wgrad_kernel(const UirDwWgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [ny][c4n][36]
   const int c4n = a.C >> 2;
   const int c4 = threadIdx.x, py = threadIdx.y, ny = blockDim.y;
   const int runs = (a.Wd + R - 1) / R;
-  const long items = (long)a.B * a.H * runs;
+  const int strips = (a.H + HS - 1) / HS;
+  const long items = (long)a.B * strips * runs;
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c4 < c4n) {
+    const float* xb = a.X + c4 * 4;
     for (long it = (long)blockIdx.x * ny + py; it < items; it += (long)gridDim.x * ny) {
       const int run = (int)(it % runs);
       long t = it / runs;
-      const int h = (int)(t % a.H);
-      const int b = (int)(t / a.H);
-      const int w0 = run * R;
-      float4 g[R];
-      const float* gp = a.dY + ((long)(b * a.H + h) * a.Wd) * a.ldy + c4 * 4;
+      const int sp = (int)(t % strips);
+      const int b = (int)(t / strips);
+      const int w0 = run * R, h0 = sp * HS;
+      const int hend = min(h0 + HS, a.H);
+      float4 r0[R + 2], r1[R + 2], r2[R + 2];
+      load_row(r0, xb, a.ldx, b, h0 - 1, w0, a.H, a.Wd);
+      load_row(r1, xb, a.ldx, b, h0, w0, a.H, a.Wd);
+      for (int h = h0; h < hend; ++h) {
+        load_row(r2, xb, a.ldx, b, h + 1, w0, a.H, a.Wd);
+        float4 g[R];
+        const float* gp = a.dY + ((long)(b * a.H + h) * a.Wd) * a.ldy + c4 * 4;
 #pragma unroll
-      for (int j = 0; j < R; ++j) g[j] = *reinterpret_cast<const float4*>(gp + (long)min(w0 + j, a.Wd - 1) * a.ldy);
+        for (int j = 0; j < R; ++j) g[j] = *reinterpret_cast<const float4*>(gp + (long)min(w0 + j, a.Wd - 1) * a.ldy);
 #pragma unroll
-      for (int j = 0; j < R; ++j)
-        if (w0 + j >= a.Wd) g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-      for (int dy = -1; dy <= 1; ++dy) {
-        const int hh = h + dy;
-        const bool hok = hh >= 0 && hh < a.H;
-        const int hc = min(max(hh, 0), a.H - 1);
-        const float* rowp = a.X + ((long)(b * a.H + hc) * a.Wd) * a.ldx + c4 * 4;
-        float4 v[R + 2];
-#pragma unroll
-        for (int j = 0; j < R + 2; ++j) {
-          const int wc = min(max(w0 - 1 + j, 0), a.Wd - 1);
-          v[j] = *reinterpret_cast<const float4*>(rowp + (long)wc * a.ldx);
-        }
-#pragma unroll
-        for (int j = 0; j < R + 2; ++j) {
-          const int ww = w0 - 1 + j;
-          if (!(hok && ww >= 0 && ww < a.Wd)) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int j = 0; j < R; ++j)
+          if (w0 + j >= a.Wd) g[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx)
 #pragma unroll
-          for (int j = 0; j < R; ++j) acc[(dy + 1) * 3 + dx] = f4_fma(g[j], v[j + dx], acc[(dy + 1) * 3 + dx]);
+          for (int j = 0; j < R; ++j) {
+            acc[dx] = f4_fma(g[j], r0[j + dx], acc[dx]);
+            acc[3 + dx] = f4_fma(g[j], r1[j + dx], acc[3 + dx]);
+            acc[6 + dx] = f4_fma(g[j], r2[j + dx], acc[6 + dx]);
+          }
+#pragma unroll
+        for (int j = 0; j < R + 2; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
       }
     }
     float* rp = red + ((long)py * c4n + c4) * 36;
@@ -147,7 +162,7 @@ extern "C" int uir_dwconv(const UirDwArgs* p, void* stream) {
   UIR_REQUIRE(uir_aligned16(a.X) && uir_aligned16(a.Y));
   const size_t lds = (size_t)9 * a.C * sizeof(float);
   UIR_REQUIRE(lds <= 64 * 1024);
-  const long total = (long)a.B * a.H * ((a.Wd + R - 1) / R) * (a.C >> 2);
+  const long total = (long)a.B * ((a.H + HS - 1) / HS) * ((a.Wd + R - 1) / R) * (a.C >> 2);
   long blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
   hipLaunchKernelGGL(uir_dwconv_kernel, dim3((unsigned)blocks), dim3(256), lds, static_cast<hipStream_t>(stream), a);

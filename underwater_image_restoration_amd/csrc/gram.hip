@@ -187,6 +187,81 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
   }
 }
 
+// 3x3 weight-gradient with N, K <= 32 (the full-resolution convs: embed, down1, outputl, output):
+// all 9 taps in one workgroup - the dY row pair is loaded once and multiplied into 9 accumulator
+// tiles against the 9 shifted X rows (neighbours in W are adjacent HWC rows: L1 hits), instead of 9
+// independent passes over dY and X.
+__global__ __launch_bounds__(256) void uir_gram_taps9_kernel(const UirGramArgs a) {
+  __shared__ float red[9 * 16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h2 = lane >> 5;
+  const int z = blockIdx.z;
+  const int chunk = blockIdx.x;
+  const float* __restrict__ A = a.A + (long)z * a.a_bs;
+  const float* __restrict__ B = a.B + (long)z * a.b_bs;
+  const int row_begin = chunk * a.rows_per_chunk;
+  const int row_end = min(a.M, row_begin + a.rows_per_chunk);
+  const int last_row = row_end - 1;
+  const bool aok_c = r < a.N, bok_c = r < a.K;
+  const int acol = min(r, a.N - 1), bcol = min(r, a.K - 1);
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+  constexpr int U = 2;
+  for (int base = row_begin + 2 * wave; base < row_end; base += 8 * U) {
+    float av[U], bv[U][9];
+    bool ok[U][9], aok[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = base + 8 * u + h2;
+      aok[u] = m < row_end;
+      const int mc = min(m, last_row);
+      av[u] = A[(long)mc * a.lda + acol];
+      const int hw = mc % (a.H * a.Wd);
+      const int ph = hw / a.Wd, pw = hw - ph * a.Wd;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dy = t / 3 - 1, dx = t % 3 - 1;
+        const int hh = ph + dy, ww = pw + dx;
+        const bool in = hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
+        ok[u][t] = in && aok[u] && bok_c;
+        const long mb = in ? (long)mc + dy * a.Wd + dx : (long)mc;
+        bv[u][t] = B[mb * a.ldb + bcol];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float avv = (aok[u] && aok_c) ? av[u] : 0.f;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[t] = uir_mfma(avv, ok[u][t] ? bv[u][t] : 0.f, acc[t]);
+    }
+  }
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float* p = &red[(t * 16 + q) * 64 + lane];
+          *p = (w == 0) ? acc[t][q] : (*p + acc[t][q]);
+        }
+    }
+    __syncthreads();
+  }
+  float* slab = a.slab + (long)chunk * a.slab_stride;
+  for (int idx = threadIdx.x; idx < 9 * 16 * 64; idx += 256) {
+    const int ln = idx & 63, q = (idx >> 6) & 15, t = idx >> 10;
+    const int n = uir_mfma_row(q, ln >> 5), k = ln & 31;
+    if (n < a.N && k < a.K) {
+      const int nr = uir_colmap(n, a.n_grp_real, a.n_grp_pad);
+      const int kr = uir_colmap(k, a.k_grp_real, a.k_grp_pad);
+      if (nr >= 0 && kr >= 0) slab[(long)z * a.o_bs + (long)nr * a.o_sn + (long)kr * a.o_sk + (long)t * a.o_st] = red[idx];
+    }
+  }
+}
+
 // out[i] = sum_c slab[c][i]: 64 outputs per workgroup, the chunks split over 16 waves with 4
 // independent accumulators each (memory-level parallelism), combined in a fixed order.
 __global__ __launch_bounds__(1024) void uir_reduce_slab_kernel(const float* __restrict__ slab, int nchunks, long stride,
@@ -233,7 +308,11 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 block(256);
   const int tn_tiles = (a.N + 31) / 32, tk_tiles = (a.K + 31) / 32;
-  if (tk_tiles == 1) {
+  if (a.taps == 9 && tn_tiles == 1 && tk_tiles == 1 && a.sq_a_off < 0 && a.sq_b_off < 0 && a.cs_a_off < 0 &&
+      a.pro_b == UIR_GRAM_PRO_NONE) {
+    dim3 grid(a.nchunks, 1, a.batches);
+    hipLaunchKernelGGL(uir_gram_taps9_kernel, grid, block, 0, st, a);
+  } else if (tk_tiles == 1) {
     const int gn = (tn_tiles + 3) / 4, gk = 1;
     dim3 grid(a.taps * gn * gk * a.nchunks, 1, a.batches);
     hipLaunchKernelGGL((uir_gram_kernel<4, 1>), grid, block, 0, st, a, gn, gk);

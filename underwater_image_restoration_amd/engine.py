@@ -245,7 +245,10 @@ class Recorder:
             groups = (tk + 3) // 4
         else:
             groups = ((tn + 1) // 2) * ((tk + 1) // 2)
-        nch, rpc = self._chunks(M, taps * groups, batches)
+        if taps == 9 and tn == 1 and tk == 1 and not extras and pro_b == 0:
+            nch, rpc = self._chunks(M, 1, batches)          # all 9 taps handled inside one workgroup
+        else:
+            nch, rpc = self._chunks(M, taps * groups, batches)
         if out_elems is None:
             out_elems = out.numel()
         a = L.GramArgs()
@@ -308,9 +311,9 @@ class Recorder:
         a.B, a.H, a.Wd = dims
         a.C, a.creal = C_, creal
         a.grp_real, a.grp_pad = grp
-        items = dims[0] * dims[1] * ((dims[2] + 3) // 4)
+        items = dims[0] * ((dims[1] + 15) // 16) * ((dims[2] + 3) // 4)     # (strip of 16 rows, run of 4 pixels)
         ny = 256 // (C_ // 4)
-        a.nblocks = max(1, min(2048, items // max(1, ny * 4)))
+        a.nblocks = max(1, min(2048, items // max(1, ny)))
         assert a.nblocks * creal * 9 <= self.scratch.numel()
         self.keep.append(a)
         rows = dims[0] * dims[1] * dims[2]
