@@ -128,6 +128,13 @@ class Recorder:
         self.bytes = 0
         self.meta: Dict[int, list] = {id(self.fwd): [], id(self.bwd): []}
         self.scratch = self.alloc(scratch_floats)
+        # lane 0 = the critical dX chain (current stream); lane 1 = weight-gradient work that nothing
+        # on the chain waits for, run on a second HIP stream with its own slab scratch
+        self.lane = 0
+        self.scratch_side = self.alloc(scratch_floats)
+        self.lanes: Dict[int, list] = {id(self.fwd): [], id(self.bwd): []}
+        self._side_stream = None
+        self._events: List[object] = []
 
     # ------------------------------------------------------------------ memory
     def alloc(self, *shape, zero: bool = False) -> torch.Tensor:
@@ -148,6 +155,27 @@ class Recorder:
         (each operand counted once; used by the roofline report, never by the launch)."""
         self.cur.append((fn, args, name))
         self.meta[id(self.cur)].append((name, fn.__name__, nbytes, flops))
+        self.lanes[id(self.cur)].append(self.lane)
+
+    class _Side:
+        def __init__(self, rec):
+            self.rec = rec
+
+        def __enter__(self):
+            self.prev = self.rec.lane
+            self.rec.lane = 1
+
+        def __exit__(self, *a):
+            self.rec.lane = self.prev
+
+    def side(self):
+        """Context: ops recorded inside run on the side stream (they may READ anything produced by
+        earlier ops of the list; nothing on the main lane may read what they WRITE before the join
+        at the end of the list)."""
+        return Recorder._Side(self)
+
+    def _slab(self) -> torch.Tensor:
+        return self.scratch_side if self.lane == 1 else self.scratch
 
     def _hold(self, *tensors):
         """Raw pointers are recorded: keep every operand alive for the lifetime of the plan."""
@@ -160,11 +188,49 @@ class Recorder:
                 self.keep.append(t)
 
     def run(self, ops: Sequence[tuple]) -> None:
-        st = C.c_void_p(torch.cuda.current_stream().cuda_stream) if self.dev.type == "cuda" else C.c_void_p(0)
-        for fn, args, name in ops:
-            rc = fn(*args, st)
+        if self.dev.type != "cuda":
+            st = C.c_void_p(0)
+            for fn, args, name in ops:
+                rc = fn(*args, st)
+                if rc:
+                    L.check(rc, name)
+            return
+        main = torch.cuda.current_stream()
+        st0 = C.c_void_p(main.cuda_stream)
+        lanes = self.lanes[id(ops)]
+        if 1 not in lanes:
+            for fn, args, name in ops:
+                rc = fn(*args, st0)
+                if rc:
+                    L.check(rc, name)
+            return
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.dev)
+        side = self._side_stream
+        st1 = C.c_void_p(side.cuda_stream)
+        nev = 0
+        main_dirty = True           # main has launched work the side stream has not been ordered after
+        for (fn, args, name), lane in zip(ops, lanes):
+            if lane == 1:
+                if main_dirty:
+                    if nev == len(self._events):
+                        self._events.append(torch.cuda.Event())
+                    ev = self._events[nev]
+                    nev += 1
+                    ev.record(main)
+                    side.wait_event(ev)
+                    main_dirty = False
+                rc = fn(*args, st1)
+            else:
+                rc = fn(*args, st0)
+                main_dirty = True
             if rc:
                 L.check(rc, name)
+        if nev == len(self._events):
+            self._events.append(torch.cuda.Event())
+        ev = self._events[nev]
+        ev.record(side)
+        main.wait_event(ev)         # join: everything after this list sees the side lane's results
 
     def run_timed(self, ops: Sequence[tuple]) -> "List[Tuple[str, str, int, int, float]]":
         """Run a launch list with a HIP event pair around EVERY launch (on the stream the kernels
@@ -252,7 +318,7 @@ class Recorder:
         if out_elems is None:
             out_elems = out.numel()
         a = L.GramArgs()
-        a.A, a.B, a.slab = _ptr(A), _ptr(Bm), _ptr(self.scratch)
+        a.A, a.B, a.slab = _ptr(A), _ptr(Bm), _ptr(self._slab())
         a.lda, a.ldb = _ld(A), _ld(Bm)
         a.a_bs, a.b_bs = M * a.lda, M * a.ldb
         a.o_sn, a.o_sk, a.o_st, a.o_bs = o_sn, o_sk, o_st, o_bs
@@ -266,7 +332,7 @@ class Recorder:
         if "cs_a" in extras:
             a.cs_a_off = stride; stride += batches * N
         a.slab_stride = stride
-        assert nch * stride <= self.scratch.numel(), (name, nch, stride)
+        assert nch * stride <= self._slab().numel(), (name, nch, stride)
         a.M, a.N, a.K, a.batches = M, N, K, batches
         a.n_grp_real, a.n_grp_pad = n_grp
         a.k_grp_real, a.k_grp_pad = k_grp
@@ -282,7 +348,7 @@ class Recorder:
         rows = M * batches
         self._op(name, lib.uir_gram, C.byref(a), nbytes=4 * rows * (N + K * (2 if pro_b == L.PRO_GATE else 1)),
                  flops=2 * rows * N * K * taps)
-        sp = self.scratch.data_ptr()
+        sp = self._slab().data_ptr()
         self._op(name + ".red", lib.uir_reduce_slab, sp, nch, stride, _ptr(out), out_elems, 0, 1.0)
         for key, off in (("sq_a", a.sq_a_off), ("sq_b", a.sq_b_off), ("cs_a", a.cs_a_off)):
             if key in extras:
@@ -306,7 +372,7 @@ class Recorder:
     def dwconv_wgrad(self, name, dY, X, out, *, C_, creal, dims, grp=(0, 0)):
         self._hold(dY, X, out)
         a = L.DwWgradArgs()
-        a.dY, a.X, a.slab = _ptr(dY), _ptr(X), _ptr(self.scratch)
+        a.dY, a.X, a.slab = _ptr(dY), _ptr(X), _ptr(self._slab())
         a.ldy, a.ldx = _ld(dY), _ld(X)
         a.B, a.H, a.Wd = dims
         a.C, a.creal = C_, creal
@@ -314,11 +380,11 @@ class Recorder:
         items = dims[0] * ((dims[1] + 15) // 16) * ((dims[2] + 3) // 4)     # (strip of 16 rows, run of 4 pixels)
         ny = 256 // (C_ // 4)
         a.nblocks = max(1, min(2048, items // max(1, ny)))
-        assert a.nblocks * creal * 9 <= self.scratch.numel()
+        assert a.nblocks * creal * 9 <= self._slab().numel()
         self.keep.append(a)
         rows = dims[0] * dims[1] * dims[2]
         self._op(name, lib.uir_dwconv_wgrad, C.byref(a), nbytes=8 * rows * C_, flops=18 * rows * C_)
-        self._op(name + ".red", lib.uir_reduce_slab, _ptr(self.scratch), a.nblocks, creal * 9, _ptr(out), creal * 9, 0, 1.0)
+        self._op(name + ".red", lib.uir_reduce_slab, _ptr(self._slab()), a.nblocks, creal * 9, _ptr(out), creal * 9, 0, 1.0)
 
     def ln_bwd(self, name, dT, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_):
         self._hold(dT, X, stats, gamma, dRes, dX, dgamma, dbeta)
@@ -341,8 +407,8 @@ class Recorder:
         M = src.shape[0]
         slots = 256 // C_
         nb = max(1, min(512, M // max(1, slots * 8)))
-        self._op(name, lib.uir_colsum_partials, _ptr(src), _ld(src), col, M, C_, _ptr(self.scratch), nb, nbytes=4 * M * C_)
-        self._op(name + ".red", lib.uir_reduce_slab, _ptr(self.scratch), nb, C_, _ptr(out), C_, 0, 1.0)
+        self._op(name, lib.uir_colsum_partials, _ptr(src), _ld(src), col, M, C_, _ptr(self._slab()), nb, nbytes=4 * M * C_)
+        self._op(name + ".red", lib.uir_reduce_slab, _ptr(self._slab()), nb, C_, _ptr(out), C_, 0, 1.0)
 
     def copy_cols(self, name, src, scol, dst, dcol, C_, accumulate=0):
         self._hold(src, dst)
@@ -444,19 +510,23 @@ class Plan(Recorder):
             dPb, dWofb, dTb, dPsum = self.alloc(B, C_ * C_), self.alloc(B, C_ * C_), self.alloc(B, heads), self.alloc(C_, C_)
             dx = self.alloc(M, C_)
             # GDFN
-            self.gram(n + ".dWout", dy, g, Gr(f"{pfx}.ffn.project_out.weight"), N=C_, K=h, o_sn=h, o_sk=1,
-                      pro_b=L.PRO_GATE, gate_off=hp)
+            with self.side():
+                self.gram(n + ".dWout", dy, g, Gr(f"{pfx}.ffn.project_out.weight"), N=C_, K=h, o_sn=h, o_sk=1,
+                          pro_b=L.PRO_GATE, gate_off=hp)
             self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g, g_off=hp)
-            self.dwconv_wgrad(n + ".dWffdw", dg, gpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h, dims=dims, grp=(h, hp))
+            with self.side():
+                self.dwconv_wgrad(n + ".dWffdw", dg, gpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h, dims=dims, grp=(h, hp))
             self.dwconv(n + ".dgpre", dg, Wffdw, dgpre, C_=2 * hp, dims=dims, grp=(h, hp), flip=1)
-            self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
-                      n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
+            with self.side():
+                self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
+                          n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
             self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
             self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
             # MDTA
             self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
             self.gemm(n + ".dvf", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
-            self.dwconv_wgrad(n + ".dWkvdw", dvf, u, Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, creal=C_, dims=dims)
+            with self.side():
+                self.dwconv_wgrad(n + ".dWkvdw", dvf, u, Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, creal=C_, dims=dims)
             self.dwconv(n + ".du", dvf, Wkvdw_f, du, C_=C_, dims=dims, flip=1)
             self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
             self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
@@ -467,18 +537,21 @@ class Plan(Recorder):
             ba.B, ba.C, ba.heads = B, C_, heads
             self.keep.append(ba)
             self._op(n + ".attn_bwd", lib.uir_attn_bwd, C.byref(ba))
-            self._op(n + ".dWof", lib.uir_reduce_slab, _ptr(dWofb), B, C_ * C_, _ptr(Gr(f"{a}.project_outf.weight")), C_ * C_, 0, 1.0)
-            self._op(n + ".dPsum", lib.uir_reduce_slab, _ptr(dPb), B, C_ * C_, _ptr(dPsum), C_ * C_, 0, 1.0)
-            self._op(n + ".dT", lib.uir_reduce_slab, _ptr(dTb), B, heads, _ptr(Gr(f"{a}.temperature")), heads, 0, 1.0)
-            # P = Wkvf @ Wo  ->  dWkvf = dP Wo^T ; dWo = Wkvf^T dP
-            self.gemm(n + ".dWkvf", dPsum, Wo, Gr(f"{a}.kv.weight").view(2 * C_, C_)[C_:], N=C_, K=C_, w_sn=C_, w_sk=1)
-            self.gram(n + ".dWo", Wkvf, dPsum, Gr(f"{a}.project_out.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
+            with self.side():
+                self._op(n + ".dWof", lib.uir_reduce_slab, _ptr(dWofb), B, C_ * C_, _ptr(Gr(f"{a}.project_outf.weight")), C_ * C_, 0, 1.0)
+                self._op(n + ".dPsum", lib.uir_reduce_slab, _ptr(dPb), B, C_ * C_, _ptr(dPsum), C_ * C_, 0, 1.0)
+                self._op(n + ".dT", lib.uir_reduce_slab, _ptr(dTb), B, heads, _ptr(Gr(f"{a}.temperature")), heads, 0, 1.0)
+                # P = Wkvf @ Wo  ->  dWkvf = dP Wo^T ; dWo = Wkvf^T dP
+                self.gemm(n + ".dWkvf", dPsum, Wo, Gr(f"{a}.kv.weight").view(2 * C_, C_)[C_:], N=C_, K=C_, w_sn=C_, w_sk=1)
+                self.gram(n + ".dWo", Wkvf, dPsum, Gr(f"{a}.project_out.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
             self.gemm(n + ".dqk", qkv[:, :2 * C_], Mqk, dqkv[:, :2 * C_], N=2 * C_, K=2 * C_, w_sn=2 * C_, w_sk=1,
                       w_bs=4 * C_ * C_, batches=B)
-            self.dwconv_wgrad(n + ".dWqkvdw", dqkv, qkv_pre, Gr(f"{a}.qkv_conv.weight"), C_=3 * C_, creal=3 * C_, dims=dims)
+            with self.side():
+                self.dwconv_wgrad(n + ".dWqkvdw", dqkv, qkv_pre, Gr(f"{a}.qkv_conv.weight"), C_=3 * C_, creal=3 * C_, dims=dims)
             self.dwconv(n + ".dqkv_pre", dqkv, Wdw, dqkv_pre, C_=3 * C_, dims=dims, flip=1)
-            self.gram(n + ".dWqkv", dqkv_pre, x, Gr(f"{a}.qkv.weight"), N=3 * C_, K=C_, o_sn=C_, o_sk=1,
-                      pro_b=L.PRO_LN, ln=(g1, b1), stats=stats1)
+            with self.side():
+                self.gram(n + ".dWqkv", dqkv_pre, x, Gr(f"{a}.qkv.weight"), N=3 * C_, K=C_, o_sn=C_, o_sk=1,
+                          pro_b=L.PRO_LN, ln=(g1, b1), stats=stats1)
             self.gemm(n + ".dt1", dqkv_pre, Wqkv, dt, N=C_, K=3 * C_, w_sn=1, w_sk=C_)
             self.ln_bwd(n + ".ln1_bwd", dt, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_)
             return dx
@@ -508,8 +581,9 @@ class Plan(Recorder):
         self.gemm(name, x, Wt, y, N=Np, K=Kp, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=dims[1:], k_grp=k_grp, n_grp=n_grp)
 
         def backward(dy, need_dx=True):
-            self.gram(name + ".dW", dy, x, self.Gr(Wname), N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:],
-                      n_grp=n_grp, k_grp=k_grp)
+            with self.side():
+                self.gram(name + ".dW", dy, x, self.Gr(Wname), N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:],
+                          n_grp=n_grp, k_grp=k_grp)
             if not need_dx:
                 return None
             dx = self.alloc(M, Kp)
@@ -541,11 +615,13 @@ class Plan(Recorder):
 
         def backward(dout):
             dh, dx = self.alloc(M, C_), self.alloc(M, C_)
-            self.gram(pfx + ".2.dW", dout, hmid, self.Gr(f"{pfx}.2.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
-            self.colsum(pfx + ".2.db", dout, 0, C_, self.Gr(f"{pfx}.2.bias"))
+            with self.side():
+                self.gram(pfx + ".2.dW", dout, hmid, self.Gr(f"{pfx}.2.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
+                self.colsum(pfx + ".2.db", dout, 0, C_, self.Gr(f"{pfx}.2.bias"))
             self.gemm(pfx + ".2.dX", dout, W2, dh, N=C_, K=C_, w_sn=1, w_sk=C_, epi=L.EPI_LEAKY_BWD, G=hmid)
-            self.gram(pfx + ".0.dW", dh, x, self.Gr(f"{pfx}.0.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
-            self.colsum(pfx + ".0.db", dh, 0, C_, self.Gr(f"{pfx}.0.bias"))
+            with self.side():
+                self.gram(pfx + ".0.dW", dh, x, self.Gr(f"{pfx}.0.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
+                self.colsum(pfx + ".0.db", dh, 0, C_, self.Gr(f"{pfx}.0.bias"))
             self.gemm(pfx + ".0.dX", dh, W0, dx, N=C_, K=C_, w_sn=1, w_sk=C_)
             return dx
         return out, backward
@@ -582,17 +658,20 @@ class Plan(Recorder):
 
         def backward(dy: torch.Tensor) -> torch.Tensor:
             dcat = self.alloc(4 * M, C_)
-            self.gram(pfx + ".reduce.dW", dy, cat, self.Gr(f"{pfx}.reduce.weight"), N=Ch, K=C_, o_sn=C_, o_sk=1)
+            with self.side():
+                self.gram(pfx + ".reduce.dW", dy, cat, self.Gr(f"{pfx}.reduce.weight"), N=Ch, K=C_, o_sn=C_, o_sk=1)
             self.gemm(pfx + ".reduce.dX", dy, Wred, dcat, N=C_, K=Ch, w_sn=1, w_sk=C_)
             # shuffle branch
             ds = self.alloc(M, 2 * C_)
             self._op(pfx + ".Sups.shuffle_bwd", lib.uir_pixel_unshuffle, _ptr(dcat), _ld(dcat), Ch, _ptr(ds), _ld(ds), B, H, W, Ch)
             dx = sups_bw(ds)
             # spectral branch
-            self.colsum(f + ".post.db", dcat, 0, Ch, self.Gr(f + ".post.bias"))
+            with self.side():
+                self.colsum(f + ".post.db", dcat, 0, Ch, self.Gr(f + ".post.bias"))
             dpo = self.alloc(M, Ch)
             self._op(f + ".gather", lib.uir_gather_even, _ptr(dcat), _ld(dcat), 0, _ptr(dpo), _ld(dpo), B, H, W, Ch)
-            self.gram(f + ".post.dW", dpo, t, self.Gr(f + ".post.weight"), N=Ch, K=C_, o_sn=C_, o_sk=1)
+            with self.side():
+                self.gram(f + ".post.dW", dpo, t, self.Gr(f + ".post.weight"), N=Ch, K=C_, o_sn=C_, o_sk=1)
             dtt = self.alloc(M, C_)
             self.gemm(f + ".post.dX", dpo, Wpost, dtt, N=C_, K=Ch, w_sn=1, w_sk=C_)
             gtr, gti, gcr, gci, gzr, gzi = (self.alloc(M, C_) for _ in range(6))
@@ -668,14 +747,16 @@ class Plan(Recorder):
         ddd2 = ups3_bw(dcat1[:, :16])
         dr2 = dec2_bw(ddd2)
         dcat2 = self.alloc(M1, 64)
-        self.gram("reduces2.dW", dr2, cat2, self.Gr("reduces2.weight"), N=32, K=64, o_sn=64, o_sk=1)
+        with self.side():
+            self.gram("reduces2.dW", dr2, cat2, self.Gr("reduces2.weight"), N=32, K=64, o_sn=64, o_sk=1)
         self.gemm("reduces2.dX", dr2, P("reduces2.weight"), dcat2, N=64, K=32, w_sn=1, w_sk=64)
         de2 = self.alloc(M1, 32)
         self.copy_cols("cat2.skip_bwd", dcat2, 32, de2, 0, 32)
         ddd3 = ups2_bw(dcat2[:, :32])
         dr3 = dec3_bw(ddd3)
         dcat3 = self.alloc(M2, 128)
-        self.gram("reduces1.dW", dr3, cat3, self.Gr("reduces1.weight"), N=64, K=128, o_sn=128, o_sk=1)
+        with self.side():
+            self.gram("reduces1.dW", dr3, cat3, self.Gr("reduces1.weight"), N=64, K=128, o_sn=128, o_sk=1)
         self.gemm("reduces1.dX", dr3, P("reduces1.weight"), dcat3, N=128, K=64, w_sn=1, w_sk=128)
         de3 = self.alloc(M2, 64)
         self.copy_cols("cat3.skip_bwd", dcat3, 64, de3, 0, 64)
