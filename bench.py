@@ -114,6 +114,12 @@ def main():
     for _ in range(args.warmup):
         step(raw, ref)
     barrier()
+    th = time.perf_counter()
+    step(raw, ref)
+    host_enqueue_ms = (time.perf_counter() - th) * 1e3      # host time to enqueue one step (no sync)
+    barrier()
+    if rank == 0:
+        print(f"[bench] host enqueue time per step: {host_enqueue_ms:.1f} ms", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss, norm = step(raw, ref)

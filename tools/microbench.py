@@ -46,6 +46,7 @@ def case(name):
             r.fwd = []
             r.cur = r.fwd
             r.meta[id(r.fwd)] = []
+            r.lanes[id(r.fwd)] = []
             fn()
             cases[name] = (r.fwd, r.meta[id(r.fwd)])
         return fn

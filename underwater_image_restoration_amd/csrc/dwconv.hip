@@ -16,7 +16,7 @@ __device__ __forceinline__ float4 f4_fma(float4 a, float4 b, float4 c) {
   return make_float4(fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y), fmaf(a.z, b.z, c.z), fmaf(a.w, b.w, c.w));
 }
 
-constexpr int HS = 16;  // rows per vertical strip
+constexpr int HS_MAX = 16;  // rows per vertical strip (fewer on small images, to keep the chip full)
 
 // one HWC row segment of R+2 float4 (pixels w0-1 .. w0+R), branch-free: clamped address + select
 __device__ __forceinline__ void load_row(float4 (&v)[R + 2], const float* base, long ld, int b, int hh, int w0, int H, int Wd) {
@@ -39,7 +39,7 @@ __device__ __forceinline__ void load_row(float4 (&v)[R + 2], const float* base, 
 // rows: it keeps a rolling 3-row register window and loads each input row ONCE per strip (1.5
 // float4 loads per output instead of 4.5), so the rows above/below are not re-fetched by
 // workgroups on other XCDs (whose L2s are private).
-__global__ __launch_bounds__(256) void uir_dwconv_kernel(const UirDwArgs a) {
+__global__ __launch_bounds__(256) void uir_dwconv_kernel(const UirDwArgs a, const int HS) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][C]
   for (int i = threadIdx.x; i < 9 * a.C; i += blockDim.x) {
     const int t = i / a.C, c = i - t * a.C;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(256) void uir_dwconv_kernel(const UirDwArgs a) {
 
 // weight-gradient: thread (c4 = threadIdx.x, py = threadIdx.y) walks (strip, run) items with the same
 // rolling window and accumulates 9 float4; per-workgroup partial slab.
-__global__ __launch_bounds__(256) void uir_dwconv_wgrad_kernel(const UirDwWgradArgs a) {
+__global__ __launch_bounds__(256) void uir_dwconv_wgrad_kernel(const UirDwWgradArgs a, const int HS) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [ny][c4n][36]
   const int c4n = a.C >> 2;
   const int c4 = threadIdx.x, py = threadIdx.y, ny = blockDim.y;
@@ -154,6 +154,13 @@ __global__ __launch_bounds__(256) void uir_dwconv_wgrad_kernel(const UirDwWgradA
 
 }  // namespace
 
+// strip height: 16 rows when that still leaves >= 256K threads, else 8 / 4 / 2
+static int uir_dw_strip(int B, int H, int Wd, int C) {
+  int hs = HS_MAX;
+  while (hs > 2 && (long)B * ((H + hs - 1) / hs) * ((Wd + R - 1) / R) * (C >> 2) < 256 * 1024) hs >>= 1;
+  return hs;
+}
+
 extern "C" int uir_dwconv(const UirDwArgs* p, void* stream) {
   const UirDwArgs& a = *p;
   UIR_REQUIRE(a.X && a.Wt && a.Y);
@@ -162,10 +169,11 @@ extern "C" int uir_dwconv(const UirDwArgs* p, void* stream) {
   UIR_REQUIRE(uir_aligned16(a.X) && uir_aligned16(a.Y));
   const size_t lds = (size_t)9 * a.C * sizeof(float);
   UIR_REQUIRE(lds <= 64 * 1024);
+  const int HS = uir_dw_strip(a.B, a.H, a.Wd, a.C);
   const long total = (long)a.B * ((a.H + HS - 1) / HS) * ((a.Wd + R - 1) / R) * (a.C >> 2);
   long blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(uir_dwconv_kernel, dim3((unsigned)blocks), dim3(256), lds, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(uir_dwconv_kernel, dim3((unsigned)blocks), dim3(256), lds, static_cast<hipStream_t>(stream), a, HS);
   return uir_launch_status();
 }
 
@@ -179,6 +187,7 @@ extern "C" int uir_dwconv_wgrad(const UirDwWgradArgs* p, void* stream) {
   UIR_REQUIRE(c4n <= 256);
   const int ny = 256 / c4n;
   const size_t lds = (size_t)ny * c4n * 36 * sizeof(float);
-  hipLaunchKernelGGL(uir_dwconv_wgrad_kernel, dim3(a.nblocks), dim3(c4n, ny), lds, static_cast<hipStream_t>(stream), a);
+  hipLaunchKernelGGL(uir_dwconv_wgrad_kernel, dim3(a.nblocks), dim3(c4n, ny), lds, static_cast<hipStream_t>(stream), a,
+                     uir_dw_strip(a.B, a.H, a.Wd, a.C));
   return uir_launch_status();
 }

@@ -433,6 +433,9 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     const int Kp = ((K8 >> 2) & 1) ? K8 : K8 + 4;
     int groups1 = (tiles + 2) / 3;
     int nt1 = (tiles + groups1 - 1) / groups1;
+    // small problems (deep U-Net levels): favour many narrow column groups over A re-use - the
+    // row panel is L2-resident there and parallelism is what is missing
+    if ((long)((a.M + 127) / 128) * groups1 * a.batches < 1024) nt1 = 1;
     while (nt1 > 1 && (size_t)nt1 * 32 * Kp * 4 > 64 * 1024) { --nt1; }
     groups1 = (tiles + nt1 - 1) / nt1;
     const size_t lds = (size_t)nt1 * 32 * Kp * 4 + (a.pro == UIR_PRO_LN ? (size_t)2 * K8 * 4 : 0);

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
   // U row-pairs per trip: every load of the trip is issued before the first MFMA consumes one.
   // Loads are branch-free (clamped addresses + select): a predicated load costs a branch and a
   // vmcnt(0) drain in hipcc's codegen, which serialises the whole trip.
-  constexpr int U = 4;
+  constexpr int U = (TN * TK == 1) ? 8 : 4;
   int acol[TN], bcol[TK];
 #pragma unroll
   for (int t = 0; t < TN; ++t) acol[t] = min(n0 + 32 * t + r, a.N - 1);
@@ -312,6 +312,9 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
       a.pro_b == UIR_GRAM_PRO_NONE) {
     dim3 grid(a.nchunks, 1, a.batches);
     hipLaunchKernelGGL(uir_gram_taps9_kernel, grid, block, 0, st, a);
+  } else if (tk_tiles == 1 && tn_tiles == 1) {
+    dim3 grid(a.taps * a.nchunks, 1, a.batches);
+    hipLaunchKernelGGL((uir_gram_kernel<1, 1>), grid, block, 0, st, a, 1, 1);
   } else if (tk_tiles == 1) {
     const int gn = (tn_tiles + 3) / 4, gk = 1;
     dim3 grid(a.taps * gn * gk * a.nchunks, 1, a.batches);

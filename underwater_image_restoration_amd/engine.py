@@ -305,7 +305,9 @@ class Recorder:
         M = M_total // batches
         self._hold(A, Bm, out, ln, stats, extras)
         tn, tk = (N + 31) // 32, (K + 31) // 32
-        if tk == 1:
+        if tk == 1 and tn == 1:
+            groups = 1
+        elif tk == 1:
             groups = (tn + 3) // 4
         elif tn == 1:
             groups = (tk + 3) // 4
@@ -377,7 +379,10 @@ class Recorder:
         a.B, a.H, a.Wd = dims
         a.C, a.creal = C_, creal
         a.grp_real, a.grp_pad = grp
-        items = dims[0] * ((dims[1] + 15) // 16) * ((dims[2] + 3) // 4)     # (strip of 16 rows, run of 4 pixels)
+        hs = 16                                                            # mirror uir_dw_strip() in dwconv.hip
+        while hs > 2 and dims[0] * ((dims[1] + hs - 1) // hs) * ((dims[2] + 3) // 4) * (C_ // 4) < 256 * 1024:
+            hs //= 2
+        items = dims[0] * ((dims[1] + hs - 1) // hs) * ((dims[2] + 3) // 4)   # (strip of hs rows, run of 4 pixels)
         ny = 256 // (C_ // 4)
         a.nblocks = max(1, min(2048, items // max(1, ny)))
         assert a.nblocks * creal * 9 <= self._slab().numel()
