@@ -16,7 +16,7 @@ only = sys.argv[2] if len(sys.argv) > 2 else ""
 dev = "cuda"
 B, H, W, C = 16, 256, 256, 32
 M = B * H * W
-h, hp = 85, 88
+h, hp = 85, 96
 r = Recorder(dev, scratch_floats=64 << 20)
 g = torch.Generator(device=dev).manual_seed(0)
 

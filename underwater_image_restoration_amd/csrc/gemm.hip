@@ -42,8 +42,10 @@ __device__ __forceinline__ void uir_gemm_epilogue(const UirGemmArgs& a, const f3
       } else if (a.epi == UIR_EPI_GATE_BWD) {
         const float* gp = a.G + (long)z * a.g_bs + (long)mm * a.ldg + n;
         const float g1 = gp[0], g2 = gp[a.g_off];
-        Y[(long)mm * a.ldy + n] = v * g2 * uir_gelu_grad(g1);
-        Y[(long)mm * a.ldy + a.g_off + n] = v * uir_gelu(g1);
+        float ge, dge;
+        uir_gelu_pair(g1, ge, dge);
+        Y[(long)mm * a.ldy + n] = v * g2 * dge;
+        Y[(long)mm * a.ldy + a.g_off + n] = v * ge;
       } else {  // UIR_EPI_LEAKY_BWD: G holds the forward LeakyReLU output
         const float o = a.G[(long)z * a.g_bs + (long)mm * a.ldg + n];
         Y[(long)mm * a.ldy + n] = o > 0.f ? v : v * a.slope;
@@ -207,9 +209,25 @@ __global__ __launch_bounds__(256) void uir_gemm_kernel(const UirGemmArgs a, cons
 //    and epilogue stores: vmcnt retires in issue order on CDNA4, so the wait for the prefetched
 //    loads never waits for the younger stores (measured: 64 % of wave cycles were s_waitcnt);
 //  * the epilogue is specialised at compile time (no per-element scalar branches).
+// residual rows of one tile, loaded BEFORE the MFMA block so their latency is covered (clamped rows /
+// columns: values outside the tile are never used)
+template <int NT>
+__device__ __forceinline__ void uir_gemm1x1_load_res(const UirGemmArgs& a, float (&rv)[NT][16], int z, int m0, int n0, int r, int h2) {
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = min(n0 + 32 * nt + r, a.N - 1);
+    const float* rp = a.R + (long)z * a.r_bs + n;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int mm = min(m0 + 4 * h2 + (reg & 3) + 8 * (reg >> 2), a.M - 1);
+      rv[nt][reg] = rp[(long)mm * a.ldr];
+    }
+  }
+}
+
 template <int NT, int EPI, bool HAS_R>
-__device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f32x16 (&acc)[NT], const float (&biasv)[NT], int z,
-                                                  int m0, int n0, int r, int h2) {
+__device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f32x16 (&acc)[NT], const float (&biasv)[NT],
+                                                  const float (&rv)[HAS_R ? NT : 1][16], int z, int m0, int n0, int r, int h2) {
   float* __restrict__ Y = a.Y + (long)z * a.y_bs;
   const float slope = (a.act == UIR_ACT_LEAKY) ? a.slope : 1.0f;
   const bool full = (m0 + 32 <= a.M);
@@ -220,19 +238,20 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
     const float bias = biasv[nt];
     const long row0 = (long)m0 + 4 * h2;
     float* yp = Y + row0 * a.ldy + n;
-    const float* rp = HAS_R ? a.R + (long)z * a.r_bs + row0 * a.ldr + n : nullptr;
     const float* gp = (EPI != UIR_EPI_PLAIN) ? a.G + (long)z * a.g_bs + row0 * a.ldg + n : nullptr;
     auto put = [&](int reg) {
       const int dr = (reg & 3) + 8 * (reg >> 2);   // row offset inside the tile (compile-time)
       float v = acc[nt][reg] + bias;
       v = v > 0.f ? v : v * slope;
       if constexpr (EPI == UIR_EPI_PLAIN) {
-        if constexpr (HAS_R) v += rp[(long)dr * a.ldr];
+        if constexpr (HAS_R) v += rv[nt][reg];
         yp[(long)dr * a.ldy] = v;
       } else if constexpr (EPI == UIR_EPI_GATE_BWD) {
         const float g1 = gp[(long)dr * a.ldg], g2 = gp[(long)dr * a.ldg + a.g_off];
-        yp[(long)dr * a.ldy] = v * g2 * uir_gelu_grad(g1);
-        yp[(long)dr * a.ldy + a.g_off] = v * uir_gelu(g1);
+        float ge, dge;
+        uir_gelu_pair(g1, ge, dge);
+        yp[(long)dr * a.ldy] = v * g2 * dge;
+        yp[(long)dr * a.ldy + a.g_off] = v * ge;
       } else {
         const float o = gp[(long)dr * a.ldg];
         yp[(long)dr * a.ldy] = o > 0.f ? v : v * a.slope;
@@ -260,15 +279,19 @@ __global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, c
   const float* __restrict__ W = a.W + (long)z * a.w_bs;
   const int K8 = (a.K + 7) & ~7;
   constexpr int NC = 32 * NT;
-  for (int idx = threadIdx.x; idx < NC * K8; idx += 256) {
+  // panel [col][tap][K8] (+pad): element (n, k, tap) -> wl[nl*Kp + tap*K8 + k]; tap-flipped for input-gradients
+  for (int idx = threadIdx.x; idx < NC * K8 * a.taps; idx += 256) {
+    const int tap = idx / (NC * K8);
+    const int rem = idx - tap * (NC * K8);
     int nl, k;
-    if (a.w_sk == 1) { nl = idx / K8; k = idx - nl * K8; } else { k = idx / NC; nl = idx - k * NC; }
+    if (a.w_sk == 1) { nl = rem / K8; k = rem - nl * K8; } else { k = rem / NC; nl = rem - k * NC; }
     const int n = n0 + nl;
     const int nr = (n < a.N) ? uir_colmap(n, a.n_grp_real, a.n_grp_pad) : -1;
     const int kr = (k < a.K) ? uir_colmap(k, a.k_grp_real, a.k_grp_pad) : -1;
-    wl[nl * Kp + k] = (nr >= 0 && kr >= 0) ? W[(long)nr * a.w_sn + (long)kr * a.w_sk] : 0.f;
+    const int wt = a.flip ? (a.taps - 1 - tap) : tap;
+    wl[nl * Kp + tap * K8 + k] = (nr >= 0 && kr >= 0) ? W[(long)nr * a.w_sn + (long)kr * a.w_sk + (long)wt * a.w_st] : 0.f;
   }
-  float* lng = wl + NC * Kp;   // gamma[K8], beta[K8]
+  float* lng = wl + NC * Kp;   // gamma[K8], beta[K8] (1x1 only)
   if constexpr (PRO == UIR_PRO_LN) {
     for (int k = threadIdx.x; k < K8; k += 256) {
       lng[k] = k < a.K ? a.ln_g[k] : 0.f;
@@ -276,8 +299,10 @@ __global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, c
     }
   }
   __syncthreads();
-  const int nchunks = (K8 + 31) >> 5;
+  const int cpt = (K8 + 31) >> 5;          // 32-wide chunks per tap
+  const int nchunks = cpt * a.taps;        // units per row tile
   const float* wbase = wl + r * Kp + 4 * h2;
+  const int HW = a.H * a.Wd;
   float bias[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -295,23 +320,39 @@ __global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, c
   constexpr int NU = (PRO == UIR_PRO_GATE) ? 4 : 1;
   float4 P0[4], P1[4], U0[NU], U1[NU];
   const int kmax = (a.K + 3) & ~3;
-  auto load_unit = [&](float4 (&an)[4], float4 (&un)[NU], int tile_, int c_) {
+  // returns whether this lane's (row, tap) neighbour exists (else the loaded values must be zeroed)
+  auto load_unit = [&](float4 (&an)[4], float4 (&un)[NU], int tile_, int c_) -> bool {
     const int mm = min(tile_ * 128 + wave * 32 + r, a.M - 1);
-    const float* xr = X + (long)mm * a.ldx;
+    long row = mm;
+    bool ok = true;
+    int cc = c_;
+    if (a.taps > 1) {
+      const int tap = c_ / cpt;
+      cc = c_ - tap * cpt;
+      const int hw = mm % HW;
+      const int ph = hw / a.Wd, pw = hw - ph * a.Wd;
+      const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+      const int hh = ph + dy, ww = pw + dx;
+      ok = hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
+      row = ok ? (long)mm + dy * a.Wd + dx : (long)mm;
+    }
+    const float* xr = X + row * a.ldx;
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      int kc = 32 * c_ + 8 * s + 4 * h2;
+      int kc = 32 * cc + 8 * s + 4 * h2;
       kc = (kc < kmax) ? kc : 0;
       an[s] = *reinterpret_cast<const float4*>(xr + kc);
       if constexpr (PRO == UIR_PRO_GATE) un[s] = *reinterpret_cast<const float4*>(xr + a.gate_off + kc);
     }
+    return ok;
   };
 
   int tile = blockIdx.x, c = 0;
   float mean = 0.f, rstd = 0.f;
   f32x16 acc[NT];
 
-  auto step = [&](float4 (&an)[4], float4 (&un)[NU], float4 (&nx)[4], float4 (&nu)[NU]) -> bool {
+  bool ok0 = true, ok1 = true;
+  auto step = [&](float4 (&an)[4], float4 (&un)[NU], const bool anok, float4 (&nx)[4], float4 (&nu)[NU], bool& nxok) -> bool {
     const int m0 = tile * 128 + wave * 32;
     const int m = m0 + r;
     if (c == 0) {
@@ -351,11 +392,13 @@ __global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, c
           *reinterpret_cast<float2*>(a.stats + ((long)z * a.M + m) * 2) = make_float2(mean, rstd);
       }
     }
+    const int tapc = (a.taps > 1) ? c / cpt : 0;
+    const int cin = c - tapc * cpt;           // chunk inside the tap
     float4 ac[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      float4 v = an[s];
-      const int kc = 32 * c + 8 * s + 4 * h2;
+      float4 v = anok ? an[s] : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int kc = 32 * cin + 8 * s + 4 * h2;
       if constexpr (PRO == UIR_PRO_LN) {
         const int kq = (kc < K8) ? kc : 0;
         const float4 g = *reinterpret_cast<const float4*>(lng + kq);
@@ -377,14 +420,18 @@ __global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, c
     const bool last = (c + 1 == nchunks);
     const int tn = last ? tile + (int)gridDim.x : tile;
     const int cn = last ? 0 : c + 1;
-    load_unit(nx, nu, tn, cn);
+    nxok = load_unit(nx, nu, tn, cn);
+    float rv[HAS_R ? NT : 1][16];
+    if constexpr (HAS_R) {
+      if (last) uir_gemm1x1_load_res<NT>(a, rv, z, m0, n0, r, h2);
+    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-      const int k0 = 32 * c + 8 * s;
+      const int k0 = 32 * cin + 8 * s;
       if (k0 < K8) {
         float4 b[NT];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(wbase + nt * 32 * Kp + k0);
+        for (int nt = 0; nt < NT; ++nt) b[nt] = *reinterpret_cast<const float4*>(wbase + nt * 32 * Kp + tapc * K8 + k0);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           acc[nt] = uir_mfma(ac[s].x, b[nt].x, acc[nt]);
@@ -394,17 +441,17 @@ __global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, c
         }
       }
     }
-    if (last && m0 < a.M) uir_gemm1x1_store<NT, EPI, HAS_R>(a, acc, bias, z, m0, n0, r, h2);
+    if (last && m0 < a.M) uir_gemm1x1_store<NT, EPI, HAS_R>(a, acc, bias, rv, z, m0, n0, r, h2);
     tile = tn;
     c = cn;
     return tile < tiles;
   };
 
   if (tile < tiles) {
-    load_unit(P0, U0, tile, 0);
+    ok0 = load_unit(P0, U0, tile, 0);
     while (true) {
-      if (!step(P0, U0, P1, U1)) break;
-      if (!step(P1, U1, P0, U0)) break;
+      if (!step(P0, U0, ok0, P1, U1, ok1)) break;
+      if (!step(P1, U1, ok1, P0, U0, ok0)) break;
     }
   }
 }
@@ -427,10 +474,11 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   if (a.R) UIR_REQUIRE(a.ldr >= a.N);
   const int tiles = (a.N + 31) / 32;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (a.taps == 1) {
-    // LDS-resident weight panel: pick the widest column group (<= 4 tiles... 3 keeps 4 waves/SIMD) that fits 64 KB
+  {
+    // LDS-resident weight panel (all taps): pick the widest column group (<= 3 tiles) that fits 64 KB
     const int K8 = (a.K + 7) & ~7;
-    const int Kp = ((K8 >> 2) & 1) ? K8 : K8 + 4;
+    const int Kt = K8 * a.taps;
+    const int Kp = ((Kt >> 2) & 1) ? Kt : Kt + 4;
     int groups1 = (tiles + 2) / 3;
     int nt1 = (tiles + groups1 - 1) / groups1;
     // small problems (deep U-Net levels): favour many narrow column groups over A re-use - the
@@ -440,7 +488,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     groups1 = (tiles + nt1 - 1) / nt1;
     const size_t lds = (size_t)nt1 * 32 * Kp * 4 + (a.pro == UIR_PRO_LN ? (size_t)2 * K8 * 4 : 0);
     const bool combo_ok = (a.pro == UIR_PRO_NONE) || (a.epi == UIR_EPI_PLAIN && !(a.pro == UIR_PRO_LN && a.R));
-    if (lds <= 96 * 1024 && combo_ok) {
+    if (lds <= 100 * 1024 && combo_ok) {
       const int rtiles = (a.M + 127) / 128;
       int gx = 1536 / (groups1 * a.batches);
       if (gx < 1) gx = 1;

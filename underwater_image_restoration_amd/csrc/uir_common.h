@@ -29,14 +29,33 @@ __device__ __forceinline__ int uir_colmap(int c, int grp_real, int grp_pad) {
   return r < grp_real ? g * grp_real + r : -1;
 }
 
-// exact-erf GELU (torch F.gelu default) and its derivative
+// erf-GELU (torch F.gelu default, SpectralTransformer.py:129) and its derivative from ONE
+// exponential: Phi(x) via Abramowitz-Stegun 7.1.26 (|erf error| <= 1.5e-7, i.e. fp32 rounding
+// level; the tails are evaluated without cancellation), phi(x) = exp(-x^2/2)/sqrt(2 pi) reuses
+// the same exp.  ~15 VALU ops instead of ~60 for erff() + expf(): the gate kernels were VALU-bound.
+__device__ __forceinline__ void uir_gelu_pair(float x, float& g, float& dg) {
+  const float ax = fabsf(x);
+  const float z = ax * 0.70710678118654752440f;
+  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float e = __expf(-z * z);
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(t, poly, 1.421413741f);
+  poly = fmaf(t, poly, -0.284496736f);
+  poly = fmaf(t, poly, 0.254829592f);
+  const float tail = 0.5f * poly * t * e;               // 1 - Phi(|x|)
+  const float cdf = x >= 0.f ? 1.0f - tail : tail;
+  g = x * cdf;
+  dg = fmaf(x, 0.39894228040143267794f * e, cdf);
+}
 __device__ __forceinline__ float uir_gelu(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  float g, dg;
+  uir_gelu_pair(x, g, dg);
+  return g;
 }
 __device__ __forceinline__ float uir_gelu_grad(float x) {
-  float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-  float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-  return cdf + x * pdf;
+  float g, dg;
+  uir_gelu_pair(x, g, dg);
+  return dg;
 }
 
 // row index held by accumulator register `reg` of a 32x32 f32 MFMA tile for lane half h2

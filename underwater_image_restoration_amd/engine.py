@@ -47,6 +47,12 @@ def pad4(n: int) -> int:
     return (n + 3) & ~3
 
 
+def pad16(n: int) -> int:
+    """GDFN half-width padding: 2*pad16(h) floats is a multiple of 128 bytes, so every HWC row of
+    the gated tensors starts on a cache line (704-byte rows measured ~35 % slower than aligned ones)."""
+    return (n + 15) & ~15
+
+
 def is_dead_param(name: str) -> bool:
     """Parameters the reference never uses on the live path (grad stays None):
     SpectralTransformer.py:103-106,112 (q1X1_*) and :231,233,248,250."""
@@ -459,7 +465,7 @@ class Plan(Recorder):
         """TransformerBlock (SpectralTransformer.py:142-148) on HWC rows x [M, C]."""
         B, H, W = dims
         M, HW = B * H * W, H * W
-        h, hp = hidden_of(C_), pad4(hidden_of(C_))
+        h, hp = hidden_of(C_), pad16(hidden_of(C_))
         P, Gr = self.P, self.Gr
         a = f"{pfx}.attn"
         Wqkv, Wdw = P(f"{a}.qkv.weight"), P(f"{a}.qkv_conv.weight")
