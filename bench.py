@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--breakdown-file", default="")
+    ap.add_argument("--timeline-file", default="")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -143,6 +144,18 @@ def main():
                 "algorithmic_bytes_per_step": alg_bytes_step,
                 "launch": "one train step = forward+backward launch lists + loss + clip/Adam",
                 "mfma_frac_fp32": (ALG_FLOPS_PER_IMAGE_256 * scale * B / (ms * 1e-3)) / 157.3e12}
+        if args.timeline_file:
+            plan = model._plan_for(raw)
+            mk = []
+            torch.cuda.synchronize()
+            plan.run(plan.fwd, marks=mk)
+            plan.run(plan.bwd, marks=mk)
+            torch.cuda.synchronize()
+            with open(args.timeline_file, "w") as f:
+                f.write("stage,ms (main-stream timeline of the overlapped two-lane run)\n")
+                for (n0_, e0), (n1_, e1) in zip(mk[:-1], mk[1:]):
+                    if n1_ != "bwd.start":
+                        f.write(f"{n1_},{e0.elapsed_time(e1):.3f}\n")
         if not args.no_kernel_breakdown:
             plan = model._plan_for(raw)
             rows = plan.run_timed(plan.fwd) + plan.run_timed(plan.bwd)

@@ -37,28 +37,43 @@ __global__ __launch_bounds__(256) void uir_dft_kernel(const UirDftArgs a, int ct
 
   const long line = (o * a.N * a.I + i) * a.C;  // element (o, n=0, i, c=0)
   const long nstride = (long)a.I * a.C;
-  for (int n = 0; n < a.N; n += 2) {
-    const int nn = n + h2;
-    const bool nok = nn < a.N;
-    float bre = 0.f, bim = 0.f;
-    if (nok && cok) {
-      bre = a.in_re[line + nn * nstride + c];
-      if (has_im) bim = a.in_im[line + nn * nstride + c];
+  // branch-free loads (clamped indices + select), U n-pairs per trip so 2U..4U loads are in flight
+  const int cc = min(c, a.C - 1);
+  const float* imp = has_im ? a.in_im : a.in_re;   // always a valid address; zeroed by select when real-only
+  int kcl[KT];
+  bool kok[KT];
+#pragma unroll
+  for (int kt = 0; kt < KT; ++kt) { const int k = k0 + 32 * kt + r; kok[kt] = k < a.N; kcl[kt] = min(k, a.N - 1); }
+  constexpr int U = 4;
+  for (int n = 0; n < a.N; n += 2 * U) {
+    float bre[U], bim[U], cv[U][KT], sv[U][KT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int nn = min(n + 2 * u + h2, a.N - 1);
+      bre[u] = a.in_re[line + nn * nstride + cc];
+      bim[u] = imp[line + nn * nstride + cc];
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        cv[u][kt] = a.cos_t[(long)nn * a.N + kcl[kt]];
+        sv[u][kt] = a.sin_t[(long)nn * a.N + kcl[kt]];
+      }
     }
 #pragma unroll
-    for (int kt = 0; kt < KT; ++kt) {
-      const int k = k0 + 32 * kt + r;
-      float cv = 0.f, sv = 0.f;
-      if (nok && k < a.N) {
-        cv = a.cos_t[(long)nn * a.N + k];
-        sv = a.sign * a.sin_t[(long)nn * a.N + k];
-      }
-      // e^{i s th}(re + i im) = (cos re - s sin im) + i (cos im + s sin re)
-      are[kt] = uir_mfma(cv, bre, are[kt]);
-      if (has_im) are[kt] = uir_mfma(-sv, bim, are[kt]);
-      if (want_im) {
-        aim[kt] = uir_mfma(sv, bre, aim[kt]);
-        if (has_im) aim[kt] = uir_mfma(cv, bim, aim[kt]);
+    for (int u = 0; u < U; ++u) {
+      const bool nok = (n + 2 * u + h2) < a.N;
+      const float br = (nok && cok) ? bre[u] : 0.f;
+      const float bi = (nok && cok && has_im) ? bim[u] : 0.f;
+#pragma unroll
+      for (int kt = 0; kt < KT; ++kt) {
+        const float c_ = (nok && kok[kt]) ? cv[u][kt] : 0.f;
+        const float s_ = (nok && kok[kt]) ? a.sign * sv[u][kt] : 0.f;
+        // e^{i s th}(re + i im) = (cos re - s sin im) + i (cos im + s sin re)
+        are[kt] = uir_mfma(c_, br, are[kt]);
+        if (has_im) are[kt] = uir_mfma(-s_, bi, are[kt]);
+        if (want_im) {
+          aim[kt] = uir_mfma(s_, br, aim[kt]);
+          if (has_im) aim[kt] = uir_mfma(c_, bi, aim[kt]);
+        }
       }
     }
   }

@@ -180,6 +180,19 @@ class Recorder:
         at the end of the list)."""
         return Recorder._Side(self)
 
+    def mark(self, name: str) -> None:
+        """Stage marker: `run(ops, marks=[])` records an event on the main stream here (timeline of
+        the real, overlapped execution; nothing is serialised)."""
+        self.cur.append((None, (), name))
+        self.meta[id(self.cur)].append((name, "mark", 0, 0))
+        self.lanes[id(self.cur)].append(3)
+
+    def join(self, name: str = "join") -> None:
+        """Mid-list join: the main lane waits for everything recorded so far on the side lane."""
+        self.cur.append((None, (), name))
+        self.meta[id(self.cur)].append((name, "join", 0, 0))
+        self.lanes[id(self.cur)].append(2)
+
     def _slab(self) -> torch.Tensor:
         return self.scratch_side if self.lane == 1 else self.scratch
 
@@ -193,10 +206,12 @@ class Recorder:
             elif t is not None:
                 self.keep.append(t)
 
-    def run(self, ops: Sequence[tuple]) -> None:
+    def run(self, ops: Sequence[tuple], marks: "list | None" = None) -> None:
         if self.dev.type != "cuda":
             st = C.c_void_p(0)
             for fn, args, name in ops:
+                if fn is None:
+                    continue
                 rc = fn(*args, st)
                 if rc:
                     L.check(rc, name)
@@ -206,6 +221,8 @@ class Recorder:
         lanes = self.lanes[id(ops)]
         if 1 not in lanes:
             for fn, args, name in ops:
+                if fn is None:
+                    continue
                 rc = fn(*args, st0)
                 if rc:
                     L.check(rc, name)
@@ -217,6 +234,20 @@ class Recorder:
         nev = 0
         main_dirty = True           # main has launched work the side stream has not been ordered after
         for (fn, args, name), lane in zip(ops, lanes):
+            if lane == 3:                       # stage marker
+                if marks is not None:
+                    e = torch.cuda.Event(enable_timing=True)
+                    e.record(main)
+                    marks.append((name, e))
+                continue
+            if lane == 2:                       # join marker
+                if nev == len(self._events):
+                    self._events.append(torch.cuda.Event())
+                ev = self._events[nev]
+                nev += 1
+                ev.record(side)
+                main.wait_event(ev)
+                continue
             if lane == 1:
                 if main_dirty:
                     if nev == len(self._events):
@@ -246,9 +277,10 @@ class Recorder:
         evs = [torch.cuda.Event(enable_timing=True) for _ in range(len(ops) + 1)]
         evs[0].record()
         for i, (fn, args, name) in enumerate(ops):
-            rc = fn(*args, st)
-            if rc:
-                L.check(rc, name)
+            if fn is not None:
+                rc = fn(*args, st)
+                if rc:
+                    L.check(rc, name)
             evs[i + 1].record()
         torch.cuda.synchronize()
         meta = self.meta[id(ops)]
@@ -304,7 +336,7 @@ class Recorder:
 
     def gram(self, name, A, Bm, out, *, N, K, o_sn, o_sk, o_st=0, o_bs=0, batches=1, taps=1, hw=None,
              n_grp=(0, 0), k_grp=(0, 0), pro_b=0, gate_off=0, ln=None, stats=None, out_elems=None,
-             extras: "Dict[str, torch.Tensor] | None" = None):
+             extras: "Dict[str, torch.Tensor] | None" = None, fused_out: "torch.Tensor | None" = None):
         """out[...] = sum_m A[m][n] * pro(B[nbr(m)][k]); `out` is a flat view of out_elems floats.
         extras: {'sq_a': tensor[batches*N], 'sq_b': tensor[batches*K], 'cs_a': tensor[batches*N]}."""
         M_total = A.shape[0]
@@ -357,6 +389,12 @@ class Recorder:
         self._op(name, lib.uir_gram, C.byref(a), nbytes=4 * rows * (N + K * (2 if pro_b == L.PRO_GATE else 1)),
                  flops=2 * rows * N * K * taps)
         sp = self._slab().data_ptr()
+        if fused_out is not None:
+            # `fused_out` = [out | sq_a | sq_b | cs_a] contiguous, i.e. exactly one slab row: one reduction launch
+            assert fused_out.numel() == stride and fused_out.data_ptr() == out.data_ptr()
+            self._hold(fused_out)
+            self._op(name + ".red", lib.uir_reduce_slab, sp, nch, stride, _ptr(fused_out), stride, 0, 1.0)
+            return
         self._op(name + ".red", lib.uir_reduce_slab, sp, nch, stride, _ptr(out), out_elems, 0, 1.0)
         for key, off in (("sq_a", a.sq_a_off), ("sq_b", a.sq_b_off), ("cs_a", a.cs_a_off)):
             if key in extras:
@@ -493,9 +531,12 @@ class Plan(Recorder):
         # ---- MDTA (live path of :93-100,107,110,113) ----
         self.gemm(n + ".qkv", x, Wqkv, qkv_pre, N=3 * C_, K=C_, w_sn=C_, w_sk=1, pro=L.PRO_LN, ln=(g1, b1), stats=stats1)
         self.dwconv(n + ".qkv_conv", qkv_pre, Wdw, qkv, C_=3 * C_, dims=dims)
+        # P = W_kv[vf] @ W_o depends on weights only: side lane, joined right before its first use
+        with self.side():
+            self.gemm(n + ".P", Wkvf, Wo, Pm, N=C_, K=C_, w_sn=1, w_sk=C_)
         self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
-                  out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk})
-        self.gemm(n + ".P", Wkvf, Wo, Pm, N=C_, K=C_, w_sn=1, w_sk=C_)
+                  out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, fused_out=gbuf)
+        self.join(n + ".P.join")
         fa = L.AttnFwdArgs()
         fa.G, fa.sq_q, fa.sq_k, fa.temperature, fa.P, fa.Wof = _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp), _ptr(Pm), _ptr(Wof)
         fa.attn, fa.WA, fa.WB = _ptr(attn), _ptr(WA), _ptr(WB)
@@ -662,8 +703,11 @@ class Plan(Recorder):
         self.gemm(f + ".post", t, Wpost, po, N=Ch, K=C_, w_sn=C_, w_sk=1, bias=bpost)
         cat = self.alloc(4 * M, C_)
         self._op(f + ".scatter", lib.uir_scatter_even, _ptr(po), _ld(po), _ptr(bpost), _ptr(cat), _ld(cat), 0, B, H, W, Ch)
-        s, sups_bw = self._conv3(pfx + ".Sups", x, f"{pfx}.Sups.body.0.weight", C_, 2 * C_, dims)
-        self._op(pfx + ".Sups.shuffle", lib.uir_pixel_shuffle, _ptr(s), _ld(s), _ptr(cat), _ld(cat), Ch, B, H, W, Ch)
+        # the 3x3 shuffle branch is independent of the long spectral chain: side lane, joined before `reduce`
+        with self.side():
+            s, sups_bw = self._conv3(pfx + ".Sups", x, f"{pfx}.Sups.body.0.weight", C_, 2 * C_, dims)
+            self._op(pfx + ".Sups.shuffle", lib.uir_pixel_shuffle, _ptr(s), _ld(s), _ptr(cat), _ld(cat), Ch, B, H, W, Ch)
+        self.join(pfx + ".join")
         Wred = self.P(f"{pfx}.reduce.weight")
         self.gemm(pfx + ".reduce", cat, Wred, y_out, N=Ch, K=C_, w_sn=C_, w_sk=1)
 
@@ -674,8 +718,9 @@ class Plan(Recorder):
             self.gemm(pfx + ".reduce.dX", dy, Wred, dcat, N=C_, K=Ch, w_sn=1, w_sk=C_)
             # shuffle branch
             ds = self.alloc(M, 2 * C_)
-            self._op(pfx + ".Sups.shuffle_bwd", lib.uir_pixel_unshuffle, _ptr(dcat), _ld(dcat), Ch, _ptr(ds), _ld(ds), B, H, W, Ch)
-            dx = sups_bw(ds)
+            with self.side():
+                self._op(pfx + ".Sups.shuffle_bwd", lib.uir_pixel_unshuffle, _ptr(dcat), _ld(dcat), Ch, _ptr(ds), _ld(ds), B, H, W, Ch)
+                dx = sups_bw(ds)
             # spectral branch
             with self.side():
                 self.colsum(f + ".post.db", dcat, 0, Ch, self.Gr(f + ".post.bias"))
@@ -698,6 +743,7 @@ class Plan(Recorder):
             self.dft(f + ".dftH_bwd", gfr, gfi, gar, gai, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0)
             dxf = self.alloc(M, C_)
             self.dft(f + ".dftW_bwd", gar, gai, dxf, None, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0)
+            self.join(pfx + ".join_bwd")
             self.copy_cols(pfx + ".dx_sum", dxf, 0, dx, 0, C_, accumulate=1)
             return dx
         return backward
@@ -714,49 +760,68 @@ class Plan(Recorder):
         x4 = self.alloc(M0, 4)
         self.cur = self.fwd
         self._op("in.to_hwc", lib.uir_nchw3_to_hwc4, _ptr(self.in_nchw), _ptr(x4), B, H, W)
+        self.mark("fwd.start")
         f0, embed_bw = self._conv3("embed", x4, "embed_conv_rgb.weight", 3, 16, d0, k_grp=(3, 4), Kp=4)
         e1, enc1_bw = self._stack("encoders.0", f0, 2, 16, 1, d0)
+        self.mark("fwd.enc0(L0,C16)")
         t1, down1_bw = self._down("down1", e1, 16, d0)
         e2, enc2_bw = self._stack("encoders.1", t1, 3, 32, 2, d1)
+        self.mark("fwd.enc1(L1)")
         t2, down2_bw = self._down("down2", e2, 32, d1)
         e3, enc3_bw = self._stack("encoders.2", t2, 3, 64, 4, d2)
+        self.mark("fwd.enc2(L2)")
         t3, down3_bw = self._down("down3", e3, 64, d2)
         e4, enc4_bw = self._stack("encoders.3", t3, 4, 128, 8, d3)
+        self.mark("fwd.enc3(L3)")
         # decoder level 3: cat[ups_1(e4), e3] -> reduces1 (SpectralTransformer.py:263-264)
         cat3 = self.alloc(M2, 128)
         ups1_bw = self._ups("ups_1", e4, 128, d3, cat3[:, :64])
         self.copy_cols("cat3.skip", e3, 0, cat3, 64, 64)
         r3 = self.alloc(M2, 64)
         self.gemm("reduces1", cat3, P("reduces1.weight"), r3, N=64, K=128, w_sn=128, w_sk=1)
+        self.mark("fwd.ups_1")
         dd3, dec3_bw = self._stack("decoders.0", r3, 3, 64, 4, d2)
+        self.mark("fwd.dec0(L2)")
         cat2 = self.alloc(M1, 64)
         ups2_bw = self._ups("ups_2", dd3, 64, d2, cat2[:, :32])
         self.copy_cols("cat2.skip", e2, 0, cat2, 32, 32)
         r2 = self.alloc(M1, 32)
         self.gemm("reduces2", cat2, P("reduces2.weight"), r2, N=32, K=64, w_sn=64, w_sk=1)
+        self.mark("fwd.ups_2")
         dd2, dec2_bw = self._stack("decoders.1", r2, 3, 32, 2, d1)
+        self.mark("fwd.dec1(L1)")
         cat1 = self.alloc(M0, 32)
         ups3_bw = self._ups("ups_3", dd2, 32, d1, cat1[:, :16])
         self.copy_cols("cat1.skip", e1, 0, cat1, 16, 16)
+        self.mark("fwd.ups_3")
         fd, dec1_bw = self._stack("decoders.2", cat1, 2, 32, 1, d0)
+        self.mark("fwd.dec2(L0,C32)")
         fr, ref_bw = self._stack("refinement", fd, 4, 32, 1, d0)
+        self.mark("fwd.refine(L0,C32)")
         y8, outl_bw = self._conv3("outputl", fr, "outputl.weight", 32, 8, d0)
         y4, out_bw = self._conv3("output", y8, "output.weight", 8, 3, d0, n_grp=(3, 4), Np=4)
         self._op("out.to_nchw", lib.uir_hwc4_to_nchw3, _ptr(y4), _ptr(self.out_nchw), B, H, W)
+        self.mark("fwd.output")
         if not self.want_backward:
             return
         # ------------------------------ backward ------------------------------
         self.cur = self.bwd
         dy4 = self.alloc(M0, 4)
         self._op("dout.to_hwc", lib.uir_nchw3_to_hwc4, _ptr(self.dout_nchw), _ptr(dy4), B, H, W)
+        self.mark("bwd.start")
         dy8 = out_bw(dy4)
         dfr = outl_bw(dy8)
+        self.mark("bwd.output")
         dfd = ref_bw(dfr)
+        self.mark("bwd.refine(L0,C32)")
         dcat1 = dec1_bw(dfd)
+        self.mark("bwd.dec2(L0,C32)")
         de1 = self.alloc(M0, 16)
         self.copy_cols("cat1.skip_bwd", dcat1, 16, de1, 0, 16)
         ddd2 = ups3_bw(dcat1[:, :16])
+        self.mark("bwd.ups_3")
         dr2 = dec2_bw(ddd2)
+        self.mark("bwd.dec1(L1)")
         dcat2 = self.alloc(M1, 64)
         with self.side():
             self.gram("reduces2.dW", dr2, cat2, self.Gr("reduces2.weight"), N=32, K=64, o_sn=64, o_sk=1)
@@ -764,7 +829,9 @@ class Plan(Recorder):
         de2 = self.alloc(M1, 32)
         self.copy_cols("cat2.skip_bwd", dcat2, 32, de2, 0, 32)
         ddd3 = ups2_bw(dcat2[:, :32])
+        self.mark("bwd.ups_2")
         dr3 = dec3_bw(ddd3)
+        self.mark("bwd.dec0(L2)")
         dcat3 = self.alloc(M2, 128)
         with self.side():
             self.gram("reduces1.dW", dr3, cat3, self.Gr("reduces1.weight"), N=64, K=128, o_sn=128, o_sk=1)
@@ -772,17 +839,23 @@ class Plan(Recorder):
         de3 = self.alloc(M2, 64)
         self.copy_cols("cat3.skip_bwd", dcat3, 64, de3, 0, 64)
         de4 = ups1_bw(dcat3[:, :64])
+        self.mark("bwd.ups_1")
         dt3 = enc4_bw(de4)
+        self.mark("bwd.enc3(L3)")
         d_e3 = down3_bw(dt3)
         self.copy_cols("e3.grad_sum", d_e3, 0, de3, 0, 64, accumulate=1)
         dt2 = enc3_bw(de3)
+        self.mark("bwd.enc2(L2)")
         d_e2 = down2_bw(dt2)
         self.copy_cols("e2.grad_sum", d_e2, 0, de2, 0, 32, accumulate=1)
         dt1 = enc2_bw(de2)
+        self.mark("bwd.enc1(L1)")
         d_e1 = down1_bw(dt1)
         self.copy_cols("e1.grad_sum", d_e1, 0, de1, 0, 16, accumulate=1)
         df0 = enc1_bw(de1)
+        self.mark("bwd.enc0(L0,C16)")
         embed_bw(df0, need_dx=False)
+        self.mark("bwd.embed")
         self.cur = self.fwd
 
     # ------------------------------------------------------------------- run
