@@ -41,11 +41,14 @@ __device__ __forceinline__ void load_row(float4 (&v)[R + 2], const float* base, 
 // workgroups on other XCDs (whose L2s are private).
 __global__ __launch_bounds__(256) void uir_dwconv_kernel(const UirDwArgs a, const int HS) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][C]
-  for (int i = threadIdx.x; i < 9 * a.C; i += blockDim.x) {
-    const int t = i / a.C, c = i - t * a.C;
+  for (int c = threadIdx.x; c < a.C; c += blockDim.x) {     // one colmap (integer division) per channel, not per tap
     const int cr = uir_colmap(c, a.grp_real, a.grp_pad);
-    const int ts = a.flip ? 8 - t : t;
-    wl[i] = cr >= 0 ? a.Wt[(long)cr * 9 + ts] : 0.f;
+    const float* wp = a.Wt + (long)max(cr, 0) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float v = wp[a.flip ? 8 - t : t];
+      wl[t * a.C + c] = cr >= 0 ? v : 0.f;
+    }
   }
   __syncthreads();
   const int c4n = a.C >> 2;

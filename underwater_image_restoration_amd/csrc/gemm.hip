@@ -17,6 +17,7 @@
 // Epilogues: bias, LeakyReLU, residual add, GATE_BWD (dgate -> dg1, dg2), LEAKY_BWD.
 #include "uir_common.h"
 #include "../../include/uir_kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -279,38 +280,9 @@ __global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, c
   const float* __restrict__ W = a.W + (long)z * a.w_bs;
   const int K8 = (a.K + 7) & ~7;
   constexpr int NC = 32 * NT;
-  // panel [col][tap][K8] (+pad): element (n, k, tap) -> wl[nl*Kp + tap*K8 + k]; tap-flipped for input-gradients
-  for (int idx = threadIdx.x; idx < NC * K8 * a.taps; idx += 256) {
-    const int tap = idx / (NC * K8);
-    const int rem = idx - tap * (NC * K8);
-    int nl, k;
-    if (a.w_sk == 1) { nl = rem / K8; k = rem - nl * K8; } else { k = rem / NC; nl = rem - k * NC; }
-    const int n = n0 + nl;
-    const int nr = (n < a.N) ? uir_colmap(n, a.n_grp_real, a.n_grp_pad) : -1;
-    const int kr = (k < a.K) ? uir_colmap(k, a.k_grp_real, a.k_grp_pad) : -1;
-    const int wt = a.flip ? (a.taps - 1 - tap) : tap;
-    wl[nl * Kp + tap * K8 + k] = (nr >= 0 && kr >= 0) ? W[(long)nr * a.w_sn + (long)kr * a.w_sk + (long)wt * a.w_st] : 0.f;
-  }
-  float* lng = wl + NC * Kp;   // gamma[K8], beta[K8] (1x1 only)
-  if constexpr (PRO == UIR_PRO_LN) {
-    for (int k = threadIdx.x; k < K8; k += 256) {
-      lng[k] = k < a.K ? a.ln_g[k] : 0.f;
-      lng[K8 + k] = k < a.K ? a.ln_b[k] : 0.f;
-    }
-  }
-  __syncthreads();
   const int cpt = (K8 + 31) >> 5;          // 32-wide chunks per tap
   const int nchunks = cpt * a.taps;        // units per row tile
-  const float* wbase = wl + r * Kp + 4 * h2;
   const int HW = a.H * a.Wd;
-  float bias[NT];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + 32 * nt + r;
-    const int nr = (n < a.N) ? uir_colmap(n, a.n_grp_real, a.n_grp_pad) : -1;
-    bias[nt] = (a.bias && nr >= 0) ? a.bias[nr] : 0.f;
-  }
-
   // Branch-free loads (a predicated load costs a branch + a full vmcnt(0) drain in hipcc's
   // codegen): rows past M are clamped to the last row (their results are never stored) and k
   // past K to column 0 (they meet exact-zero weights staged in LDS), so every address is valid.
@@ -347,11 +319,78 @@ __global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, c
     return ok;
   };
 
+  // first A panel in flight before (and during) the weight staging below
+  bool ok0 = true, ok1 = true;
+  if ((int)blockIdx.x < tiles) ok0 = load_unit(P0, U0, blockIdx.x, 0);
+
+  // panel [col][tap][K8] (+pad): element (n, k, tap) -> wl[nl*Kp + tap*K8 + k]; tap-flipped for
+  // input-gradients.  Row/column weight offsets are tabulated once per workgroup (the colmap
+  // divisions cost ~30 VALU ops each: done NC + K8 times, not NC*K8 times) and the panel is walked
+  // with 2-D loops whose fast index follows the contiguous weight dimension.
+  float* lng = wl + NC * Kp;                              // gamma[K8], beta[K8] (LN prologue only)
+  int* nmap = reinterpret_cast<int*>(lng + 2 * K8);       // [NC]  weight offset of column nl, or -1
+  int* kmap = nmap + NC;                                  // [K8]  weight offset of k, or -1
+  for (int i = threadIdx.x; i < NC + K8; i += 256) {
+    if (i < NC) {
+      const int n = n0 + i;
+      const int nr = (n < a.N) ? uir_colmap(n, a.n_grp_real, a.n_grp_pad) : -1;
+      nmap[i] = nr < 0 ? -1 : nr * (int)a.w_sn;
+    } else {
+      const int k = i - NC;
+      const int kr = (k < a.K) ? uir_colmap(k, a.k_grp_real, a.k_grp_pad) : -1;
+      kmap[k] = kr < 0 ? -1 : kr * (int)a.w_sk;
+    }
+  }
+  if constexpr (PRO == UIR_PRO_LN) {
+    for (int k = threadIdx.x; k < K8; k += 256) {
+      lng[k] = k < a.K ? a.ln_g[k] : 0.f;
+      lng[K8 + k] = k < a.K ? a.ln_b[k] : 0.f;
+    }
+  }
+  __syncthreads();
+  {
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int tap = 0; tap < a.taps; ++tap) {
+      const int wt = (a.flip ? (a.taps - 1 - tap) : tap) * (int)a.w_st;
+      float* wp = wl + tap * K8;
+      if (a.w_sk == 1) {          // k contiguous in memory: lanes along k
+        for (int nl = ty; nl < NC; nl += 8) {
+          const int no = nmap[nl];
+          for (int k = tx; k < K8; k += 32) {
+            const int ko = kmap[k];
+            const bool ok = no >= 0 && ko >= 0;
+            const float v = W[ok ? no + ko + wt : 0];
+            wp[nl * Kp + k] = ok ? v : 0.f;
+          }
+        }
+      } else {                    // n (or neither) contiguous: lanes along n
+        for (int k = ty; k < K8; k += 8) {
+          const int ko = kmap[k];
+#pragma unroll
+          for (int nl = tx; nl < NC; nl += 32) {
+            const int no = nmap[nl];
+            const bool ok = no >= 0 && ko >= 0;
+            const float v = W[ok ? no + ko + wt : 0];
+            wp[nl * Kp + k] = ok ? v : 0.f;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const float* wbase = wl + r * Kp + 4 * h2;
+  float bias[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + 32 * nt + r;
+    const int nr = (n < a.N) ? uir_colmap(n, a.n_grp_real, a.n_grp_pad) : -1;
+    bias[nt] = (a.bias && nr >= 0) ? a.bias[nr] : 0.f;
+  }
+
   int tile = blockIdx.x, c = 0;
   float mean = 0.f, rstd = 0.f;
   f32x16 acc[NT];
 
-  bool ok0 = true, ok1 = true;
   auto step = [&](float4 (&an)[4], float4 (&un)[NU], const bool anok, float4 (&nx)[4], float4 (&nu)[NU], bool& nxok) -> bool {
     const int m0 = tile * 128 + wave * 32;
     const int m = m0 + r;
@@ -448,7 +487,6 @@ __global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, c
   };
 
   if (tile < tiles) {
-    ok0 = load_unit(P0, U0, tile, 0);
     while (true) {
       if (!step(P0, U0, ok0, P1, U1, ok1)) break;
       if (!step(P1, U1, ok1, P0, U0, ok0)) break;
@@ -484,9 +522,10 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // small problems (deep U-Net levels): favour many narrow column groups over A re-use - the
     // row panel is L2-resident there and parallelism is what is missing
     if ((long)((a.M + 127) / 128) * groups1 * a.batches < 1024) nt1 = 1;
-    while (nt1 > 1 && (size_t)nt1 * 32 * Kp * 4 > 64 * 1024) { --nt1; }
+    if (const char* e = getenv("UIR_NT")) { const int v = atoi(e); if (v >= 1 && v <= 3) nt1 = v < tiles ? v : tiles; }  // tuning aid
+    while (nt1 > 1 && (size_t)nt1 * 32 * Kp * 4 > 60 * 1024) { --nt1; }
     groups1 = (tiles + nt1 - 1) / nt1;
-    const size_t lds = (size_t)nt1 * 32 * Kp * 4 + (a.pro == UIR_PRO_LN ? (size_t)2 * K8 * 4 : 0);
+    const size_t lds = (size_t)nt1 * 32 * Kp * 4 + (size_t)2 * K8 * 4 + (size_t)(nt1 * 32 + K8) * 4;
     const bool combo_ok = (a.pro == UIR_PRO_NONE) || (a.epi == UIR_EPI_PLAIN && !(a.pro == UIR_PRO_LN && a.R));
     if (lds <= 100 * 1024 && combo_ok) {
       const int rtiles = (a.M + 127) / 128;
