@@ -30,6 +30,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ALG_BYTES_PER_IMAGE_256 = 10.0625e9     # SURVEY.md 8(d) / BASELINE.md section 3 (train step, 256x256)
+# HBM traffic per step from the committed PMC passes of THIS command (tools/pmc_traffic.py: separate
+# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH x2 on gfx950); a bench run cannot collect PMCs itself
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01", "c_pmc_traffic_275imgs.json")
 ALG_FLOPS_PER_IMAGE_256 = 90.14e9
 HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
@@ -139,8 +142,13 @@ def main():
         scale = (S * S) / (256.0 * 256.0)
         alg_bytes_step = ALG_BYTES_PER_IMAGE_256 * scale * B          # per GPU per step
         achieved = alg_bytes_step / (ms * 1e-3)
+        traffic, traffic_src = None, None
+        if S == 256 and B == 16 and os.path.exists(TRAFFIC_FILE):
+            with open(TRAFFIC_FILE) as tf:
+                traffic = json.load(tf)["hbm_bytes_per_step"]
+            traffic_src = os.path.relpath(TRAFFIC_FILE, ROOT) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
         roof = {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK, "traffic": None,
+                "frac": achieved / HBM_PEAK, "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_step": alg_bytes_step,
                 "launch": "one train step = forward+backward launch lists + loss + clip/Adam",
                 "mfma_frac_fp32": (ALG_FLOPS_PER_IMAGE_256 * scale * B / (ms * 1e-3)) / 157.3e12}

@@ -249,3 +249,52 @@ def test_train_trajectory_cfg1_vs_reference():
     fin = dict(zip(g["final_names"], g["final_norms"]))
     for n, p in model.named_parameters():
         assert abs(float(p.detach().double().norm()) - fin[n]) <= 1e-4 * max(fin[n], 1e-6), n
+
+
+def test_full_size_properties_b16_256():
+    """BASELINE workload size (B=16, 256x256): size-independent properties of the train step.
+    (1) bitwise run-to-run determinism of output and of every gradient (slab reductions, no float atomics);
+    (2) batch-permutation equivariance: permuting the samples permutes the outputs and leaves the summed
+        weight gradients unchanged up to fp32 summation order; (3) the kf half of kv/kv_conv and the 63 dead
+        tensors get exactly zero gradient; (4) loss/PSNR reductions agree with torch on the same tensors."""
+    torch.manual_seed(7)
+    model = init_model("SpectralTransformer").to(DEV)
+    fp = model.flat_params()
+    B, S = 16, 256
+    g = torch.Generator(device="cpu").manual_seed(3)
+    raw = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
+    ref = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
+    plan = model._plan_for(raw)
+
+    def run(x, t):
+        out = plan.forward(x).clone()
+        res = ops.loss_sums(out, t, L.LOSS_KINDS["L1withColor"]).clone()
+        dout = ops.loss_grad(out, t, torch.ones(1, device=DEV), L.LOSS_KINDS["L1withColor"])
+        plan.backward(dout)
+        torch.cuda.synchronize()
+        return out, res, fp.grad.clone()
+
+    o1, r1, g1 = run(raw, ref)
+    o2, r2, g2 = run(raw, ref)
+    assert torch.equal(o1, o2) and torch.equal(g1, g2) and torch.equal(r1, r2)           # (1)
+    perm = torch.randperm(B, generator=g).to(DEV)
+    o3, r3, g3 = run(raw[perm].contiguous(), ref[perm].contiguous())
+    assert float((o3 - o1[perm]).abs().max()) <= 1e-6 * float(o1.abs().max())           # (2) per-sample independence
+    gmax = float(g1.abs().max())
+    assert float((g3 - g1).abs().max()) <= 2e-4 * gmax
+    assert abs(float(r3[0]) - float(r1[0])) <= 1e-6 * abs(float(r1[0]))
+    assert float(g1[fp.n_live:].abs().max()) == 0.0                                      # (3)
+    for n in fp.live_names:
+        if n.endswith(".attn.kv.weight"):
+            c = fp.shapes[n][1]
+            assert float(fp.gview(n)[:c].abs().max()) == 0.0
+        if n.endswith(".attn.kv_conv.weight"):
+            c = fp.shapes[n][0] // 2
+            assert float(fp.gview(n)[:c].abs().max()) == 0.0
+    d = o1 - ref                                                                         # (4)
+    lum = (d * torch.tensor([0.299, 0.587, 0.114], device=DEV).view(1, 3, 1, 1)).sum(1)
+    want = (0.5 * (d ** 2).mean() + 0.25 * d.abs().mean() + 0.25 * (lum ** 2).mean()) / (B * 3)
+    assert abs(float(r1[0]) - float(want)) <= 1e-5 * abs(float(want))
+    ps = 20 * torch.log10(1 / ((o1.clamp(0, 1) - ref.clamp(0, 1)) ** 2).mean().sqrt())
+    assert abs(float(r1[1]) - float(ps)) < 1e-3
+    assert torch.isfinite(g1).all() and torch.isfinite(o1).all()
