@@ -119,6 +119,18 @@ typedef struct UirDwWgradArgs {
 } UirDwWgradArgs;
 int uir_dwconv_wgrad(const UirDwWgradArgs* args, void* stream);
 
+/* fused backward of the depthwise conv: dX = conv(dY, W flipped) AND slab[block][Creal][9] partials of dW
+ * in one pass (dY read once).  Autograd's convolution_backward of the three depthwise sites above. */
+typedef struct UirDwBwdArgs {
+  const float* dY; const float* X; const float* Wt; float* dX; float* slab;
+  int ldy, ldx, ldo;
+  int B, H, Wd, C;
+  int grp_real, grp_pad;
+  int creal;
+  int nblocks;
+} UirDwBwdArgs;
+int uir_dwconv_bwd_fused(const UirDwBwdArgs* args, void* stream);
+
 /* ----------------------------------------------------------- uir_layernorm */
 /* Input-gradient of the channel LayerNorm (+ residual-path gradient) and per-block partials
  * of dgamma/dbeta: dX = dRes + LN'(dT).  slab[block][2*C] = (dgamma | dbeta).

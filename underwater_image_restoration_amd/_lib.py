@@ -58,6 +58,13 @@ class DwWgradArgs(C.Structure):
                 ("grp_real", C.c_int), ("grp_pad", C.c_int), ("creal", C.c_int), ("nblocks", C.c_int)]
 
 
+class DwBwdArgs(C.Structure):
+    _fields_ = [("dY", fp), ("X", fp), ("Wt", fp), ("dX", fp), ("slab", fp),
+                ("ldy", C.c_int), ("ldx", C.c_int), ("ldo", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
+                ("grp_real", C.c_int), ("grp_pad", C.c_int), ("creal", C.c_int), ("nblocks", C.c_int)]
+
+
 class LnBwdArgs(C.Structure):
     _fields_ = [("dT", fp), ("X", fp), ("stats", fp), ("gamma", fp), ("dRes", fp), ("dX", fp), ("slab", fp),
                 ("ldt", C.c_int), ("ldx", C.c_int), ("ldr", C.c_int), ("ldo", C.c_int),
@@ -96,6 +103,7 @@ SIGNATURES = {
     "uir_reduce_slab": [fp, i32, i64, fp, i64, i32, f32, fp],
     "uir_dwconv": [C.POINTER(DwArgs), fp],
     "uir_dwconv_wgrad": [C.POINTER(DwWgradArgs), fp],
+    "uir_dwconv_bwd_fused": [C.POINTER(DwBwdArgs), fp],
     "uir_layernorm_bwd": [C.POINTER(LnBwdArgs), fp],
     "uir_attn_fwd": [C.POINTER(AttnFwdArgs), fp],
     "uir_attn_bwd": [C.POINTER(AttnBwdArgs), fp],

@@ -270,7 +270,7 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
 }
 
 template <int NT, int PRO, int EPI, bool HAS_R>
-__global__ __launch_bounds__(256) void uir_gemm1x1_kernel(const UirGemmArgs a, const int Kp, const int tiles) {
+__global__ __launch_bounds__(256, 3) void uir_gemm1x1_kernel(const UirGemmArgs a, const int Kp, const int tiles) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h2 = lane >> 5;

@@ -5,6 +5,8 @@ flat gradient buffer is all-reduced once over RCCL/xGMI between backward and the
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -26,10 +28,27 @@ class TrainStep:
         if self.world > 1:
             parallel.broadcast_flat_params(self.flat.flat, process_group)
         self._one = torch.ones(1, dtype=torch.float32, device=self.flat.device)
+        # optional (UIR_MAIN_HIPRIO=1): critical chain on a high-priority stream; measured neutral on MI355X
+        self._hp = None
+        if self.flat.device.type == "cuda" and os.environ.get("UIR_MAIN_HIPRIO", "0") == "1":
+            hi = min(torch.cuda.Stream.priority_range()) if hasattr(torch.cuda.Stream, "priority_range") else 0
+            self._hp = torch.cuda.Stream(device=self.flat.device, priority=hi)
 
     def __call__(self, raw: torch.Tensor, ref: torch.Tensor, lr: float | None = None):
         """One optimisation step on a device-resident batch.  Returns (loss, grad_norm) as
         device tensors (reading them is the only synchronisation, and it is the caller's)."""
+        if self._hp is not None:
+            cur = torch.cuda.current_stream()
+            self._hp.wait_stream(cur)
+            with torch.cuda.stream(self._hp):
+                res, norm = self._step(raw, ref, lr)
+            cur.wait_stream(self._hp)
+            res.record_stream(cur)      # allocated on the high-priority stream, consumed by the caller's stream
+            norm.record_stream(cur)
+            return res, norm
+        return self._step(raw, ref, lr)
+
+    def _step(self, raw, ref, lr):
         plan = self.model._plan_for(raw)
         out = plan.forward(raw)
         res = ops.loss_sums(out, ref, self.kind)
