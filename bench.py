@@ -95,8 +95,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback for the HIP path)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("UIR_FORCE_ALLREDUCE") == "1":
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)   # "nccl" is RCCL on ROCm
 
     from underwater_image_restoration_amd import init_model
@@ -204,7 +207,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

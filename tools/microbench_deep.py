@@ -22,6 +22,8 @@ for lvl, (M, C) in (("L2", (65536, 64)), ("L3", (16384, 128))):
         r.fwd = []; r.cur = r.fwd; r.meta[id(r.fwd)] = []; r.lanes[id(r.fwd)] = []
         fn(); cases[name] = (r.fwd, r.meta[id(r.fwd)])
     case("qkv_ln", lambda: r.gemm("a", x, Wqkv, qkvb, N=3 * C, K=C, w_sn=C, w_sk=1, pro=L.PRO_LN, ln=(g1, b1), stats=st))
+    case("qkv_plain", lambda: r.gemm("a", x, Wqkv, qkvb, N=3 * C, K=C, w_sn=C, w_sk=1))
+    case("ffn_in_plain", lambda: r.gemm("a", x, Win, gout, N=2 * hp, K=C, w_sn=C, w_sk=1, n_grp=(h, hp)))
     case("ffn_in_ln", lambda: r.gemm("a", x, Win, gout, N=2 * hp, K=C, w_sn=C, w_sk=1, n_grp=(h, hp), pro=L.PRO_LN, ln=(g1, b1), stats=st))
     case("ffn_out_gate", lambda: r.gemm("a", gp, Wout, y, N=C, K=h, w_sn=h, w_sk=1, pro=L.PRO_GATE, gate_off=hp, R=x))
     case("dgate", lambda: r.gemm("a", x, Wout, gout, N=hp, K=C, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=gp, g_off=hp))
