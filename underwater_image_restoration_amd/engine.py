@@ -50,8 +50,6 @@ def pad4(n: int) -> int:
 
 
 def pad16(n: int) -> int:
-    """GDFN half-width padding: 2*pad16(h) floats is a multiple of 128 bytes, so every HWC row of
-    the gated tensors starts on a cache line (704-byte rows measured ~35 % slower than aligned ones)."""
     return (n + 15) & ~15
 
 
@@ -575,7 +573,9 @@ class Plan(Recorder):
         """TransformerBlock (SpectralTransformer.py:142-148) on HWC rows x [M, C]."""
         B, H, W = dims
         M, HW = B * H * W, H * W
-        h, hp = hidden_of(C_), pad16(hidden_of(C_))
+        h = hidden_of(C_)
+        hp = pad16(h)      # full 128-B rows: A/B 57.6 ms/step vs 59.7 with hp = pad4(h) inside a 128-B aligned row stride
+        ldg = (2 * hp + 31) & ~31          # row stride of the GDFN tensors: 128-byte aligned rows, only 2*hp columns touched
         P, Gr = self.P, self.Gr
         a = f"{pfx}.attn"
         Wqkv, Wdw = P(f"{a}.qkv.weight"), P(f"{a}.qkv_conv.weight")
@@ -595,7 +595,7 @@ class Plan(Recorder):
         Pm = self.alloc(C_, C_)
         attn, WA, WB = self.alloc(B * C_ * (C_ // heads)), self.alloc(B, C_ * C_), self.alloc(B, C_ * C_)
         u, vf, x1 = self.alloc(M, C_), self.alloc(M, C_), self.alloc(M, C_)
-        gpre, g = self.alloc(M, 2 * hp), self.alloc(M, 2 * hp)
+        gpre, g = self.alloc(M, ldg)[:, :2 * hp], self.alloc(M, ldg)[:, :2 * hp]
         y = self.alloc(M, C_)
         q_, k_, v_ = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
 
@@ -624,7 +624,7 @@ class Plan(Recorder):
         self.gemm(n + ".ffn_out", g, Wout, y, N=C_, K=h, w_sn=h, w_sk=1, pro=L.PRO_GATE, gate_off=hp, R=x1)
 
         def backward(dy: torch.Tensor) -> torch.Tensor:
-            dg, dgpre = self.alloc(M, 2 * hp), self.alloc(M, 2 * hp)
+            dg, dgpre = self.alloc(M, ldg)[:, :2 * hp], self.alloc(M, ldg)[:, :2 * hp]
             dt = self.alloc(M, C_)
             dx1 = self.alloc(M, C_)
             dWB, dWA = self.alloc(B, C_ * C_), self.alloc(B, C_ * C_)
