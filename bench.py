@@ -106,7 +106,9 @@ def main():
     from underwater_image_restoration_amd.trainer import TrainStep
 
     torch.manual_seed(1234)                               # same random init on every rank (replicated weights)
-    model = init_model("SpectralTransformer").to(dev)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # the factory prints "modelCreated" like the reference: keep stdout = ONE JSON line
+        model = init_model("SpectralTransformer").to(dev)
     step = TrainStep(model, args.loss, lr=3e-4)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     B, S = args.batch, args.size
