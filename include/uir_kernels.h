@@ -254,6 +254,7 @@ int uir_sumsq_partials(const float* g, long n, float* slab, int nblocks, void* s
 typedef struct UirAdamArgs {
   float* p; const float* g; float* m; float* v;
   const float* sumsq; float* norm_out;
+  const float* hyper;  /* optional device float[4] = {lr, bc1, bc2, gscale}: overrides the by-value fields (hipGraph replay) */
   long n;
   float lr, beta1, beta2, eps, bc1, bc2, max_norm, gscale;
 } UirAdamArgs;

@@ -266,17 +266,21 @@ def test_full_size_properties_b16_256():
     ref = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
     plan = model._plan_for(raw)
 
-    def run(x, t):
-        out = plan.forward(x).clone()
+    def run(x, t, serial=False):
+        out = plan.forward(x, serial=serial).clone()
         res = ops.loss_sums(out, t, L.LOSS_KINDS["L1withColor"]).clone()
         dout = ops.loss_grad(out, t, torch.ones(1, device=DEV), L.LOSS_KINDS["L1withColor"])
-        plan.backward(dout)
+        fp.grad.zero_()                                   # live slots are rewritten; the kf halves are never written (exact 0)
+        plan.backward(dout, serial=serial)
         torch.cuda.synchronize()
         return out, res, fp.grad.clone()
 
+    o0, r0, g0 = run(raw, ref, serial=True)               # one stream, list order: the reference schedule
     o1, r1, g1 = run(raw, ref)
-    o2, r2, g2 = run(raw, ref)
-    assert torch.equal(o1, o2) and torch.equal(g1, g2) and torch.equal(r1, r2)           # (1)
+    assert torch.equal(o1, o0) and torch.equal(g1, g0) and torch.equal(r1, r0)           # (1) 3-stream overlap == serial, bitwise
+    for _ in range(3):                                                                    #     ... and stays so (no hidden races)
+        o2, r2, g2 = run(raw, ref)
+        assert torch.equal(o1, o2) and torch.equal(g1, g2) and torch.equal(r1, r2)
     perm = torch.randperm(B, generator=g).to(DEV)
     o3, r3, g3 = run(raw[perm].contiguous(), ref[perm].contiguous())
     assert float((o3 - o1[perm]).abs().max()) <= 1e-6 * float(o1.abs().max())           # (2) per-sample independence

@@ -89,7 +89,7 @@ class DftArgs(C.Structure):
 
 
 class AdamArgs(C.Structure):
-    _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("sumsq", fp), ("norm_out", fp), ("n", C.c_long),
+    _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("sumsq", fp), ("norm_out", fp), ("hyper", fp), ("n", C.c_long),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
                 ("bc1", C.c_float), ("bc2", C.c_float), ("max_norm", C.c_float), ("gscale", C.c_float)]
 

@@ -25,7 +25,10 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __rest
   if (threadIdx.x == 0) slab[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-__global__ __launch_bounds__(256) void clip_adam_kernel(const UirAdamArgs a) {
+__global__ __launch_bounds__(256) void clip_adam_kernel(UirAdamArgs a) {
+  if (a.hyper) {  // per-step values live in device memory so a captured hipGraph replays with fresh ones
+    a.lr = a.hyper[0]; a.bc1 = a.hyper[1]; a.bc2 = a.hyper[2]; a.gscale = a.hyper[3];
+  }
   const float total = sqrtf(a.sumsq[0]) * a.gscale;
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.norm_out) a.norm_out[0] = total;
   float coef = a.max_norm / (total + 1e-6f);
@@ -54,7 +57,7 @@ extern "C" int uir_sumsq_partials(const float* g, long n, float* slab, int nbloc
 extern "C" int uir_clip_adam_step(const UirAdamArgs* p, void* stream) {
   const UirAdamArgs& a = *p;
   UIR_REQUIRE(a.p && a.g && a.m && a.v && a.sumsq && a.n > 0);
-  UIR_REQUIRE(a.bc1 > 0.f && a.bc2 > 0.f);
+  UIR_REQUIRE(a.hyper || (a.bc1 > 0.f && a.bc2 > 0.f));
   long blocks = (a.n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);

@@ -218,7 +218,9 @@ class Recorder:
             elif t is not None:
                 self.keep.append(t)
 
-    def run(self, ops: Sequence[tuple], marks: "list | None" = None) -> None:
+    def run(self, ops: Sequence[tuple], marks: "list | None" = None, serial: bool = False) -> None:
+        """Execute a launch list.  serial=True ignores the lanes (everything on the current stream, in list
+        order): the reference schedule the overlapped execution must reproduce bit for bit."""
         if self.dev.type != "cuda":
             st = C.c_void_p(0)
             for fn, args, name in ops:
@@ -231,7 +233,7 @@ class Recorder:
         main = torch.cuda.current_stream()
         st0 = C.c_void_p(main.cuda_stream)
         lanes = self.lanes[id(ops)]
-        if 1 not in lanes and 4 not in lanes:
+        if serial or (1 not in lanes and 4 not in lanes):
             for fn, args, name in ops:
                 if fn is None:
                     continue
@@ -251,7 +253,8 @@ class Recorder:
         st4 = C.c_void_p(bulk.cuda_stream)
         nev = 0
         main_dirty = True           # main has launched work the side stream has not been ordered after
-        bulk_dirty = True
+        bulk_dirty = True           # ... the bulk stream has not been ordered after
+        side_dirty = False          # side has launched work the bulk stream has not been ordered after
         for (fn, args, name), lane in zip(ops, lanes):
             if lane == 3:                       # stage marker
                 if marks is not None:
@@ -278,6 +281,14 @@ class Recorder:
                     ev.record(main)
                     bulk.wait_event(ev)
                     bulk_dirty = False
+                if side_dirty:      # bulk work may consume side-lane results (e.g. the Sups weight gradient reads `ds`)
+                    if nev == len(self._events):
+                        self._events.append(torch.cuda.Event())
+                    ev = self._events[nev]
+                    nev += 1
+                    ev.record(side)
+                    bulk.wait_event(ev)
+                    side_dirty = False
                 rc = fn(*args, st4)
                 if rc:
                     L.check(rc, name)
@@ -292,6 +303,7 @@ class Recorder:
                     side.wait_event(ev)
                     main_dirty = False
                 rc = fn(*args, st1)
+                side_dirty = True
             else:
                 rc = fn(*args, st0)
                 main_dirty = True
@@ -948,12 +960,12 @@ class Plan(Recorder):
         meta[:] = [meta[i] for i in order]
 
     # ------------------------------------------------------------------- run
-    def forward(self, x_nchw: torch.Tensor) -> torch.Tensor:
+    def forward(self, x_nchw: torch.Tensor, serial: bool = False) -> torch.Tensor:
         self.in_nchw.copy_(x_nchw)
-        self.run(self.fwd)
+        self.run(self.fwd, serial=serial)
         return self.out_nchw
 
-    def backward(self, dout_nchw: torch.Tensor) -> None:
+    def backward(self, dout_nchw: torch.Tensor, serial: bool = False) -> None:
         """Fills fp.grad (every live parameter's slot is overwritten, not accumulated)."""
         self.dout_nchw.copy_(dout_nchw)
-        self.run(self.bwd)
+        self.run(self.bwd, serial=serial)

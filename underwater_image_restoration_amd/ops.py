@@ -66,23 +66,37 @@ class FusedClipAdam:
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.t = 0
         self.args = L.AdamArgs()
+        # per-step scalars {lr, bc1, bc2, gscale} live in device memory (written from a pinned host
+        # staging buffer on the launch stream), so the kernels can be captured once in a hipGraph
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
+        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
 
-    def step(self, lr: float | None = None, grad_scale: float = 1.0) -> torch.Tensor:
-        """Returns the (pre-clip) total gradient norm as a device tensor [1]; no host sync."""
+    def advance(self, lr: float | None = None, grad_scale: float = 1.0) -> None:
+        """Host side of one step: bump the step count and stage this step's scalars (async H2D, 16 bytes)."""
         if lr is not None:
             self.lr = lr
         self.t += 1
+        h = self._hyper_host
+        h[0], h[1], h[2], h[3] = self.lr, 1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t, grad_scale
+        self.hyper.copy_(h, non_blocking=True)
+
+    def launch(self) -> torch.Tensor:
+        """Device side: sum of squares -> reduce -> clip + Adam.  Capturable (no host values baked in)."""
         fp, st = self.flat, _stream()
         L.check(lib.uir_sumsq_partials(fp.grad.data_ptr(), self.n, self.slab.data_ptr(), _SUMSQ_BLOCKS, st), "uir_sumsq_partials")
         L.check(lib.uir_reduce_slab(self.slab.data_ptr(), _SUMSQ_BLOCKS, 1, self.sumsq.data_ptr(), 1, 0, 1.0, st), "uir_reduce_slab")
         a = self.args
         a.p, a.g, a.m, a.v = fp.flat.data_ptr(), fp.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
         a.sumsq, a.norm_out, a.n = self.sumsq.data_ptr(), self.norm.data_ptr(), self.n
-        a.lr, a.beta1, a.beta2, a.eps = self.lr, self.betas[0], self.betas[1], self.eps
-        a.bc1, a.bc2 = 1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t
-        a.max_norm, a.gscale = self.max_norm, grad_scale
+        a.hyper = self.hyper.data_ptr()
+        a.beta1, a.beta2, a.eps, a.max_norm = self.betas[0], self.betas[1], self.eps, self.max_norm
         L.check(lib.uir_clip_adam_step(C.byref(a), st), "uir_clip_adam_step")
         return self.norm
+
+    def step(self, lr: float | None = None, grad_scale: float = 1.0) -> torch.Tensor:
+        """Returns the (pre-clip) total gradient norm as a device tensor [1]; no host sync."""
+        self.advance(lr, grad_scale)
+        return self.launch()
 
     def state_dict(self):
         return {"step": self.t, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr}
