@@ -302,3 +302,46 @@ def test_full_size_properties_b16_256():
     ps = 20 * torch.log10(1 / ((o1.clamp(0, 1) - ref.clamp(0, 1)) ** 2).mean().sqrt())
     assert abs(float(r1[1]) - float(ps)) < 1e-3
     assert torch.isfinite(g1).all() and torch.isfinite(o1).all()
+
+
+def test_model_trainer_end_to_end(tmp_path, capsys):
+    """The reference's driver surface on the GPU: ModelTrainer(dirs).train(args, arch, epochs, lr) on a tiny PNG
+    dataset (file names like the reference's `N_img_.png`), then the checkpoint it wrote loads into a fresh model
+    and reproduces the trained model's output."""
+    import os
+    import types
+    from PIL import Image
+    from underwater_image_restoration_amd.ModelTrainer import ModelTrainer
+    rng = np.random.RandomState(0)
+    dirs = {}
+    for d in ("a", "b", "ta", "tb"):
+        p = tmp_path / d
+        p.mkdir()
+        dirs[d] = str(p)
+        for i in range(4 if d in ("a", "b") else 2):
+            Image.fromarray(rng.randint(0, 255, (64, 64, 3), dtype=np.uint8)).save(p / f"{i}_img_.png")
+    args = types.SimpleNamespace(train_batch_size=2, lossf="L1", lr=3e-4, arch="SpectralTransformer", use_dwt="Fourier",
+                                 optim="adam", image_size=64, workers=0)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        torch.manual_seed(11)
+        model = ModelTrainer(dirs["a"], dirs["b"], dirs["ta"], dirs["tb"]).train(args, "SpectralTransformer", 2, 3e-4, "cuda")
+    finally:
+        os.chdir(cwd)
+    out = capsys.readouterr().out
+    assert "Batch 2/2, Loss:" in out and "Validation Loss:" in out and "Training completed!" in out
+    ckpts = [os.path.join(r, f) for r, _, fs in os.walk(tmp_path) for f in fs if f.endswith(".pth")]
+    assert ckpts, "no checkpoint written"
+    ck = torch.load(sorted(ckpts)[-1], weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}          # src/ModelTrainer.py:176-181
+    man = np.load(os.path.join(GOLDEN, "st_manifest.npz"))
+    assert list(ck["model_state_dict"].keys()) == list(man["names"])
+    fresh = init_model("SpectralTransformer")
+    fresh.load_state_dict(ck["model_state_dict"])
+    fresh = fresh.to(DEV)
+    x = O.closed_form_images(2, 64, 5).to(DEV)
+    with torch.no_grad():
+        assert torch.equal(fresh(x), model(x))
+    with pytest.raises(RuntimeError):
+        ModelTrainer(dirs["a"], dirs["b"], dirs["ta"], dirs["tb"]).train(args, "SpectralTransformer", 1, 3e-4, "cpu")
