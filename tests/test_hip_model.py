@@ -345,3 +345,33 @@ def test_model_trainer_end_to_end(tmp_path, capsys):
         assert torch.equal(fresh(x), model(x))
     with pytest.raises(RuntimeError):
         ModelTrainer(dirs["a"], dirs["b"], dirs["ta"], dirs["tb"]).train(args, "SpectralTransformer", 1, 3e-4, "cpu")
+
+
+@pytest.mark.parametrize("B,H,W", [(3, 72, 40), (1, 8, 8), (2, 24, 56)])
+def test_ragged_shapes_vs_oracle(B, H, W):
+    """Shapes the tiles do not divide: H != W, odd-length spectra at the deepest level (9x5, 1x1, 3x7), row counts
+    that are not multiples of 32/128, one-pixel feature maps.  Output and every gradient vs the fp64 oracle."""
+    P64 = O.closed_form_state(torch.float64)
+    n = B * 3 * H * W
+    raw = torch.from_numpy(O._hash_uniform(n, 91 + H).reshape(B, 3, H, W))
+    ref = torch.from_numpy(O._hash_uniform(n, 92 + W).reshape(B, 3, H, W))
+    loss64, out64, grads64 = O.loss_and_grads(P64, raw, ref, "charbonnier")
+    fp = flat_from_state(P64)
+    plan = Plan(fp, B, H, W)
+    out = plan.forward(raw.float().to(DEV)).clone()
+    res = ops.loss_sums(out, ref.float().to(DEV), L.LOSS_KINDS["charbonnier"])
+    dout = ops.loss_grad(out, ref.float().to(DEV), torch.ones(1, device=DEV), L.LOSS_KINDS["charbonnier"])
+    plan.backward(dout)
+    torch.cuda.synchronize()
+    e_out = rel(out, out64)
+    assert e_out < 1e-3, e_out
+    assert abs(float(res[0]) - float(loss64)) < 1e-4 * abs(float(loss64))
+    gmax = max(float(g.abs().max()) for g in grads64.values())
+    worst = ("", 0.0)
+    for name, gw in grads64.items():
+        err = float((fp.gview(name).double().cpu() - gw).abs().max())
+        tol = 2e-3 * float(gw.abs().max()) + 2e-6 * gmax
+        if err / tol > worst[1]:
+            worst = (name, err / tol)
+        assert err <= tol, (name, err, float(gw.abs().max()))
+    print(f"ragged {B}x{H}x{W}: out err {e_out:.2e}, worst grad err/tol {worst}")

@@ -937,7 +937,7 @@ class Plan(Recorder):
         self.mark("bwd.enc0(L0,C16)")
         embed_bw(df0, need_dx=False)
         self.mark("bwd.embed")
-        self._defer_bulk(self.bwd, "bwd.dec2(L0,C32)")
+        self._defer_bulk(self.bwd, os.environ.get("UIR_DEFER_AT", "bwd.dec2(L0,C32)"))
         self.cur = self.fwd
 
     def _defer_bulk(self, ops: list, marker: str) -> None:
