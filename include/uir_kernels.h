@@ -131,6 +131,32 @@ typedef struct UirDwBwdArgs {
 } UirDwBwdArgs;
 int uir_dwconv_bwd_fused(const UirDwBwdArgs* args, void* stream);
 
+/* ---------------------------------------------------------------- uir_gdfn */
+/* Tile-fused GDFN forward of one TransformerBlock:
+ *   Y = X + W_out . ( gelu(dw3x3(W_in . LN(X))[:h]) * dw3x3(W_in . LN(X))[h:] )
+ * One pass over the pixels instead of project_in -> conv -> gate/project_out as three kernels.
+ * Replaces SpectralTransformer.py:127-130 (GDFN.forward) together with norm2 and the residual
+ * add of :147-148.  T1/T2 (both or neither): the pre-/post-depthwise tensors the backward
+ * kernels read, x1 half at column c, x2 half at column hp + c, pad columns c in [h, hp) zero. */
+typedef struct UirGdfnFwdArgs {
+  const float* X;      /* [B*H*W][ldx] block input (also the residual), float4-aligned rows     */
+  const float* ln_g;   /* norm2 gamma[C], beta[C] (16-B aligned)                                 */
+  const float* ln_b;
+  const float* Win;    /* project_in  [2h][C]   (16-B aligned)                                   */
+  const float* Wdw;    /* conv        [2h][1][3][3]                                              */
+  const float* Wout;   /* project_out [C][h]                                                     */
+  float* Y;            /* [B*H*W][ldy]                                                           */
+  float* T1;           /* optional [B*H*W][ldt]                                                  */
+  float* T2;           /* optional [B*H*W][ldt]                                                  */
+  float* stats;        /* optional [B*H*W][2] = (mean, rstd) of norm2 for the backward           */
+  int ldx, ldy, ldt;
+  int B, H, Wd;
+  int C;               /* in {16,32,64,128}                                                      */
+  int h, hp;           /* hidden = int(2.66 C); hp = h padded to a multiple of 16                */
+  float ln_eps;
+} UirGdfnFwdArgs;
+int uir_gdfn_fwd(const UirGdfnFwdArgs* args, void* stream);
+
 /* ----------------------------------------------------------- uir_layernorm */
 /* Input-gradient of the channel LayerNorm (+ residual-path gradient) and per-block partials
  * of dgamma/dbeta: dX = dRes + LN'(dT).  slab[block][2*C] = (dgamma | dbeta).

@@ -332,6 +332,46 @@ def test_dwconv_padded_groups():
     assert rel(dW.reshape(2 * h, 1, 3, 3), dw) < TOL
 
 
+# ---------------------------------------------------------------- uir_gdfn
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 16), (1, 19, 37, 32), (2, 8, 16, 64), (1, 11, 9, 128), (1, 1, 1, 32),
+                                     (1, 40, 24, 16)])
+@pytest.mark.parametrize("store", [True, False])
+def test_gdfn_fwd_fused(B, H, W, C, store):
+    """Tile-fused GDFN forward (+ norm2 + residual) vs torch fp64; ragged tiles, image edges, pad channels."""
+    h = int(C * 2.66)
+    hp = (h + 15) & ~15
+    ldt = (2 * hp + 31) & ~31
+    x = rnd(B, C, H, W, seed=1, scale=2)
+    gam, bet = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    win, wdw, wout = rnd(2 * h, C, 1, 1, seed=4, scale=C ** -0.5), rnd(2 * h, 1, 3, 3, seed=5, scale=1 / 3), rnd(C, h, 1, 1, seed=6, scale=h ** -0.5)
+    rows = hwc(x)
+    xn = F.layer_norm(rows, (C,), gam, bet, 1e-5)
+    xn_img = xn.reshape(B, H, W, C).permute(0, 3, 1, 2)
+    t1 = F.conv2d(xn_img, win)
+    t2 = F.conv2d(t1, wdw, padding=1, groups=2 * h)
+    y = x + F.conv2d(F.gelu(t2[:, :h]) * t2[:, h:], wout)
+    r = rec()
+    M = B * H * W
+    Y, st = r.alloc(M, C), r.alloc(M, 2)
+    T1 = r.alloc(M, ldt)[:, :2 * hp] if store else None
+    T2 = r.alloc(M, ldt)[:, :2 * hp] if store else None
+    if store:
+        T1.fill_(7.0)
+        T2.fill_(7.0)
+    r.gdfn_fwd("g", dev(rows), (dev(gam), dev(bet)), dev(win), dev(wdw), dev(wout), Y, C_=C, h=h, hp=hp, dims=(B, H, W),
+               T1=T1, T2=T2, stats=st)
+    r.run(r.fwd)
+    assert rel(chw(Y, B, H, W), y) < TOL
+    mean = rows.mean(1)
+    rstd = (rows.var(1, unbiased=False) + 1e-5).rsqrt()
+    assert rel(st[:, 0], mean) < TOL and rel(st[:, 1], rstd) < TOL
+    if store:
+        for T, t in ((T1, t1), (T2, t2)):
+            tr = hwc(t)
+            assert rel(T[:, :h], tr[:, :h]) < TOL and rel(T[:, hp:hp + h], tr[:, h:]) < TOL
+            assert float(T[:, h:hp].abs().max()) == 0 and float(T[:, hp + h:2 * hp].abs().max()) == 0
+
+
 # ------------------------------------------------------------- uir_layernorm
 @pytest.mark.parametrize("M,C", [(1000, 16), (333, 32), (129, 64), (70, 128)])
 def test_layernorm_bwd(M, C):

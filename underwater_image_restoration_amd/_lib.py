@@ -65,6 +65,14 @@ class DwBwdArgs(C.Structure):
                 ("grp_real", C.c_int), ("grp_pad", C.c_int), ("creal", C.c_int), ("nblocks", C.c_int)]
 
 
+class GdfnFwdArgs(C.Structure):
+    _fields_ = [("X", fp), ("ln_g", fp), ("ln_b", fp), ("Win", fp), ("Wdw", fp), ("Wout", fp),
+                ("Y", fp), ("T1", fp), ("T2", fp), ("stats", fp),
+                ("ldx", C.c_int), ("ldy", C.c_int), ("ldt", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
+                ("h", C.c_int), ("hp", C.c_int), ("ln_eps", C.c_float)]
+
+
 class LnBwdArgs(C.Structure):
     _fields_ = [("dT", fp), ("X", fp), ("stats", fp), ("gamma", fp), ("dRes", fp), ("dX", fp), ("slab", fp),
                 ("ldt", C.c_int), ("ldx", C.c_int), ("ldr", C.c_int), ("ldo", C.c_int),
@@ -104,6 +112,7 @@ SIGNATURES = {
     "uir_dwconv": [C.POINTER(DwArgs), fp],
     "uir_dwconv_wgrad": [C.POINTER(DwWgradArgs), fp],
     "uir_dwconv_bwd_fused": [C.POINTER(DwBwdArgs), fp],
+    "uir_gdfn_fwd": [C.POINTER(GdfnFwdArgs), fp],
     "uir_layernorm_bwd": [C.POINTER(LnBwdArgs), fp],
     "uir_attn_fwd": [C.POINTER(AttnFwdArgs), fp],
     "uir_attn_bwd": [C.POINTER(AttnBwdArgs), fp],

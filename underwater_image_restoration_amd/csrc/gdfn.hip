@@ -1,0 +1,394 @@
+// uir_gdfn_fwd: the whole GDFN forward of one TransformerBlock in ONE pass over the pixels
+//   y = x + W_out . ( gelu(dw3x3(W_in . LN(x))[x1 half]) * dw3x3(W_in . LN(x))[x2 half] )
+// (SpectralTransformer.py:127-130 with the norm2 / residual of :147-148).
+//
+// One workgroup owns a TH x TW pixel tile of one image.  The block input is read once (tile + a
+// one-pixel ring), LayerNorm'd in registers and kept there in MFMA A-operand layout (pixel on the
+// accumulator row, channel on the contraction index).  The hidden dimension is walked in chunks of
+// 16 x1-channels + their 16 x2 partners (one 32-column MFMA tile):
+//   (a) t1 chunk = LN(x) . W_in^T            f32 MFMA, K = C, on tile + ring        -> LDS
+//   (b) t2 = depthwise 3x3 of t1 from LDS (packed-fp32 VALU)                        -> LDS
+//   (c) y += (gelu(t2a) * t2b) . W_out^T     gate applied on the A-operand load; f32 MFMA, K = 16,
+//                                            accumulators live across chunks
+// so the two 2*hp-column intermediates never round-trip through HBM between the three ops.  For
+// training they are still WRITTEN once (the backward kernels read them), as 16-byte stores staged
+// through the LDS copies (a dword store per value costs ~75 SIMD cycles per wave instruction:
+// measured +260 us per 1.6 GB); inference passes T1 = T2 = NULL and the kernel moves 2*C floats
+// per pixel instead of ~27*C.
+// f32 MFMA and VALU work of two waves on one SIMD do NOT overlap on gfx950
+// (tools/probes/mfma_valu_overlap.hip: MFMA-only wave + VALU-only wave = sum of both), so the
+// kernel's floor is MFMA time + VALU time, not their maximum.
+// Out-of-image ring pixels get LN(x) := 0, hence t1 = 0 there: exactly Conv2d's zero padding
+// (project_in has no bias).
+#include "uir_common.h"
+#include "../../include/uir_kernels.h"
+
+namespace {
+
+template <int C, int TH, int TW>
+struct GdfnTile {
+  static constexpr int RW = TW + 2, RH = TH + 2;
+  static constexpr int NPX1 = RW * RH;              // tile + ring pixels
+  static constexpr int NRT1 = (NPX1 + 31) / 32;     // 32-pixel MFMA row tiles over tile + ring
+  static constexpr int RTW = (NRT1 + 3) / 4;        // ... per wave
+  static constexpr int NI = TH * TW;                // interior pixels (multiple of 32)
+  static constexpr int NRTI = NI / 32;
+  static constexpr int UNITS = NRTI * ((C + 31) / 32);  // (c) work units
+  static constexpr int UPW = (UNITS + 3) / 4;
+  static constexpr int S1 = 40;                     // LDS row stride of the t1 chunk (32 cols + 8)
+  static constexpr int SG = 36;                     // LDS row stride of the t2 chunk (16 + 16 cols + 4)
+  static constexpr int NT = (C + 31) / 32;          // 32-column output tiles
+  static constexpr int KJ = C / 8;                  // float4 groups along K=C per lane half
+  static constexpr int SEG = 16 / TW;               // vertical segments of the depthwise walk
+  static constexpr int ROWS = TH / SEG;
+  static constexpr int LDS_FLOATS = NRT1 * 32 * S1 + NI * SG;
+  static constexpr int NST = (NI * 8 + 255) / 256;  // float4 write-out passes (8 lanes per pixel row of 32 floats)
+  static_assert(NI % 32 == 0 && (16 % TW) == 0 && TH % SEG == 0 && C % 8 == 0 && 4 % NT == 0, "tile shape");
+};
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt, i.e. every
+// in-flight global store (the t1/t2 write-out) and load (the next chunk's weights) would be waited
+// for at each of the two barriers per chunk.
+// t1/t2 are next read by the backward pass, a whole forward later: streaming (nt) stores keep them from evicting the
+// tile inputs and weights in L2 (A/B at C=16, 256x256: 309 vs 376 us; C=32: 661 vs 684 us)
+__device__ __forceinline__ void st4(char* p, const float4& v) {
+  __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+}
+__device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }   // value must be in its VGPR here
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+
+template <int C, int TH, int TW, bool STORE>
+__global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdArgs a) {
+  using T = GdfnTile<C, TH, TW>;
+  extern __shared__ float smem[];
+  float* T1s = smem;
+  float* Gs = smem + T::NRT1 * 32 * T::S1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
+  const int tiles_x = (a.Wd + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const long img = (long)b * a.H * a.Wd;
+  const int h = a.h, hp = a.hp;
+
+  // ---- phase 0: x on tile + ring -> LayerNorm -> A-operand registers (k = 8jj + 4h2 + e) ----
+  float A[T::RTW][C / 2];
+  {
+    float4 gam[T::KJ], bet[T::KJ];
+#pragma unroll
+    for (int jj = 0; jj < T::KJ; ++jj) {
+      gam[jj] = *reinterpret_cast<const float4*>(a.ln_g + 8 * jj + 4 * h2);
+      bet[jj] = *reinterpret_cast<const float4*>(a.ln_b + 8 * jj + 4 * h2);
+    }
+#pragma unroll
+    for (int q = 0; q < T::RTW; ++q) {
+      const int r = wave + 4 * q;
+      if (r < T::NRT1) {
+        const int p = r * 32 + li;
+        const int ry = p / T::RW, rx = p - ry * T::RW;
+        const int iy = y0 + ry - 1, ix = x0 + rx - 1;
+        const bool valid = p < T::NPX1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
+        const long m = valid ? img + (long)iy * a.Wd + ix : img;
+        const float* xr = a.X + m * a.ldx + 4 * h2;
+        float4 v[T::KJ];
+        float s = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) {
+          v[jj] = *reinterpret_cast<const float4*>(xr + 8 * jj);
+          s += (v[jj].x + v[jj].y) + (v[jj].z + v[jj].w);
+        }
+        s += __shfl_xor(s, 32);
+        const float mean = s / (float)C;
+        float qq = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) {
+          const float d0 = v[jj].x - mean, d1 = v[jj].y - mean, d2 = v[jj].z - mean, d3 = v[jj].w - mean;
+          qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        qq += __shfl_xor(qq, 32);
+        const float rstd = rsqrtf(qq / (float)C + a.ln_eps);
+        const float keep = valid ? 1.f : 0.f;
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) {
+          A[q][4 * jj + 0] = keep * fmaf((v[jj].x - mean) * rstd, gam[jj].x, bet[jj].x);
+          A[q][4 * jj + 1] = keep * fmaf((v[jj].y - mean) * rstd, gam[jj].y, bet[jj].y);
+          A[q][4 * jj + 2] = keep * fmaf((v[jj].z - mean) * rstd, gam[jj].z, bet[jj].z);
+          A[q][4 * jj + 3] = keep * fmaf((v[jj].w - mean) * rstd, gam[jj].w, bet[jj].w);
+        }
+        const bool interior = ry >= 1 && ry <= TH && rx >= 1 && rx <= TW;
+        if (a.stats && h2 == 0 && valid && interior)
+          *reinterpret_cast<float2*>(a.stats + m * 2) = make_float2(mean, rstd);
+      }
+    }
+  }
+
+  // (c) work units (interior row tile, 32-column output tile): unit u = wave + 4 j -> rt = u / NT, nt = u % NT;
+  // NT divides 4, so a wave keeps ONE output tile nt = wave % NT and its W_out columns
+  f32x16 acc[T::UPW];
+#pragma unroll
+  for (int j = 0; j < T::UPW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int my_n = (wave % T::NT) * 32 + li;
+
+  // depthwise-walk coordinates of this thread: channel pair cp, column sx, rows [ys, ys + ROWS)
+  // The four 16-lane groups of a wave take columns {0, 2, 1, 3} of the wave's four: the two groups of a
+  // 32-lane half then sit 2 * S1 = 80 floats apart = 16 banks (ds_read_b32 banks are address % 32), conflict-free.
+  const int cp = tid & 15;
+  const int strip = (tid >> 6) * 4 + (((lane >> 4) & 1) << 1 | (lane >> 5));
+  const int sx = strip % TW, ys = (strip / TW) * T::ROWS;
+
+  auto load_w = [&](int c0, float4 (&win)[T::KJ], float (&wo)[8], float (&w1)[9], float (&w2)[9]) {
+    // clamped loads, zeroed by select: no divergent branches
+    {
+      const int cc = c0 + (li & 15);
+      const bool ok = cc < h;
+      const long row = ok ? (li < 16 ? cc : h + cc) : 0;
+      const float* wr = a.Win + row * C + 4 * h2;
+#pragma unroll
+      for (int jj = 0; jj < T::KJ; ++jj) {
+        const float4 t = *reinterpret_cast<const float4*>(wr + 8 * jj);
+        win[jj] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int k = c0 + 8 * (s >> 2) + 4 * h2 + (s & 3);
+      const bool ok = my_n < C && k < h;
+      const float t = a.Wout[ok ? (long)my_n * h + k : 0];
+      wo[s] = ok ? t : 0.f;
+    }
+    {
+      const int cc = c0 + cp;
+      const bool ok = cc < h;
+      const float* p1 = a.Wdw + (long)(ok ? cc : 0) * 9;
+      const float* p2 = a.Wdw + (long)(ok ? h + cc : 0) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float u1 = p1[t], u2 = p2[t];
+        w1[t] = ok ? u1 : 0.f;
+        w2[t] = ok ? u2 : 0.f;
+      }
+    }
+  };
+  // write-out slots of this thread: float4 j of pixel p (8 lanes cover the 16 x1 + 16 x2 floats of a pixel);
+  // byte offset into T1/T2 without the chunk term (fits 32 bits: checked by the launcher), ~0 = not written
+  unsigned st_off[STORE ? T::NST : 1];
+  int st_lds[STORE ? T::NST : 1];
+  if (STORE) {
+#pragma unroll
+    for (int it = 0; it < T::NST; ++it) {
+      const int e = tid + 256 * it, p = e >> 3, j = e & 7;
+      const int py = p / TW, px = p - py * TW;
+      const int iy = y0 + py, ix = x0 + px;
+      const bool ok = p < T::NI && iy < a.H && ix < a.Wd;
+      st_off[it] = ok ? (unsigned)(((img + (long)iy * a.Wd + ix) * a.ldt + (j < 4 ? 4 * j : hp + 4 * (j - 4))) * 4) : ~0u;
+      st_lds[it] = ((py + 1) * T::RW + px + 1) * T::S1 + 4 * j;
+    }
+  }
+
+  // C <= 32: the next chunk's weights are prefetched into a second register set; wider levels have no
+  // registers to spare (W_in alone is C/2 per lane) and load at the top of the chunk
+  constexpr bool PF = C <= 32;
+  constexpr int NPF = PF ? T::KJ : 1;
+  float4 win[T::KJ], win_n[NPF];
+  float wo[8], wo_n[8], w1[9], w2[9], w1_n[9], w2_n[9];
+  if (PF) load_w(0, win, wo, w1, w2);
+
+  for (int c0 = 0; c0 < hp; c0 += 16) {
+    if constexpr (PF) {
+      // in flight across (a) and (b): the LDS-only barriers do not wait for them
+      load_w(c0 + 16 < hp ? c0 + 16 : c0, win_n, wo_n, w1_n, w2_n);
+    } else {
+      load_w(c0, win, wo, w1, w2);
+    }
+
+    // ---- (a) t1 chunk on tile + ring ----
+#pragma unroll
+    for (int q = 0; q < T::RTW; ++q) {
+      const int r = wave + 4 * q;
+      if (r < T::NRT1) {
+        f32x16 d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) {
+          d = uir_mfma(A[q][4 * jj + 0], win[jj].x, d);
+          d = uir_mfma(A[q][4 * jj + 1], win[jj].y, d);
+          d = uir_mfma(A[q][4 * jj + 2], win[jj].z, d);
+          d = uir_mfma(A[q][4 * jj + 3], win[jj].w, d);
+        }
+        float* dst = T1s + (r * 32 + 4 * h2) * T::S1 + li;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::S1] = d[i];
+      }
+    }
+    lds_barrier();
+
+    // The prefetched weights are needed only at the end of the chunk, but the compiler would wait for them with
+    // vmcnt(0) AFTER this chunk's T1/T2 stores were issued (VMEM ops retire in issue order and it cannot count stores
+    // issued under branches), exposing the full store latency every chunk (measured: +250 us per 1.6 GB).  Pin them
+    // here instead: the wait lands before the stores, when the youngest outstanding store is a whole phase old.
+    if constexpr (PF) {
+#pragma unroll
+      for (int jj = 0; jj < T::KJ; ++jj) { pin(win_n[jj].x); pin(win_n[jj].y); pin(win_n[jj].z); pin(win_n[jj].w); }
+#pragma unroll
+      for (int t = 0; t < 8; ++t) pin(wo_n[t]);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { pin(w1_n[t]); pin(w2_n[t]); }
+    }
+
+    // ---- T1 write-out (training): interior rows of the LDS chunk as 16-byte stores, 8 lanes per pixel ----
+    if (STORE) {
+#pragma unroll
+      for (int it = 0; it < T::NST; ++it)
+        if (st_off[it] != ~0u) {
+          const float4 v = *reinterpret_cast<const float4*>(T1s + st_lds[it]);
+          st4(reinterpret_cast<char*>(a.T1) + (st_off[it] + (unsigned)c0 * 4u), v);
+        }
+    }
+
+    // ---- (b) depthwise 3x3: rolling three-row window (rotating register names, no shifts), row y+3
+    //      loaded while row y is being computed; x1/x2 as packed pairs (v_pk_fma_f32) ----
+    {
+      const float* rp = T1s + (ys * T::RW + sx) * T::S1 + cp;
+      f32x2 rw[3][3], wv[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wv[t] = f32x2{w1[t], w2[t]};
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          rw[rr][dx] = f32x2{rp[(rr * T::RW + dx) * T::S1], rp[(rr * T::RW + dx) * T::S1 + 16]};
+      rp += 3 * T::RW * T::S1;
+      float* gdst = Gs + (ys * TW + sx) * T::SG + cp;
+      auto step = [&](f32x2 (&p0)[3], f32x2 (&p1)[3], f32x2 (&p2)[3]) {
+        f32x2 t = wv[0] * p0[0];
+        t = __builtin_elementwise_fma(wv[1], p0[1], t);
+        t = __builtin_elementwise_fma(wv[2], p0[2], t);
+        // p0 is free now: fetch ring row y+3 (the last fetches read past the ring: inside smem, never used)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) p0[dx] = f32x2{rp[dx * T::S1], rp[dx * T::S1 + 16]};
+        rp += T::RW * T::S1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          t = __builtin_elementwise_fma(wv[3 + kx], p1[kx], t);
+          t = __builtin_elementwise_fma(wv[6 + kx], p2[kx], t);
+        }
+        gdst[0] = t.x;
+        gdst[16] = t.y;
+        gdst += TW * T::SG;
+      };
+#pragma unroll 1
+      for (int yb = 0; yb < T::ROWS; yb += 3) {
+        step(rw[0], rw[1], rw[2]);
+        if (yb + 1 < T::ROWS) step(rw[1], rw[2], rw[0]);
+        if (yb + 2 < T::ROWS) step(rw[2], rw[0], rw[1]);
+      }
+    }
+    lds_barrier();
+
+    // ---- T2 write-out (training) ----
+    if (STORE) {
+#pragma unroll
+      for (int it = 0; it < T::NST; ++it)
+        if (st_off[it] != ~0u) {
+          const int e = tid + 256 * it;
+          const float4 v = *reinterpret_cast<const float4*>(Gs + (e >> 3) * T::SG + 4 * (e & 7));
+          st4(reinterpret_cast<char*>(a.T2) + (st_off[it] + (unsigned)c0 * 4u), v);
+        }
+    }
+
+    // ---- (c) y += (gelu(t2a) * t2b) . W_out^T over this chunk's 16 hidden channels ----
+#pragma unroll
+    for (int j = 0; j < T::UPW; ++j) {
+      const int u = wave + 4 * j;
+      if (u < T::UNITS) {
+        const int rt = u / T::NT;
+        const float* gr = Gs + (rt * 32 + li) * T::SG + 4 * h2;
+        const float4 a0 = *reinterpret_cast<const float4*>(gr);
+        const float4 a1 = *reinterpret_cast<const float4*>(gr + 8);
+        const float4 b0 = *reinterpret_cast<const float4*>(gr + 16);
+        const float4 b1 = *reinterpret_cast<const float4*>(gr + 24);
+        acc[j] = uir_mfma(uir_gelu(a0.x) * b0.x, wo[0], acc[j]);
+        acc[j] = uir_mfma(uir_gelu(a0.y) * b0.y, wo[1], acc[j]);
+        acc[j] = uir_mfma(uir_gelu(a0.z) * b0.z, wo[2], acc[j]);
+        acc[j] = uir_mfma(uir_gelu(a0.w) * b0.w, wo[3], acc[j]);
+        acc[j] = uir_mfma(uir_gelu(a1.x) * b1.x, wo[4], acc[j]);
+        acc[j] = uir_mfma(uir_gelu(a1.y) * b1.y, wo[5], acc[j]);
+        acc[j] = uir_mfma(uir_gelu(a1.z) * b1.z, wo[6], acc[j]);
+        acc[j] = uir_mfma(uir_gelu(a1.w) * b1.w, wo[7], acc[j]);
+      }
+    }
+    if constexpr (PF) {
+#pragma unroll
+      for (int jj = 0; jj < T::KJ; ++jj) win[jj] = win_n[jj];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) wo[t] = wo_n[t];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
+    }
+    // no barrier: (a) of the next chunk writes T1s (all reads of it finished before the barrier
+    // above) and Gs is rewritten only after the next barrier, which every wave reaches after its (c)
+  }
+
+  // ---- epilogue: residual add (all loads first, clamped, no branches), predicated stores ----
+#pragma unroll
+  for (int j = 0; j < T::UPW; ++j) {
+    const int u = wave + 4 * j;
+    if (u < T::UNITS) {
+      const int rt = u / T::NT;
+      const int nn = my_n < C ? my_n : 0;
+      long mm[16];
+      float res[16];
+      bool ok[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int p = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+        const int iy = y0 + p / TW, ix = x0 + p % TW;
+        ok[i] = iy < a.H && ix < a.Wd && my_n < C;
+        mm[i] = ok[i] ? img + (long)iy * a.Wd + ix : img;
+        res[i] = a.X[mm[i] * a.ldx + nn];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (ok[i]) a.Y[mm[i] * a.ldy + nn] = acc[j][i] + res[i];
+    }
+  }
+}
+
+template <int C, int TH, int TW>
+int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
+  using T = GdfnTile<C, TH, TW>;
+  const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
+  const size_t lds = (size_t)T::LDS_FLOATS * 4;
+  if (a.T1) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true>), dim3(tiles), dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false>), dim3(tiles), dim3(256), lds, st, a);
+  return uir_launch_status();
+}
+
+}  // namespace
+
+extern "C" int uir_gdfn_fwd(const UirGdfnFwdArgs* p, void* stream) {
+  const UirGdfnFwdArgs& a = *p;
+  UIR_REQUIRE(a.X && a.ln_g && a.ln_b && a.Win && a.Wdw && a.Wout && a.Y);
+  UIR_REQUIRE((a.T1 == nullptr) == (a.T2 == nullptr));
+  UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0 && a.h > 0 && a.hp >= a.h && (a.hp & 15) == 0);
+  UIR_REQUIRE(a.ldx >= a.C && (a.ldx & 3) == 0 && a.ldy >= a.C && uir_aligned16(a.X));
+  UIR_REQUIRE(uir_aligned16(a.ln_g) && uir_aligned16(a.ln_b) && uir_aligned16(a.Win));
+  UIR_REQUIRE(!a.T1 || (a.ldt >= 2 * a.hp && (a.ldt & 3) == 0 && uir_aligned16(a.T1) && uir_aligned16(a.T2) &&
+                        (long)a.B * a.H * a.Wd * a.ldt < (1L << 30)));
+  UIR_REQUIRE((long)a.B * ((a.H + 7) / 8) * ((a.Wd + 7) / 8) < (1L << 30));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a.C) {
+    case 16: return gdfn_fwd_launch<16, 12, 16>(a, st);
+    case 32: return gdfn_fwd_launch<32, 12, 16>(a, st);
+    case 64: return gdfn_fwd_launch<64, 8, 16>(a, st);
+    case 128: return gdfn_fwd_launch<128, 8, 8>(a, st);
+    default: return UIR_EINVAL;
+  }
+}

@@ -6,6 +6,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define UIR_OK 0
 #define UIR_EINVAL 1
@@ -36,7 +37,7 @@ __device__ __forceinline__ int uir_colmap(int c, int grp_real, int grp_pad) {
 __device__ __forceinline__ void uir_gelu_pair(float x, float& g, float& dg) {
   const float ax = fabsf(x);
   const float z = ax * 0.70710678118654752440f;
-  const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));   // v_rcp_f32 (1 ulp); __frcp_rn is a 10-instruction IEEE division
   const float e = __expf(-z * z);
   float poly = fmaf(t, 1.061405429f, -1.453152027f);
   poly = fmaf(t, poly, 1.421413741f);

@@ -38,6 +38,8 @@ NUM_REFINEMENT = 4
 EXPANSION = 2.66
 LN_EPS = 1e-5
 _SKIP_SIDE = os.environ.get("UIR_SKIP_SIDE", "0") == "1"
+# channel counts whose GDFN forward runs as the tile-fused kernel (csrc/gdfn.hip); "" = three separate kernels
+_GDFN_FUSED = set(filter(None, os.environ.get("UIR_GDFN_FUSED", "16,32,64,128").split(",")))
 SCRATCH_FLOATS = 96 * 1024 * 1024  # 384 MB of slab scratch shared by every reduction
 
 
@@ -468,6 +470,28 @@ class Recorder:
         rows = dims[0] * dims[1] * dims[2]
         self._op(name, lib.uir_dwconv, C.byref(a), nbytes=8 * rows * C_, flops=18 * rows * C_)
 
+    def gdfn_fwd(self, name, X, ln, Win, Wdw, Wout, Y, *, C_, h, hp, dims, T1=None, T2=None, stats=None, eps=1e-5):
+        """Tile-fused GDFN forward (csrc/gdfn.hip): Y = X + W_out.(gelu(dw(W_in.LN(X))[:h]) * dw(...)[h:])."""
+        self._hold(X, ln[0], ln[1], Win, Wdw, Wout, Y, T1, T2, stats)
+        a = L.GdfnFwdArgs()
+        a.X, a.ln_g, a.ln_b, a.Win, a.Wdw, a.Wout, a.Y = (_ptr(X), _ptr(ln[0]), _ptr(ln[1]), _ptr(Win), _ptr(Wdw),
+                                                           _ptr(Wout), _ptr(Y))
+        a.T1 = _ptr(T1) if T1 is not None else None
+        a.T2 = _ptr(T2) if T2 is not None else None
+        a.stats = _ptr(stats) if stats is not None else None
+        a.ldx, a.ldy = _ld(X), _ld(Y)
+        a.ldt = _ld(T1) if T1 is not None else 0
+        a.B, a.H, a.Wd = dims
+        a.C, a.h, a.hp = C_, h, hp
+        a.ln_eps = eps
+        rows = dims[0] * dims[1] * dims[2]
+        assert X.shape[0] == rows and C_ in (16, 32, 64, 128) and hp % 16 == 0 and hp >= h
+        assert (T1 is None) == (T2 is None) and (T1 is None or (_ld(T1) == _ld(T2) and _ld(T1) >= 2 * hp))
+        self.keep.append(a)
+        stored = 0 if T1 is None else 16 * hp
+        self._op(name, lib.uir_gdfn_fwd, C.byref(a), nbytes=rows * (12 * C_ + stored),
+                 flops=rows * (2 * C_ * 2 * hp + 18 * 2 * hp + 2 * hp * C_))
+
     def dwconv_wgrad(self, name, dY, X, out, *, C_, creal, dims, grp=(0, 0)):
         self._hold(dY, X, out)
         a = L.DwWgradArgs()
@@ -631,9 +655,15 @@ class Plan(Recorder):
         self.dwconv(n + ".kv_conv", u, Wkvdw_f, vf, C_=C_, dims=dims)
         self.gemm(n + ".WB", vf, WB, x1, N=C_, K=C_, w_sn=C_, w_sk=1, w_bs=C_ * C_, batches=B, R=x)
         # ---- GDFN (:127-130) ----
-        self.gemm(n + ".ffn_in", x1, Win, gpre, N=2 * hp, K=C_, w_sn=C_, w_sk=1, n_grp=(h, hp), pro=L.PRO_LN, ln=(g2, b2), stats=stats2)
-        self.dwconv(n + ".ffn_conv", gpre, Wffdw, g, C_=2 * hp, dims=dims, grp=(h, hp))
-        self.gemm(n + ".ffn_out", g, Wout, y, N=C_, K=h, w_sn=h, w_sk=1, pro=L.PRO_GATE, gate_off=hp, R=x1)
+        if str(C_) in _GDFN_FUSED:
+            # one pass over the pixels; t1/t2 written once for the backward kernels, never re-read in the forward
+            self.gdfn_fwd(n + ".gdfn", x1, (g2, b2), Win, Wffdw, Wout, y, C_=C_, h=h, hp=hp, dims=dims,
+                          T1=gpre, T2=g, stats=stats2)
+        else:
+            self.gemm(n + ".ffn_in", x1, Win, gpre, N=2 * hp, K=C_, w_sn=C_, w_sk=1, n_grp=(h, hp), pro=L.PRO_LN, ln=(g2, b2),
+                      stats=stats2)
+            self.dwconv(n + ".ffn_conv", gpre, Wffdw, g, C_=2 * hp, dims=dims, grp=(h, hp))
+            self.gemm(n + ".ffn_out", g, Wout, y, N=C_, K=h, w_sn=h, w_sk=1, pro=L.PRO_GATE, gate_off=hp, R=x1)
 
         def backward(dy: torch.Tensor) -> torch.Tensor:
             dg, dgpre = self.alloc(M, ldg)[:, :2 * hp], self.alloc(M, ldg)[:, :2 * hp]
