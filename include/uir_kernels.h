@@ -157,6 +157,27 @@ typedef struct UirGdfnFwdArgs {
 } UirGdfnFwdArgs;
 int uir_gdfn_fwd(const UirGdfnFwdArgs* args, void* stream);
 
+/* Tile-fused input-gradient chain of the GDFN (everything between dY and the gradient of the
+ * norm2 output):  dg = dY . W_out;  dt2 = gate'(dg, t2);  dt1 = dw3x3^T(dt2);  dT = dt1 . W_in.
+ * Replaces autograd's backward of SpectralTransformer.py:127-130 (conv1x1 / depthwise conv /
+ * gelu-gate input gradients).  DT2 and DT1 are written for the weight-gradient kernels
+ * (uir_dwconv_wgrad, uir_gram); same column layout as T1/T2 of uir_gdfn_fwd. */
+typedef struct UirGdfnBwdArgs {
+  const float* dY;     /* [B*H*W][ldy] gradient of the block output, float4-aligned rows          */
+  const float* T2;     /* [B*H*W][ldt] post-depthwise tensor saved by the forward                 */
+  const float* Wout;   /* project_out [C][h]                                                      */
+  const float* Wdw;    /* conv        [2h][1][3][3]                                               */
+  const float* Win;    /* project_in  [2h][C]                                                     */
+  float* DT2;          /* [B*H*W][ldt] gradient of the depthwise output                           */
+  float* DT1;          /* [B*H*W][ldt] gradient of the depthwise input                            */
+  float* dT;           /* [B*H*W][ldo] gradient of the norm2 output                               */
+  int ldy, ldt, ldo;
+  int B, H, Wd;
+  int C;               /* in {16,32}                                                              */
+  int h, hp;
+} UirGdfnBwdArgs;
+int uir_gdfn_bwd(const UirGdfnBwdArgs* args, void* stream);
+
 /* ----------------------------------------------------------- uir_layernorm */
 /* Input-gradient of the channel LayerNorm (+ residual-path gradient) and per-block partials
  * of dgamma/dbeta: dX = dRes + LN'(dT).  slab[block][2*C] = (dgamma | dbeta).

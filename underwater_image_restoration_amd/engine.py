@@ -40,6 +40,7 @@ LN_EPS = 1e-5
 _SKIP_SIDE = os.environ.get("UIR_SKIP_SIDE", "0") == "1"
 # channel counts whose GDFN forward runs as the tile-fused kernel (csrc/gdfn.hip); "" = three separate kernels
 _GDFN_FUSED = set(filter(None, os.environ.get("UIR_GDFN_FUSED", "16,32,64,128").split(",")))
+_GDFN_BWD_FUSED = set(filter(None, os.environ.get("UIR_GDFN_BWD_FUSED", "16,32").split(",")))
 SCRATCH_FLOATS = 96 * 1024 * 1024  # 384 MB of slab scratch shared by every reduction
 
 
@@ -492,6 +493,22 @@ class Recorder:
         self._op(name, lib.uir_gdfn_fwd, C.byref(a), nbytes=rows * (12 * C_ + stored),
                  flops=rows * (2 * C_ * 2 * hp + 18 * 2 * hp + 2 * hp * C_))
 
+    def gdfn_bwd(self, name, dY, T2, Wout, Wdw, Win, DT2, DT1, dT, *, C_, h, hp, dims):
+        """Tile-fused GDFN input-gradient chain (csrc/gdfn.hip): dY -> dt2 -> dt1 -> gradient of the norm2 output."""
+        self._hold(dY, T2, Wout, Wdw, Win, DT2, DT1, dT)
+        a = L.GdfnBwdArgs()
+        a.dY, a.T2, a.Wout, a.Wdw, a.Win = _ptr(dY), _ptr(T2), _ptr(Wout), _ptr(Wdw), _ptr(Win)
+        a.DT2, a.DT1, a.dT = _ptr(DT2), _ptr(DT1), _ptr(dT)
+        a.ldy, a.ldt, a.ldo = _ld(dY), _ld(T2), _ld(dT)
+        a.B, a.H, a.Wd = dims
+        a.C, a.h, a.hp = C_, h, hp
+        rows = dims[0] * dims[1] * dims[2]
+        assert dY.shape[0] == rows and C_ in (16, 32) and hp % 16 == 0 and hp >= h
+        assert _ld(DT2) == _ld(T2) == _ld(DT1) and _ld(T2) >= 2 * hp
+        self.keep.append(a)
+        self._op(name, lib.uir_gdfn_bwd, C.byref(a), nbytes=rows * (8 * C_ + 24 * hp),
+                 flops=rows * (2 * C_ * hp + 18 * 2 * hp + 2 * 2 * hp * C_))
+
     def dwconv_wgrad(self, name, dY, X, out, *, C_, creal, dims, grp=(0, 0)):
         self._hold(dY, X, out)
         a = L.DwWgradArgs()
@@ -679,13 +696,22 @@ class Plan(Recorder):
             with self.bulk():
                 self.gram(n + ".dWout", dy, g, Gr(f"{pfx}.ffn.project_out.weight"), N=C_, K=h, o_sn=h, o_sk=1,
                           pro_b=L.PRO_GATE, gate_off=hp)
-            self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g, g_off=hp)
-            self.dwconv_bwd(n + ".dgpre+dWffdw", dg, gpre, Wffdw, dgpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
-                            dims=dims, grp=(h, hp))
-            with self.bulk():
-                self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
-                          n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
-            self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
+            if str(C_) in _GDFN_BWD_FUSED:
+                # dY -> dt2 -> dt1 -> dt in one pass; dt2 / dt1 are written once for the weight-gradient lane
+                self.gdfn_bwd(n + ".gdfn_bwd", dy, g, Wout, Wffdw, Win, dg, dgpre, dt, C_=C_, h=h, hp=hp, dims=dims)
+                with self.bulk():
+                    self.dwconv_wgrad(n + ".dgpre+dWffdw.dW", dg, gpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
+                                      dims=dims, grp=(h, hp))
+                    self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
+                              n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
+            else:
+                self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g, g_off=hp)
+                self.dwconv_bwd(n + ".dgpre+dWffdw", dg, gpre, Wffdw, dgpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
+                                dims=dims, grp=(h, hp))
+                with self.bulk():
+                    self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
+                              n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
+                self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
             self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
             # MDTA
             self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
