@@ -259,8 +259,35 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
       }
     };
     if (full) {
+      if constexpr (EPI == UIR_EPI_PLAIN) {
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) put(reg);
+        for (int reg = 0; reg < 16; ++reg) put(reg);
+      } else {
+        // All operand loads of the tile first, then compute + store.  Written load/compute/store per register the
+        // compiler must keep every load behind the previous stores (G may alias Y for all it knows): 16 serialized
+        // HBM round trips per 32x32 tile (ISA: [global_load x2, s_waitcnt vmcnt(0), global_store x2] x16).
+        float g1[16], g2[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const long o = (long)((reg & 3) + 8 * (reg >> 2)) * a.ldg;
+          g1[reg] = gp[o];
+          if constexpr (EPI == UIR_EPI_GATE_BWD) g2[reg] = gp[o + a.g_off];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const long o = (long)((reg & 3) + 8 * (reg >> 2)) * a.ldy;
+          float v = acc[nt][reg] + bias;
+          v = v > 0.f ? v : v * slope;
+          if constexpr (EPI == UIR_EPI_GATE_BWD) {
+            float ge, dge;
+            uir_gelu_pair(g1[reg], ge, dge);
+            yp[o] = v * g2[reg] * dge;
+            yp[o + a.g_off] = v * ge;
+          } else {
+            yp[o] = g1[reg] > 0.f ? v : v * a.slope;
+          }
+        }
+      }
     } else {
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg)
@@ -269,68 +296,8 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
   }
 }
 
-// Epilogue through a per-wave LDS transpose: the MFMA layout (lane = channel, register = pixel) is turned
-// into whole-row float4 runs, so every global access of the epilogue (stores, residual / gate / LeakyReLU
-// operand loads) is a 16-byte access on contiguous row segments - 4x fewer memory instructions (the
-// dword epilogue was store-issue bound on the wide-N GEMMs).  tl: [32 rows][TLS] floats, private to the wave.
-template <int NT, int EPI, bool HAS_R>
-__device__ __forceinline__ void uir_gemm1x1_store_v4(const UirGemmArgs& a, const f32x16 (&acc)[NT], const float (&biasv)[NT],
-                                                     float* tl, int z, int m0, int n0, int lane) {
-  constexpr int TLS = NT * 32 + 4;
-  const int r = lane & 31, h2 = lane >> 5;
-  const float slope = (a.act == UIR_ACT_LEAKY) ? a.slope : 1.0f;
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      float v = acc[nt][reg] + biasv[nt];
-      v = v > 0.f ? v : v * slope;
-      tl[(4 * h2 + (reg & 3) + 8 * (reg >> 2)) * TLS + 32 * nt + r] = v;
-    }
-  // same wave wrote and now reads: LDS operations of one wave complete in order
-  float* __restrict__ Y = a.Y + (long)z * a.y_bs;
-  constexpr int C4 = NT * 8;                 // float4 per row
-  const int ncol4 = min(C4, (a.N - n0 + 3) >> 2);
-#pragma unroll
-  for (int it = 0; it < (32 * C4 + 63) / 64; ++it) {
-    const int idx = it * 64 + lane;
-    const int row = idx / C4, c4 = idx - row * C4;
-    const int mm = m0 + row;
-    if (row < 32 && mm < a.M && c4 < ncol4) {
-      float4 v = *reinterpret_cast<const float4*>(tl + row * TLS + 4 * c4);
-      const int n = n0 + 4 * c4;
-      if constexpr (EPI == UIR_EPI_PLAIN) {
-        if constexpr (HAS_R) {
-          const float4 rr = *reinterpret_cast<const float4*>(a.R + (long)z * a.r_bs + (long)mm * a.ldr + n);
-          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
-        }
-        *reinterpret_cast<float4*>(Y + (long)mm * a.ldy + n) = v;
-      } else if constexpr (EPI == UIR_EPI_GATE_BWD) {
-        const float* gp = a.G + (long)z * a.g_bs + (long)mm * a.ldg + n;
-        const float4 g1 = *reinterpret_cast<const float4*>(gp);
-        const float4 g2 = *reinterpret_cast<const float4*>(gp + a.g_off);
-        float4 o1, o2;
-        float ge, dge;
-        uir_gelu_pair(g1.x, ge, dge); o1.x = v.x * g2.x * dge; o2.x = v.x * ge;
-        uir_gelu_pair(g1.y, ge, dge); o1.y = v.y * g2.y * dge; o2.y = v.y * ge;
-        uir_gelu_pair(g1.z, ge, dge); o1.z = v.z * g2.z * dge; o2.z = v.z * ge;
-        uir_gelu_pair(g1.w, ge, dge); o1.w = v.w * g2.w * dge; o2.w = v.w * ge;
-        *reinterpret_cast<float4*>(Y + (long)mm * a.ldy + n) = o1;
-        *reinterpret_cast<float4*>(Y + (long)mm * a.ldy + a.g_off + n) = o2;
-      } else {
-        const float4 o = *reinterpret_cast<const float4*>(a.G + (long)z * a.g_bs + (long)mm * a.ldg + n);
-        v.x = o.x > 0.f ? v.x : v.x * a.slope;
-        v.y = o.y > 0.f ? v.y : v.y * a.slope;
-        v.z = o.z > 0.f ? v.z : v.z * a.slope;
-        v.w = o.w > 0.f ? v.w : v.w * a.slope;
-        *reinterpret_cast<float4*>(Y + (long)mm * a.ldy + n) = v;
-      }
-    }
-  }
-}
-
 template <int NT, int PRO, int EPI, bool HAS_R>
-__global__ __launch_bounds__(256, 3) void uir_gemm1x1_kernel(const UirGemmArgs a, const int Kp, const int tiles, const int v4) {
+__global__ __launch_bounds__(256, 3) void uir_gemm1x1_kernel(const UirGemmArgs a, const int Kp, const int tiles) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h2 = lane >> 5;
@@ -391,7 +358,6 @@ __global__ __launch_bounds__(256, 3) void uir_gemm1x1_kernel(const UirGemmArgs a
   int* nmap = reinterpret_cast<int*>(lng + 2 * K8);       // [NC]  weight offset of column nl, or -1
   int* kmap = nmap + NC;                                  // [K8]  weight offset of k, or -1
   // per-wave transpose buffer of the float4 epilogue (16-byte aligned: everything before it is a multiple of 4 floats)
-  float* tl = reinterpret_cast<float*>(kmap + K8) + wave * (32 * (NC + 4));
   for (int i = threadIdx.x; i < NC + K8; i += 256) {
     if (i < NC) {
       const int n = n0 + i;
@@ -524,7 +490,7 @@ __global__ __launch_bounds__(256, 3) void uir_gemm1x1_kernel(const UirGemmArgs a
     nxok = load_unit(nx, nu, tn, cn);
     float rv[HAS_R ? NT : 1][16];
     if constexpr (HAS_R) {
-      if (last && !v4) uir_gemm1x1_load_res<NT>(a, rv, z, m0, n0, r, h2);
+      if (last) uir_gemm1x1_load_res<NT>(a, rv, z, m0, n0, r, h2);
     }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
@@ -543,8 +509,7 @@ __global__ __launch_bounds__(256, 3) void uir_gemm1x1_kernel(const UirGemmArgs a
       }
     }
     if (last && m0 < a.M) {
-      if (v4) uir_gemm1x1_store_v4<NT, EPI, HAS_R>(a, acc, bias, tl, z, m0, n0, lane);
-      else uir_gemm1x1_store<NT, EPI, HAS_R>(a, acc, bias, rv, z, m0, n0, r, h2);
+      uir_gemm1x1_store<NT, EPI, HAS_R>(a, acc, bias, rv, z, m0, n0, r, h2);
     }
     tile = tn;
     c = cn;
@@ -590,14 +555,8 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     if (const char* e = getenv("UIR_NT")) { const int v = atoi(e); if (v >= 1 && v <= 3) nt1 = v < tiles ? v : tiles; }  // tuning aid
     while (nt1 > 1 && (size_t)nt1 * 32 * Kp * 4 > 60 * 1024) { --nt1; }
     groups1 = (tiles + nt1 - 1) / nt1;
-    // float4 epilogue: needs 16-B aligned row segments on every epilogue operand
-    static const int v4_env = getenv("UIR_EPI_V4") ? atoi(getenv("UIR_EPI_V4")) : 0;   // opt-in: A/B measured slower (profiles/r01/d_ab_notes.md)
-    const bool al = (a.N & 3) == 0 && (a.ldy & 3) == 0 && uir_aligned16(a.Y) && (a.y_bs & 3) == 0 &&
-                    (!a.R || ((a.ldr & 3) == 0 && uir_aligned16(a.R) && (a.r_bs & 3) == 0)) &&
-                    (!a.G || ((a.ldg & 3) == 0 && uir_aligned16(a.G) && (a.g_bs & 3) == 0 && (a.g_off & 3) == 0));
-    const int v4 = (v4_env && al && nt1 == 1) ? 1 : 0;   // wide-N: the 51 KB of LDS costs more occupancy than it saves (A/B)
-    const size_t lds = (size_t)nt1 * 32 * Kp * 4 + (size_t)2 * K8 * 4 + (size_t)(nt1 * 32 + K8) * 4 +
-                       (v4 ? (size_t)4 * 32 * (nt1 * 32 + 4) * 4 : 0);
+    // (a float4 epilogue through a per-wave LDS transpose was tried and measured slower: profiles/r01/d_ab_notes.md)
+    const size_t lds = (size_t)nt1 * 32 * Kp * 4 + (size_t)2 * K8 * 4 + (size_t)(nt1 * 32 + K8) * 4;
     const bool combo_ok = (a.pro == UIR_PRO_NONE) || (a.epi == UIR_EPI_PLAIN && !(a.pro == UIR_PRO_LN && a.R));
     if (lds <= 100 * 1024 && combo_ok) {
       const int rtiles = (a.M + 127) / 128;
@@ -606,7 +565,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
       if (gx > rtiles) gx = rtiles;
       dim3 grid1(gx, groups1, a.batches);
 #define UIR_L1(NTV, PROV, EPIV, RV) \
-  hipLaunchKernelGGL((uir_gemm1x1_kernel<NTV, PROV, EPIV, RV>), grid1, dim3(256), lds, st, a, Kp, rtiles, v4)
+  hipLaunchKernelGGL((uir_gemm1x1_kernel<NTV, PROV, EPIV, RV>), grid1, dim3(256), lds, st, a, Kp, rtiles)
 #define UIR_L1E(NTV, PROV)                                                          \
   do {                                                                              \
     if (a.epi == UIR_EPI_GATE_BWD) UIR_L1(NTV, PROV, UIR_EPI_GATE_BWD, false);      \
