@@ -11,7 +11,7 @@
 
 namespace {
 
-template <int TN, int TK>
+template <int TN, int TK, int PRO>
 __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int gn, int gk) {
   __shared__ float red[TN * TK * 16 * 64];
   __shared__ float redv[4 * 32 * (2 * TN + TK)];
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
     int k = k0 + 32 * t + r;
     bcol_ok[t] = k < a.K;
     lng[t] = 1.f; lnb[t] = 0.f;
-    if (a.pro_b == UIR_GRAM_PRO_LN && bcol_ok[t]) { lng[t] = a.ln_g[k]; lnb[t] = a.ln_b[k]; }
+    if (PRO == UIR_GRAM_PRO_LN && bcol_ok[t]) { lng[t] = a.ln_g[k]; lnb[t] = a.ln_b[k]; }
   }
 
   f32x16 acc[TN][TK];
@@ -66,55 +66,77 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
 #pragma unroll
   for (int t = 0; t < TK; ++t) bcol[t] = min(k0 + 32 * t + r, a.K - 1);
   const int last_row = row_end - 1;
-  for (int base = row_begin + 2 * wave; base < row_end; base += 8 * U) {
-    float av[U][TN], bv[U][TK], bg[U][TK];
-    float2 st[U];
-    bool aok[U], bok[U];
+  // One trip = U row pairs per wave.  Two named register panels, loop unrolled x2: the loads of trip t+1 are
+  // issued before the MFMAs of trip t (vmcnt retires in issue order, so a rotating-index prefetch would wait for
+  // the newest loads; with static panels the wait before compute(P) only covers P's own, older loads).
+  // (plain arrays passed by reference: a struct of arrays is not scalarised by hipcc and lands in scratch)
+  constexpr int TG = (PRO == UIR_GRAM_PRO_GATE) ? TK : 1, US = (PRO == UIR_GRAM_PRO_LN) ? U : 1;
+  auto load = [&](float (&Pav)[U][TN], float (&Pbv)[U][TK], float (&Pbg)[U][TG], float2 (&Pst)[US], float (&Pak)[U],
+                  float (&Pbk)[U], int base) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int m = base + 8 * u + h2;
-      aok[u] = m < row_end;
+      const bool aok = m < row_end;
+      bool bok = aok;
       const int mc = min(m, last_row);
       const float* ap = A + (long)mc * a.lda;
 #pragma unroll
-      for (int t = 0; t < TN; ++t) av[u][t] = ap[acol[t]];
-      bok[u] = aok[u];
+      for (int t = 0; t < TN; ++t) Pav[u][t] = ap[acol[t]];
       long mb = mc;
       if (a.taps > 1) {
         const int hw = mc % (a.H * a.Wd);
         const int ph = hw / a.Wd, pw = hw - ph * a.Wd;
         const int hh = ph + dy, ww = pw + dx;
         const bool in = hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
-        bok[u] = bok[u] && in;
+        bok = bok && in;
         mb = in ? (long)mc + dy * a.Wd + dx : (long)mc;
       }
-      if (a.pro_b == UIR_GRAM_PRO_LN) st[u] = *reinterpret_cast<const float2*>(a.stats + ((long)z * a.M + mb) * 2);
+      Pak[u] = aok ? 1.f : 0.f;
+      Pbk[u] = bok ? 1.f : 0.f;
+      if constexpr (PRO == UIR_GRAM_PRO_LN) Pst[u] = *reinterpret_cast<const float2*>(a.stats + ((long)z * a.M + mb) * 2);
       const float* bp = B + mb * a.ldb;
 #pragma unroll
       for (int t = 0; t < TK; ++t) {
-        bv[u][t] = bp[bcol[t]];
-        if (a.pro_b == UIR_GRAM_PRO_GATE) bg[u][t] = bp[a.gate_off + bcol[t]];
+        Pbv[u][t] = bp[bcol[t]];
+        if constexpr (PRO == UIR_GRAM_PRO_GATE) Pbg[u][t] = bp[a.gate_off + bcol[t]];
       }
     }
+  };
+  auto compute = [&](float (&Pav)[U][TN], float (&Pbv)[U][TK], float (&Pbg)[U][TG], float2 (&Pst)[US], float (&Pak)[U],
+                     float (&Pbk)[U]) {
 #pragma unroll
     for (int u = 0; u < U; ++u) {
+      float av[TN], bv[TK];
 #pragma unroll
-      for (int t = 0; t < TN; ++t) av[u][t] = (aok[u] && acol_ok[t]) ? av[u][t] : 0.f;
+      for (int t = 0; t < TN; ++t) av[t] = (Pak[u] != 0.f && acol_ok[t]) ? Pav[u][t] : 0.f;
 #pragma unroll
       for (int t = 0; t < TK; ++t) {
-        float v = bv[u][t];
-        if (a.pro_b == UIR_GRAM_PRO_LN) v = (v - st[u].x) * st[u].y * lng[t] + lnb[t];
-        else if (a.pro_b == UIR_GRAM_PRO_GATE) v = uir_gelu(v) * bg[u][t];
-        bv[u][t] = (bok[u] && bcol_ok[t]) ? v : 0.f;
+        float v = Pbv[u][t];
+        if constexpr (PRO == UIR_GRAM_PRO_LN) v = (v - Pst[u].x) * Pst[u].y * lng[t] + lnb[t];
+        else if constexpr (PRO == UIR_GRAM_PRO_GATE) v = uir_gelu(v) * Pbg[u][t];
+        bv[t] = (Pbk[u] != 0.f && bcol_ok[t]) ? v : 0.f;
       }
 #pragma unroll
       for (int i = 0; i < TN; ++i)
 #pragma unroll
-        for (int j = 0; j < TK; ++j) acc[i][j] = uir_mfma(av[u][i], bv[u][j], acc[i][j]);
+        for (int j = 0; j < TK; ++j) acc[i][j] = uir_mfma(av[i], bv[j], acc[i][j]);
 #pragma unroll
-      for (int t = 0; t < TN; ++t) { sqa[t] += av[u][t] * av[u][t]; csa[t] += av[u][t]; }
+      for (int t = 0; t < TN; ++t) { sqa[t] += av[t] * av[t]; csa[t] += av[t]; }
 #pragma unroll
-      for (int t = 0; t < TK; ++t) sqb[t] += bv[u][t] * bv[u][t];
+      for (int t = 0; t < TK; ++t) sqb[t] += bv[t] * bv[t];
+    }
+  };
+  {
+    float av0[U][TN], bv0[U][TK], bg0[U][TG], ak0[U], bk0[U], av1[U][TN], bv1[U][TK], bg1[U][TG], ak1[U], bk1[U];
+    float2 st0[US], st1[US];
+    int base = row_begin + 2 * wave;
+    if (base < row_end) load(av0, bv0, bg0, st0, ak0, bk0, base);
+    // rows past row_end load clamped addresses and contribute exact zeros (mask 0): no tail code
+    for (; base < row_end; base += 16 * U) {
+      load(av1, bv1, bg1, st1, ak1, bk1, base + 8 * U);
+      compute(av0, bv0, bg0, st0, ak0, bk0);
+      load(av0, bv0, bg0, st0, ak0, bk0, base + 16 * U);
+      compute(av1, bv1, bg1, st1, ak1, bk1);
     }
   }
 
@@ -307,27 +329,45 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
   if (a.pro_b == UIR_GRAM_PRO_GATE) UIR_REQUIRE(a.ldb >= a.gate_off + a.K);
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 block(256);
+#define UIR_GRAM_LAUNCH(TNV, TKV, GN, GK)                                                                              \
+  do {                                                                                                                 \
+    if (a.pro_b == UIR_GRAM_PRO_LN) hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_LN>), grid, block, 0, st, a, GN, GK);         \
+    else if (a.pro_b == UIR_GRAM_PRO_GATE) hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_GATE>), grid, block, 0, st, a, GN, GK); \
+    else hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_NONE>), grid, block, 0, st, a, GN, GK);                                   \
+  } while (0)
   const int tn_tiles = (a.N + 31) / 32, tk_tiles = (a.K + 31) / 32;
   if (a.taps == 9 && tn_tiles == 1 && tk_tiles == 1 && a.sq_a_off < 0 && a.sq_b_off < 0 && a.cs_a_off < 0 &&
       a.pro_b == UIR_GRAM_PRO_NONE) {
     dim3 grid(a.nchunks, 1, a.batches);
     hipLaunchKernelGGL(uir_gram_taps9_kernel, grid, block, 0, st, a);
-  } else if (tk_tiles == 1 && tn_tiles == 1) {
-    dim3 grid(a.taps * a.nchunks, 1, a.batches);
-    hipLaunchKernelGGL((uir_gram_kernel<1, 1>), grid, block, 0, st, a, 1, 1);
-  } else if (tk_tiles == 1) {
-    const int gn = (tn_tiles + 3) / 4, gk = 1;
-    dim3 grid(a.taps * gn * gk * a.nchunks, 1, a.batches);
-    hipLaunchKernelGGL((uir_gram_kernel<4, 1>), grid, block, 0, st, a, gn, gk);
-  } else if (tn_tiles == 1) {
-    const int gn = 1, gk = (tk_tiles + 3) / 4;
-    dim3 grid(a.taps * gn * gk * a.nchunks, 1, a.batches);
-    hipLaunchKernelGGL((uir_gram_kernel<1, 4>), grid, block, 0, st, a, gn, gk);
+  } else if (tk_tiles == 1 || tn_tiles == 1) {
+    // one operand is a single 32-column tile: the other is split into the fewest groups of <= 4 tiles, each group
+    // as narrow as possible (6 tiles -> 2 x 3, not 4 + 2 padded: a padded tile still issues its clamped loads)
+    const int tiles = tk_tiles == 1 ? tn_tiles : tk_tiles;
+    const int groups = (tiles + 3) / 4;
+    const int T = (tiles + groups - 1) / groups;
+    const int gn = tk_tiles == 1 ? groups : 1, gk = tk_tiles == 1 ? 1 : groups;
+    dim3 grid(a.taps * groups * a.nchunks, 1, a.batches);
+    if (tk_tiles == 1) {
+      switch (T) {
+        case 1: UIR_GRAM_LAUNCH(1, 1, gn, gk); break;
+        case 2: UIR_GRAM_LAUNCH(2, 1, gn, gk); break;
+        case 3: UIR_GRAM_LAUNCH(3, 1, gn, gk); break;
+        default: UIR_GRAM_LAUNCH(4, 1, gn, gk); break;
+      }
+    } else {
+      switch (T) {
+        case 2: UIR_GRAM_LAUNCH(1, 2, gn, gk); break;
+        case 3: UIR_GRAM_LAUNCH(1, 3, gn, gk); break;
+        default: UIR_GRAM_LAUNCH(1, 4, gn, gk); break;
+      }
+    }
   } else {
     const int gn = (tn_tiles + 1) / 2, gk = (tk_tiles + 1) / 2;
     dim3 grid(a.taps * gn * gk * a.nchunks, 1, a.batches);
-    hipLaunchKernelGGL((uir_gram_kernel<2, 2>), grid, block, 0, st, a, gn, gk);
+    UIR_GRAM_LAUNCH(2, 2, gn, gk);
   }
+#undef UIR_GRAM_LAUNCH
   return uir_launch_status();
 }
 
