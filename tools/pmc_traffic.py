@@ -17,6 +17,13 @@ def load(d, counter):
 fd, wd, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
 fetch, nf = load(fd, "FETCH_SIZE")
 write, nw = load(wd, "WRITE_SIZE")
+# the number of train steps in the profiled run = dispatches of the once-per-step fused clip+Adam kernel
+# (bench.py runs warm-up + timed steps + one host-enqueue-timing step); argv[3] is only the fallback
+adam = 0
+for f in glob.glob(os.path.join(fd, "**", "*counter_collection.csv"), recursive=True):
+    adam += sum(1 for row in csv.DictReader(open(f)) if row["Counter_Name"] == "FETCH_SIZE" and "clip_adam_kernel" in row["Kernel_Name"])
+if adam > 0:
+    steps = adam
 KB = 1024.0
 res = {"steps_in_profiled_run": steps, "dispatches_fetch_pass": nf, "dispatches_write_pass": nw,
        "fetch_bytes_per_step_raw": sum(fetch.values()) * KB / steps,

@@ -40,7 +40,9 @@ LN_EPS = 1e-5
 _SKIP_SIDE = os.environ.get("UIR_SKIP_SIDE", "0") == "1"
 # channel counts whose GDFN forward runs as the tile-fused kernel (csrc/gdfn.hip); "" = three separate kernels
 _GDFN_FUSED = set(filter(None, os.environ.get("UIR_GDFN_FUSED", "16,32,64,128").split(",")))
-_GDFN_BWD_FUSED = set(filter(None, os.environ.get("UIR_GDFN_BWD_FUSED", "16,32").split(",")))
+# opt-in: after the gate-backward epilogue fix the three HBM-bound kernels (869 us at C=32, 256x256) beat the fused,
+# latency-bound kernel (959 us, SIMDs 47 % busy); full step 51.9 vs 52.7 ms (profiles/r01/d_ab_notes.md)
+_GDFN_BWD_FUSED = set(filter(None, os.environ.get("UIR_GDFN_BWD_FUSED", "").split(",")))
 SCRATCH_FLOATS = 96 * 1024 * 1024  # 384 MB of slab scratch shared by every reduction
 
 
@@ -769,10 +771,15 @@ class Plan(Recorder):
             y = self.alloc(M, Np)
         self.gemm(name, x, Wt, y, N=Np, K=Kp, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=dims[1:], k_grp=k_grp, n_grp=n_grp)
 
-        def backward(dy, need_dx=True):
-            with self.bulk():
+        def backward(dy, need_dx=True, dw_on_chain=False):
+            def dw():
                 self.gram(name + ".dW", dy, x, self.Gr(Wname), N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:],
                           n_grp=n_grp, k_grp=k_grp)
+            if dw_on_chain:      # last op of the step: the chain has nothing left to do, the bulk lane still has a queue
+                dw()
+            else:
+                with self.bulk():
+                    dw()
             if not need_dx:
                 return None
             dx = self.alloc(M, Kp)
@@ -991,7 +998,7 @@ class Plan(Recorder):
         self.copy_cols("e1.grad_sum", d_e1, 0, de1, 0, 16, accumulate=1)
         df0 = enc1_bw(de1)
         self.mark("bwd.enc0(L0,C16)")
-        embed_bw(df0, need_dx=False)
+        embed_bw(df0, need_dx=False, dw_on_chain=True)
         self.mark("bwd.embed")
         self._defer_bulk(self.bwd, os.environ.get("UIR_DEFER_AT", "bwd.dec2(L0,C32)"))
         self.cur = self.fwd
