@@ -157,8 +157,28 @@ __global__ __launch_bounds__(256) void uir_dwconv_wgrad_kernel(const UirDwWgradA
 
 // Fused backward: input-gradient AND weight-gradient partials in one pass over dY.
 //   dX[h][w] = sum_t dY[h-dy_t][w-dx_t] * W[t]          dW[t] = sum_q X[q] * dY[q - off_t]
-// Both need the same rolling 3 x (R+2) window of dY; the weight-gradient additionally needs only the
-// CENTRE run of X.  Versus separate kernels dY is read once instead of twice (HBM-bound: -25 % bytes).
+// Both need the same rolling 3 x (RR+2) window of dY; the weight-gradient additionally needs only the
+// CENTRE run of X.  Versus separate kernels dY is read once instead of twice (-25 % bytes).
+// RR = 2 pixels per run and a window that rotates by register NAME (rows unrolled x3, no shift
+// copies): ~130 VGPRs instead of the > 256 of the 4-pixel version, which ran at one wave per SIMD.
+template <int RR>
+__device__ __forceinline__ void load_row_t(float4 (&v)[RR + 2], const float* base, long ld, int b, int hh, int w0, int H, int Wd) {
+  const bool hok = hh >= 0 && hh < H;
+  const int hc = min(max(hh, 0), H - 1);
+  const float* rowp = base + ((long)(b * H + hc) * Wd) * ld;
+#pragma unroll
+  for (int j = 0; j < RR + 2; ++j) {
+    const int wc = min(max(w0 - 1 + j, 0), Wd - 1);
+    v[j] = *reinterpret_cast<const float4*>(rowp + (long)wc * ld);
+  }
+#pragma unroll
+  for (int j = 0; j < RR + 2; ++j) {
+    const int ww = w0 - 1 + j;
+    if (!(hok && ww >= 0 && ww < Wd)) v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+template <int RR>
 __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBwdArgs a, const int HS) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [9][C] weights, then [ny][c4n][36] reduction
   const int c4n = a.C >> 2;
@@ -173,7 +193,7 @@ __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBw
     for (int t = 0; t < 9; ++t) wl[t * a.C + c] = cr >= 0 ? wp[t] : 0.f;
   }
   __syncthreads();
-  const int runs = (a.Wd + R - 1) / R;
+  const int runs = (a.Wd + RR - 1) / RR;
   const int strips = (a.H + HS - 1) / HS;
   const long items = (long)a.B * strips * runs;
   float4 acc[9];
@@ -186,46 +206,51 @@ __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBw
       long t = it / runs;
       const int sp = (int)(t % strips);
       const int b = (int)(t / strips);
-      const int w0 = run * R, h0 = sp * HS;
+      const int w0 = run * RR, h0 = sp * HS;
       const int hend = min(h0 + HS, a.H);
-      float4 g0[R + 2], g1[R + 2], g2[R + 2];   // dY rows h-1, h, h+1
-      load_row(g0, gb, a.ldy, b, h0 - 1, w0, a.H, a.Wd);
-      load_row(g1, gb, a.ldy, b, h0, w0, a.H, a.Wd);
-      for (int h = h0; h < hend; ++h) {
-        load_row(g2, gb, a.ldy, b, h + 1, w0, a.H, a.Wd);
-        float4 x[R];
+      float4 g0[RR + 2], g1[RR + 2], g2[RR + 2];
+      load_row_t<RR>(g0, gb, a.ldy, b, h0 - 1, w0, a.H, a.Wd);
+      load_row_t<RR>(g1, gb, a.ldy, b, h0, w0, a.H, a.Wd);
+      // gm = dY row h-1, gc = row h, gp = row h+1 (loaded here)
+      auto step = [&](float4 (&gm)[RR + 2], float4 (&gc)[RR + 2], float4 (&gp)[RR + 2], int h) {
+        load_row_t<RR>(gp, gb, a.ldy, b, h + 1, w0, a.H, a.Wd);
+        float4 x[RR];
         const float* xp = a.X + ((long)(b * a.H + h) * a.Wd) * a.ldx + c4 * 4;
 #pragma unroll
-        for (int j = 0; j < R; ++j) x[j] = *reinterpret_cast<const float4*>(xp + (long)min(w0 + j, a.Wd - 1) * a.ldx);
+        for (int j = 0; j < RR; ++j) x[j] = *reinterpret_cast<const float4*>(xp + (long)min(w0 + j, a.Wd - 1) * a.ldx);
 #pragma unroll
-        for (int j = 0; j < R; ++j)
+        for (int j = 0; j < RR; ++j)
           if (w0 + j >= a.Wd) x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        float* op = a.dX + ((long)(b * a.H + h) * a.Wd) * a.ldo + c4 * 4;
-        float4 o[R];
+        float4 o[RR];
 #pragma unroll
-        for (int j = 0; j < R; ++j) o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < RR; ++j) o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
-          // tap (dy, dx): dY row h-dy = {g2 (dy=-1), g1 (dy=0), g0 (dy=+1)}, column index j+1-dx
+          // tap (dy, dx): dY row h-dy = {gp (dy=-1), gc (dy=0), gm (dy=+1)}, column index j+1-dx
           const float4 wm = *reinterpret_cast<const float4*>(&wl[(0 * 3 + dx + 1) * a.C + c4 * 4]);   // dy = -1
           const float4 w0v = *reinterpret_cast<const float4*>(&wl[(1 * 3 + dx + 1) * a.C + c4 * 4]);  // dy =  0
           const float4 wp = *reinterpret_cast<const float4*>(&wl[(2 * 3 + dx + 1) * a.C + c4 * 4]);   // dy = +1
 #pragma unroll
-          for (int j = 0; j < R; ++j) {
+          for (int j = 0; j < RR; ++j) {
             const int jj = j + 1 - dx;
-            o[j] = f4_fma(g2[jj], wm, o[j]);
-            o[j] = f4_fma(g1[jj], w0v, o[j]);
-            o[j] = f4_fma(g0[jj], wp, o[j]);
-            acc[0 * 3 + dx + 1] = f4_fma(x[j], g2[jj], acc[0 * 3 + dx + 1]);
-            acc[1 * 3 + dx + 1] = f4_fma(x[j], g1[jj], acc[1 * 3 + dx + 1]);
-            acc[2 * 3 + dx + 1] = f4_fma(x[j], g0[jj], acc[2 * 3 + dx + 1]);
+            o[j] = f4_fma(gp[jj], wm, o[j]);
+            o[j] = f4_fma(gc[jj], w0v, o[j]);
+            o[j] = f4_fma(gm[jj], wp, o[j]);
+            acc[0 * 3 + dx + 1] = f4_fma(x[j], gp[jj], acc[0 * 3 + dx + 1]);
+            acc[1 * 3 + dx + 1] = f4_fma(x[j], gc[jj], acc[1 * 3 + dx + 1]);
+            acc[2 * 3 + dx + 1] = f4_fma(x[j], gm[jj], acc[2 * 3 + dx + 1]);
           }
         }
+        float* op = a.dX + ((long)(b * a.H + h) * a.Wd) * a.ldo + c4 * 4;
 #pragma unroll
-        for (int j = 0; j < R; ++j)
+        for (int j = 0; j < RR; ++j)
           if (w0 + j < a.Wd) *reinterpret_cast<float4*>(op + (long)(w0 + j) * a.ldo) = o[j];
-#pragma unroll
-        for (int j = 0; j < R + 2; ++j) { g0[j] = g1[j]; g1[j] = g2[j]; }
+      };
+#pragma unroll 1
+      for (int h = h0; h < hend; h += 3) {
+        step(g0, g1, g2, h);
+        if (h + 1 < hend) step(g1, g2, g0, h + 1);
+        if (h + 2 < hend) step(g2, g0, g1, h + 2);
       }
     }
     float* rp = red + ((long)py * c4n + c4) * 36;
@@ -296,7 +321,7 @@ extern "C" int uir_dwconv_bwd_fused(const UirDwBwdArgs* p, void* stream) {
   const int ny = 256 / c4n;
   const size_t lds = ((size_t)9 * a.C + (size_t)ny * c4n * 36) * sizeof(float);
   UIR_REQUIRE(lds <= 96 * 1024);
-  hipLaunchKernelGGL(uir_dwconv_bwd_fused_kernel, dim3(a.nblocks), dim3(c4n, ny), lds, static_cast<hipStream_t>(stream), a,
+  hipLaunchKernelGGL(uir_dwconv_bwd_fused_kernel<2>, dim3(a.nblocks), dim3(c4n, ny), lds, static_cast<hipStream_t>(stream), a,
                      uir_dw_strip(a.B, a.H, a.Wd, a.C));
   return uir_launch_status();
 }

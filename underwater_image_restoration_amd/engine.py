@@ -533,17 +533,18 @@ class Recorder:
 
     def dwconv_bwd(self, name, dY, X, Wt, dX, dW, *, C_, creal, dims, grp=(0, 0)):
         """Fused input-gradient + weight-gradient of a depthwise 3x3 (dY read once)."""
-        if os.environ.get("UIR_FUSED_DW", "0") != "1":
-            # default: two kernels (input-gradient on the chain, weight-gradient on the bulk lane).  The fused
-            # kernel moves 25 % fewer bytes but needs 256 VGPRs (1 wave/SIMD): A/B on one MI355X, same
-            # process settings: 57.2 ms/step fused vs 56.6 ms/step separate (profiles/r01/d_ab_notes.md)
+        if os.environ.get("UIR_FUSED_DW", "1") != "1":
+            # two kernels (input-gradient on the chain, weight-gradient on the bulk lane): dY is read twice.  The fused
+            # kernel (2-pixel runs, window rotating by register name, ~240 VGPRs, 2 waves/SIMD) reads it once:
+            # A/B on one MI355X 51.3 vs 51.9 ms/step (profiles/r01/d_ab_notes.md); the first fused version
+            # (4-pixel runs, > 256 VGPRs, 1 wave/SIMD) had been slower than the split.
             with self.bulk():
                 self.dwconv_wgrad(name + ".dW", dY, X, dW, C_=C_, creal=creal, dims=dims, grp=grp)
             self.dwconv(name + ".dX", dY, Wt, dX, C_=C_, dims=dims, grp=grp, flip=1)
             return
         self._hold(dY, X, Wt, dX, dW)
         a = L.DwBwdArgs()
-        a.dY, a.X, a.Wt, a.dX, a.slab = _ptr(dY), _ptr(X), _ptr(Wt), _ptr(dX), _ptr(self._slab())
+        a.dY, a.X, a.Wt, a.dX = _ptr(dY), _ptr(X), _ptr(Wt), _ptr(dX)
         a.ldy, a.ldx, a.ldo = _ld(dY), _ld(X), _ld(dX)
         a.B, a.H, a.Wd = dims
         a.C, a.creal = C_, creal
@@ -554,11 +555,15 @@ class Recorder:
         items = dims[0] * ((dims[1] + hs - 1) // hs) * ((dims[2] + 3) // 4)
         ny = 256 // (C_ // 4)
         a.nblocks = max(1, min(2048, items // max(1, ny)))
-        assert a.nblocks * creal * 9 <= self._slab().numel()
+        # private partial-slab buffer: the kernel runs on the chain, its (tiny) reduction on the bulk lane, so the
+        # shared chain scratch may be overwritten in between
+        slab = self.alloc(a.nblocks * creal * 9)
+        a.slab = _ptr(slab)
         self.keep.append(a)
         rows = dims[0] * dims[1] * dims[2]
         self._op(name, lib.uir_dwconv_bwd_fused, C.byref(a), nbytes=12 * rows * C_, flops=36 * rows * C_)
-        self._op(name + ".red", lib.uir_reduce_slab, _ptr(self._slab()), a.nblocks, creal * 9, _ptr(dW), creal * 9, 0, 1.0)
+        with self.bulk():
+            self._op(name + ".red", lib.uir_reduce_slab, _ptr(slab), a.nblocks, creal * 9, _ptr(dW), creal * 9, 0, 1.0)
 
     def ln_bwd(self, name, dT, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_):
         self._hold(dT, X, stats, gamma, dRes, dX, dgamma, dbeta)
