@@ -172,6 +172,7 @@ def main():
         if not args.no_kernel_breakdown:
             plan = model._plan_for(raw)
             rows = plan.run_timed(plan.fwd) + plan.run_timed(plan.bwd)
+            lanes = list(plan.lanes[id(plan.fwd)]) + list(plan.lanes[id(plan.bwd)])
             agg = {}
             for name, sym, nb, fl, t_ms in rows:
                 a = agg.setdefault(sym, [0, 0.0, 0, 0])
@@ -188,9 +189,9 @@ def main():
                     f.write("symbol,launches,ms_per_step,alg_GB,alg_GBps,TFLOPs\n")
                     for sym, (cnt, tms, nb, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                         f.write(f"{sym},{cnt},{tms:.4f},{nb / 1e9:.3f},{nb / max(tms, 1e-9) / 1e6:.1f},{fl / max(tms, 1e-9) / 1e9:.2f}\n")
-                    f.write("\nop,symbol,ms,alg_MB\n")
-                    for name, sym, nb, fl, t_ms in sorted(rows, key=lambda r: -r[4]):
-                        f.write(f"{name},{sym},{t_ms:.4f},{nb / 1e6:.2f}\n")
+                    f.write("\nop,symbol,ms,alg_MB,lane (0 chain, 1 side, 4 bulk; serial per-launch times)\n")
+                    for (name, sym, nb, fl, t_ms), ln in sorted(zip(rows, lanes), key=lambda r: -r[0][4]):
+                        f.write(f"{name},{sym},{t_ms:.4f},{nb / 1e6:.2f},{ln}\n")
         out = {"metric": "train images/sec at 256x256 bs=16/GPU (SpectralTransformer full train step)",
                "value": imgs_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
