@@ -568,18 +568,24 @@ class Recorder:
     def ln_bwd(self, name, dT, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_):
         self._hold(dT, X, stats, gamma, dRes, dX, dgamma, dbeta)
         a = L.LnBwdArgs()
-        a.dT, a.X, a.stats, a.gamma, a.dRes, a.dX, a.slab = (_ptr(dT), _ptr(X), _ptr(stats), _ptr(gamma), _ptr(dRes),
-                                                            _ptr(dX), _ptr(self.scratch))
+        a.dT, a.X, a.stats, a.gamma, a.dRes, a.dX = (_ptr(dT), _ptr(X), _ptr(stats), _ptr(gamma), _ptr(dRes), _ptr(dX))
         a.ldt, a.ldx, a.ldo = _ld(dT), _ld(X), _ld(dX)
         a.ldr = _ld(dRes) if dRes is not None else 0
         a.M, a.C = X.shape[0], C_
         rows_per_block = 256 // (C_ // 4)
         a.nblocks = max(1, min(512, (a.M + rows_per_block * 4 - 1) // (rows_per_block * 4)))
+        # private partial slab: the (tiny) dgamma/dbeta reductions leave the chain for the bulk lane
+        slab = self.alloc(a.nblocks * 2 * C_)
+        a.slab = _ptr(slab)
         self.keep.append(a)
         self._op(name, lib.uir_layernorm_bwd, C.byref(a), nbytes=4 * a.M * C_ * (4 if dRes is not None else 3), flops=16 * a.M * C_)
-        sp = self.scratch.data_ptr()
-        self._op(name + ".dg", lib.uir_reduce_slab, sp, a.nblocks, 2 * C_, _ptr(dgamma), C_, 0, 1.0)
-        self._op(name + ".db", lib.uir_reduce_slab, sp + 4 * C_, a.nblocks, 2 * C_, _ptr(dbeta), C_, 0, 1.0)
+        sp = slab.data_ptr()
+        with self.bulk():
+            if dbeta.data_ptr() == dgamma.data_ptr() + 4 * C_:      # weight | bias adjacent in the flat gradient bucket
+                self._op(name + ".dgb", lib.uir_reduce_slab, sp, a.nblocks, 2 * C_, _ptr(dgamma), 2 * C_, 0, 1.0)
+            else:
+                self._op(name + ".dg", lib.uir_reduce_slab, sp, a.nblocks, 2 * C_, _ptr(dgamma), C_, 0, 1.0)
+                self._op(name + ".db", lib.uir_reduce_slab, sp + 4 * C_, a.nblocks, 2 * C_, _ptr(dbeta), C_, 0, 1.0)
 
     def colsum(self, name, src, col, C_, out):
         self._hold(src, out)
