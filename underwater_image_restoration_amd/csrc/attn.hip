@@ -59,11 +59,16 @@ __global__ __launch_bounds__(256) void uir_attn_fwd_kernel(const UirAttnFwdArgs 
 __global__ __launch_bounds__(256) void uir_attn_bwd_kernel(const UirAttnBwdArgs a) {
   __shared__ float at[1024], dA[1024], S[1024], dS[1024];
   __shared__ float acoef[32], bcoef[32], rowdT[32], nqs[32], nks[32];
+  __shared__ float wA[128 * 32], wB[128 * 32];   // this head's d columns of dWA / dWB, [r][j]: read twice below
   const int b = blockIdx.x, h = blockIdx.y, C = a.C, d = C / a.heads;
   const float* G = a.G + (long)b * C * C;
-  const float* dWA = a.dWA + (long)b * C * C;
-  const float* dWB = a.dWB + (long)b * C * C;
   const float T = a.temperature[h];
+  for (int e = threadIdx.x; e < C * d; e += blockDim.x) {
+    const int r = e / d, j = e - r * d;
+    const long idx = (long)b * C * C + (long)r * C + h * d + j;
+    wA[e] = a.dWA[idx];
+    wB[e] = a.dWB[idx];
+  }
   for (int i = threadIdx.x; i < d; i += blockDim.x) {
     nqs[i] = fmaxf(sqrtf(a.sq_q[(long)b * C + h * d + i]), NORM_EPS);
     nks[i] = fmaxf(sqrtf(a.sq_k[(long)b * C + h * d + i]), NORM_EPS);
@@ -76,8 +81,8 @@ __global__ __launch_bounds__(256) void uir_attn_bwd_kernel(const UirAttnBwdArgs 
     // dA[i][j] = sum_r P[r][t] dWA[r][hd+j] + Wof[r][t] dWB[r][hd+j]
     float s = 0.f;
     for (int r = 0; r < C; ++r) {
-      s = fmaf(a.P[(long)r * C + t], dWA[(long)r * C + h * d + j], s);
-      s = fmaf(a.Wof[(long)r * C + t], dWB[(long)r * C + h * d + j], s);
+      s = fmaf(a.P[(long)r * C + t], wA[r * d + j], s);
+      s = fmaf(a.Wof[(long)r * C + t], wB[r * d + j], s);
     }
     dA[e] = s;
   }
@@ -135,8 +140,8 @@ __global__ __launch_bounds__(256) void uir_attn_bwd_kernel(const UirAttnBwdArgs 
     float sp = 0.f, so = 0.f;
     for (int j = 0; j < d; ++j) {
       const float p = at[i * d + j];
-      sp = fmaf(dWA[(long)r * C + h * d + j], p, sp);
-      so = fmaf(dWB[(long)r * C + h * d + j], p, so);
+      sp = fmaf(wA[r * d + j], p, sp);
+      so = fmaf(wB[r * d + j], p, so);
     }
     dP[(long)r * C + h * d + i] = sp;
     dWof[(long)r * C + h * d + i] = so;
