@@ -246,6 +246,19 @@ typedef struct UirDftArgs {
 } UirDftArgs;
 int uir_dft_axis(const UirDftArgs* args, void* stream);
 
+/* Same transform for N = 16*N2 in {32, 64, 128} as a two-stage (16 x N2) Cooley-Tukey factorisation on the
+ * matrix cores (4x fewer MFMAs at N = 128).  ta / tb are host-built (fp64) MFMA operand tables for this
+ * (N, sign): ta[16][64] = stage-A operand per (k-step, lane); tb[8][2*N2][64] = stage-B block-diagonal operand
+ * per (k1 pair, k-step, lane) with the inter-stage twiddle folded in (layout: csrc/spectral.hip, engine.dft2_tables). */
+typedef struct UirDft2Args {
+  const float* in_re; const float* in_im;   /* in_im may be NULL (real input)                    */
+  float* out_re; float* out_im;             /* out_im may be NULL (only the real part wanted)    */
+  const float* ta; const float* tb;
+  int O, N, I, C;                            /* tensor viewed as [O][N][I][C], transform along N  */
+  float scale;
+} UirDft2Args;
+int uir_dft_axis2(const UirDft2Args* args, void* stream);
+
 /* mag = |F|, pha = atan2(im, re) with Im forced to +0 at the self-conjugate bins (what
  * torch.fft.fft2 of a real tensor yields; tests/golden/fft_zero_sign.npz).  :177-178 */
 int uir_magpha_fwd(const float* re, const float* im, float* mag, float* pha, int B, int H, int Wd, int C, void* stream);

@@ -482,7 +482,8 @@ def test_attn_fwd_bwd(C, heads):
 
 
 # -------------------------------------------------------------- uir_spectral
-@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 40), (1, 16, 16, 32), (1, 6, 10, 64), (1, 32, 32, 128)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 8, 12, 40), (1, 16, 16, 32), (1, 6, 10, 64), (1, 32, 32, 128),
+                                     (1, 64, 128, 32), (2, 128, 32, 16), (1, 32, 64, 72)])   # 32/64/128: two-stage kernel
 def test_dft_matches_fft2_and_adjoint(B, H, W, C):
     x = rnd(B, C, H, W, seed=1)
     f = torch.fft.fft2(x)

@@ -102,6 +102,11 @@ class DftArgs(C.Structure):
                 ("sign", C.c_float), ("scale", C.c_float)]
 
 
+class Dft2Args(C.Structure):
+    _fields_ = [("in_re", fp), ("in_im", fp), ("out_re", fp), ("out_im", fp), ("ta", fp), ("tb", fp),
+                ("O", C.c_int), ("N", C.c_int), ("I", C.c_int), ("C", C.c_int), ("scale", C.c_float)]
+
+
 class AdamArgs(C.Structure):
     _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("sumsq", fp), ("norm_out", fp), ("hyper", fp), ("n", C.c_long),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -124,6 +129,7 @@ SIGNATURES = {
     "uir_attn_fwd": [C.POINTER(AttnFwdArgs), fp],
     "uir_attn_bwd": [C.POINTER(AttnBwdArgs), fp],
     "uir_dft_axis": [C.POINTER(DftArgs), fp],
+    "uir_dft_axis2": [C.POINTER(Dft2Args), fp],
     "uir_magpha_fwd": [fp, fp, fp, fp, i32, i32, i32, i32, fp],
     "uir_magpha_bwd": [fp, fp, fp, fp, fp, fp, i64, fp],
     "uir_polar_fwd": [fp, fp, fp, fp, i64, fp],

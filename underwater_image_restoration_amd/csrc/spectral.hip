@@ -90,6 +90,83 @@ __global__ __launch_bounds__(256) void uir_dft_kernel(const UirDftArgs a, int ct
     }
 }
 
+// Two-stage (Cooley-Tukey 16 x N2) DFT axis for N = 16 * N2 in {32, 64, 128}: 4x fewer MFMAs than the dense
+// contraction at N = 128.  n = N2 n1 + n2, k = k1 + 16 k2:
+//   stage A (per n2):  Y[n2][k1] = sum_n1 W16^(n1 k1) x[N2 n1 + n2]      one 32x32 real tile: rows (Re|Im, k1), K = (re|im, n1)
+//   stage B (per k1):  X[k1 + 16 k2] = sum_n2 W^(n2 (k1 + 16 k2)) Y[n2][k1]   (the twiddle W^(n2 k1) is folded into the matrix)
+// Stage A leaves Y in the MFMA accumulator layout (lane = channel, register = (Re|Im, k1)): lane half 0 owns
+// k1 in {0-3, 8-11}, half 1 owns k1 + 4.  Stage B therefore transforms the PAIR (k1, k1 + 4) per MFMA tile with a
+// block-diagonal operand (rows (which k1, Re|Im, k2), contraction (n2, Re|Im) x lane half): its B operand is simply
+// accumulator register j (+8 for Im) of stage A - no shuffles, no LDS.  Operand tables are built on the host in fp64.
+template <int N2>
+__global__ __launch_bounds__(256) void uir_dft2_kernel(const UirDft2Args a, int ctiles, long items) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, h2 = lane >> 5;
+  const long item = (long)blockIdx.x * 4 + wave;
+  if (item >= items) return;
+  const int ct = (int)(item % ctiles);
+  long t = item / ctiles;
+  const int i = (int)(t % a.I);
+  const long o = t / a.I;
+  constexpr int N = 16 * N2;
+  const int c = ct * 32 + li;
+  const bool cok = c < a.C;
+  const int cc = min(c, a.C - 1);
+  const long nstride = (long)a.I * a.C;
+  const long line = (o * N * a.I + i) * a.C;
+  const bool has_im = a.in_im != nullptr, want_im = a.out_im != nullptr;
+  const float* imp = has_im ? a.in_im : a.in_re;
+
+  float ta[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) ta[s] = a.ta[s * 64 + lane];
+
+  f32x16 D[N2];
+#pragma unroll
+  for (int n2 = 0; n2 < N2; ++n2) {
+    float br[8], bi[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const long off = line + (long)(N2 * (2 * s + h2) + n2) * nstride + cc;
+      br[s] = a.in_re[off];
+      bi[s] = imp[off];
+    }
+    f32x16 d;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) d[q] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 8; ++s) d = uir_mfma(ta[s], cok ? br[s] : 0.f, d);
+    if (has_im) {
+#pragma unroll
+      for (int s = 0; s < 8; ++s) d = uir_mfma(ta[8 + s], cok ? bi[s] : 0.f, d);
+    }
+    D[n2] = d;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float tb[2 * N2];
+#pragma unroll
+    for (int s = 0; s < 2 * N2; ++s) tb[s] = a.tb[(j * 2 * N2 + s) * 64 + lane];
+    f32x16 e;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) e[q] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2 * N2; ++s) e = uir_mfma(tb[s], D[s >> 1][j + 8 * (s & 1)], e);
+    const int aj = (j & 3) + 8 * (j >> 2);          // k1 of lane half 0; half 1 holds k1 + 4 ... as ROW blocks w = 0 / 1
+    if (cok) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k2 = (q & 3) + 4 * h2, p = (q >> 2) & 1, w = q >> 3;
+        if (k2 < N2 && (p == 0 || want_im)) {
+          const int k = aj + 4 * w + 16 * k2;
+          float* dst = p ? a.out_im : a.out_re;
+          dst[line + (long)k * nstride + c] = e[q] * a.scale;
+        }
+      }
+    }
+  }
+}
+
 __global__ void uir_magpha_fwd_kernel(const float* __restrict__ re, const float* __restrict__ im, float* __restrict__ mag,
                                       float* __restrict__ pha, int H, int Wd, int C, long n) {
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
@@ -212,5 +289,22 @@ extern "C" int uir_cabs_fwd(const float* zr, const float* zi, float* t, long n, 
 extern "C" int uir_cabs_bwd(const float* zr, const float* zi, const float* t, const float* g_t, float* g_zr, float* g_zi, long n, void* stream) {
   UIR_REQUIRE(zr && zi && t && g_t && g_zr && g_zi && n > 0);
   hipLaunchKernelGGL(uir_cabs_bwd_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), zr, zi, t, g_t, g_zr, g_zi, n);
+  return uir_launch_status();
+}
+
+extern "C" int uir_dft_axis2(const UirDft2Args* p, void* stream) {
+  const UirDft2Args& a = *p;
+  UIR_REQUIRE(a.in_re && a.out_re && a.ta && a.tb);
+  UIR_REQUIRE(a.O > 0 && a.I > 0 && a.C > 0 && (a.N == 32 || a.N == 64 || a.N == 128));
+  const int ctiles = (a.C + 31) / 32;
+  const long items = (long)a.O * a.I * ctiles;
+  const long blocks = (items + 3) / 4;
+  UIR_REQUIRE(blocks < (1L << 31));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a.N) {
+    case 32: hipLaunchKernelGGL(uir_dft2_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a, ctiles, items); break;
+    case 64: hipLaunchKernelGGL(uir_dft2_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, a, ctiles, items); break;
+    default: hipLaunchKernelGGL(uir_dft2_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a, ctiles, items); break;
+  }
   return uir_launch_status();
 }

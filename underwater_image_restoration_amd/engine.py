@@ -115,6 +115,49 @@ def twiddles(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     return _TWIDDLE_CACHE[key]
 
 
+_DFT2_CACHE: dict = {}
+
+
+def dft2_tables(n: int, sign: float, device) -> Tuple[torch.Tensor, torch.Tensor]:
+    """MFMA operand tables of the two-stage (16 x N2) DFT (csrc/spectral.hip uir_dft2_kernel), float64-built.
+    ta[s][lane]: stage A, rows (Re|Im, k1), contraction (re|im, n1), k-step s <-> k = 2s + (lane >> 5).
+    tb[j][s][lane]: stage B for the k1 pair (a_j, a_j + 4): rows (w, Re|Im, k2), k-step s = 2 n2 + (re|im), the lane half
+    selects w (block diagonal); angle 2 pi n2 (k1 + 16 k2) / n, i.e. the inter-stage twiddle is folded in."""
+    key = (n, float(sign), str(device))
+    if key not in _DFT2_CACHE:
+        n2c = n // 16
+        lane = np.arange(64)
+        li, h2 = lane & 31, lane >> 5
+
+        def cs(num, den):                      # exact residues, exact 0 / +-1 at multiples of pi/2
+            r = np.asarray(num, dtype=np.int64) % den
+            ang = 2.0 * np.pi * r.astype(np.float64) / den
+            c, s_ = np.cos(ang), np.sin(ang)
+            q = (4 * r) % den == 0
+            c = np.where(q, np.round(c), c)
+            s_ = np.where(q, np.round(s_), s_)
+            return c, sign * s_
+        ta = np.zeros((16, 64))
+        for s_ in range(16):
+            k = 2 * s_ + h2                    # contraction index: < 16 real input n1 = k, else imaginary n1 = k - 16
+            out_im, k1 = li >= 16, li & 15
+            in_im, n1 = k >= 16, k & 15
+            c, sg = cs(n1 * k1, 16)
+            ta[s_] = np.where(out_im == in_im, c, np.where(out_im, sg, -sg))
+        tb = np.zeros((8, 2 * n2c, 64))
+        w, p, k2 = li >> 4, (li >> 3) & 1, li & 7
+        for j in range(8):
+            aj = (j & 3) + 8 * (j >> 2)
+            for s_ in range(2 * n2c):
+                nn2, pp = s_ >> 1, s_ & 1
+                c, sg = cs(nn2 * (aj + 4 * w + 16 * k2), n)
+                v = np.where(p == pp, c, np.where(p == 1, sg, -sg))
+                tb[j, s_] = np.where((w == h2) & (k2 < n2c), v, 0.0)
+        _DFT2_CACHE[key] = (torch.from_numpy(ta.astype(np.float32)).to(device).contiguous(),
+                            torch.from_numpy(tb.astype(np.float32)).to(device).contiguous())
+    return _DFT2_CACHE[key]
+
+
 def _ptr(t) -> int:
     return 0 if t is None else t.data_ptr()
 
@@ -533,7 +576,10 @@ class Recorder:
 
     def dwconv_bwd(self, name, dY, X, Wt, dX, dW, *, C_, creal, dims, grp=(0, 0)):
         """Fused input-gradient + weight-gradient of a depthwise 3x3 (dY read once)."""
-        if os.environ.get("UIR_FUSED_DW", "1") != "1":
+        # fused only where bytes bind (full and half resolution); at the deep levels the chain is latency-bound and the
+        # split keeps the weight-gradient half off it
+        rows_total = dims[0] * dims[1] * dims[2]
+        if os.environ.get("UIR_FUSED_DW", "1") != "1" or rows_total < int(os.environ.get("UIR_FUSED_DW_MINROWS", 16 * 128 * 128)):
             # two kernels (input-gradient on the chain, weight-gradient on the bulk lane): dY is read twice.  The fused
             # kernel (2-pixel runs, window rotating by register name, ~240 VGPRs, 2 waves/SIMD) reads it once:
             # A/B on one MI355X 51.3 vs 51.9 ms/step (profiles/r01/d_ab_notes.md); the first fused version
@@ -602,6 +648,20 @@ class Recorder:
 
     def dft(self, name, in_re, in_im, out_re, out_im, *, O, N, I, C_, sign, scale):
         self._hold(in_re, in_im, out_re, out_im)
+        elems = O * N * I * C_
+        planes = (1 if in_im is None else 2) + (1 if out_im is None else 2)
+        if N in (32, 64, 128) and os.environ.get("UIR_DFT2", "1") == "1":
+            a = L.Dft2Args()
+            a.in_re, a.in_im, a.out_re, a.out_im = _ptr(in_re), _ptr(in_im), _ptr(out_re), _ptr(out_im)
+            ta, tb = dft2_tables(N, sign, self.dev)
+            self.keep += [ta, tb]
+            a.ta, a.tb = _ptr(ta), _ptr(tb)
+            a.O, a.N, a.I, a.C = O, N, I, C_
+            a.scale = scale
+            self.keep.append(a)
+            self._op(name, lib.uir_dft_axis2, C.byref(a), nbytes=4 * elems * planes,
+                     flops=2 * elems * (16 + N // 16) * (1 if in_im is None else 2) * 2)
+            return
         a = L.DftArgs()
         a.in_re, a.in_im, a.out_re, a.out_im = _ptr(in_re), _ptr(in_im), _ptr(out_re), _ptr(out_im)
         ct, st = twiddles(N, self.dev)
