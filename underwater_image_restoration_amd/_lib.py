@@ -15,7 +15,7 @@ fp = C.c_void_p  # device pointers travel as integers
 
 # enums (mirror include/uir_kernels.h)
 PRO_NONE, PRO_LN, PRO_GATE = 0, 1, 2
-EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD = 0, 1, 2
+EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW = 0, 1, 2, 3
 ACT_NONE, ACT_LEAKY = 0, 1
 LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4}
 
@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
                 ("taps", C.c_int), ("flip", C.c_int), ("H", C.c_int), ("Wd", C.c_int),
                 ("n_grp_real", C.c_int), ("n_grp_pad", C.c_int), ("k_grp_real", C.c_int), ("k_grp_pad", C.c_int),
                 ("pro", C.c_int), ("gate_off", C.c_int), ("epi", C.c_int), ("g_off", C.c_int), ("act", C.c_int),
-                ("slope", C.c_float), ("ln_eps", C.c_float)]
+                ("slope", C.c_float), ("ln_eps", C.c_float), ("dw_slab", fp), ("dw_stride", C.c_long)]
 
 
 class GramArgs(C.Structure):

@@ -296,8 +296,59 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
   }
 }
 
+// Gate-backward epilogue that ALSO accumulates the project_out weight gradient (EPI_GATE_BWD_DW, K <= 32, full tiles):
+//   dW_out[c][j] = sum_px dY[px][c] * g[px][j],   g = gelu(t2a) * t2b  (computed here anyway).
+// The accumulator layout of the main MFMA (lane = hidden column j, register = pixel) IS the B-operand layout of a
+// contraction over pixels, so g feeds the second MFMA straight from registers; the A operand dY^T (lane = channel)
+// is 16 coalesced dword loads of rows this wave has just read.  gacc lives across the workgroup's row tiles.
+template <int NT>
+__device__ __forceinline__ void uir_gemm1x1_store_gate_dw(const UirGemmArgs& a, const f32x16 (&acc)[NT], f32x16 (&gacc)[NT],
+                                                           int m0, int n0, int r, int h2) {
+  float ap[16];
+  {
+    const int kc = r < a.K ? r : 0;
+    const float* xp = a.X + ((long)m0 + 4 * h2) * a.ldx + kc;
+#pragma unroll
+    for (int s = 0; s < 16; ++s) ap[s] = xp[(long)((s & 3) + 8 * (s >> 2)) * a.ldx];
+    if (r >= a.K) {
+#pragma unroll
+      for (int s = 0; s < 16; ++s) ap[s] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + 32 * nt + r;
+    const bool nok = n < a.N;
+    const int nn = nok ? n : a.N - 1;                    // clamped: no lane-divergent control flow around the MFMAs
+    const long row0 = (long)m0 + 4 * h2;
+    float* yp = a.Y + row0 * a.ldy + nn;
+    const float* gp = a.G + row0 * a.ldg + nn;
+    float g1[16], g2[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const long o = (long)((reg & 3) + 8 * (reg >> 2)) * a.ldg;
+      g1[reg] = gp[o];
+      g2[reg] = gp[o + a.g_off];
+    }
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const long o = (long)((reg & 3) + 8 * (reg >> 2)) * a.ldy;
+      const float v = acc[nt][reg];
+      float ge, dge;
+      uir_gelu_pair(g1[reg], ge, dge);
+      if (nok) {
+        yp[o] = v * g2[reg] * dge;
+        yp[o + a.g_off] = v * ge;
+      }
+      g1[reg] = nok ? ge * g2[reg] : 0.f;                // g, in B-operand position
+    }
+#pragma unroll
+    for (int s = 0; s < 16; ++s) gacc[nt] = uir_mfma(ap[s], g1[s], gacc[nt]);
+  }
+}
+
 template <int NT, int PRO, int EPI, bool HAS_R>
-__global__ __launch_bounds__(256, 3) void uir_gemm1x1_kernel(const UirGemmArgs a, const int Kp, const int tiles) {
+__global__ __launch_bounds__(256, EPI == UIR_EPI_GATE_BWD_DW ? 2 : 3) void uir_gemm1x1_kernel(const UirGemmArgs a, const int Kp, const int tiles) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h2 = lane >> 5;
@@ -418,6 +469,13 @@ __global__ __launch_bounds__(256, 3) void uir_gemm1x1_kernel(const UirGemmArgs a
   int tile = blockIdx.x, c = 0;
   float mean = 0.f, rstd = 0.f;
   f32x16 acc[NT];
+  f32x16 gacc[EPI == UIR_EPI_GATE_BWD_DW ? NT : 1];   // fused weight-gradient accumulators (live across row tiles)
+  if constexpr (EPI == UIR_EPI_GATE_BWD_DW) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) gacc[nt][q] = 0.f;
+  }
 
   auto step = [&](float4 (&an)[4], float4 (&un)[NU], const bool anok, float4 (&nx)[4], float4 (&nu)[NU], bool& nxok) -> bool {
     const int m0 = tile * 128 + wave * 32;
@@ -509,7 +567,8 @@ __global__ __launch_bounds__(256, 3) void uir_gemm1x1_kernel(const UirGemmArgs a
       }
     }
     if (last && m0 < a.M) {
-      uir_gemm1x1_store<NT, EPI, HAS_R>(a, acc, bias, rv, z, m0, n0, r, h2);
+      if constexpr (EPI == UIR_EPI_GATE_BWD_DW) uir_gemm1x1_store_gate_dw<NT>(a, acc, gacc, m0, n0, r, h2);
+      else uir_gemm1x1_store<NT, EPI, HAS_R>(a, acc, bias, rv, z, m0, n0, r, h2);
     }
     tile = tn;
     c = cn;
@@ -520,6 +579,32 @@ __global__ __launch_bounds__(256, 3) void uir_gemm1x1_kernel(const UirGemmArgs a
     while (true) {
       if (!step(P0, U0, ok0, P1, U1, ok1)) break;
       if (!step(P1, U1, ok1, P0, U0, ok0)) break;
+    }
+  }
+  if constexpr (EPI == UIR_EPI_GATE_BWD_DW) {
+    // sum the 4 waves' partial dW tiles through LDS in a fixed order (the weight panel is dead now) and write this
+    // workgroup's slab row; uir_reduce_slab sums the rows: deterministic, no atomics
+    __syncthreads();
+    float* red = wl;
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            float* p = &red[(nt * 16 + q) * 64 + lane];
+            *p = (w == 0) ? gacc[nt][q] : (*p + gacc[nt][q]);
+          }
+      }
+      __syncthreads();
+    }
+    float* slab = a.dw_slab + (long)blockIdx.x * a.dw_stride;
+    const int hreal = a.n_grp_pad > 0 ? a.n_grp_real : a.N;   // real hidden width (columns n_grp_real.. are pads)
+    for (int e = threadIdx.x; e < NT * 1024; e += 256) {
+      const int ln = e & 63, q = (e >> 6) & 15, nt = e >> 10;
+      const int cch = uir_mfma_row(q, ln >> 5);               // dY channel = row of the dW tile
+      const int j = n0 + 32 * nt + (ln & 31);                 // hidden column
+      if (cch < a.K && j < hreal) slab[(long)cch * hreal + j] = red[e];
     }
   }
 }
@@ -539,6 +624,13 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   if (a.pro == UIR_PRO_GATE) UIR_REQUIRE((a.gate_off & 3) == 0 && a.ldx >= a.gate_off + ((a.K + 3) & ~3));
   if (a.epi == UIR_EPI_GATE_BWD) UIR_REQUIRE(a.G && a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N && !a.R);
   if (a.epi == UIR_EPI_LEAKY_BWD) UIR_REQUIRE(a.G && a.ldg >= a.N && !a.R);
+  if (a.epi == UIR_EPI_GATE_BWD_DW) {
+    // fused dW_out: one column group (N <= 96), K <= 32 channels, whole 128-row tiles, pads only at the tail (N = hp)
+    UIR_REQUIRE(a.G && a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N && !a.R && !a.bias && a.act == UIR_ACT_NONE);
+    UIR_REQUIRE(a.dw_slab && a.dw_stride >= (long)a.K * (a.n_grp_pad > 0 ? a.n_grp_real : a.N) && a.K <= 32 && a.N <= 96 &&
+                a.taps == 1 && a.batches == 1);
+    UIR_REQUIRE((a.M & 127) == 0 && a.pro == UIR_PRO_NONE && (a.n_grp_pad <= 0 || a.n_grp_pad == a.N));
+  }
   if (a.R) UIR_REQUIRE(a.ldr >= a.N);
   const int tiles = (a.N + 31) / 32;
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -556,7 +648,8 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     while (nt1 > 1 && (size_t)nt1 * 32 * Kp * 4 > 60 * 1024) { --nt1; }
     groups1 = (tiles + nt1 - 1) / nt1;
     // (a float4 epilogue through a per-wave LDS transpose was tried and measured slower: profiles/r01/d_ab_notes.md)
-    const size_t lds = (size_t)nt1 * 32 * Kp * 4 + (size_t)2 * K8 * 4 + (size_t)(nt1 * 32 + K8) * 4;
+    size_t lds = (size_t)nt1 * 32 * Kp * 4 + (size_t)2 * K8 * 4 + (size_t)(nt1 * 32 + K8) * 4;
+    if (a.epi == UIR_EPI_GATE_BWD_DW && lds < (size_t)nt1 * 1024 * 4) lds = (size_t)nt1 * 1024 * 4;   // 4-wave dW sum
     const bool combo_ok = (a.pro == UIR_PRO_NONE) || (a.epi == UIR_EPI_PLAIN && !(a.pro == UIR_PRO_LN && a.R));
     if (lds <= 100 * 1024 && combo_ok) {
       const int rtiles = (a.M + 127) / 128;
@@ -569,6 +662,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
 #define UIR_L1E(NTV, PROV)                                                          \
   do {                                                                              \
     if (a.epi == UIR_EPI_GATE_BWD) UIR_L1(NTV, PROV, UIR_EPI_GATE_BWD, false);      \
+    else if (a.epi == UIR_EPI_GATE_BWD_DW) UIR_L1(NTV, PROV, UIR_EPI_GATE_BWD_DW, false); \
     else if (a.epi == UIR_EPI_LEAKY_BWD) UIR_L1(NTV, PROV, UIR_EPI_LEAKY_BWD, false); \
     else if (a.R) UIR_L1(NTV, PROV, UIR_EPI_PLAIN, true);                           \
     else UIR_L1(NTV, PROV, UIR_EPI_PLAIN, false);                                   \

@@ -390,7 +390,7 @@ class Recorder:
     # ---------------------------------------------------------------- kernels
     def gemm(self, name, X, W, Y, *, N, K, w_sn, w_sk, w_st=0, w_bs=0, batches=1, bias=None, R=None,
              taps=1, flip=0, hw=None, n_grp=(0, 0), k_grp=(0, 0), pro=L.PRO_NONE, gate_off=0, ln=None, stats=None,
-             epi=L.EPI_PLAIN, G=None, g_off=0, act=L.ACT_NONE):
+             epi=L.EPI_PLAIN, G=None, g_off=0, act=L.ACT_NONE, dw_slab=None):
         M_total = X.shape[0]
         assert M_total % batches == 0 and Y.shape[0] == M_total
         M = M_total // batches
@@ -419,14 +419,17 @@ class Recorder:
             a.G, a.ldg = _ptr(G), _ld(G)
             a.g_bs = M * a.ldg
         a.slope, a.ln_eps = 0.1, LN_EPS
+        if dw_slab is not None:
+            self._hold(dw_slab)
+            a.dw_slab, a.dw_stride = _ptr(dw_slab), dw_slab.stride(0)
         assert a.ldx % 4 == 0 and a.ldx >= pad4(K) and a.ldy >= N, (name, a.ldx, K, a.ldy, N)
-        assert Y.shape[1] >= N or epi == L.EPI_GATE_BWD, (name, Y.shape, N)
+        assert Y.shape[1] >= N or epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW), (name, Y.shape, N)
         self.keep.append(a)
         rows = M * batches
         kreal = k_grp[0] * (K // k_grp[1]) if k_grp[1] else K
         nreal = n_grp[0] * (N // n_grp[1]) if n_grp[1] else N
-        nb = 4 * rows * (K * (2 if pro == L.PRO_GATE else 1) + N * (2 if epi == L.EPI_GATE_BWD else 1)
-                         + (N if R is not None else 0) + (N * (2 if epi == L.EPI_GATE_BWD else 1) if G is not None else 0))
+        nb = 4 * rows * (K * (2 if pro == L.PRO_GATE else 1) + N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1)
+                         + (N if R is not None else 0) + (N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1) if G is not None else 0))
         self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps)
 
     def _chunks(self, M, ngroups, batches):
@@ -766,9 +769,12 @@ class Plan(Recorder):
             dPb, dWofb, dTb, dPsum = self.alloc(B, C_ * C_), self.alloc(B, C_ * C_), self.alloc(B, heads), self.alloc(C_, C_)
             dx = self.alloc(M, C_)
             # GDFN
-            with self.bulk():
-                self.gram(n + ".dWout", dy, g, Gr(f"{pfx}.ffn.project_out.weight"), N=C_, K=h, o_sn=h, o_sk=1,
-                          pro_b=L.PRO_GATE, gate_off=hp)
+            fuse_dwout = (str(C_) not in _GDFN_BWD_FUSED and C_ <= 32 and hp <= 96 and M % 128 == 0 and
+                          os.environ.get("UIR_DWOUT_FUSED", "1") == "1")
+            if not fuse_dwout:
+                with self.bulk():
+                    self.gram(n + ".dWout", dy, g, Gr(f"{pfx}.ffn.project_out.weight"), N=C_, K=h, o_sn=h, o_sk=1,
+                              pro_b=L.PRO_GATE, gate_off=hp)
             if str(C_) in _GDFN_BWD_FUSED:
                 # dY -> dt2 -> dt1 -> dt in one pass; dt2 / dt1 are written once for the weight-gradient lane
                 self.gdfn_bwd(n + ".gdfn_bwd", dy, g, Wout, Wffdw, Win, dg, dgpre, dt, C_=C_, h=h, hp=hp, dims=dims)
@@ -778,7 +784,19 @@ class Plan(Recorder):
                     self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
                               n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
             else:
-                self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g, g_off=hp)
+                if fuse_dwout:
+                    # project_out weight gradient inside the gate-backward GEMM (its accumulator layout is the
+                    # B-operand layout of the pixel contraction): the bulk lane keeps only the tiny slab reduction.
+                    # Rows beyond the launch's gridDim.x are never written: the slab is zero-filled once, here.
+                    dws = torch.zeros(1536, C_ * h, device=self.dev, dtype=torch.float32)
+                    self.gemm(n + ".dgate+dWout", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp),
+                              epi=L.EPI_GATE_BWD_DW, G=g, g_off=hp, dw_slab=dws)
+                    with self.bulk():
+                        self._op(n + ".dWout.red", lib.uir_reduce_slab, _ptr(dws), 1536, C_ * h,
+                                 _ptr(Gr(f"{pfx}.ffn.project_out.weight")), C_ * h, 0, 1.0)
+                else:
+                    self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g,
+                              g_off=hp)
                 self.dwconv_bwd(n + ".dgpre+dWffdw", dg, gpre, Wffdw, dgpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
                                 dims=dims, grp=(h, hp))
                 with self.bulk():
