@@ -414,6 +414,8 @@ class Recorder:
         if pro == L.PRO_LN:
             a.ln_g, a.ln_b = _ptr(ln[0]), _ptr(ln[1])
             a.stats = _ptr(stats)
+        if epi == L.EPI_LN_BWD:      # LayerNorm backward in the epilogue: gamma, the forward statistics, G = the LN input
+            a.ln_g, a.stats = _ptr(ln[0]), _ptr(stats)
         a.epi, a.g_off, a.act = epi, g_off, act
         if G is not None:
             a.G, a.ldg = _ptr(G), _ld(G)
@@ -556,6 +558,19 @@ class Recorder:
         self.keep.append(a)
         self._op(name, lib.uir_gdfn_bwd, C.byref(a), nbytes=rows * (8 * C_ + 24 * hp),
                  flops=rows * (2 * C_ * hp + 18 * 2 * hp + 2 * 2 * hp * C_))
+
+    def gemm_ln_bwd(self, name, A, W, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_, K, k_grp=(0, 0)):
+        """dX = LayerNorm'(A . W) + dRes with the LayerNorm backward as the GEMM epilogue (the gradient of the LN output
+        never reaches HBM); dgamma / dbeta as per-workgroup slab rows, summed on the bulk lane."""
+        slab = torch.zeros(1536, 2 * C_, device=self.dev, dtype=torch.float32)   # rows past gridDim.x stay zero
+        self.gemm(name, A, W, dX, N=C_, K=K, w_sn=1, w_sk=C_, k_grp=k_grp, epi=L.EPI_LN_BWD, G=X, stats=stats,
+                  ln=(gamma, None), R=dRes, dw_slab=slab)
+        with self.bulk():
+            if dbeta.data_ptr() == dgamma.data_ptr() + 4 * C_:
+                self._op(name + ".dgb", lib.uir_reduce_slab, _ptr(slab), 1536, 2 * C_, _ptr(dgamma), 2 * C_, 0, 1.0)
+            else:
+                self._op(name + ".dg", lib.uir_reduce_slab, _ptr(slab), 1536, 2 * C_, _ptr(dgamma), C_, 0, 1.0)
+                self._op(name + ".db", lib.uir_reduce_slab, slab.data_ptr() + 4 * C_, 1536, 2 * C_, _ptr(dbeta), C_, 0, 1.0)
 
     def dwconv_wgrad(self, name, dY, X, out, *, C_, creal, dims, grp=(0, 0)):
         self._hold(dY, X, out)
@@ -769,6 +784,8 @@ class Plan(Recorder):
             dPb, dWofb, dTb, dPsum = self.alloc(B, C_ * C_), self.alloc(B, C_ * C_), self.alloc(B, heads), self.alloc(C_, C_)
             dx = self.alloc(M, C_)
             # GDFN
+            # LayerNorm backward as the epilogue of the GEMM that produces its output gradient (one 32-column tile)
+            fuse_ln = C_ <= 32 and M % 128 == 0 and os.environ.get("UIR_LNBWD_FUSED", "1") == "1"
             fuse_dwout = (str(C_) not in _GDFN_BWD_FUSED and C_ <= 32 and hp <= 96 and M % 128 == 0 and
                           os.environ.get("UIR_DWOUT_FUSED", "1") == "1")
             if not fuse_dwout:
@@ -802,8 +819,13 @@ class Plan(Recorder):
                 with self.bulk():
                     self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
                               n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
-                self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
-            self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
+                if fuse_ln:
+                    self.gemm_ln_bwd(n + ".dt2+ln2_bwd", dgpre, Win, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"),
+                                     Gr(f"{pfx}.norm2.bias"), C_=C_, K=2 * hp, k_grp=(h, hp))
+                else:
+                    self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
+            if not (fuse_ln and str(C_) not in _GDFN_BWD_FUSED):
+                self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
             # MDTA
             self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
             self.gemm(n + ".dvf", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
@@ -832,8 +854,12 @@ class Plan(Recorder):
             with self.bulk():
                 self.gram(n + ".dWqkv", dqkv_pre, x, Gr(f"{a}.qkv.weight"), N=3 * C_, K=C_, o_sn=C_, o_sk=1,
                           pro_b=L.PRO_LN, ln=(g1, b1), stats=stats1)
-            self.gemm(n + ".dt1", dqkv_pre, Wqkv, dt, N=C_, K=3 * C_, w_sn=1, w_sk=C_)
-            self.ln_bwd(n + ".ln1_bwd", dt, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_)
+            if fuse_ln:
+                self.gemm_ln_bwd(n + ".dt1+ln1_bwd", dqkv_pre, Wqkv, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"),
+                                 Gr(f"{pfx}.norm1.bias"), C_=C_, K=3 * C_)
+            else:
+                self.gemm(n + ".dt1", dqkv_pre, Wqkv, dt, N=C_, K=3 * C_, w_sn=1, w_sk=C_)
+                self.ln_bwd(n + ".ln1_bwd", dt, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_)
             return dx
 
         return y, backward
