@@ -297,6 +297,9 @@ int uir_copy_cols(const float* src, int lds, int scol, float* dst, int ldd, int 
 int uir_colsum_partials(const float* src, int ld, int col, long M, int C, float* slab, int nblocks, void* stream);
 /* NCHW [B,3,H,W] <-> HWC rows [B*H*W][4] (4th column zero) at the model boundary */
 int uir_nchw3_to_hwc4(const float* src, float* dst, int B, int H, int Wd, void* stream);
+/* 3x3 patches (pad 1) of the NCHW [B,3,H,W] input as rows [B*H*W][28]: column cin*9 + ky*3 + kx, column 27 zero.
+ * embed_conv_rgb (SpectralTransformer.py:219,254) and its weight gradient become a K = 27 uir_gemm / uir_gram. */
+int uir_im2col3x3_c3(const float* src, float* dst, int B, int H, int Wd, void* stream);
 int uir_hwc4_to_nchw3(const float* src, float* dst, int B, int H, int Wd, void* stream);
 
 /* ---------------------------------------------------------------- uir_loss */

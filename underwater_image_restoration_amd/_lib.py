@@ -143,6 +143,7 @@ SIGNATURES = {
     "uir_copy_cols": [fp, i32, i32, fp, i32, i32, i64, i32, i32, fp],
     "uir_colsum_partials": [fp, i32, i32, i64, i32, fp, i32, fp],
     "uir_nchw3_to_hwc4": [fp, fp, i32, i32, i32, fp],
+    "uir_im2col3x3_c3": [fp, fp, i32, i32, i32, fp],
     "uir_hwc4_to_nchw3": [fp, fp, i32, i32, i32, fp],
     "uir_loss_partials": [fp, fp, fp, i32, i32, i32, fp],
     "uir_loss_finalize": [fp, fp, i32, i32, i32, fp],

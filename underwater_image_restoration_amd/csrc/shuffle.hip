@@ -95,6 +95,30 @@ __global__ void nchw3_to_hwc4_kernel(const float* __restrict__ src, float* __res
   }
 }
 
+// 3x3 patches of the 3-channel NCHW input as HWC rows of 28 floats: column cin*9 + tap (= the Conv2d weight's own
+// [cin][ky][kx] order), zero outside the image, column 27 zero.  Turns embed_conv_rgb (SpectralTransformer.py:219,254)
+// and its weight gradient into a plain K = 27 GEMM / Gram instead of nine 4-channel taps on 32x32 MFMA tiles.
+__global__ void im2col3x3_c3_kernel(const float* __restrict__ src, float* __restrict__ dst, int H, int Wd, long HW, long n) {
+  GRID_STRIDE(idx, n) {  // idx over [B][HW]
+    const long b = idx / HW, p = idx - b * HW;
+    const int y = (int)(p / Wd), x = (int)(p - (long)y * Wd);
+    float v[28];
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        const bool in = yy >= 0 && yy < H && xx >= 0 && xx < Wd;
+        const float u = src[(b * 3 + c) * HW + (in ? (long)yy * Wd + xx : p)];
+        v[c * 9 + t] = in ? u : 0.f;
+      }
+    v[27] = 0.f;
+    float4* d = reinterpret_cast<float4*>(dst + idx * 28);
+#pragma unroll
+    for (int q = 0; q < 7; ++q) d[q] = make_float4(v[4 * q], v[4 * q + 1], v[4 * q + 2], v[4 * q + 3]);
+  }
+}
+
 __global__ void hwc4_to_nchw3_kernel(const float* __restrict__ src, float* __restrict__ dst, long HW, long n) {
   GRID_STRIDE(idx, n) {
     const long b = idx / HW, p = idx - b * HW;
@@ -141,6 +165,12 @@ extern "C" int uir_nchw3_to_hwc4(const float* src, float* dst, int B, int H, int
   UIR_REQUIRE(src && dst && B > 0 && H > 0 && Wd > 0 && uir_aligned16(dst));
   const long HW = (long)H * Wd, n = (long)B * HW;
   hipLaunchKernelGGL(nchw3_to_hwc4_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, HW, n);
+  return uir_launch_status();
+}
+extern "C" int uir_im2col3x3_c3(const float* src, float* dst, int B, int H, int Wd, void* stream) {
+  UIR_REQUIRE(src && dst && B > 0 && H > 0 && Wd > 0 && uir_aligned16(dst));
+  const long HW = (long)H * Wd, n = (long)B * HW;
+  hipLaunchKernelGGL(im2col3x3_c3_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), src, dst, H, Wd, HW, n);
   return uir_launch_status();
 }
 extern "C" int uir_hwc4_to_nchw3(const float* src, float* dst, int B, int H, int Wd, void* stream) {

@@ -1016,11 +1016,24 @@ class Plan(Recorder):
         self.in_nchw = self.alloc(B, 3, H, W)
         self.out_nchw = self.alloc(B, 3, H, W)
         self.dout_nchw = self.alloc(B, 3, H, W)
-        x4 = self.alloc(M0, 4)
         self.cur = self.fwd
-        self._op("in.to_hwc", lib.uir_nchw3_to_hwc4, _ptr(self.in_nchw), _ptr(x4), B, H, W)
-        self.mark("fwd.start")
-        f0, embed_bw = self._conv3("embed", x4, "embed_conv_rgb.weight", 3, 16, d0, k_grp=(3, 4), Kp=4)
+        if os.environ.get("UIR_EMBED_IM2COL", "1") == "1":
+            # embed_conv_rgb (3 -> 16, 3x3) on 3x3 patches [M][28]: one K = 27 GEMM forward and one <1,1> Gram for its weight
+            # gradient (the last launch of the step) instead of nine 4-channel taps on 32x32 MFMA tiles
+            x27 = self.alloc(M0, 28)
+            Wemb = P("embed_conv_rgb.weight")
+            self._op("in.im2col", lib.uir_im2col3x3_c3, _ptr(self.in_nchw), _ptr(x27), B, H, W, nbytes=4 * M0 * 31)
+            self.mark("fwd.start")
+            f0 = self.alloc(M0, 16)
+            self.gemm("embed", x27, Wemb, f0, N=16, K=27, w_sn=27, w_sk=1)
+
+            def embed_bw(dy, need_dx=False, dw_on_chain=True):
+                self.gram("embed.dW", dy, x27, self.Gr("embed_conv_rgb.weight"), N=16, K=27, o_sn=27, o_sk=1)
+        else:
+            x4 = self.alloc(M0, 4)
+            self._op("in.to_hwc", lib.uir_nchw3_to_hwc4, _ptr(self.in_nchw), _ptr(x4), B, H, W)
+            self.mark("fwd.start")
+            f0, embed_bw = self._conv3("embed", x4, "embed_conv_rgb.weight", 3, 16, d0, k_grp=(3, 4), Kp=4)
         e1, enc1_bw = self._stack("encoders.0", f0, 2, 16, 1, d0)
         self.mark("fwd.enc0(L0,C16)")
         t1, down1_bw = self._down("down1", e1, 16, d0)
