@@ -164,6 +164,24 @@ typedef struct UirGdfnFwdArgs {
 } UirGdfnFwdArgs;
 int uir_gdfn_fwd(const UirGdfnFwdArgs* args, void* stream);
 
+/* Tile-fused front of an MDTA block: Y = dw3x3(W_qkv . LN(X)) (SpectralTransformer.py:93-94 with norm1 of :144),
+ * Ypre = W_qkv . LN(X) (saved for the depthwise weight gradient).  3C output channels, chunks of 32. */
+typedef struct UirQkvFwdArgs {
+  const float* X;      /* [B*H*W][ldx] block input, float4-aligned rows                           */
+  const float* ln_g;   /* norm1 gamma[C], beta[C] (16-B aligned)                                  */
+  const float* ln_b;
+  const float* Wqkv;   /* qkv      [3C][C]   (16-B aligned)                                       */
+  const float* Wdw;    /* qkv_conv [3C][1][3][3]                                                  */
+  float* Ypre;         /* [B*H*W][ldp] pre-depthwise                                              */
+  float* Y;            /* [B*H*W][ldq] q | k | v                                                  */
+  float* stats;        /* optional [B*H*W][2] = (mean, rstd) of norm1 for the backward            */
+  int ldx, ldp, ldq;
+  int B, H, Wd;
+  int C;               /* in {16,32,64,128}                                                       */
+  float ln_eps;
+} UirQkvFwdArgs;
+int uir_qkv_fwd(const UirQkvFwdArgs* args, void* stream);
+
 /* Tile-fused input-gradient chain of the GDFN (everything between dY and the gradient of the
  * norm2 output):  dg = dY . W_out;  dt2 = gate'(dg, t2);  dt1 = dw3x3^T(dt2);  dT = dt1 . W_in.
  * Replaces autograd's backward of SpectralTransformer.py:127-130 (conv1x1 / depthwise conv /

@@ -372,6 +372,25 @@ def test_gdfn_fwd_fused(B, H, W, C, store):
             assert float(T[:, h:hp].abs().max()) == 0 and float(T[:, hp + h:2 * hp].abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 16), (1, 19, 37, 32), (1, 9, 16, 64), (1, 11, 9, 128), (1, 1, 1, 16)])
+def test_qkv_fwd_fused(B, H, W, C):
+    """Tile-fused norm1 -> qkv 1x1 -> depthwise 3x3 vs torch fp64 (ragged tiles, partial 32-channel chunk at C=16)."""
+    x = rnd(B, C, H, W, seed=1, scale=2)
+    gam, bet = 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    wq, wdw = rnd(3 * C, C, 1, 1, seed=4, scale=C ** -0.5), rnd(3 * C, 1, 3, 3, seed=5, scale=1 / 3)
+    rows = hwc(x)
+    xn = F.layer_norm(rows, (C,), gam, bet, 1e-5).reshape(B, H, W, C).permute(0, 3, 1, 2)
+    pre = F.conv2d(xn, wq)
+    out = F.conv2d(pre, wdw, padding=1, groups=3 * C)
+    r = rec()
+    M = B * H * W
+    Ypre, Y, st = r.alloc(M, 3 * C), r.alloc(M, 3 * C), r.alloc(M, 2)
+    r.qkv_fwd("q", dev(rows), (dev(gam), dev(bet)), dev(wq), dev(wdw), Ypre, Y, C_=C, dims=(B, H, W), stats=st)
+    r.run(r.fwd)
+    assert rel(Ypre, hwc(pre)) < TOL and rel(Y, hwc(out)) < TOL
+    assert rel(st[:, 0], rows.mean(1)) < TOL and rel(st[:, 1], (rows.var(1, unbiased=False) + 1e-5).rsqrt()) < TOL
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 16), (1, 19, 37, 32), (1, 1, 1, 32), (1, 40, 24, 16), (2, 5, 3, 32)])
 def test_gdfn_bwd_fused(B, H, W, C):
     """Tile-fused GDFN input-gradient chain vs torch autograd (fp64): dt2, dt1 and the gradient of the norm2 output."""

@@ -73,6 +73,12 @@ class GdfnFwdArgs(C.Structure):
                 ("h", C.c_int), ("hp", C.c_int), ("ln_eps", C.c_float)]
 
 
+class QkvFwdArgs(C.Structure):
+    _fields_ = [("X", fp), ("ln_g", fp), ("ln_b", fp), ("Wqkv", fp), ("Wdw", fp), ("Ypre", fp), ("Y", fp), ("stats", fp),
+                ("ldx", C.c_int), ("ldp", C.c_int), ("ldq", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int), ("ln_eps", C.c_float)]
+
+
 class GdfnBwdArgs(C.Structure):
     _fields_ = [("dY", fp), ("T2", fp), ("Wout", fp), ("Wdw", fp), ("Win", fp), ("DT2", fp), ("DT1", fp), ("dT", fp),
                 ("ldy", C.c_int), ("ldt", C.c_int), ("ldo", C.c_int),
@@ -125,6 +131,7 @@ SIGNATURES = {
     "uir_dwconv_bwd_fused": [C.POINTER(DwBwdArgs), fp],
     "uir_gdfn_fwd": [C.POINTER(GdfnFwdArgs), fp],
     "uir_gdfn_bwd": [C.POINTER(GdfnBwdArgs), fp],
+    "uir_qkv_fwd": [C.POINTER(QkvFwdArgs), fp],
     "uir_layernorm_bwd": [C.POINTER(LnBwdArgs), fp],
     "uir_attn_fwd": [C.POINTER(AttnFwdArgs), fp],
     "uir_attn_bwd": [C.POINTER(AttnBwdArgs), fp],

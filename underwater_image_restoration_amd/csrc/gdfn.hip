@@ -362,6 +362,232 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
 }
 
 // ------------------------------------------------------------------------------------------------
+// uir_qkv_fwd: norm1 -> qkv 1x1 (C -> 3C) -> depthwise 3x3 of an MDTA block in one pass over the pixels
+// (SpectralTransformer.py:93-94 with the norm1 of :144).  Same tile / chunk skeleton as uir_gdfn_fwd without the gate
+// and the second 1x1: chunks of 32 consecutive output channels, thread (cp, column) owns channels cp and cp + 16.
+// Both results are written once: the pre-depthwise tensor (only the backward reads it: streaming stores) and qkv.
+template <int C, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs a) {
+  using T = GdfnTile<C, TH, TW>;
+  extern __shared__ float smem[];
+  float* T1s = smem;
+  float* Gs = smem + T::NRT1 * 32 * T::S1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
+  const int tiles_x = (a.Wd + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const long img = (long)b * a.H * a.Wd;
+  constexpr int HD = 3 * C;
+
+  // ---- phase 0: x on tile + ring -> LayerNorm -> A-operand registers ----
+  float A[T::RTW][C / 2];
+  {
+    float4 gam[T::KJ], bet[T::KJ];
+#pragma unroll
+    for (int jj = 0; jj < T::KJ; ++jj) {
+      gam[jj] = *reinterpret_cast<const float4*>(a.ln_g + 8 * jj + 4 * h2);
+      bet[jj] = *reinterpret_cast<const float4*>(a.ln_b + 8 * jj + 4 * h2);
+    }
+#pragma unroll
+    for (int q = 0; q < T::RTW; ++q) {
+      const int r = wave + 4 * q;
+      if (r < T::NRT1) {
+        const int p = r * 32 + li;
+        const int ry = p / T::RW, rx = p - ry * T::RW;
+        const int iy = y0 + ry - 1, ix = x0 + rx - 1;
+        const bool valid = p < T::NPX1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
+        const long m = valid ? img + (long)iy * a.Wd + ix : img;
+        const float* xr = a.X + m * a.ldx + 4 * h2;
+        float4 v[T::KJ];
+        float s = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) {
+          v[jj] = *reinterpret_cast<const float4*>(xr + 8 * jj);
+          s += (v[jj].x + v[jj].y) + (v[jj].z + v[jj].w);
+        }
+        s += __shfl_xor(s, 32);
+        const float mean = s / (float)C;
+        float qq = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) {
+          const float d0 = v[jj].x - mean, d1 = v[jj].y - mean, d2 = v[jj].z - mean, d3 = v[jj].w - mean;
+          qq += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        qq += __shfl_xor(qq, 32);
+        const float rstd = rsqrtf(qq / (float)C + a.ln_eps);
+        const float keep = valid ? 1.f : 0.f;
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) {
+          A[q][4 * jj + 0] = keep * fmaf((v[jj].x - mean) * rstd, gam[jj].x, bet[jj].x);
+          A[q][4 * jj + 1] = keep * fmaf((v[jj].y - mean) * rstd, gam[jj].y, bet[jj].y);
+          A[q][4 * jj + 2] = keep * fmaf((v[jj].z - mean) * rstd, gam[jj].z, bet[jj].z);
+          A[q][4 * jj + 3] = keep * fmaf((v[jj].w - mean) * rstd, gam[jj].w, bet[jj].w);
+        }
+        const bool interior = ry >= 1 && ry <= TH && rx >= 1 && rx <= TW;
+        if (a.stats && h2 == 0 && valid && interior)
+          *reinterpret_cast<float2*>(a.stats + m * 2) = make_float2(mean, rstd);
+      }
+    }
+  }
+
+  const int cp = tid & 15;
+  const int strip = (tid >> 6) * 4 + (((lane >> 4) & 1) << 1 | (lane >> 5));
+  const int sx = strip % TW, ys = (strip / TW) * T::ROWS;
+
+  // write-out slots: float4 j (0..7) of pixel p covers chunk columns 4j..4j+3; byte offsets without the chunk term
+  unsigned st_pre[T::NST], st_out[T::NST];
+  int st_lds[T::NST];
+#pragma unroll
+  for (int it = 0; it < T::NST; ++it) {
+    const int e = tid + 256 * it, p = e >> 3, j = e & 7;
+    const int py = p / TW, px = p - py * TW;
+    const int iy = y0 + py, ix = x0 + px;
+    const bool ok = p < T::NI && iy < a.H && ix < a.Wd;
+    const long m = img + (long)iy * a.Wd + ix;
+    st_pre[it] = ok ? (unsigned)((m * a.ldp + 4 * j) * 4) : ~0u;
+    st_out[it] = ok ? (unsigned)((m * a.ldq + 4 * j) * 4) : ~0u;
+    st_lds[it] = ((py + 1) * T::RW + px + 1) * T::S1 + 4 * j;
+  }
+
+  auto load_w = [&](int c0, float4 (&win)[T::KJ], float (&w1)[9], float (&w2)[9]) {
+    {
+      const int cc = c0 + li;
+      const bool ok = cc < HD;
+      const float* wr = a.Wqkv + (long)(ok ? cc : 0) * C + 4 * h2;
+#pragma unroll
+      for (int jj = 0; jj < T::KJ; ++jj) {
+        const float4 t = *reinterpret_cast<const float4*>(wr + 8 * jj);
+        win[jj] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    {
+      const int c1 = c0 + cp, c2 = c0 + 16 + cp;
+      const bool ok1 = c1 < HD, ok2 = c2 < HD;
+      const float* p1 = a.Wdw + (long)(ok1 ? c1 : 0) * 9;
+      const float* p2 = a.Wdw + (long)(ok2 ? c2 : 0) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float u1 = p1[t], u2 = p2[t];
+        w1[t] = ok1 ? u1 : 0.f;
+        w2[t] = ok2 ? u2 : 0.f;
+      }
+    }
+  };
+  constexpr bool PF = C <= 32;
+  constexpr int NPF = PF ? T::KJ : 1;
+  float4 win[T::KJ], win_n[NPF];
+  float w1[9], w2[9], w1_n[9], w2_n[9];
+  if (PF) load_w(0, win, w1, w2);
+
+  for (int c0 = 0; c0 < HD; c0 += 32) {
+    if constexpr (PF) {
+      load_w(c0 + 32 < HD ? c0 + 32 : c0, win_n, w1_n, w2_n);
+    } else {
+      load_w(c0, win, w1, w2);
+    }
+    // ---- (a) 32 output channels of the 1x1 on tile + ring ----
+#pragma unroll
+    for (int q = 0; q < T::RTW; ++q) {
+      const int r = wave + 4 * q;
+      if (r < T::NRT1) {
+        f32x16 d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) {
+          d = uir_mfma(A[q][4 * jj + 0], win[jj].x, d);
+          d = uir_mfma(A[q][4 * jj + 1], win[jj].y, d);
+          d = uir_mfma(A[q][4 * jj + 2], win[jj].z, d);
+          d = uir_mfma(A[q][4 * jj + 3], win[jj].w, d);
+        }
+        float* dst = T1s + (r * 32 + 4 * h2) * T::S1 + li;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::S1] = d[i];
+      }
+    }
+    lds_barrier();
+    if constexpr (PF) {   // see uir_gdfn_fwd_kernel: the prefetched weights must be complete before this chunk's stores
+#pragma unroll
+      for (int jj = 0; jj < T::KJ; ++jj) { pin(win_n[jj].x); pin(win_n[jj].y); pin(win_n[jj].z); pin(win_n[jj].w); }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { pin(w1_n[t]); pin(w2_n[t]); }
+    }
+    // ---- pre-depthwise write-out (read again only by the backward: streaming stores) ----
+#pragma unroll
+    for (int it = 0; it < T::NST; ++it)
+      if (st_pre[it] != ~0u && c0 + 4 * ((tid + 256 * it) & 7) < HD) {
+        const float4 v = *reinterpret_cast<const float4*>(T1s + st_lds[it]);
+        st4(reinterpret_cast<char*>(a.Ypre) + (st_pre[it] + (unsigned)c0 * 4u), v);
+      }
+    // ---- (b) depthwise 3x3 ----
+    {
+      const float* rp = T1s + (ys * T::RW + sx) * T::S1 + cp;
+      f32x2 rw[3][3], wv[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wv[t] = f32x2{w1[t], w2[t]};
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          rw[rr][dx] = f32x2{rp[(rr * T::RW + dx) * T::S1], rp[(rr * T::RW + dx) * T::S1 + 16]};
+      rp += 3 * T::RW * T::S1;
+      float* gdst = Gs + (ys * TW + sx) * T::SG + cp;
+      auto step = [&](f32x2 (&p0)[3], f32x2 (&p1)[3], f32x2 (&p2)[3]) {
+        f32x2 t = wv[0] * p0[0];
+        t = __builtin_elementwise_fma(wv[1], p0[1], t);
+        t = __builtin_elementwise_fma(wv[2], p0[2], t);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) p0[dx] = f32x2{rp[dx * T::S1], rp[dx * T::S1 + 16]};
+        rp += T::RW * T::S1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          t = __builtin_elementwise_fma(wv[3 + kx], p1[kx], t);
+          t = __builtin_elementwise_fma(wv[6 + kx], p2[kx], t);
+        }
+        gdst[0] = t.x;
+        gdst[16] = t.y;
+        gdst += TW * T::SG;
+      };
+#pragma unroll 1
+      for (int yb = 0; yb < T::ROWS; yb += 3) {
+        step(rw[0], rw[1], rw[2]);
+        if (yb + 1 < T::ROWS) step(rw[1], rw[2], rw[0]);
+        if (yb + 2 < T::ROWS) step(rw[2], rw[0], rw[1]);
+      }
+    }
+    lds_barrier();
+    // ---- qkv write-out ----
+#pragma unroll
+    for (int it = 0; it < T::NST; ++it)
+      if (st_out[it] != ~0u && c0 + 4 * ((tid + 256 * it) & 7) < HD) {
+        const int e = tid + 256 * it;
+        const float4 v = *reinterpret_cast<const float4*>(Gs + (e >> 3) * T::SG + 4 * (e & 7));
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.Y) + (st_out[it] + (unsigned)c0 * 4u)) = v;
+      }
+    if constexpr (PF) {
+#pragma unroll
+      for (int jj = 0; jj < T::KJ; ++jj) win[jj] = win_n[jj];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
+    }
+    // the next (a) writes T1s (all reads done before the barrier above); Gs is rewritten after the next barrier,
+    // which every wave reaches only after its qkv write-out
+  }
+}
+
+template <int C, int TH, int TW>
+int qkv_fwd_launch(const UirQkvFwdArgs& a, hipStream_t st) {
+  using T = GdfnTile<C, TH, TW>;
+  const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
+  hipLaunchKernelGGL((uir_qkv_fwd_kernel<C, TH, TW>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
+  return uir_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // uir_gdfn_bwd: the input-gradient chain of the GDFN in one pass over the pixels
 //   dg   = dY . W_out                      (a)  f32 MFMA, K = C, on tile + ring        -> LDS
 //   dt2a = dg * t2b * gelu'(t2a), dt2b = dg * gelu(t2a)        (b1) VALU, in place over the staged t2 chunk
@@ -709,5 +935,23 @@ extern "C" int uir_gdfn_bwd(const UirGdfnBwdArgs* p, void* stream) {
     case 16: return gdfn_bwd_launch<16, 12, 16>(a, st);
     case 32: return gdfn_bwd_launch<32, 12, 16>(a, st);
     default: return UIR_EINVAL;   // wider levels: the per-lane W_out / dY operands alone exceed the register file
+  }
+}
+
+extern "C" int uir_qkv_fwd(const UirQkvFwdArgs* p, void* stream) {
+  const UirQkvFwdArgs& a = *p;
+  UIR_REQUIRE(a.X && a.ln_g && a.ln_b && a.Wqkv && a.Wdw && a.Ypre && a.Y);
+  UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0);
+  UIR_REQUIRE(a.ldx >= a.C && (a.ldx & 3) == 0 && uir_aligned16(a.X) && uir_aligned16(a.ln_g) && uir_aligned16(a.ln_b) &&
+              uir_aligned16(a.Wqkv));
+  UIR_REQUIRE(a.ldp >= 3 * a.C && a.ldq >= 3 * a.C && (a.ldp & 3) == 0 && (a.ldq & 3) == 0 && uir_aligned16(a.Ypre) && uir_aligned16(a.Y));
+  UIR_REQUIRE((long)a.B * a.H * a.Wd * (a.ldp > a.ldq ? a.ldp : a.ldq) < (1L << 30));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a.C) {
+    case 16: return qkv_fwd_launch<16, 12, 16>(a, st);
+    case 32: return qkv_fwd_launch<32, 12, 16>(a, st);
+    case 64: return qkv_fwd_launch<64, 8, 16>(a, st);
+    case 128: return qkv_fwd_launch<128, 8, 8>(a, st);
+    default: return UIR_EINVAL;
   }
 }

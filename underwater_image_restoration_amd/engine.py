@@ -40,6 +40,7 @@ LN_EPS = 1e-5
 _SKIP_SIDE = os.environ.get("UIR_SKIP_SIDE", "0") == "1"
 # channel counts whose GDFN forward runs as the tile-fused kernel (csrc/gdfn.hip); "" = three separate kernels
 _GDFN_FUSED = set(filter(None, os.environ.get("UIR_GDFN_FUSED", "16,32,64,128").split(",")))
+_QKV_FUSED = set(filter(None, os.environ.get("UIR_QKV_FUSED", "16,32,64,128").split(",")))
 # opt-in: after the gate-backward epilogue fix the three HBM-bound kernels (869 us at C=32, 256x256) beat the fused,
 # latency-bound kernel (959 us, SIMDs 47 % busy); full step 51.9 vs 52.7 ms (profiles/r01/d_ab_notes.md)
 _GDFN_BWD_FUSED = set(filter(None, os.environ.get("UIR_GDFN_BWD_FUSED", "").split(",")))
@@ -543,6 +544,22 @@ class Recorder:
         self._op(name, lib.uir_gdfn_fwd, C.byref(a), nbytes=rows * (12 * C_ + stored),
                  flops=rows * (2 * C_ * 2 * hp + 18 * 2 * hp + 2 * hp * C_))
 
+    def qkv_fwd(self, name, X, ln, Wqkv, Wdw, Ypre, Y, *, C_, dims, stats=None, eps=1e-5):
+        """Tile-fused norm1 -> qkv 1x1 -> depthwise 3x3 (csrc/gdfn.hip uir_qkv_fwd)."""
+        self._hold(X, ln[0], ln[1], Wqkv, Wdw, Ypre, Y, stats)
+        a = L.QkvFwdArgs()
+        a.X, a.ln_g, a.ln_b, a.Wqkv, a.Wdw, a.Ypre, a.Y = (_ptr(X), _ptr(ln[0]), _ptr(ln[1]), _ptr(Wqkv), _ptr(Wdw),
+                                                            _ptr(Ypre), _ptr(Y))
+        a.stats = _ptr(stats) if stats is not None else None
+        a.ldx, a.ldp, a.ldq = _ld(X), _ld(Ypre), _ld(Y)
+        a.B, a.H, a.Wd = dims
+        a.C = C_
+        a.ln_eps = eps
+        rows = dims[0] * dims[1] * dims[2]
+        assert X.shape[0] == rows and C_ in (16, 32, 64, 128)
+        self.keep.append(a)
+        self._op(name, lib.uir_qkv_fwd, C.byref(a), nbytes=rows * 4 * (C_ + 6 * C_), flops=rows * (2 * C_ * 3 * C_ + 18 * 3 * C_))
+
     def gdfn_bwd(self, name, dY, T2, Wout, Wdw, Win, DT2, DT1, dT, *, C_, h, hp, dims):
         """Tile-fused GDFN input-gradient chain (csrc/gdfn.hip): dY -> dt2 -> dt1 -> gradient of the norm2 output."""
         self._hold(dY, T2, Wout, Wdw, Win, DT2, DT1, dT)
@@ -745,8 +762,11 @@ class Plan(Recorder):
 
         n = pfx
         # ---- MDTA (live path of :93-100,107,110,113) ----
-        self.gemm(n + ".qkv", x, Wqkv, qkv_pre, N=3 * C_, K=C_, w_sn=C_, w_sk=1, pro=L.PRO_LN, ln=(g1, b1), stats=stats1)
-        self.dwconv(n + ".qkv_conv", qkv_pre, Wdw, qkv, C_=3 * C_, dims=dims)
+        if str(C_) in _QKV_FUSED:
+            self.qkv_fwd(n + ".qkv+conv", x, (g1, b1), Wqkv, Wdw, qkv_pre, qkv, C_=C_, dims=dims, stats=stats1)
+        else:
+            self.gemm(n + ".qkv", x, Wqkv, qkv_pre, N=3 * C_, K=C_, w_sn=C_, w_sk=1, pro=L.PRO_LN, ln=(g1, b1), stats=stats1)
+            self.dwconv(n + ".qkv_conv", qkv_pre, Wdw, qkv, C_=3 * C_, dims=dims)
         # P = W_kv[vf] @ W_o depends on weights only: side lane, joined right before its first use
         with self.side():
             self.gemm(n + ".P", Wkvf, Wo, Pm, N=C_, K=C_, w_sn=1, w_sk=C_)
