@@ -182,6 +182,24 @@ typedef struct UirQkvFwdArgs {
 } UirQkvFwdArgs;
 int uir_qkv_fwd(const UirQkvFwdArgs* args, void* stream);
 
+/* Tile-fused pixel-sized tail of MDTA: U = V . WA[b]^T, VF = dw3x3(U), Y = VF . WB[b]^T + R with the per-sample
+ * C x C matrices of uir_attn_fwd (SpectralTransformer.py:100,107,110,113 after the folding of DESIGN.md section 5;
+ * R = the block input: residual of :146). */
+typedef struct UirAttnvFwdArgs {
+  const float* V;      /* [B*H*W][ldv] v slice of qkv, float4-aligned rows                        */
+  const float* WA;     /* [B][C][C]                                                               */
+  const float* WB;     /* [B][C][C]                                                               */
+  const float* Wdw;    /* kv_conv weights of the vf half [C][1][3][3]                             */
+  const float* R;      /* [B*H*W][ldr] residual                                                   */
+  float* U;            /* [B*H*W][ldu]                                                            */
+  float* VF;           /* [B*H*W][ldf]                                                            */
+  float* Y;            /* [B*H*W][ldy]                                                            */
+  int ldv, ldr, ldu, ldf, ldy;
+  int B, H, Wd;
+  int C;               /* in {16,32,64,128}                                                       */
+} UirAttnvFwdArgs;
+int uir_attnv_fwd(const UirAttnvFwdArgs* args, void* stream);
+
 /* Tile-fused input-gradient chain of the GDFN (everything between dY and the gradient of the
  * norm2 output):  dg = dY . W_out;  dt2 = gate'(dg, t2);  dt1 = dw3x3^T(dt2);  dT = dt1 . W_in.
  * Replaces autograd's backward of SpectralTransformer.py:127-130 (conv1x1 / depthwise conv /

@@ -372,6 +372,24 @@ def test_gdfn_fwd_fused(B, H, W, C, store):
             assert float(T[:, h:hp].abs().max()) == 0 and float(T[:, hp + h:2 * hp].abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 16), (2, 19, 37, 32), (2, 9, 16, 64), (1, 11, 9, 128), (3, 1, 1, 32)])
+def test_attnv_fwd_fused(B, H, W, C):
+    """Tile-fused MDTA tail: u = v.WA[b]^T, vf = dw3x3(u), x1 = vf.WB[b]^T + x, per-sample matrices; vs torch fp64."""
+    v, x = rnd(B, C, H, W, seed=1), rnd(B, C, H, W, seed=2)
+    WA, WB = rnd(B, C, C, seed=3, scale=C ** -0.5), rnd(B, C, C, seed=4, scale=C ** -0.5)
+    wdw = rnd(C, 1, 3, 3, seed=5, scale=1 / 3)
+    u = torch.einsum("bnk,bkhw->bnhw", WA, v)
+    vf = F.conv2d(u, wdw, padding=1, groups=C)
+    x1 = torch.einsum("bnk,bkhw->bnhw", WB, vf) + x
+    r = rec()
+    M = B * H * W
+    U, VF, Y = r.alloc(M, C), r.alloc(M, C), r.alloc(M, C)
+    r.attnv_fwd("a", dev(hwc(v)), dev(WA.reshape(B, C * C)), dev(WB.reshape(B, C * C)), dev(wdw), dev(hwc(x)), U, VF, Y, C_=C,
+                dims=(B, H, W))
+    r.run(r.fwd)
+    assert rel(U, hwc(u)) < TOL and rel(VF, hwc(vf)) < TOL and rel(Y, hwc(x1)) < TOL
+
+
 @pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 16), (1, 19, 37, 32), (1, 9, 16, 64), (1, 11, 9, 128), (1, 1, 1, 16)])
 def test_qkv_fwd_fused(B, H, W, C):
     """Tile-fused norm1 -> qkv 1x1 -> depthwise 3x3 vs torch fp64 (ragged tiles, partial 32-channel chunk at C=16)."""

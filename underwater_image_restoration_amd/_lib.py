@@ -79,6 +79,12 @@ class QkvFwdArgs(C.Structure):
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int), ("ln_eps", C.c_float)]
 
 
+class AttnvFwdArgs(C.Structure):
+    _fields_ = [("V", fp), ("WA", fp), ("WB", fp), ("Wdw", fp), ("R", fp), ("U", fp), ("VF", fp), ("Y", fp),
+                ("ldv", C.c_int), ("ldr", C.c_int), ("ldu", C.c_int), ("ldf", C.c_int), ("ldy", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int)]
+
+
 class GdfnBwdArgs(C.Structure):
     _fields_ = [("dY", fp), ("T2", fp), ("Wout", fp), ("Wdw", fp), ("Win", fp), ("DT2", fp), ("DT1", fp), ("dT", fp),
                 ("ldy", C.c_int), ("ldt", C.c_int), ("ldo", C.c_int),
@@ -132,6 +138,7 @@ SIGNATURES = {
     "uir_gdfn_fwd": [C.POINTER(GdfnFwdArgs), fp],
     "uir_gdfn_bwd": [C.POINTER(GdfnBwdArgs), fp],
     "uir_qkv_fwd": [C.POINTER(QkvFwdArgs), fp],
+    "uir_attnv_fwd": [C.POINTER(AttnvFwdArgs), fp],
     "uir_layernorm_bwd": [C.POINTER(LnBwdArgs), fp],
     "uir_attn_fwd": [C.POINTER(AttnFwdArgs), fp],
     "uir_attn_bwd": [C.POINTER(AttnBwdArgs), fp],

@@ -588,6 +588,238 @@ int qkv_fwd_launch(const UirQkvFwdArgs& a, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// uir_attnv_fwd: the pixel-sized tail of MDTA in one pass over the pixels (SpectralTransformer.py:100,107,110,113 after the
+// algebraic folding of DESIGN.md section 5):  u = v . WA[b]^T,  vf = dw3x3(u),  x1 = vf . WB[b]^T + x
+// with the per-sample C x C matrices WA, WB from uir_attn_fwd.  Same skeleton as uir_gdfn_fwd (no LayerNorm, no gate):
+// chunks of 32 channels of u / vf; both are written once (the backward reads them).
+template <int C, int TH, int TW>
+__global__ __launch_bounds__(256, 2) void uir_attnv_fwd_kernel(const UirAttnvFwdArgs a) {
+  using T = GdfnTile<C, TH, TW>;
+  extern __shared__ float smem[];
+  float* T1s = smem;
+  float* Gs = smem + T::NRT1 * 32 * T::S1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
+  const int tiles_x = (a.Wd + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
+  int bid = blockIdx.x;
+  const int tx = bid % tiles_x;
+  bid /= tiles_x;
+  const int ty = bid % tiles_y;
+  const int b = bid / tiles_y;
+  const int y0 = ty * TH, x0 = tx * TW;
+  const long img = (long)b * a.H * a.Wd;
+  const float* WA = a.WA + (long)b * C * C;
+  const float* WB = a.WB + (long)b * C * C;
+
+  // ---- phase 0: v on tile + ring in A-operand registers, zero outside the image ----
+  float A[T::RTW][C / 2];
+#pragma unroll
+  for (int q = 0; q < T::RTW; ++q) {
+    const int r = wave + 4 * q;
+    if (r < T::NRT1) {
+      const int p = r * 32 + li;
+      const int ry = p / T::RW, rx = p - ry * T::RW;
+      const int iy = y0 + ry - 1, ix = x0 + rx - 1;
+      const bool valid = p < T::NPX1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
+      const long m = valid ? img + (long)iy * a.Wd + ix : img;
+      const float* vr = a.V + m * a.ldv + 4 * h2;
+      const float keep = valid ? 1.f : 0.f;
+#pragma unroll
+      for (int jj = 0; jj < T::KJ; ++jj) {
+        const float4 v = *reinterpret_cast<const float4*>(vr + 8 * jj);
+        A[q][4 * jj + 0] = keep * v.x;
+        A[q][4 * jj + 1] = keep * v.y;
+        A[q][4 * jj + 2] = keep * v.z;
+        A[q][4 * jj + 3] = keep * v.w;
+      }
+    }
+  }
+  f32x16 acc[T::UPW];
+#pragma unroll
+  for (int j = 0; j < T::UPW; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  const int my_n = (wave % T::NT) * 32 + li;
+
+  const int cp = tid & 15;
+  const int strip = (tid >> 6) * 4 + (((lane >> 4) & 1) << 1 | (lane >> 5));
+  const int sx = strip % TW, ys = (strip / TW) * T::ROWS;
+
+  unsigned st_u[T::NST], st_vf[T::NST];
+  int st_lds[T::NST];
+#pragma unroll
+  for (int it = 0; it < T::NST; ++it) {
+    const int e = tid + 256 * it, p = e >> 3, j = e & 7;
+    const int py = p / TW, px = p - py * TW;
+    const int iy = y0 + py, ix = x0 + px;
+    const bool ok = p < T::NI && iy < a.H && ix < a.Wd;
+    const long m = img + (long)iy * a.Wd + ix;
+    st_u[it] = ok ? (unsigned)((m * a.ldu + 4 * j) * 4) : ~0u;
+    st_vf[it] = ok ? (unsigned)((m * a.ldf + 4 * j) * 4) : ~0u;
+    st_lds[it] = ((py + 1) * T::RW + px + 1) * T::S1 + 4 * j;
+  }
+
+  for (int c0 = 0; c0 < C; c0 += 32) {
+    // per-chunk weights (small: C <= 128, L2-resident per sample)
+    float4 wa[T::KJ];
+    {
+      const int cc = c0 + li;
+      const bool ok = cc < C;
+      const float* wr = WA + (long)(ok ? cc : 0) * C + 4 * h2;
+#pragma unroll
+      for (int jj = 0; jj < T::KJ; ++jj) {
+        const float4 t = *reinterpret_cast<const float4*>(wr + 8 * jj);
+        wa[jj] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    float4 wb[4];   // (c) B operand: WB[my_n][c0 + 8 jj + 4 h2 + e]
+    {
+      const bool nok = my_n < C;
+      const float* wr = WB + (long)(nok ? my_n : 0) * C + c0 + 4 * h2;
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const bool ok = nok && (c0 + 8 * jj + 4 * h2) < C;
+        const float4 t = *reinterpret_cast<const float4*>(wr + (ok ? 8 * jj : 0));
+        wb[jj] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    f32x2 wv[9];
+    {
+      const int c1 = c0 + cp, c2 = c0 + 16 + cp;
+      const bool ok1 = c1 < C, ok2 = c2 < C;
+      const float* p1 = a.Wdw + (long)(ok1 ? c1 : 0) * 9;
+      const float* p2 = a.Wdw + (long)(ok2 ? c2 : 0) * 9;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const float u1 = p1[t], u2 = p2[t];
+        wv[t] = f32x2{ok1 ? u1 : 0.f, ok2 ? u2 : 0.f};
+      }
+    }
+    // ---- (a) u chunk on tile + ring ----
+#pragma unroll
+    for (int q = 0; q < T::RTW; ++q) {
+      const int r = wave + 4 * q;
+      if (r < T::NRT1) {
+        f32x16 d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = 0.f;
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) {
+          d = uir_mfma(A[q][4 * jj + 0], wa[jj].x, d);
+          d = uir_mfma(A[q][4 * jj + 1], wa[jj].y, d);
+          d = uir_mfma(A[q][4 * jj + 2], wa[jj].z, d);
+          d = uir_mfma(A[q][4 * jj + 3], wa[jj].w, d);
+        }
+        float* dst = T1s + (r * 32 + 4 * h2) * T::S1 + li;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::S1] = d[i];
+      }
+    }
+    lds_barrier();
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) { pin(wb[jj].x); pin(wb[jj].y); pin(wb[jj].z); pin(wb[jj].w); }
+    // ---- u write-out ----
+#pragma unroll
+    for (int it = 0; it < T::NST; ++it)
+      if (st_u[it] != ~0u && c0 + 4 * ((tid + 256 * it) & 7) < C) {
+        const float4 v = *reinterpret_cast<const float4*>(T1s + st_lds[it]);
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.U) + (st_u[it] + (unsigned)c0 * 4u)) = v;
+      }
+    // ---- (b) depthwise 3x3 ----
+    {
+      const float* rp = T1s + (ys * T::RW + sx) * T::S1 + cp;
+      f32x2 rw[3][3];
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx)
+          rw[rr][dx] = f32x2{rp[(rr * T::RW + dx) * T::S1], rp[(rr * T::RW + dx) * T::S1 + 16]};
+      rp += 3 * T::RW * T::S1;
+      float* gdst = Gs + (ys * TW + sx) * T::SG + cp;
+      auto step = [&](f32x2 (&p0)[3], f32x2 (&p1)[3], f32x2 (&p2)[3]) {
+        f32x2 t = wv[0] * p0[0];
+        t = __builtin_elementwise_fma(wv[1], p0[1], t);
+        t = __builtin_elementwise_fma(wv[2], p0[2], t);
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) p0[dx] = f32x2{rp[dx * T::S1], rp[dx * T::S1 + 16]};
+        rp += T::RW * T::S1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+          t = __builtin_elementwise_fma(wv[3 + kx], p1[kx], t);
+          t = __builtin_elementwise_fma(wv[6 + kx], p2[kx], t);
+        }
+        gdst[0] = t.x;
+        gdst[16] = t.y;
+        gdst += TW * T::SG;
+      };
+#pragma unroll 1
+      for (int yb = 0; yb < T::ROWS; yb += 3) {
+        step(rw[0], rw[1], rw[2]);
+        if (yb + 1 < T::ROWS) step(rw[1], rw[2], rw[0]);
+        if (yb + 2 < T::ROWS) step(rw[2], rw[0], rw[1]);
+      }
+    }
+    lds_barrier();
+    // ---- vf write-out ----
+#pragma unroll
+    for (int it = 0; it < T::NST; ++it)
+      if (st_vf[it] != ~0u && c0 + 4 * ((tid + 256 * it) & 7) < C) {
+        const int e = tid + 256 * it;
+        const float4 v = *reinterpret_cast<const float4*>(Gs + (e >> 3) * T::SG + 4 * (e & 7));
+        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.VF) + (st_vf[it] + (unsigned)c0 * 4u)) = v;
+      }
+    // ---- (c) x1 += vf chunk . WB^T ----
+#pragma unroll
+    for (int j = 0; j < T::UPW; ++j) {
+      const int u = wave + 4 * j;
+      if (u < T::UNITS) {
+        const int rt = u / T::NT;
+        const float* gr = Gs + (rt * 32 + li) * T::SG + 4 * h2;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const float4 v = *reinterpret_cast<const float4*>(gr + 8 * jj);
+          acc[j] = uir_mfma(v.x, wb[jj].x, acc[j]);
+          acc[j] = uir_mfma(v.y, wb[jj].y, acc[j]);
+          acc[j] = uir_mfma(v.z, wb[jj].z, acc[j]);
+          acc[j] = uir_mfma(v.w, wb[jj].w, acc[j]);
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: + residual (block input), store ----
+#pragma unroll
+  for (int j = 0; j < T::UPW; ++j) {
+    const int u = wave + 4 * j;
+    if (u < T::UNITS) {
+      const int rt = u / T::NT;
+      const int nn = my_n < C ? my_n : 0;
+      long mm[16];
+      float res[16];
+      bool ok[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int p = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+        const int iy = y0 + p / TW, ix = x0 + p % TW;
+        ok[i] = iy < a.H && ix < a.Wd && my_n < C;
+        mm[i] = ok[i] ? img + (long)iy * a.Wd + ix : img;
+        res[i] = a.R[mm[i] * a.ldr + nn];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+        if (ok[i]) a.Y[mm[i] * a.ldy + nn] = acc[j][i] + res[i];
+    }
+  }
+}
+
+template <int C, int TH, int TW>
+int attnv_fwd_launch(const UirAttnvFwdArgs& a, hipStream_t st) {
+  using T = GdfnTile<C, TH, TW>;
+  const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
+  hipLaunchKernelGGL((uir_attnv_fwd_kernel<C, TH, TW>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
+  return uir_launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
 // uir_gdfn_bwd: the input-gradient chain of the GDFN in one pass over the pixels
 //   dg   = dY . W_out                      (a)  f32 MFMA, K = C, on tile + ring        -> LDS
 //   dt2a = dg * t2b * gelu'(t2a), dt2b = dg * gelu(t2a)        (b1) VALU, in place over the staged t2 chunk
@@ -952,6 +1184,24 @@ extern "C" int uir_qkv_fwd(const UirQkvFwdArgs* p, void* stream) {
     case 32: return qkv_fwd_launch<32, 12, 16>(a, st);
     case 64: return qkv_fwd_launch<64, 8, 16>(a, st);
     case 128: return qkv_fwd_launch<128, 8, 8>(a, st);
+    default: return UIR_EINVAL;
+  }
+}
+
+extern "C" int uir_attnv_fwd(const UirAttnvFwdArgs* p, void* stream) {
+  const UirAttnvFwdArgs& a = *p;
+  UIR_REQUIRE(a.V && a.WA && a.WB && a.Wdw && a.R && a.U && a.VF && a.Y);
+  UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0);
+  UIR_REQUIRE(a.ldv >= a.C && (a.ldv & 3) == 0 && uir_aligned16(a.V) && uir_aligned16(a.WA) && uir_aligned16(a.WB));
+  UIR_REQUIRE(a.ldu >= a.C && a.ldf >= a.C && (a.ldu & 3) == 0 && (a.ldf & 3) == 0 && uir_aligned16(a.U) && uir_aligned16(a.VF));
+  UIR_REQUIRE(a.ldr >= a.C && a.ldy >= a.C);
+  UIR_REQUIRE((long)a.B * a.H * a.Wd * (a.ldu > a.ldf ? a.ldu : a.ldf) < (1L << 30));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a.C) {
+    case 16: return attnv_fwd_launch<16, 12, 16>(a, st);
+    case 32: return attnv_fwd_launch<32, 12, 16>(a, st);
+    case 64: return attnv_fwd_launch<64, 8, 16>(a, st);
+    case 128: return attnv_fwd_launch<128, 8, 8>(a, st);
     default: return UIR_EINVAL;
   }
 }

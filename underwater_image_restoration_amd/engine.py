@@ -40,6 +40,7 @@ LN_EPS = 1e-5
 _SKIP_SIDE = os.environ.get("UIR_SKIP_SIDE", "0") == "1"
 # channel counts whose GDFN forward runs as the tile-fused kernel (csrc/gdfn.hip); "" = three separate kernels
 _GDFN_FUSED = set(filter(None, os.environ.get("UIR_GDFN_FUSED", "16,32,64,128").split(",")))
+_ATTNV_FUSED = set(filter(None, os.environ.get("UIR_ATTNV_FUSED", "16,32,64,128").split(",")))
 _QKV_FUSED = set(filter(None, os.environ.get("UIR_QKV_FUSED", "16,32,64,128").split(",")))
 # opt-in: after the gate-backward epilogue fix the three HBM-bound kernels (869 us at C=32, 256x256) beat the fused,
 # latency-bound kernel (959 us, SIMDs 47 % busy); full step 51.9 vs 52.7 ms (profiles/r01/d_ab_notes.md)
@@ -560,6 +561,19 @@ class Recorder:
         self.keep.append(a)
         self._op(name, lib.uir_qkv_fwd, C.byref(a), nbytes=rows * 4 * (C_ + 6 * C_), flops=rows * (2 * C_ * 3 * C_ + 18 * 3 * C_))
 
+    def attnv_fwd(self, name, V, WA, WB, Wdw, R, U, VF, Y, *, C_, dims):
+        """Tile-fused MDTA tail (csrc/gdfn.hip uir_attnv_fwd): U = V.WA[b]^T, VF = dw3x3(U), Y = VF.WB[b]^T + R."""
+        self._hold(V, WA, WB, Wdw, R, U, VF, Y)
+        a = L.AttnvFwdArgs()
+        a.V, a.WA, a.WB, a.Wdw, a.R, a.U, a.VF, a.Y = (_ptr(V), _ptr(WA), _ptr(WB), _ptr(Wdw), _ptr(R), _ptr(U), _ptr(VF), _ptr(Y))
+        a.ldv, a.ldr, a.ldu, a.ldf, a.ldy = _ld(V), _ld(R), _ld(U), _ld(VF), _ld(Y)
+        a.B, a.H, a.Wd = dims
+        a.C = C_
+        rows = dims[0] * dims[1] * dims[2]
+        assert V.shape[0] == rows and C_ in (16, 32, 64, 128)
+        self.keep.append(a)
+        self._op(name, lib.uir_attnv_fwd, C.byref(a), nbytes=rows * 4 * 5 * C_, flops=rows * (4 * C_ * C_ + 18 * C_))
+
     def gdfn_bwd(self, name, dY, T2, Wout, Wdw, Win, DT2, DT1, dT, *, C_, h, hp, dims):
         """Tile-fused GDFN input-gradient chain (csrc/gdfn.hip): dY -> dt2 -> dt1 -> gradient of the norm2 output."""
         self._hold(dY, T2, Wout, Wdw, Win, DT2, DT1, dT)
@@ -779,9 +793,12 @@ class Plan(Recorder):
         fa.B, fa.C, fa.heads = B, C_, heads
         self.keep.append(fa)
         self._op(n + ".attn_fwd", lib.uir_attn_fwd, C.byref(fa))
-        self.gemm(n + ".WA", v_, WA, u, N=C_, K=C_, w_sn=C_, w_sk=1, w_bs=C_ * C_, batches=B)
-        self.dwconv(n + ".kv_conv", u, Wkvdw_f, vf, C_=C_, dims=dims)
-        self.gemm(n + ".WB", vf, WB, x1, N=C_, K=C_, w_sn=C_, w_sk=1, w_bs=C_ * C_, batches=B, R=x)
+        if str(C_) in _ATTNV_FUSED:
+            self.attnv_fwd(n + ".WA+kv_conv+WB", v_, WA, WB, Wkvdw_f, x, u, vf, x1, C_=C_, dims=dims)
+        else:
+            self.gemm(n + ".WA", v_, WA, u, N=C_, K=C_, w_sn=C_, w_sk=1, w_bs=C_ * C_, batches=B)
+            self.dwconv(n + ".kv_conv", u, Wkvdw_f, vf, C_=C_, dims=dims)
+            self.gemm(n + ".WB", vf, WB, x1, N=C_, K=C_, w_sn=C_, w_sk=1, w_bs=C_ * C_, batches=B, R=x)
         # ---- GDFN (:127-130) ----
         if str(C_) in _GDFN_FUSED:
             # one pass over the pixels; t1/t2 written once for the backward kernels, never re-read in the forward
