@@ -444,7 +444,8 @@ class Recorder:
 
     def gram(self, name, A, Bm, out, *, N, K, o_sn, o_sk, o_st=0, o_bs=0, batches=1, taps=1, hw=None,
              n_grp=(0, 0), k_grp=(0, 0), pro_b=0, gate_off=0, ln=None, stats=None, out_elems=None,
-             extras: "Dict[str, torch.Tensor] | None" = None, fused_out: "torch.Tensor | None" = None):
+             extras: "Dict[str, torch.Tensor] | None" = None, fused_out: "torch.Tensor | None" = None,
+             own_slab: bool = False):
         """out[...] = sum_m A[m][n] * pro(B[nbr(m)][k]); `out` is a flat view of out_elems floats.
         extras: {'sq_a': tensor[batches*N], 'sq_b': tensor[batches*K], 'cs_a': tensor[batches*N]}."""
         M_total = A.shape[0]
@@ -480,7 +481,12 @@ class Recorder:
         if "cs_a" in extras:
             a.cs_a_off = stride; stride += batches * N
         a.slab_stride = stride
-        assert nch * stride <= self._slab().numel(), (name, nch, stride)
+        if own_slab:     # private partial-slab buffer: the launch may run on a lane that shares its scratch with another
+            slab_t = self.alloc(nch * stride)
+            a.slab = _ptr(slab_t)
+        else:
+            slab_t = self._slab()
+            assert nch * stride <= slab_t.numel(), (name, nch, stride)
         a.M, a.N, a.K, a.batches = M, N, K, batches
         a.n_grp_real, a.n_grp_pad = n_grp
         a.k_grp_real, a.k_grp_pad = k_grp
@@ -496,7 +502,7 @@ class Recorder:
         rows = M * batches
         self._op(name, lib.uir_gram, C.byref(a), nbytes=4 * rows * (N + K * (2 if pro_b == L.PRO_GATE else 1)),
                  flops=2 * rows * N * K * taps)
-        sp = self._slab().data_ptr()
+        sp = slab_t.data_ptr()
         if fused_out is not None:
             # `fused_out` = [out | sq_a | sq_b | cs_a] contiguous, i.e. exactly one slab row: one reduction launch
             assert fused_out.numel() == stride and fused_out.data_ptr() == out.data_ptr()
@@ -864,12 +870,26 @@ class Plan(Recorder):
             if not (fuse_ln and str(C_) not in _GDFN_BWD_FUSED):
                 self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
             # MDTA
-            self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
+            # the two per-sample weight-gradient Grams are needed only by uir_attn_bwd: side lane, joined right before it
+            side_grams = os.environ.get("UIR_SIDE_GRAMS", "0") == "1"   # opt-in: A/B neutral (46.1-46.2 vs 46.2-46.3 ms/step)
+            if side_grams:
+                with self.side():
+                    self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
+                              out_elems=B * C_ * C_, own_slab=True)
+            else:
+                self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
             self.gemm(n + ".dvf", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
             self.dwconv_bwd(n + ".du+dWkvdw", dvf, u, Wkvdw_f, du, Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, creal=C_,
                             dims=dims)
-            self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
+            if side_grams:
+                with self.side():
+                    self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
+                              out_elems=B * C_ * C_, own_slab=True)
+            else:
+                self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
             self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
+            if side_grams:
+                self.join(n + ".dWAB.join")
             ba = L.AttnBwdArgs()
             ba.dWA, ba.dWB, ba.G, ba.sq_q, ba.sq_k, ba.temperature = _ptr(dWA), _ptr(dWB), _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp)
             ba.attn, ba.P, ba.Wof = _ptr(attn), _ptr(Pm), _ptr(Wof)
