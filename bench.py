@@ -173,25 +173,46 @@ def main():
             plan = model._plan_for(raw)
             rows = plan.run_timed(plan.fwd) + plan.run_timed(plan.bwd)
             lanes = list(plan.lanes[id(plan.fwd)]) + list(plan.lanes[id(plan.bwd)])
+            # the same launches timed in the REAL three-lane execution: an event pair around every launch on the stream
+            # it runs on (what rocprofv3 --kernel-trace sees; kernels of different lanes contend for HBM and CUs)
+            ov = {}
+            for _rep in range(3):
+                tf, tb = [], []
+                plan.run(plan.fwd, timed=tf)
+                plan.run(plan.bwd, timed=tb)
+                torch.cuda.synchronize()
+                nf = len(plan.fwd)
+                for i, e0, e1 in tf:
+                    ov.setdefault(i, []).append(e0.elapsed_time(e1))
+                for i, e0, e1 in tb:
+                    ov.setdefault(nf + i, []).append(e0.elapsed_time(e1))
+            ov_ms = {i: sum(v) / len(v) for i, v in ov.items()}
             agg = {}
-            for name, sym, nb, fl, t_ms in rows:
-                a = agg.setdefault(sym, [0, 0.0, 0, 0])
-                a[0] += 1; a[1] += t_ms; a[2] += nb; a[3] += fl
+            for idx, (name, sym, nb, fl, t_ms) in enumerate(rows):
+                if idx not in ov_ms:
+                    continue
+                a = agg.setdefault(sym, [0, 0.0, 0, 0, 0.0])
+                a[0] += 1; a[1] += ov_ms[idx]; a[2] += nb; a[3] += fl; a[4] += t_ms
             top = max(agg.items(), key=lambda kv: kv[1][1])
-            sym, (cnt, tms, nb, fl) = top
+            sym, (cnt, tms, nb, fl, tser) = top
             roof["dominant_kernel"] = {"symbol": sym, "launches_per_step": cnt, "ms_per_step": tms,
                                        "avg_launch_ms": tms / cnt, "algorithmic_bytes_per_step": nb,
                                        "achieved_GBps": nb / (tms * 1e-3) / 1e9, "frac_of_peak": nb / (tms * 1e-3) / HBM_PEAK,
-                                       "achieved_TFLOPs": fl / (tms * 1e-3) / 1e12}
+                                       "achieved_TFLOPs": fl / (tms * 1e-3) / 1e12,
+                                       "timing": "HIP event pair per launch on its own stream, overlapped three-lane execution "
+                                                 "(mean of 3 passes)",
+                                       "avg_launch_ms_serialized": tser / cnt}
             roof["instrumented_step_ms"] = sum(r[4] for r in rows)
             if args.breakdown_file:
                 with open(args.breakdown_file, "w") as f:
-                    f.write("symbol,launches,ms_per_step,alg_GB,alg_GBps,TFLOPs\n")
-                    for sym, (cnt, tms, nb, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
-                        f.write(f"{sym},{cnt},{tms:.4f},{nb / 1e9:.3f},{nb / max(tms, 1e-9) / 1e6:.1f},{fl / max(tms, 1e-9) / 1e9:.2f}\n")
-                    f.write("\nop,symbol,ms,alg_MB,lane (0 chain, 1 side, 4 bulk; serial per-launch times)\n")
-                    for (name, sym, nb, fl, t_ms), ln in sorted(zip(rows, lanes), key=lambda r: -r[0][4]):
-                        f.write(f"{name},{sym},{t_ms:.4f},{nb / 1e6:.2f},{ln}\n")
+                    f.write("symbol,launches,ms_per_step(overlapped run),alg_GB,alg_GBps,TFLOPs,ms_per_step(serialized)\n")
+                    for sym, (cnt, tms, nb, fl, tser) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                        f.write(f"{sym},{cnt},{tms:.4f},{nb / 1e9:.3f},{nb / max(tms, 1e-9) / 1e6:.1f},{fl / max(tms, 1e-9) / 1e9:.2f},{tser:.4f}\n")
+                    f.write("\nop,symbol,ms,alg_MB,lane (0 chain, 1 side, 4 bulk; serial per-launch times),ms in the overlapped run\n")
+                    order = sorted(range(len(rows)), key=lambda i: -rows[i][4])
+                    for i in order:
+                        name, sym, nb, fl, t_ms = rows[i]
+                        f.write(f"{name},{sym},{t_ms:.4f},{nb / 1e6:.2f},{lanes[i]},{ov_ms.get(i, 0.0):.4f}\n")
         out = {"metric": "train images/sec at 256x256 bs=16/GPU (SpectralTransformer full train step)",
                "value": imgs_per_s, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,

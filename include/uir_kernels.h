@@ -22,6 +22,7 @@ extern "C" {
 
 /* ---------------------------------------------------------------- uir_gemm */
 enum { UIR_PRO_NONE = 0, UIR_PRO_LN = 1, UIR_PRO_GATE = 2 };
+#define UIR_GEMM_SLAB_ROWS 512   /* max workgroups (= slab rows) of the GEMM variants with fused reductions */
 enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2, UIR_EPI_GATE_BWD_DW = 3, UIR_EPI_LN_BWD = 4 };
 enum { UIR_ACT_NONE = 0, UIR_ACT_LEAKY = 1 };
 
@@ -57,7 +58,7 @@ typedef struct UirGemmArgs {
   float ln_eps;
   float* dw_slab;      /* GATE_BWD_DW: per-workgroup partials [gridDim.x][dw_stride] of the project_out     */
   long dw_stride;      /* weight gradient dW[k][n] = sum_m X[m][k] * gate(G)[m][n], summed by uir_reduce_slab;*/
-                       /* gridDim.x = min(M/128, 1536).  Requires K <= 32, N <= 96, M % 128 == 0            */
+                       /* gridDim.x = min(M/128, UIR_GEMM_SLAB_ROWS).  Requires K <= 32, N <= 96, M % 128 == 0 */
                        /* LN_BWD: the GEMM result is the gradient of a LayerNorm output; the epilogue applies  */
                        /* the LayerNorm backward (G = LN input [M][ldg], stats, ln_g = gamma, R = residual-   */
                        /* path gradient or NULL), writes dX to Y and per-workgroup rows [dgamma(N) | dbeta(N)] */

@@ -778,6 +778,10 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
       const int rtiles = (a.M + 127) / 128;
       int gx = 1536 / (groups1 * a.batches);
       if (gx < 1) gx = 1;
+      // the variants with fused reductions run 2 workgroups per CU (launch bounds): 512 resident workgroups take all
+      // the tiles, and every workgroup writes one slab row for uir_reduce_slab - no point in more rows than that
+      static const int slab_rows = getenv("UIR_GEMM_ROWS") ? atoi(getenv("UIR_GEMM_ROWS")) : UIR_GEMM_SLAB_ROWS;   // tuning aid (<= engine's slab)
+      if ((a.epi == UIR_EPI_GATE_BWD_DW || a.epi == UIR_EPI_LN_BWD) && gx > slab_rows) gx = slab_rows;
       if (gx > rtiles) gx = rtiles;
       dim3 grid1(gx, groups1, a.batches);
 #define UIR_L1(NTV, PROV, EPIV, RV) \

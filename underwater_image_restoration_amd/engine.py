@@ -38,6 +38,7 @@ NUM_REFINEMENT = 4
 EXPANSION = 2.66
 LN_EPS = 1e-5
 _SKIP_SIDE = os.environ.get("UIR_SKIP_SIDE", "0") == "1"
+_SKIP_RED = os.environ.get("UIR_SKIP_RED", "0") == "1"
 # channel counts whose GDFN forward runs as the tile-fused kernel (csrc/gdfn.hip); "" = three separate kernels
 _GDFN_FUSED = set(filter(None, os.environ.get("UIR_GDFN_FUSED", "16,32,64,128").split(",")))
 _ATTNV_FUSED = set(filter(None, os.environ.get("UIR_ATTNV_FUSED", "16,32,64,128").split(",")))
@@ -117,6 +118,7 @@ def twiddles(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     return _TWIDDLE_CACHE[key]
 
 
+GEMM_SLAB_ROWS = int(os.environ.get("UIR_GEMM_ROWS", 512))      # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
 _DFT2_CACHE: dict = {}
 
 
@@ -268,9 +270,12 @@ class Recorder:
             elif t is not None:
                 self.keep.append(t)
 
-    def run(self, ops: Sequence[tuple], marks: "list | None" = None, serial: bool = False) -> None:
+    def run(self, ops: Sequence[tuple], marks: "list | None" = None, serial: bool = False,
+            timed: "list | None" = None) -> None:
         """Execute a launch list.  serial=True ignores the lanes (everything on the current stream, in list
-        order): the reference schedule the overlapped execution must reproduce bit for bit."""
+        order): the reference schedule the overlapped execution must reproduce bit for bit.
+        timed=[]: a HIP event pair is recorded around every launch ON THE STREAM IT IS LAUNCHED ON, in the real
+        three-lane execution (nothing is serialised across lanes); entries (op index, start event, end event)."""
         if self.dev.type != "cuda":
             st = C.c_void_p(0)
             for fn, args, name in ops:
@@ -305,7 +310,7 @@ class Recorder:
         main_dirty = True           # main has launched work the side stream has not been ordered after
         bulk_dirty = True           # ... the bulk stream has not been ordered after
         side_dirty = False          # side has launched work the bulk stream has not been ordered after
-        for (fn, args, name), lane in zip(ops, lanes):
+        for opi, ((fn, args, name), lane) in enumerate(zip(ops, lanes)):
             if lane == 3:                       # stage marker
                 if marks is not None:
                     e = torch.cuda.Event(enable_timing=True)
@@ -323,6 +328,8 @@ class Recorder:
             if lane == 4:
                 if _SKIP_SIDE:      # timing experiment only (UIR_SKIP_SIDE=1): results are wrong
                     continue
+                if _SKIP_RED and fn is lib.uir_reduce_slab:   # timing experiment only (UIR_SKIP_RED=1): results are wrong
+                    continue
                 if bulk_dirty:
                     if nev == len(self._events):
                         self._events.append(torch.cuda.Event())
@@ -339,7 +346,13 @@ class Recorder:
                     ev.record(side)
                     bulk.wait_event(ev)
                     side_dirty = False
+                if timed is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(bulk)
                 rc = fn(*args, st4)
+                if timed is not None:
+                    e1.record(bulk)
+                    timed.append((opi, e0, e1))
                 if rc:
                     L.check(rc, name)
                 continue
@@ -352,10 +365,22 @@ class Recorder:
                     ev.record(main)
                     side.wait_event(ev)
                     main_dirty = False
+                if timed is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(side)
                 rc = fn(*args, st1)
+                if timed is not None:
+                    e1.record(side)
+                    timed.append((opi, e0, e1))
                 side_dirty = True
             else:
+                if timed is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(main)
                 rc = fn(*args, st0)
+                if timed is not None:
+                    e1.record(main)
+                    timed.append((opi, e0, e1))
                 main_dirty = True
                 bulk_dirty = True
             if rc:
@@ -599,15 +624,15 @@ class Recorder:
     def gemm_ln_bwd(self, name, A, W, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_, K, k_grp=(0, 0)):
         """dX = LayerNorm'(A . W) + dRes with the LayerNorm backward as the GEMM epilogue (the gradient of the LN output
         never reaches HBM); dgamma / dbeta as per-workgroup slab rows, summed on the bulk lane."""
-        slab = torch.zeros(1536, 2 * C_, device=self.dev, dtype=torch.float32)   # rows past gridDim.x stay zero
+        slab = torch.zeros(GEMM_SLAB_ROWS, 2 * C_, device=self.dev, dtype=torch.float32)   # rows past gridDim.x stay zero
         self.gemm(name, A, W, dX, N=C_, K=K, w_sn=1, w_sk=C_, k_grp=k_grp, epi=L.EPI_LN_BWD, G=X, stats=stats,
                   ln=(gamma, None), R=dRes, dw_slab=slab)
         with self.bulk():
             if dbeta.data_ptr() == dgamma.data_ptr() + 4 * C_:
-                self._op(name + ".dgb", lib.uir_reduce_slab, _ptr(slab), 1536, 2 * C_, _ptr(dgamma), 2 * C_, 0, 1.0)
+                self._op(name + ".dgb", lib.uir_reduce_slab, _ptr(slab), GEMM_SLAB_ROWS, 2 * C_, _ptr(dgamma), 2 * C_, 0, 1.0)
             else:
-                self._op(name + ".dg", lib.uir_reduce_slab, _ptr(slab), 1536, 2 * C_, _ptr(dgamma), C_, 0, 1.0)
-                self._op(name + ".db", lib.uir_reduce_slab, slab.data_ptr() + 4 * C_, 1536, 2 * C_, _ptr(dbeta), C_, 0, 1.0)
+                self._op(name + ".dg", lib.uir_reduce_slab, _ptr(slab), GEMM_SLAB_ROWS, 2 * C_, _ptr(dgamma), C_, 0, 1.0)
+                self._op(name + ".db", lib.uir_reduce_slab, slab.data_ptr() + 4 * C_, GEMM_SLAB_ROWS, 2 * C_, _ptr(dbeta), C_, 0, 1.0)
 
     def dwconv_wgrad(self, name, dY, X, out, *, C_, creal, dims, grp=(0, 0)):
         self._hold(dY, X, out)
@@ -848,11 +873,11 @@ class Plan(Recorder):
                     # project_out weight gradient inside the gate-backward GEMM (its accumulator layout is the
                     # B-operand layout of the pixel contraction): the bulk lane keeps only the tiny slab reduction.
                     # Rows beyond the launch's gridDim.x are never written: the slab is zero-filled once, here.
-                    dws = torch.zeros(1536, C_ * h, device=self.dev, dtype=torch.float32)
+                    dws = torch.zeros(GEMM_SLAB_ROWS, C_ * h, device=self.dev, dtype=torch.float32)
                     self.gemm(n + ".dgate+dWout", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp),
                               epi=L.EPI_GATE_BWD_DW, G=g, g_off=hp, dw_slab=dws)
                     with self.bulk():
-                        self._op(n + ".dWout.red", lib.uir_reduce_slab, _ptr(dws), 1536, C_ * h,
+                        self._op(n + ".dWout.red", lib.uir_reduce_slab, _ptr(dws), GEMM_SLAB_ROWS, C_ * h,
                                  _ptr(Gr(f"{pfx}.ffn.project_out.weight")), C_ * h, 0, 1.0)
                 else:
                     self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g,
