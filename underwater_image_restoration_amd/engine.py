@@ -884,14 +884,20 @@ class Plan(Recorder):
                               g_off=hp)
                 self.dwconv_bwd(n + ".dgpre+dWffdw", dg, gpre, Wffdw, dgpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
                                 dims=dims, grp=(h, hp))
-                with self.bulk():
-                    self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
-                              n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
+                def dwin():
+                    with self.bulk():
+                        self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
+                                  n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
+                late = os.environ.get("UIR_LATE_GRAMS", "1") == "1"
+                if not late:
+                    dwin()
                 if fuse_ln:
                     self.gemm_ln_bwd(n + ".dt2+ln2_bwd", dgpre, Win, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"),
                                      Gr(f"{pfx}.norm2.bias"), C_=C_, K=2 * hp, k_grp=(h, hp))
                 else:
                     self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
+                if late:      # released after the GEMM that shares its dgpre operand (the persistent 2-WG/CU GEMM with the
+                    dwin()    # LayerNorm epilogue lost 60 % when this Gram started beside it: serial 267 us, overlapped 430 us)
             if not (fuse_ln and str(C_) not in _GDFN_BWD_FUSED):
                 self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
             # MDTA
@@ -933,15 +939,21 @@ class Plan(Recorder):
                       w_bs=4 * C_ * C_, batches=B)
             self.dwconv_bwd(n + ".dqkv_pre+dWqkvdw", dqkv, qkv_pre, Wdw, dqkv_pre, Gr(f"{a}.qkv_conv.weight"), C_=3 * C_,
                             creal=3 * C_, dims=dims)
-            with self.bulk():
-                self.gram(n + ".dWqkv", dqkv_pre, x, Gr(f"{a}.qkv.weight"), N=3 * C_, K=C_, o_sn=C_, o_sk=1,
-                          pro_b=L.PRO_LN, ln=(g1, b1), stats=stats1)
+            def dwqkv():
+                with self.bulk():
+                    self.gram(n + ".dWqkv", dqkv_pre, x, Gr(f"{a}.qkv.weight"), N=3 * C_, K=C_, o_sn=C_, o_sk=1,
+                              pro_b=L.PRO_LN, ln=(g1, b1), stats=stats1)
+            late_q = os.environ.get("UIR_LATE_GRAMS", "1") == "1"
+            if not late_q:
+                dwqkv()
             if fuse_ln:
                 self.gemm_ln_bwd(n + ".dt1+ln1_bwd", dqkv_pre, Wqkv, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"),
                                  Gr(f"{pfx}.norm1.bias"), C_=C_, K=3 * C_)
             else:
                 self.gemm(n + ".dt1", dqkv_pre, Wqkv, dt, N=C_, K=3 * C_, w_sn=1, w_sk=C_)
                 self.ln_bwd(n + ".ln1_bwd", dt, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_)
+            if late_q:
+                dwqkv()
             return dx
 
         return y, backward
