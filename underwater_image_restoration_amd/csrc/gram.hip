@@ -284,33 +284,31 @@ __global__ __launch_bounds__(256) void uir_gram_taps9_kernel(const UirGramArgs a
   }
 }
 
-// out[i] = sum_c slab[c][i]: 64 outputs per workgroup, the chunks split over 16 waves with 4
-// independent accumulators each (memory-level parallelism), combined in a fixed order.
-__global__ __launch_bounds__(1024) void uir_reduce_slab_kernel(const float* __restrict__ slab, int nchunks, long stride,
-                                                               float* __restrict__ out, long n, int accumulate, float scale) {
-  __shared__ float red[16][64];
+// out[i] = sum_c slab[c][i]: 64 outputs per workgroup, the chunks split over 4 waves with 8 independent
+// accumulators each (memory-level parallelism), combined in a fixed order.  256 threads: a 1024-thread block needs 16
+// free wave slots on ONE CU at once (A/B against the 1024-thread version in the full step: no difference).
+__global__ __launch_bounds__(256) void uir_reduce_slab_kernel(const float* __restrict__ slab, int nchunks, long stride,
+                                                              float* __restrict__ out, long n, int accumulate, float scale) {
+  __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
   const long i = (long)blockIdx.x * 64 + lane;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = 0.f;
   if (i < n) {
     const float* p = slab + i;
     int c = cl;
-    for (; c + 48 < nchunks; c += 64) {
-      s0 += p[(long)c * stride];
-      s1 += p[(long)(c + 16) * stride];
-      s2 += p[(long)(c + 32) * stride];
-      s3 += p[(long)(c + 48) * stride];
+    for (; c + 28 < nchunks; c += 32) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += p[(long)(c + 4 * k) * stride];
     }
-    for (; c < nchunks; c += 16) s0 += p[(long)c * stride];
+    for (; c < nchunks; c += 4) s[0] += p[(long)c * stride];
   }
-  red[cl][lane] = (s0 + s1) + (s2 + s3);
+  red[cl][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
   __syncthreads();
   if (cl == 0 && i < n) {
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < 16; ++w) s += red[w][lane];
-    s *= scale;
-    out[i] = accumulate ? out[i] + s : s;
+    float t = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * scale;
+    out[i] = accumulate ? out[i] + t : t;
   }
 }
 
@@ -376,7 +374,7 @@ extern "C" int uir_reduce_slab(const float* slab, int nchunks, long stride, floa
   UIR_REQUIRE(slab && out && nchunks > 0 && n > 0);
   const long blocks = (n + 63) / 64;
   UIR_REQUIRE(blocks < (1L << 31));
-  hipLaunchKernelGGL(uir_reduce_slab_kernel, dim3((unsigned)blocks), dim3(1024), 0, static_cast<hipStream_t>(stream),
+  hipLaunchKernelGGL(uir_reduce_slab_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
                      slab, nchunks, stride, out, n, accumulate, scale);
   return uir_launch_status();
 }
