@@ -214,11 +214,14 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
 // tiles against the 9 shifted X rows (neighbours in W are adjacent HWC rows: L1 hits), instead of 9
 // independent passes over dY and X.
 __global__ __launch_bounds__(256) void uir_gram_taps9_kernel(const UirGramArgs a) {
-  __shared__ float red[9 * 16 * 64];
+  // blockIdx.y = kernel row ky: this workgroup accumulates taps 3 ky .. 3 ky + 2 (48 accumulator registers instead of
+  // 144: at 300 registers per thread the 9-tap version ran one wave per SIMD and kept the other lanes' kernels off its CUs)
+  __shared__ float red[3 * 16 * 64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h2 = lane >> 5;
   const int z = blockIdx.z;
   const int chunk = blockIdx.x;
+  const int ky = blockIdx.y, dy = ky - 1;
   const float* __restrict__ A = a.A + (long)z * a.a_bs;
   const float* __restrict__ B = a.B + (long)z * a.b_bs;
   const int row_begin = chunk * a.rows_per_chunk;
@@ -226,15 +229,15 @@ __global__ __launch_bounds__(256) void uir_gram_taps9_kernel(const UirGramArgs a
   const int last_row = row_end - 1;
   const bool aok_c = r < a.N, bok_c = r < a.K;
   const int acol = min(r, a.N - 1), bcol = min(r, a.K - 1);
-  f32x16 acc[9];
+  f32x16 acc[3];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
-  constexpr int U = 2;
+  constexpr int U = 4;
   for (int base = row_begin + 2 * wave; base < row_end; base += 8 * U) {
-    float av[U], bv[U][9];
-    bool ok[U][9], aok[U];
+    float av[U], bv[U][3];
+    bool ok[U][3], aok[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int m = base + 8 * u + h2;
@@ -243,10 +246,11 @@ __global__ __launch_bounds__(256) void uir_gram_taps9_kernel(const UirGramArgs a
       av[u] = A[(long)mc * a.lda + acol];
       const int hw = mc % (a.H * a.Wd);
       const int ph = hw / a.Wd, pw = hw - ph * a.Wd;
+      const int hh = ph + dy;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3 - 1, dx = t % 3 - 1;
-        const int hh = ph + dy, ww = pw + dx;
+      for (int t = 0; t < 3; ++t) {
+        const int dx = t - 1;
+        const int ww = pw + dx;
         const bool in = hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
         ok[u][t] = in && aok[u] && bok_c;
         const long mb = in ? (long)mc + dy * a.Wd + dx : (long)mc;
@@ -257,13 +261,13 @@ __global__ __launch_bounds__(256) void uir_gram_taps9_kernel(const UirGramArgs a
     for (int u = 0; u < U; ++u) {
       const float avv = (aok[u] && aok_c) ? av[u] : 0.f;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc[t] = uir_mfma(avv, ok[u][t] ? bv[u][t] : 0.f, acc[t]);
+      for (int t = 0; t < 3; ++t) acc[t] = uir_mfma(avv, ok[u][t] ? bv[u][t] : 0.f, acc[t]);
     }
   }
   for (int w = 0; w < 4; ++w) {
     if (wave == w) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
+      for (int t = 0; t < 3; ++t)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
           float* p = &red[(t * 16 + q) * 64 + lane];
@@ -273,8 +277,8 @@ __global__ __launch_bounds__(256) void uir_gram_taps9_kernel(const UirGramArgs a
     __syncthreads();
   }
   float* slab = a.slab + (long)chunk * a.slab_stride;
-  for (int idx = threadIdx.x; idx < 9 * 16 * 64; idx += 256) {
-    const int ln = idx & 63, q = (idx >> 6) & 15, t = idx >> 10;
+  for (int idx = threadIdx.x; idx < 3 * 16 * 64; idx += 256) {
+    const int ln = idx & 63, q = (idx >> 6) & 15, t = 3 * ky + (idx >> 10);
     const int n = uir_mfma_row(q, ln >> 5), k = ln & 31;
     if (n < a.N && k < a.K) {
       const int nr = uir_colmap(n, a.n_grp_real, a.n_grp_pad);
@@ -336,7 +340,7 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
   const int tn_tiles = (a.N + 31) / 32, tk_tiles = (a.K + 31) / 32;
   if (a.taps == 9 && tn_tiles == 1 && tk_tiles == 1 && a.sq_a_off < 0 && a.sq_b_off < 0 && a.cs_a_off < 0 &&
       a.pro_b == UIR_GRAM_PRO_NONE) {
-    dim3 grid(a.nchunks, 1, a.batches);
+    dim3 grid(a.nchunks, 3, a.batches);
     hipLaunchKernelGGL(uir_gram_taps9_kernel, grid, block, 0, st, a);
   } else if (tk_tiles == 1 || tn_tiles == 1) {
     // one operand is a single 32-column tile: the other is split into the fewest groups of <= 4 tiles, each group
