@@ -9,6 +9,10 @@
 #include "uir_common.h"
 #include "../../include/uir_kernels.h"
 
+#ifndef UIR_GRAM_U3
+#define UIR_GRAM_U3 3   // row pairs per trip of the 3-tile variants: 3 keeps them at 3 waves/SIMD (4: 174 registers -> 2 waves)
+#endif
+
 namespace {
 
 template <int TN, int TK, int PRO>
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
   // U row-pairs per trip: every load of the trip is issued before the first MFMA consumes one.
   // Loads are branch-free (clamped addresses + select): a predicated load costs a branch and a
   // vmcnt(0) drain in hipcc's codegen, which serialises the whole trip.
-  constexpr int U = (TN * TK == 1) ? 8 : 4;
+  constexpr int U = (TN * TK == 1) ? 8 : (TN * TK == 3 ? UIR_GRAM_U3 : 4);
   int acol[TN], bcol[TK];
 #pragma unroll
   for (int t = 0; t < TN; ++t) acol[t] = min(n0 + 32 * t + r, a.N - 1);
