@@ -39,6 +39,7 @@ EXPANSION = 2.66
 LN_EPS = 1e-5
 _SKIP_SIDE = os.environ.get("UIR_SKIP_SIDE", "0") == "1"
 _SKIP_RED = os.environ.get("UIR_SKIP_RED", "0") == "1"
+_SKIP_OPS = [k for k in os.environ.get("UIR_SKIP_OPS", "").split(",") if k]
 # channel counts whose GDFN forward runs as the tile-fused kernel (csrc/gdfn.hip); "" = three separate kernels
 _GDFN_FUSED = set(filter(None, os.environ.get("UIR_GDFN_FUSED", "16,32,64,128").split(",")))
 _ATTNV_FUSED = set(filter(None, os.environ.get("UIR_ATTNV_FUSED", "16,32,64,128").split(",")))
@@ -329,6 +330,8 @@ class Recorder:
                 if _SKIP_SIDE:      # timing experiment only (UIR_SKIP_SIDE=1): results are wrong
                     continue
                 if _SKIP_RED and fn is lib.uir_reduce_slab:   # timing experiment only (UIR_SKIP_RED=1): results are wrong
+                    continue
+                if _SKIP_OPS and any(k in name for k in _SKIP_OPS):   # timing experiment only (UIR_SKIP_OPS=a,b): wrong results
                     continue
                 if bulk_dirty:
                     if nev == len(self._events):
