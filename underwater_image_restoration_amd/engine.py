@@ -42,7 +42,7 @@ _SKIP_RED = os.environ.get("UIR_SKIP_RED", "0") == "1"
 _SKIP_OPS = [k for k in os.environ.get("UIR_SKIP_OPS", "").split(",") if k]
 # channel counts whose GDFN forward runs as the tile-fused kernel (csrc/gdfn.hip); "" = three separate kernels
 _GDFN_FUSED = set(filter(None, os.environ.get("UIR_GDFN_FUSED", "16,32,64,128").split(",")))
-_ATTNV_FUSED = set(filter(None, os.environ.get("UIR_ATTNV_FUSED", "16,32,64,128").split(",")))
+_ATTNV_FUSED = set(filter(None, os.environ.get("UIR_ATTNV_FUSED", "32,64").split(",")))   # C=16 / 128: half-empty tiles / one WG per CU, unfused is as fast
 _QKV_FUSED = set(filter(None, os.environ.get("UIR_QKV_FUSED", "16,32,64,128").split(",")))
 # opt-in: after the gate-backward epilogue fix the three HBM-bound kernels (869 us at C=32, 256x256) beat the fused,
 # latency-bound kernel (959 us, SIMDs 47 % busy); full step 51.9 vs 52.7 ms (profiles/r01/d_ab_notes.md)
