@@ -64,6 +64,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
   extern __shared__ float smem[];
   float* T1s = smem;
   float* Gs = smem + T::NRT1 * 32 * T::S1;
+  float* Ws = smem + T::LDS_FLOATS;       // wide levels: two staged W_in chunks [32 rows][C + 4]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
   const int tiles_x = (a.Wd + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   int bid = blockIdx.x;
@@ -191,20 +192,69 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     }
   }
 
-  // C <= 32: the next chunk's weights are prefetched into a second register set; wider levels have no
-  // registers to spare (W_in alone is C/2 per lane) and load at the top of the chunk
+  // C <= 32: the next chunk's weights are prefetched into a second register set.  Wider levels have no registers for
+  // that (W_in alone is C/2 per lane): their W_in chunk goes through LDS, double-buffered - fetched one chunk ahead
+  // with the other small operands loaded one phase ahead into the registers their last use just released.
   constexpr bool PF = C <= 32;
   constexpr int NPF = PF ? T::KJ : 1;
-  float4 win[T::KJ], win_n[NPF];
+  constexpr int WS = C + 4;                       // staged row stride (floats): 16-byte aligned, conflict-free b128 reads
+  constexpr int NSTG = PF ? 1 : (32 * (C / 4)) / 256;   // float4 per thread and chunk
+  float4 win[PF ? T::KJ : 1], win_n[NPF];
   float wo[8], wo_n[8], w1[9], w2[9], w1_n[9], w2_n[9];
-  if (PF) load_w(0, win, wo, w1, w2);
+  float4 stg[NSTG];
+  auto stage_load = [&](int c0) {                 // global -> registers (rows of the chunk: 16 x1 rows | 16 x2 rows)
+#pragma unroll
+    for (int it = 0; it < NSTG; ++it) {
+      const int e = tid + 256 * it, r = e / (C / 4), q = e - r * (C / 4);
+      const int cc = c0 + (r & 15);
+      const bool ok = cc < h;
+      const float4 t = *reinterpret_cast<const float4*>(a.Win + (long)(ok ? (r < 16 ? cc : h + cc) : 0) * C + 4 * q);
+      stg[it] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto stage_store = [&](int buf) {               // registers -> LDS
+#pragma unroll
+    for (int it = 0; it < NSTG; ++it) {
+      const int e = tid + 256 * it, r = e / (C / 4), q = e - r * (C / 4);
+      *reinterpret_cast<float4*>(Ws + buf * 32 * WS + r * WS + 4 * q) = stg[it];
+    }
+  };
+  auto load_small = [&](int c0, float (&wo_)[8], float (&w1_)[9], float (&w2_)[9]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int kk = c0 + 8 * (s >> 2) + 4 * h2 + (s & 3);
+      const bool ok = my_n < C && kk < h;
+      const float t = a.Wout[ok ? (long)my_n * h + kk : 0];
+      wo_[s] = ok ? t : 0.f;
+    }
+    const int cc = c0 + cp;
+    const bool ok = cc < h;
+    const float* p1 = a.Wdw + (long)(ok ? cc : 0) * 9;
+    const float* p2 = a.Wdw + (long)(ok ? h + cc : 0) * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const float u1 = p1[t], u2 = p2[t];
+      w1_[t] = ok ? u1 : 0.f;
+      w2_[t] = ok ? u2 : 0.f;
+    }
+  };
+  if constexpr (PF) {
+    load_w(0, win, wo, w1, w2);
+  } else {
+    stage_load(0);
+    load_small(0, wo, w1, w2);
+    stage_store(0);
+    lds_barrier();
+  }
 
+  int wbuf = 0;
   for (int c0 = 0; c0 < hp; c0 += 16) {
     if constexpr (PF) {
       // in flight across (a) and (b): the LDS-only barriers do not wait for them
       load_w(c0 + 16 < hp ? c0 + 16 : c0, win_n, wo_n, w1_n, w2_n);
     } else {
-      load_w(c0, win, wo, w1, w2);
+      stage_load(c0 + 16 < hp ? c0 + 16 : c0);     // next chunk's W_in rows; written to the other LDS buffer after (a)
+      load_small(c0 + 16 < hp ? c0 + 16 : c0, wo_n, w1_n, w2_n);
     }
 
     // ---- (a) t1 chunk on tile + ring ----
@@ -217,10 +267,13 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         for (int i = 0; i < 16; ++i) d[i] = 0.f;
 #pragma unroll
         for (int jj = 0; jj < T::KJ; ++jj) {
-          d = uir_mfma(A[q][4 * jj + 0], win[jj].x, d);
-          d = uir_mfma(A[q][4 * jj + 1], win[jj].y, d);
-          d = uir_mfma(A[q][4 * jj + 2], win[jj].z, d);
-          d = uir_mfma(A[q][4 * jj + 3], win[jj].w, d);
+          float4 wv_;
+          if constexpr (PF) wv_ = win[jj];
+          else wv_ = *reinterpret_cast<const float4*>(Ws + wbuf * 32 * WS + li * WS + 8 * jj + 4 * h2);
+          d = uir_mfma(A[q][4 * jj + 0], wv_.x, d);
+          d = uir_mfma(A[q][4 * jj + 1], wv_.y, d);
+          d = uir_mfma(A[q][4 * jj + 2], wv_.z, d);
+          d = uir_mfma(A[q][4 * jj + 3], wv_.w, d);
         }
         float* dst = T1s + (r * 32 + 4 * h2) * T::S1 + li;
 #pragma unroll
@@ -236,11 +289,13 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     if constexpr (PF) {
 #pragma unroll
       for (int jj = 0; jj < T::KJ; ++jj) { pin(win_n[jj].x); pin(win_n[jj].y); pin(win_n[jj].z); pin(win_n[jj].w); }
-#pragma unroll
-      for (int t = 0; t < 8; ++t) pin(wo_n[t]);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) { pin(w1_n[t]); pin(w2_n[t]); }
+    } else {
+      stage_store(wbuf ^ 1);     // (a) of chunk c-1 was the last reader of that buffer; visible after the next barrier
     }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) pin(wo_n[t]);
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { pin(w1_n[t]); pin(w2_n[t]); }
 
     // ---- T1 write-out (training): interior rows of the LDS chunk as 16-byte stores, 8 lanes per pixel ----
     if (STORE) {
@@ -327,11 +382,12 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     if constexpr (PF) {
 #pragma unroll
       for (int jj = 0; jj < T::KJ; ++jj) win[jj] = win_n[jj];
-#pragma unroll
-      for (int t = 0; t < 8; ++t) wo[t] = wo_n[t];
-#pragma unroll
-      for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
     }
+#pragma unroll
+    for (int t = 0; t < 8; ++t) wo[t] = wo_n[t];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
+    wbuf ^= 1;
     // no barrier: (a) of the next chunk writes T1s (all reads of it finished before the barrier
     // above) and Gs is rewritten only after the next barrier, which every wave reaches after its (c)
   }
@@ -1127,7 +1183,7 @@ template <int C, int TH, int TW>
 int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
   const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
-  const size_t lds = (size_t)T::LDS_FLOATS * 4;
+  const size_t lds = ((size_t)T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : 0)) * 4;   // + two staged W_in chunks
   if (a.T1) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true>), dim3(tiles), dim3(256), lds, st, a);
   else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false>), dim3(tiles), dim3(256), lds, st, a);
   return uir_launch_status();
