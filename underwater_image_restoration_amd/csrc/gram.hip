@@ -15,7 +15,9 @@
 
 namespace {
 
-template <int TN, int TK, int PRO>
+// EXTRAS: also the column sums of squares / column sums (only the q.k^T Gram and the bias gradients ask for them: the
+// 3 extra VALU ops per operand element are pure overhead elsewhere - MFMA and VALU time add up on gfx950)
+template <int TN, int TK, int PRO, bool EXTRAS>
 __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int gn, int gk) {
   __shared__ float red[TN * TK * 16 * 64];
   __shared__ float redv[4 * 32 * (2 * TN + TK)];
@@ -125,9 +127,9 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
 #pragma unroll
         for (int j = 0; j < TK; ++j) acc[i][j] = uir_mfma(av[i], bv[j], acc[i][j]);
 #pragma unroll
-      for (int t = 0; t < TN; ++t) { sqa[t] += av[t] * av[t]; csa[t] += av[t]; }
+      for (int t = 0; t < TN; ++t) { if constexpr (EXTRAS) { sqa[t] += av[t] * av[t]; csa[t] += av[t]; } }
 #pragma unroll
-      for (int t = 0; t < TK; ++t) sqb[t] += bv[t] * bv[t];
+      for (int t = 0; t < TK; ++t) { if constexpr (EXTRAS) sqb[t] += bv[t] * bv[t]; }
     }
   };
   {
@@ -337,10 +339,13 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
   dim3 block(256);
 #define UIR_GRAM_LAUNCH(TNV, TKV, GN, GK)                                                                              \
   do {                                                                                                                 \
-    if (a.pro_b == UIR_GRAM_PRO_LN) hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_LN>), grid, block, 0, st, a, GN, GK);         \
-    else if (a.pro_b == UIR_GRAM_PRO_GATE) hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_GATE>), grid, block, 0, st, a, GN, GK); \
-    else hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_NONE>), grid, block, 0, st, a, GN, GK);                                   \
+    if (a.pro_b == UIR_GRAM_PRO_LN) hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_LN, false>), grid, block, 0, st, a, GN, GK);         \
+    else if (a.pro_b == UIR_GRAM_PRO_GATE) hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_GATE, false>), grid, block, 0, st, a, GN, GK); \
+    else if (extras) hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_NONE, true>), grid, block, 0, st, a, GN, GK);                       \
+    else hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_NONE, false>), grid, block, 0, st, a, GN, GK);                                  \
   } while (0)
+  const bool extras = a.sq_a_off >= 0 || a.sq_b_off >= 0 || a.cs_a_off >= 0;
+  UIR_REQUIRE(!extras || a.pro_b == UIR_GRAM_PRO_NONE);
   const int tn_tiles = (a.N + 31) / 32, tk_tiles = (a.K + 31) / 32;
   if (a.taps == 9 && tn_tiles == 1 && tk_tiles == 1 && a.sq_a_off < 0 && a.sq_b_off < 0 && a.cs_a_off < 0 &&
       a.pro_b == UIR_GRAM_PRO_NONE) {
