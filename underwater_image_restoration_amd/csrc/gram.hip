@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
 #pragma unroll
   for (int t = 0; t < TK; ++t) bcol[t] = min(k0 + 32 * t + r, a.K - 1);
   const int last_row = row_end - 1;
+  const float* statz = (PRO == UIR_GRAM_PRO_LN) ? a.stats + (long)z * a.M * 2 : nullptr;
   // One trip = U row pairs per wave.  Two named register panels, loop unrolled x2: the loads of trip t+1 are
   // issued before the MFMAs of trip t (vmcnt retires in issue order, so a rotating-index prefetch would wait for
   // the newest loads; with static panels the wait before compute(P) only covers P's own, older loads).
@@ -85,26 +86,28 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
       const bool aok = m < row_end;
       bool bok = aok;
       const int mc = min(m, last_row);
-      const float* ap = A + (long)mc * a.lda;
+      // uniform base + 32-bit per-lane offsets (element counts < 2^30: checked by the launcher): one VALU op per address
+      // instead of a 64-bit multiply-add chain - the loop was as busy with address math as with its MFMAs
+      const unsigned oa = (unsigned)mc * (unsigned)a.lda;
 #pragma unroll
-      for (int t = 0; t < TN; ++t) Pav[u][t] = ap[acol[t]];
-      long mb = mc;
+      for (int t = 0; t < TN; ++t) Pav[u][t] = A[oa + (unsigned)acol[t]];
+      int mb = mc;
       if (a.taps > 1) {
         const int hw = mc % (a.H * a.Wd);
         const int ph = hw / a.Wd, pw = hw - ph * a.Wd;
         const int hh = ph + dy, ww = pw + dx;
         const bool in = hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
         bok = bok && in;
-        mb = in ? (long)mc + dy * a.Wd + dx : (long)mc;
+        mb = in ? mc + dy * a.Wd + dx : mc;
       }
       Pak[u] = aok ? 1.f : 0.f;
       Pbk[u] = bok ? 1.f : 0.f;
-      if constexpr (PRO == UIR_GRAM_PRO_LN) Pst[u] = *reinterpret_cast<const float2*>(a.stats + ((long)z * a.M + mb) * 2);
-      const float* bp = B + mb * a.ldb;
+      if constexpr (PRO == UIR_GRAM_PRO_LN) Pst[u] = *reinterpret_cast<const float2*>(statz + 2u * (unsigned)mb);
+      const unsigned ob = (unsigned)mb * (unsigned)a.ldb;
 #pragma unroll
       for (int t = 0; t < TK; ++t) {
-        Pbv[u][t] = bp[bcol[t]];
-        if constexpr (PRO == UIR_GRAM_PRO_GATE) Pbg[u][t] = bp[a.gate_off + bcol[t]];
+        Pbv[u][t] = B[ob + (unsigned)bcol[t]];
+        if constexpr (PRO == UIR_GRAM_PRO_GATE) Pbg[u][t] = B[ob + (unsigned)(a.gate_off + bcol[t])];
       }
     }
   };
@@ -344,6 +347,7 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
     else if (extras) hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_NONE, true>), grid, block, 0, st, a, GN, GK);                       \
     else hipLaunchKernelGGL((uir_gram_kernel<TNV, TKV, UIR_GRAM_PRO_NONE, false>), grid, block, 0, st, a, GN, GK);                                  \
   } while (0)
+  UIR_REQUIRE((long)a.M * a.lda < (1L << 30) && (long)a.M * a.ldb < (1L << 30));   // 32-bit element offsets per batch
   const bool extras = a.sq_a_off >= 0 || a.sq_b_off >= 0 || a.cs_a_off >= 0;
   UIR_REQUIRE(!extras || a.pro_b == UIR_GRAM_PRO_NONE);
   const int tn_tiles = (a.N + 31) / 32, tk_tiles = (a.K + 31) / 32;
