@@ -473,7 +473,7 @@ class Recorder:
     def gram(self, name, A, Bm, out, *, N, K, o_sn, o_sk, o_st=0, o_bs=0, batches=1, taps=1, hw=None,
              n_grp=(0, 0), k_grp=(0, 0), pro_b=0, gate_off=0, ln=None, stats=None, out_elems=None,
              extras: "Dict[str, torch.Tensor] | None" = None, fused_out: "torch.Tensor | None" = None,
-             own_slab: bool = False):
+             own_slab: bool = False, shared_slab=None):
         """out[...] = sum_m A[m][n] * pro(B[nbr(m)][k]); `out` is a flat view of out_elems floats.
         extras: {'sq_a': tensor[batches*N], 'sq_b': tensor[batches*K], 'cs_a': tensor[batches*N]}."""
         M_total = A.shape[0]
@@ -509,7 +509,15 @@ class Recorder:
         if "cs_a" in extras:
             a.cs_a_off = stride; stride += batches * N
         a.slab_stride = stride
-        if own_slab:     # private partial-slab buffer: the launch may run on a lane that shares its scratch with another
+        if shared_slab is not None:
+            # (tensor, column offset, chunk stride): several Grams write side by side into one slab and the caller issues
+            # ONE reduction launch for all of them; returns nch so the caller can check that the chunking agrees
+            slab_t, col0, cstride = shared_slab
+            assert not extras and fused_out is None and col0 + stride <= cstride and nch * cstride <= slab_t.numel()
+            a.slab = slab_t.data_ptr() + 4 * col0
+            a.slab_stride = cstride
+            self._hold(slab_t)
+        elif own_slab:     # private partial-slab buffer: the launch may run on a lane that shares its scratch with another
             slab_t = self.alloc(nch * stride)
             a.slab = _ptr(slab_t)
         else:
@@ -530,6 +538,8 @@ class Recorder:
         rows = M * batches
         self._op(name, lib.uir_gram, C.byref(a), nbytes=4 * rows * (N + K * (2 if pro_b == L.PRO_GATE else 1)),
                  flops=2 * rows * N * K * taps)
+        if shared_slab is not None:
+            return nch
         sp = slab_t.data_ptr()
         if fused_out is not None:
             # `fused_out` = [out | sq_a | sq_b | cs_a] contiguous, i.e. exactly one slab row: one reduction launch
@@ -848,7 +858,8 @@ class Plan(Recorder):
             dg, dgpre = self.alloc(M, ldg)[:, :2 * hp], self.alloc(M, ldg)[:, :2 * hp]
             dt = self.alloc(M, C_)
             dx1 = self.alloc(M, C_)
-            dWB, dWA = self.alloc(B, C_ * C_), self.alloc(B, C_ * C_)
+            dWBA = self.alloc(2 * B * C_ * C_)                      # dWB | dWA adjacent: one reduction writes both
+            dWB, dWA = dWBA[:B * C_ * C_].view(B, C_ * C_), dWBA[B * C_ * C_:].view(B, C_ * C_)
             dvf, du = self.alloc(M, C_), self.alloc(M, C_)
             dqkv, dqkv_pre = self.alloc(M, 3 * C_), self.alloc(M, 3 * C_)
             Mqk = self.alloc(B, 4 * C_ * C_)
@@ -911,7 +922,15 @@ class Plan(Recorder):
                     self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
                               out_elems=B * C_ * C_, own_slab=True)
             else:
-                self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
+                # dWB | dWA partials side by side in one slab: a single reduction launch (before uir_attn_bwd) instead of two
+                nab = B * C_ * C_
+                tn_ = (C_ + 31) // 32
+                nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B)
+                slab_ab = self.alloc(nch_ab * 2 * nab)
+                assert dWA.data_ptr() == dWB.data_ptr() + 4 * nab
+                got = self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
+                                shared_slab=(slab_ab, 0, 2 * nab))
+                assert got == nch_ab
             self.gemm(n + ".dvf", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
             self.dwconv_bwd(n + ".du+dWkvdw", dvf, u, Wkvdw_f, du, Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, creal=C_,
                             dims=dims)
@@ -920,7 +939,10 @@ class Plan(Recorder):
                     self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
                               out_elems=B * C_ * C_, own_slab=True)
             else:
-                self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=B * C_ * C_)
+                got = self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
+                                shared_slab=(slab_ab, nab, 2 * nab))
+                assert got == nch_ab
+                self._op(n + ".dWAB.red", lib.uir_reduce_slab, _ptr(slab_ab), nch_ab, 2 * nab, _ptr(dWB), 2 * nab, 0, 1.0)
             self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
             if side_grams:
                 self.join(n + ".dWAB.join")
