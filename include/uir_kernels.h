@@ -367,6 +367,43 @@ typedef struct UirAdamArgs {
 } UirAdamArgs;
 int uir_clip_adam_step(const UirAdamArgs* args, void* stream);
 
+/* -------------------------------------------------------------- uir_resize */
+/* Input stage.  Replaces transforms.Resize((1024,1024), BILINEAR) -> ToTensor ->
+ * Normalize(0.5, 0.5) of src/DataManipulation/DataLoader.py:13-20 (applied per item, UIEBDataset.py:30-32):
+ * Pillow's 8-bit two-pass fixed-point resampler (horizontal, then vertical, 22-bit weights, uint8 intermediate)
+ * followed by a 256-entry byte -> fp32 table.  Integer work: results are bit-identical to PIL.Image.resize.
+ *
+ * uir_resize_ksize / uir_resize_coeffs are HOST functions (no GPU): the window table bounds[out][2] = (first
+ * source index, tap count) and the weights kk[out][ksize] of one axis, computed in double precision in the order
+ * of Pillow's precompute_coeffs + normalize_coeffs_8bpc.  coeffs returns ksize, or -1 on a bad argument or when
+ * out_size*ksize > kk_cap. */
+int uir_resize_ksize(int in_size, int out_size);
+int uir_resize_coeffs(int in_size, int out_size, int* bounds, int* kk, long kk_cap);
+#define UIR_RESIZE_SRC_SLACK 16
+typedef struct UirResizeImage {
+  long src_off;        /* byte offset of the image in `src`: packed RGB, 3 bytes per pixel, rows of in_w pixels  */
+  int in_h, in_w;
+  int kh, kv;          /* taps per output column / row (the ksize of each axis table)                            */
+  int hb, hk;          /* offsets (ints) into `tab`: horizontal bounds [out_w][2], weights [out_w][kh]           */
+  int vb, vk;          /* vertical bounds [out_h][2], weights [out_h][kv]                                        */
+} UirResizeImage;
+typedef struct UirResizeArgs {
+  const unsigned char* src;        /* DEVICE: all source images of the batch, back to back                        */
+  long src_bytes;                  /* bytes the images occupy                                                     */
+  long src_capacity;               /* readable bytes at src: >= src_bytes + UIR_RESIZE_SRC_SLACK (windows are     */
+                                   /* fetched as 12-byte runs; the bytes past a window never reach the result)    */
+  const UirResizeImage* img;       /* DEVICE [n_img]                                                              */
+  const UirResizeImage* img_host;  /* HOST copy of img: argument checks (every window inside its image)            */
+  const int* tab;                  /* DEVICE: the axis tables the descriptors point into                          */
+  const int* tab_host;             /* HOST copy of tab                                                            */
+  long tab_ints;
+  const float* lut;                /* DEVICE [256]: fp32 value of each byte after ToTensor + Normalize             */
+  float* out_f32;                  /* DEVICE [n_img][3][out_h][out_w] (the loader's item layout) or NULL          */
+  unsigned char* out_u8;           /* DEVICE [n_img][out_h][out_w][3]: the resampled bytes, or NULL               */
+  int n_img, out_h, out_w;
+} UirResizeArgs;
+int uir_resize_norm_u8(const UirResizeArgs* args, void* stream);
+
 /* library self-description (used by the loader test) */
 const char* uir_version(void);
 

@@ -2,7 +2,11 @@
 train loader shuffled, test loader not, items (raw, ref) float32 [3,S,S] in [-1,1].  The reference
 hard-codes S = 1024 (:14); ``image_size`` makes that explicit (default 1024 = reference) so the
 256x256 benchmark configuration can be fed from files too.  Under torch.distributed each rank
-reads a disjoint shard (DistributedSampler)."""
+reads a disjoint shard (DistributedSampler).
+
+``device_resize=True`` keeps only the decode in the worker processes and runs the reference's
+Resize -> ToTensor -> Normalize (:13-20) as one HIP launch per batch on ``device`` (device_resize.py): the loaders
+then yield device tensors, bit-identical to the CPU items."""
 from __future__ import annotations
 
 import torch
@@ -13,13 +17,22 @@ from .UIEBDataset import UIEBDataset
 
 
 def get_dataloaders(raw_dir, ref_dir, test_raw_dir, test_ref_dir, batch_size=16, num_workers=4, image_size=1024,
-                    shuffle=True, pin_memory=True):
-    train_ds = UIEBDataset(raw_dir, ref_dir, image_size)
-    test_ds = UIEBDataset(test_raw_dir, test_ref_dir, image_size)
+                    shuffle=True, pin_memory=True, device_resize=False, device="cuda"):
+    train_ds = UIEBDataset(raw_dir, ref_dir, image_size, decode_only=device_resize)
+    test_ds = UIEBDataset(test_raw_dir, test_ref_dir, image_size, decode_only=device_resize)
     sampler = None
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
         sampler = DistributedSampler(train_ds, shuffle=shuffle, drop_last=True)
+    extra = {}
+    if device_resize:
+        from .device_resize import DevicePrefetchLoader, collate_decoded
+        extra = {"collate_fn": collate_decoded}
+        pin_memory = False                 # items are variable-size byte arrays; the resizer owns the pinned staging
     train_loader = DataLoader(train_ds, batch_size=batch_size, shuffle=(shuffle and sampler is None), sampler=sampler,
-                              num_workers=num_workers, pin_memory=pin_memory, drop_last=sampler is not None)
-    test_loader = DataLoader(test_ds, batch_size=batch_size, shuffle=False, num_workers=num_workers, pin_memory=pin_memory)
+                              num_workers=num_workers, pin_memory=pin_memory, drop_last=sampler is not None, **extra)
+    test_loader = DataLoader(test_ds, batch_size=batch_size, shuffle=False, num_workers=num_workers, pin_memory=pin_memory,
+                             **extra)
+    if device_resize:
+        train_loader = DevicePrefetchLoader(train_loader, image_size, device)
+        test_loader = DevicePrefetchLoader(test_loader, image_size, device)
     return train_loader, test_loader

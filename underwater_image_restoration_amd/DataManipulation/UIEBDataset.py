@@ -25,17 +25,28 @@ def load_image(path: str, image_size) -> torch.Tensor:
     return (t - 0.5) / 0.5
 
 
+def decode_image(path: str) -> np.ndarray:
+    """Decode only: packed RGB bytes [h][w][3] of the file's own size (the resize runs on the GPU, device_resize.py)."""
+    from PIL import Image
+    with Image.open(path) as im:
+        return np.asarray(im.convert("RGB"), dtype=np.uint8).copy()
+
+
 class UIEBDataset(Dataset):
-    def __init__(self, raw_dir, ref_dir, image_size=1024):
+    def __init__(self, raw_dir, ref_dir, image_size=1024, decode_only=False):
         self.raw_dir, self.ref_dir = raw_dir, ref_dir
         self.raw_images = sorted(os.listdir(raw_dir))
         self.ref_images = sorted(os.listdir(ref_dir))
         self.image_size = image_size
+        self.decode_only = decode_only
 
     def __len__(self):
         return len(self.raw_images)
 
     def __getitem__(self, idx):
+        if self.decode_only:
+            return (decode_image(os.path.join(self.raw_dir, self.raw_images[idx])),
+                    decode_image(os.path.join(self.ref_dir, self.ref_images[idx])))
         raw = load_image(os.path.join(self.raw_dir, self.raw_images[idx]), self.image_size)
         ref = load_image(os.path.join(self.ref_dir, self.ref_images[idx]), self.image_size)
         return raw, ref

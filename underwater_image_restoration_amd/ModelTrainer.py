@@ -47,7 +47,8 @@ class ModelTrainer:
         print("Preparing data loaders...batch size" + str(args.train_batch_size))
         train_loader, test_loader = get_dataloaders(self.inputDir, self.referenceDir, self.testInputDir, self.testReferenceDir,
                                                     args.train_batch_size, num_workers=getattr(args, "workers", 4),
-                                                    image_size=image_size)
+                                                    image_size=image_size,
+                                                    device_resize=bool(getattr(args, "device_resize", True)), device=dev)
         print("Initializing model...")
         model = Models.init_model(name=arch, use_dwt=getattr(args, "use_dwt", "Fourier")).to(dev)
         if getattr(args, "optim", "adam") != "adam":

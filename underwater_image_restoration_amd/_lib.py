@@ -119,6 +119,20 @@ class Dft2Args(C.Structure):
                 ("O", C.c_int), ("N", C.c_int), ("I", C.c_int), ("C", C.c_int), ("scale", C.c_float)]
 
 
+RESIZE_SRC_SLACK = 16
+
+
+class ResizeImage(C.Structure):
+    _fields_ = [("src_off", C.c_long), ("in_h", C.c_int), ("in_w", C.c_int), ("kh", C.c_int), ("kv", C.c_int),
+                ("hb", C.c_int), ("hk", C.c_int), ("vb", C.c_int), ("vk", C.c_int)]
+
+
+class ResizeArgs(C.Structure):
+    _fields_ = [("src", fp), ("src_bytes", C.c_long), ("src_capacity", C.c_long), ("img", fp), ("img_host", fp), ("tab", fp), ("tab_host", fp),
+                ("tab_ints", C.c_long), ("lut", fp), ("out_f32", fp), ("out_u8", fp),
+                ("n_img", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int)]
+
+
 class AdamArgs(C.Structure):
     _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("sumsq", fp), ("norm_out", fp), ("hyper", fp), ("n", C.c_long),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -164,6 +178,9 @@ SIGNATURES = {
     "uir_loss_bwd": [fp, fp, fp, fp, i32, i32, i32, fp],
     "uir_sumsq_partials": [fp, i64, fp, i32, fp],
     "uir_clip_adam_step": [C.POINTER(AdamArgs), fp],
+    "uir_resize_ksize": [i32, i32],                      # host-only helpers: return ksize (or -1), not a status
+    "uir_resize_coeffs": [i32, i32, fp, fp, i64],
+    "uir_resize_norm_u8": [C.POINTER(ResizeArgs), fp],
 }
 
 
