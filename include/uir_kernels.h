@@ -63,6 +63,9 @@ typedef struct UirGemmArgs {
                        /* the LayerNorm backward (G = LN input [M][ldg], stats, ln_g = gamma, R = residual-   */
                        /* path gradient or NULL), writes dX to Y and per-workgroup rows [dgamma(N) | dbeta(N)] */
                        /* to dw_slab.  Requires N <= 96 in one column group, M % 128 == 0                    */
+  int tap0, ntap;      /* taps == 9 only: contract taps [tap0, tap0 + ntap) (ntap <= 0: all nine).  uir_gemm  */
+                       /* itself uses this to run a 3x3 convolution whose weight panel exceeds LDS as a few   */
+                       /* launches over tap groups that accumulate into Y (R = Y)                             */
 } UirGemmArgs;
 int uir_gemm(const UirGemmArgs* args, void* stream);
 

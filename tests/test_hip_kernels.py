@@ -163,7 +163,8 @@ def test_gemm_per_batch_weights():
     assert rel(Yt, torch.einsum("bpk,bkn->bpn", q, w).reshape(B * HW, C)) < TOL
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 5, 7, 8, 12), (1, 8, 8, 16, 8), (2, 6, 4, 32, 64), (1, 9, 5, 128, 40)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 5, 7, 8, 12), (1, 8, 8, 16, 8), (2, 6, 4, 32, 64), (1, 9, 5, 128, 40),
+                                            (2, 6, 4, 64, 128), (2, 8, 8, 128, 256)])   # the last two: tap-group launches
 def test_gemm_conv3x3_fwd_and_input_grad(B, H, W, Cin, Cout):
     x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
     w = rnd(Cout, Cin, 3, 3, seed=2)
@@ -175,9 +176,15 @@ def test_gemm_conv3x3_fwd_and_input_grad(B, H, W, Cin, Cout):
     Y, dX = r.alloc(B * H * W, Cout), r.alloc(B * H * W, Cin)
     r.gemm("c", dev(hwc(x.detach())), Wd, Y, N=Cout, K=Cin, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=(H, W))
     r.gemm("c.dx", dev(hwc(dy)), Wd, dX, N=Cin, K=Cout, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=(H, W))
+    # bias + residual through the same path (the tap-group launches add bias once and accumulate into Y)
+    bias, res = rnd(Cout, seed=4), rnd(B * H * W, Cout, seed=5)
+    Yb = r.alloc(B * H * W, Cout)
+    r.gemm("c.b", dev(hwc(x.detach())), Wd, Yb, N=Cout, K=Cin, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=(H, W), bias=dev(bias),
+           R=dev(res))
     r.run(r.fwd)
     assert rel(chw(Y, B, H, W), y) < TOL
     assert rel(chw(dX, B, H, W), dx) < TOL
+    assert rel(chw(Yb, B, H, W), y + bias.view(1, -1, 1, 1) + chw(res, B, H, W)) < TOL
 
 
 def test_gemm_embed_and_output_padding():

@@ -437,7 +437,8 @@ __global__ __launch_bounds__(256, (EPI == UIR_EPI_GATE_BWD_DW || EPI == UIR_EPI_
   const int K8 = (a.K + 7) & ~7;
   constexpr int NC = 32 * NT;
   const int cpt = (K8 + 31) >> 5;          // 32-wide chunks per tap
-  const int nchunks = cpt * a.taps;        // units per row tile
+  const int ntap = a.ntap > 0 ? a.ntap : a.taps;   // taps [tap0, tap0 + ntap) are contracted (panel slots 0..ntap-1)
+  const int nchunks = cpt * ntap;          // units per row tile
   const int HW = a.H * a.Wd;
   // Branch-free loads (a predicated load costs a branch + a full vmcnt(0) drain in hipcc's
   // codegen): rows past M are clamped to the last row (their results are never stored) and k
@@ -455,8 +456,9 @@ __global__ __launch_bounds__(256, (EPI == UIR_EPI_GATE_BWD_DW || EPI == UIR_EPI_
     bool ok = true;
     int cc = c_;
     if (a.taps > 1) {
-      const int tap = c_ / cpt;
-      cc = c_ - tap * cpt;
+      const int slot = c_ / cpt;
+      cc = c_ - slot * cpt;
+      const int tap = a.tap0 + slot;
       const int hw = mm % HW;
       const int ph = hw / a.Wd, pw = hw - ph * a.Wd;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
@@ -507,8 +509,8 @@ __global__ __launch_bounds__(256, (EPI == UIR_EPI_GATE_BWD_DW || EPI == UIR_EPI_
   __syncthreads();
   {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
-    for (int tap = 0; tap < a.taps; ++tap) {
-      const int wt = (a.flip ? (a.taps - 1 - tap) : tap) * (int)a.w_st;
+    for (int tap = 0; tap < ntap; ++tap) {
+      const int wt = (a.flip ? (a.taps - 1 - (a.tap0 + tap)) : (a.tap0 + tap)) * (int)a.w_st;
       float* wp = wl + tap * K8;
       if (a.w_sk == 1) {          // k contiguous in memory: lanes along k
         for (int nl = ty; nl < NC; nl += 8) {
@@ -752,12 +754,34 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     UIR_REQUIRE((a.M & 127) == 0 && a.pro == UIR_PRO_NONE && (a.n_grp_pad <= 0 || a.n_grp_pad == a.N));
   }
   if (a.R) UIR_REQUIRE(a.ldr >= a.N);
+  UIR_REQUIRE(a.ntap <= 0 || (a.taps == 9 && a.tap0 >= 0 && a.tap0 + a.ntap <= 9));
+  UIR_REQUIRE(a.ntap > 0 || a.tap0 == 0);
   const int tiles = (a.N + 31) / 32;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const int ntap = a.ntap > 0 ? a.ntap : a.taps;
   {
-    // LDS-resident weight panel (all taps): pick the widest column group (<= 3 tiles) that fits 64 KB
     const int K8 = (a.K + 7) & ~7;
-    const int Kt = K8 * a.taps;
+    // A 3x3 convolution whose nine-tap panel of even ONE 32-column tile is too large to share the CU's LDS with a second
+    // workgroup (K >= 64: ups_*.Sups and their input gradients, 9.7 GFLOP each) runs as launches over tap groups of <= 48
+    // KB that accumulate into Y; the un-staged fallback below reads weights per MFMA step and reaches 22-29 TFLOP/s there.
+    static const bool split_ok = !(getenv("UIR_TAP_SPLIT") && atoi(getenv("UIR_TAP_SPLIT")) == 0);
+    if (split_ok && a.taps == 9 && a.ntap <= 0 && (size_t)32 * (K8 * 9 + 4) * 4 > 60 * 1024 && (size_t)32 * (K8 + 4) * 4 <= 48 * 1024 &&
+        a.pro == UIR_PRO_NONE && a.epi == UIR_EPI_PLAIN && a.act == UIR_ACT_NONE) {
+      int g = 1;
+      while (g < 3 && (size_t)32 * (K8 * (g + 1) + 4) * 4 <= 50 * 1024) ++g;
+      if (g == 2) g = 1;                                        // groups of whole kernel rows (3 taps) or single taps
+      for (int t0 = 0; t0 < 9; t0 += g) {
+        UirGemmArgs b = a;
+        b.tap0 = t0;
+        b.ntap = g;
+        if (t0 > 0) { b.R = a.Y; b.ldr = a.ldy; b.r_bs = a.y_bs; b.bias = nullptr; }
+        const int rc = uir_gemm(&b, stream);
+        if (rc != UIR_OK) return rc;
+      }
+      return UIR_OK;
+    }
+    // LDS-resident weight panel (all contracted taps): pick the widest column group (<= 3 tiles) that fits 64 KB
+    const int Kt = K8 * ntap;
     const int Kp = ((Kt >> 2) & 1) ? Kt : Kt + 4;
     int groups1 = (tiles + 2) / 3;
     int nt1 = (tiles + groups1 - 1) / groups1;
@@ -812,6 +836,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
       return uir_launch_status();
     }
   }
+  UIR_REQUIRE(a.ntap <= 0);          // tap ranges exist only on the LDS-panel path above
   const int groups = (tiles + 3) / 4;
   const int nt = (tiles + groups - 1) / groups;
   dim3 grid((a.M + 127) / 128, groups, a.batches), block(256);
