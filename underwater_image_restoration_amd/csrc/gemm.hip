@@ -450,6 +450,7 @@ __global__ __launch_bounds__(256, (EPI == UIR_EPI_GATE_BWD_DW || EPI == UIR_EPI_
   float4 P0[4], P1[4], U0[NU], U1[NU];
   const int kmax = (a.K + 3) & ~3;
   // returns whether this lane's (row, tap) neighbour exists (else the loaded values must be zeroed)
+  int ct_tile = -1, ct_ph = 0, ct_pw = 0;   // 3x3: this lane's pixel coordinates, divided out once per row tile (not per unit)
   auto load_unit = [&](float4 (&an)[4], float4 (&un)[NU], int tile_, int c_) -> bool {
     const int mm = min(tile_ * 128 + wave * 32 + r, a.M - 1);
     long row = mm;
@@ -459,8 +460,13 @@ __global__ __launch_bounds__(256, (EPI == UIR_EPI_GATE_BWD_DW || EPI == UIR_EPI_
       const int slot = c_ / cpt;
       cc = c_ - slot * cpt;
       const int tap = a.tap0 + slot;
-      const int hw = mm % HW;
-      const int ph = hw / a.Wd, pw = hw - ph * a.Wd;
+      if (tile_ != ct_tile) {
+        const int hw = mm % HW;
+        ct_ph = hw / a.Wd;
+        ct_pw = hw - ct_ph * a.Wd;
+        ct_tile = tile_;
+      }
+      const int ph = ct_ph, pw = ct_pw;
       const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
       const int hh = ph + dy, ww = pw + dx;
       ok = hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;

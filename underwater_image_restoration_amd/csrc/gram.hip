@@ -78,6 +78,12 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
   // the newest loads; with static panels the wait before compute(P) only covers P's own, older loads).
   // (plain arrays passed by reference: a struct of arrays is not scalarised by hipcc and lands in scratch)
   constexpr int TG = (PRO == UIR_GRAM_PRO_GATE) ? TK : 1, US = (PRO == UIR_GRAM_PRO_LN) ? U : 1;
+  int tph = 0, tpw = 0;      // 3x3 taps: image coordinates of the next row this lane loads (one division here, none per row)
+  if (a.taps > 1) {
+    const int hw = min(row_begin + 2 * wave + h2, last_row) % (a.H * a.Wd);
+    tph = hw / a.Wd;
+    tpw = hw - tph * a.Wd;
+  }
   auto load = [&](float (&Pav)[U][TN], float (&Pbv)[U][TK], float (&Pbg)[U][TG], float2 (&Pst)[US], float (&Pak)[U],
                   float (&Pbk)[U], int base) {
 #pragma unroll
@@ -93,12 +99,16 @@ __global__ __launch_bounds__(256) void uir_gram_kernel(const UirGramArgs a, int 
       for (int t = 0; t < TN; ++t) Pav[u][t] = A[oa + (unsigned)acol[t]];
       int mb = mc;
       if (a.taps > 1) {
-        const int hw = mc % (a.H * a.Wd);
-        const int ph = hw / a.Wd, pw = hw - ph * a.Wd;
-        const int hh = ph + dy, ww = pw + dx;
-        const bool in = hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
-        bok = bok && in;
+        // (tph, tpw) = coordinates of row m, advanced by carry: load() is called with bases 8*U apart, in order
+        const int hh = tph + dy, ww = tpw + dx;
+        const bool in = aok && hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
+        bok = in;
         mb = in ? mc + dy * a.Wd + dx : mc;
+        tpw += 8;
+        while (tpw >= a.Wd) {
+          tpw -= a.Wd;
+          if (++tph == a.H) tph = 0;
+        }
       }
       Pak[u] = aok ? 1.f : 0.f;
       Pbk[u] = bok ? 1.f : 0.f;
@@ -244,6 +254,15 @@ __global__ __launch_bounds__(256) void uir_gram_taps9_kernel(const UirGramArgs a
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
   constexpr int U = 4;
+  // (ph, pw) of this lane's first pixel by one division; every later pixel is 8 rows further: the coordinates advance by
+  // carry (integer divisions per pixel pair were ~2/3 of this kernel's issue slots: 1 M pixels x 3 kernel rows)
+  int pw, ph;
+  {
+    const int m0 = min(row_begin + 2 * wave + h2, last_row);
+    const int hw = m0 % (a.H * a.Wd);
+    ph = hw / a.Wd;
+    pw = hw - ph * a.Wd;
+  }
   for (int base = row_begin + 2 * wave; base < row_end; base += 8 * U) {
     float av[U], bv[U][3];
     bool ok[U][3], aok[U];
@@ -253,17 +272,20 @@ __global__ __launch_bounds__(256) void uir_gram_taps9_kernel(const UirGramArgs a
       aok[u] = m < row_end;
       const int mc = min(m, last_row);
       av[u] = A[(long)mc * a.lda + acol];
-      const int hw = mc % (a.H * a.Wd);
-      const int ph = hw / a.Wd, pw = hw - ph * a.Wd;
       const int hh = ph + dy;
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int dx = t - 1;
         const int ww = pw + dx;
-        const bool in = hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
-        ok[u][t] = in && aok[u] && bok_c;
+        const bool in = aok[u] && hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
+        ok[u][t] = in && bok_c;
         const long mb = in ? (long)mc + dy * a.Wd + dx : (long)mc;
         bv[u][t] = B[mb * a.ldb + bcol];
+      }
+      pw += 8;
+      while (pw >= a.Wd) {
+        pw -= a.Wd;
+        if (++ph == a.H) ph = 0;
       }
     }
 #pragma unroll
