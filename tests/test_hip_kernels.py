@@ -254,7 +254,10 @@ def test_gram_ln_and_gate_prologues_and_groups():
     assert rel(dWo, dy.T @ gate) < TOL
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 5, 7, 8, 12), (2, 6, 4, 32, 64), (1, 8, 8, 64, 32)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 5, 7, 8, 12), (2, 6, 4, 32, 64), (1, 8, 8, 64, 32),
+                                            # few output channels: the column-formulated kernel (2, 3 and 5 column tiles)
+                                            (2, 9, 7, 8, 4), (3, 16, 12, 32, 8), (2, 11, 13, 16, 8), (2, 8, 8, 32, 16),
+                                            (1, 5, 3, 20, 17), (2, 6, 10, 32, 18)])
 def test_gram_conv3x3_weight_grad(B, H, W, Cin, Cout):
     x = rnd(B, Cin, H, W, seed=1)
     w = rnd(Cout, Cin, 3, 3, seed=2).requires_grad_(True)

@@ -767,11 +767,12 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   const int ntap = a.ntap > 0 ? a.ntap : a.taps;
   {
     const int K8 = (a.K + 7) & ~7;
-    // A 3x3 convolution whose nine-tap panel of even ONE 32-column tile is too large to share the CU's LDS with a second
-    // workgroup (K >= 64: ups_*.Sups and their input gradients, 9.7 GFLOP each) runs as launches over tap groups of <= 48
-    // KB that accumulate into Y; the un-staged fallback below reads weights per MFMA step and reaches 22-29 TFLOP/s there.
+    // A 3x3 convolution whose nine-tap panel of even ONE 32-column tile does not fit the LDS path (K > 80: ups_1.Sups,
+    // ups_{1,2}.Sups input gradients, 9.7 GFLOP each) runs as launches over tap groups of <= 50 KB that accumulate into Y;
+    // the un-staged fallback below reads weights per MFMA step and reaches 22-29 TFLOP/s there.  (K = 64 keeps its single
+    // 74 KB launch: 178 us against 219 us split.)
     static const bool split_ok = !(getenv("UIR_TAP_SPLIT") && atoi(getenv("UIR_TAP_SPLIT")) == 0);
-    if (split_ok && a.taps == 9 && a.ntap <= 0 && (size_t)32 * (K8 * 9 + 4) * 4 > 60 * 1024 && (size_t)32 * (K8 + 4) * 4 <= 48 * 1024 &&
+    if (split_ok && a.taps == 9 && a.ntap <= 0 && (size_t)32 * (K8 * 9 + 4) * 4 > 96 * 1024 && (size_t)32 * (K8 + 4) * 4 <= 48 * 1024 &&
         a.pro == UIR_PRO_NONE && a.epi == UIR_EPI_PLAIN && a.act == UIR_ACT_NONE) {
       int g = 1;
       while (g < 3 && (size_t)32 * (K8 * (g + 1) + 4) * 4 <= 50 * 1024) ++g;

@@ -319,6 +319,105 @@ __global__ __launch_bounds__(256) void uir_gram_taps9_kernel(const UirGramArgs a
   }
 }
 
+// 3x3 weight-gradient with few output channels (9*N <= 160, K <= 32: output, outputl, down1, down2 at full / half resolution).
+// The kernel above pads N to a 32-row MFMA tile and spends one MFMA per tap; here the roles are swapped so that nothing but the
+// last column tile is padding:  dW[n][k][tap] = sum_q X[q][k] * dY[q - off(tap)][n]  (q = px + off), i.e. ONE row operand X^T
+// (row = k, exactly the <= 32 input channels) against a column operand whose 9*N columns are the nine shifted copies of dY:
+// NT = ceil(9N/32) MFMAs per pixel pair instead of 9 (N = 8: 3), X is read once instead of three times, no kernel-row split.
+template <int NT>
+__global__ __launch_bounds__(256) void uir_gram_taps9_cols_kernel(const UirGramArgs a) {
+  __shared__ float red[NT * 16 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, h2 = lane >> 5;
+  const int z = blockIdx.z;
+  const int chunk = blockIdx.x;
+  const float* __restrict__ A = a.A + (long)z * a.a_bs;     // dY [M][lda], N columns
+  const float* __restrict__ B = a.B + (long)z * a.b_bs;     // X  [M][ldb], K columns
+  const int row_begin = chunk * a.rows_per_chunk;
+  const int row_end = min(a.M, row_begin + a.rows_per_chunk);
+  const int last_row = row_end - 1;
+  const bool kok = r < a.K;
+  const int kcol = min(r, a.K - 1);
+  // this lane's column of tile t: (tap, n) = divmod(32 t + r, N); the row it reads is q - (dy*Wd + dx)
+  int ncol[NT], sdy[NT], sdx[NT], delta[NT];
+  bool cok[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int c = 32 * t + r;
+    const int tap = min(c / a.N, 8);
+    cok[t] = c < 9 * a.N;
+    ncol[t] = c - (c / a.N) * a.N;
+    sdy[t] = tap / 3 - 1;
+    sdx[t] = tap - (tap / 3) * 3 - 1;
+    delta[t] = sdy[t] * a.Wd + sdx[t];
+  }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+  int pw, ph;                    // coordinates of this lane's next row, advanced by carry (one division here)
+  {
+    const int m0 = min(row_begin + 2 * wave + h2, last_row);
+    const int hw = m0 % (a.H * a.Wd);
+    ph = hw / a.Wd;
+    pw = hw - ph * a.Wd;
+  }
+  constexpr int U = 4;
+  for (int base = row_begin + 2 * wave; base < row_end; base += 8 * U) {
+    float xv[U], yv[U][NT];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int m = base + 8 * u + h2;
+      const bool rok = m < row_end;
+      const int mc = min(m, last_row);
+      const float x = B[(unsigned)mc * (unsigned)a.ldb + (unsigned)kcol];
+      xv[u] = (rok && kok) ? x : 0.f;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int hh = ph - sdy[t], ww = pw - sdx[t];
+        const bool in = rok && cok[t] && hh >= 0 && hh < a.H && ww >= 0 && ww < a.Wd;
+        const int ma = in ? mc - delta[t] : mc;
+        const float y = A[(unsigned)ma * (unsigned)a.lda + (unsigned)ncol[t]];
+        yv[u][t] = in ? y : 0.f;
+      }
+      pw += 8;
+      while (pw >= a.Wd) {
+        pw -= a.Wd;
+        if (++ph == a.H) ph = 0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) acc[t] = uir_mfma(xv[u], yv[u][t], acc[t]);
+  }
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float* p = &red[(t * 16 + q) * 64 + lane];
+          *p = (w == 0) ? acc[t][q] : (*p + acc[t][q]);
+        }
+    }
+    __syncthreads();
+  }
+  float* slab = a.slab + (long)chunk * a.slab_stride;
+  for (int idx = threadIdx.x; idx < NT * 16 * 64; idx += 256) {
+    const int ln = idx & 63, q = (idx >> 6) & 15, t = idx >> 10;
+    const int k = uir_mfma_row(q, ln >> 5);          // accumulator row = X channel
+    const int c = 32 * t + (ln & 31);                // accumulator column = (tap, n)
+    if (k < a.K && c < 9 * a.N) {
+      const int tap = c / a.N, n = c - tap * a.N;
+      const int nr = uir_colmap(n, a.n_grp_real, a.n_grp_pad);
+      const int kr = uir_colmap(k, a.k_grp_real, a.k_grp_pad);
+      if (nr >= 0 && kr >= 0) slab[(long)z * a.o_bs + (long)nr * a.o_sn + (long)kr * a.o_sk + (long)tap * a.o_st] = red[idx];
+    }
+  }
+}
+
 // out[i] = sum_c slab[c][i]: 64 outputs per workgroup, the chunks split over 4 waves with 8 independent
 // accumulators each (memory-level parallelism), combined in a fixed order.  256 threads: a 1024-thread block needs 16
 // free wave slots on ONE CU at once (A/B against the 1024-thread version in the full step: no difference).
@@ -373,7 +472,14 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
   const bool extras = a.sq_a_off >= 0 || a.sq_b_off >= 0 || a.cs_a_off >= 0;
   UIR_REQUIRE(!extras || a.pro_b == UIR_GRAM_PRO_NONE);
   const int tn_tiles = (a.N + 31) / 32, tk_tiles = (a.K + 31) / 32;
-  if (a.taps == 9 && tn_tiles == 1 && tk_tiles == 1 && a.sq_a_off < 0 && a.sq_b_off < 0 && a.cs_a_off < 0 &&
+  static const bool cols9 = !(getenv("UIR_GRAM_COLS9") && atoi(getenv("UIR_GRAM_COLS9")) == 0);   // A/B aid
+  if (cols9 && a.taps == 9 && 9 * a.N <= 160 && tk_tiles == 1 && !extras && a.pro_b == UIR_GRAM_PRO_NONE) {
+    dim3 grid(a.nchunks, 1, a.batches);
+    const int nt = (9 * a.N + 31) / 32;
+    if (nt <= 2) hipLaunchKernelGGL(uir_gram_taps9_cols_kernel<2>, grid, block, 0, st, a);
+    else if (nt == 3) hipLaunchKernelGGL(uir_gram_taps9_cols_kernel<3>, grid, block, 0, st, a);
+    else hipLaunchKernelGGL(uir_gram_taps9_cols_kernel<5>, grid, block, 0, st, a);
+  } else if (a.taps == 9 && tn_tiles == 1 && tk_tiles == 1 && a.sq_a_off < 0 && a.sq_b_off < 0 && a.cs_a_off < 0 &&
       a.pro_b == UIR_GRAM_PRO_NONE) {
     dim3 grid(a.nchunks, 3, a.batches);
     hipLaunchKernelGGL(uir_gram_taps9_kernel, grid, block, 0, st, a);
