@@ -693,7 +693,7 @@ class Recorder:
             hs //= 2
         items = dims[0] * ((dims[1] + hs - 1) // hs) * ((dims[2] + 3) // 4)
         ny = 256 // (C_ // 4)
-        a.nblocks = max(1, min(2048, items // max(1, ny)))
+        a.nblocks = max(1, min(int(os.environ.get("UIR_DW_NBLOCKS", "512")), items // max(1, ny)))
         # private partial-slab buffer: the kernel runs on the chain, its (tiny) reduction on the bulk lane, so the
         # shared chain scratch may be overwritten in between
         slab = self.alloc(a.nblocks * creal * 9)
