@@ -487,7 +487,7 @@ def _attn_ref(q, k, T, P, Wof, heads):
     return attn, P @ A, Wof @ A
 
 
-@pytest.mark.parametrize("C,heads", [(16, 1), (32, 1), (32, 2), (128, 8)])
+@pytest.mark.parametrize("C,heads", [(16, 1), (32, 1), (32, 2), (128, 8), (64, 4), (128, 4), (24, 2), (40, 2)])
 def test_attn_fwd_bwd(C, heads):
     B, HW = 2, 200
     d = C // heads
