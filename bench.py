@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 ALG_BYTES_PER_IMAGE_256 = 10.0625e9     # SURVEY.md 8(d) / BASELINE.md section 3 (train step, 256x256)
 # HBM traffic per step from the committed PMC passes of THIS command (tools/pmc_traffic.py: separate
 # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH x2 on gfx950); a bench run cannot collect PMCs itself
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01", "j_pmc_traffic_365imgs.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r01", "k_pmc_traffic_374imgs.json")
 ALG_FLOPS_PER_IMAGE_256 = 90.14e9
 HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
