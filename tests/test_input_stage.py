@@ -159,7 +159,8 @@ def test_resize_kernel_argument_errors():
 
 
 @pytest.mark.gpu
-def test_device_resize_loader_equals_cpu_loader(tmp_path):
+@pytest.mark.parametrize("workers", [0, 2])
+def test_device_resize_loader_equals_cpu_loader(tmp_path, workers):
     """get_dataloaders(device_resize=True) yields the same items, bit for bit, as the CPU (PIL) loader -- across
     several batches, so the prefetch / double-buffer hand-over is exercised."""
     Image = pytest.importorskip("PIL.Image")
@@ -173,7 +174,7 @@ def test_device_resize_loader_equals_cpu_loader(tmp_path):
         dirs[d] = str(p)
         for i, (h, w) in enumerate(shapes):
             Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(p / f"{i}_img_.png")
-    kw = dict(batch_size=2, num_workers=0, image_size=64, shuffle=False)
+    kw = dict(batch_size=2, num_workers=workers, image_size=64, shuffle=False)   # workers only decode, never touch the GPU
     cpu_tr, cpu_te = get_dataloaders(dirs["a"], dirs["b"], dirs["ta"], dirs["tb"], **kw)
     gpu_tr, gpu_te = get_dataloaders(dirs["a"], dirs["b"], dirs["ta"], dirs["tb"], device_resize=True, **kw)
     assert len(gpu_tr) == len(cpu_tr) == 4
