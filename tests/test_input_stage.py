@@ -81,7 +81,7 @@ def test_decode_only_dataset_items(tmp_path):
             Image.fromarray(rng.randint(0, 255, (h, w, 3), dtype=np.uint8)).save(tmp_path / d / f"{i}_img_.png")
     ds = UIEBDataset(str(tmp_path / "a"), str(tmp_path / "b"), 32, decode_only=True)
     raw, ref = ds[1]
-    assert raw.dtype == np.uint8 and raw.shape == (33, 20, 3) and ref.shape == (33, 20, 3)
+    assert raw.dtype == torch.uint8 and tuple(raw.shape) == (33, 20, 3) and tuple(ref.shape) == (33, 20, 3)
 
 
 # ------------------------------------------------------------------ GPU: the HIP kernel through the C ABI

@@ -44,9 +44,9 @@ class UIEBDataset(Dataset):
         return len(self.raw_images)
 
     def __getitem__(self, idx):
-        if self.decode_only:
-            return (decode_image(os.path.join(self.raw_dir, self.raw_images[idx])),
-                    decode_image(os.path.join(self.ref_dir, self.ref_images[idx])))
+        if self.decode_only:     # uint8 tensors: DataLoader workers hand tensors over through shared memory, arrays through a pipe
+            return (torch.from_numpy(decode_image(os.path.join(self.raw_dir, self.raw_images[idx]))),
+                    torch.from_numpy(decode_image(os.path.join(self.ref_dir, self.ref_images[idx]))))
         raw = load_image(os.path.join(self.raw_dir, self.raw_images[idx]), self.image_size)
         ref = load_image(os.path.join(self.ref_dir, self.ref_images[idx]), self.image_size)
         return raw, ref

@@ -78,6 +78,7 @@ class DeviceResizer:
     def __call__(self, images: Sequence[np.ndarray], want_u8: bool = False, stream=None):
         """Enqueue copy + resize on ``stream`` (default: the resizer's side stream).  Returns (out, event) -- the
         consumer's stream must wait on ``event`` -- or (out, out_u8, event) with ``want_u8``."""
+        images = [a.numpy() if torch.is_tensor(a) else a for a in images]      # shared-memory tensors from the workers: views
         n = len(images)
         if n == 0:
             raise ValueError("empty batch")
@@ -141,10 +142,8 @@ class DeviceResizer:
 
 
 def collate_decoded(items):
-    """DataLoader collate for decode-only items: keeps the per-image arrays (sizes differ)."""
-    raws = [np.asarray(r) for r, _ in items]
-    refs = [np.asarray(f) for _, f in items]
-    return raws, refs
+    """DataLoader collate for decode-only items: keeps the per-image uint8 tensors (sizes differ)."""
+    return [r for r, _ in items], [f for _, f in items]
 
 
 class DevicePrefetchLoader:
