@@ -186,3 +186,8 @@ def test_device_resize_loader_equals_cpu_loader(tmp_path, workers):
             assert torch.equal(gr.cpu(), cr) and torch.equal(gf.cpu(), cf)
             n += 1
         assert n == 4
+    # leaving an epoch early must not hang (the prefetch thread is stopped and joined)
+    for i, _ in enumerate(gpu_tr):
+        if i == 1:
+            break
+    assert sum(1 for _ in gpu_tr) == 4

@@ -26,17 +26,35 @@ def make_files(root, n):
             Image.fromarray(img).save(os.path.join(root, d, f"{i}_img_.png"))
 
 
-def run(step, loader, epochs, dev):
-    n = 0
+HOST = {}
+
+
+def run(step, loader, epochs, dev, tag=None):
+    """images/s; with `tag`, also the host time per batch spent waiting for the loader and enqueuing the step."""
+    n = nb = 0
+    t_load = t_step = 0.0
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(epochs):
-        for raw, ref in loader:
+        it = iter(loader)
+        while True:
+            ta = time.perf_counter()
+            try:
+                raw, ref = next(it)
+            except StopIteration:
+                break
             raw = raw.to(dev, non_blocking=True)
             ref = ref.to(dev, non_blocking=True)
+            tb = time.perf_counter()
             step(raw, ref, lr=3e-4)
+            tc = time.perf_counter()
+            t_load += tb - ta
+            t_step += tc - tb
             n += raw.shape[0]
+            nb += 1
     torch.cuda.synchronize()
+    if tag:
+        HOST[tag] = {"host_ms_per_batch_in_loader": 1e3 * t_load / nb, "host_ms_per_batch_enqueuing_step": 1e3 * t_step / nb}
     return n / (time.perf_counter() - t0)
 
 
@@ -63,7 +81,7 @@ def main():
         for name, kw in (("cpu_loader_images_per_s", {}), ("device_resize_loader_images_per_s", {"device_resize": True, "device": dev})):
             tr, _ = get_dataloaders(a, b, a, b, batch_size=16, num_workers=args.workers, image_size=256, **kw)
             run(step, tr, 1, dev)                       # warm-up epoch (worker start-up, staging buffers)
-            out[name] = run(step, tr, args.epochs, dev)
+            out[name] = run(step, tr, args.epochs, dev, tag=name)
         # what the loaders alone deliver (no train step): the host-side ceiling of each
         for name, kw in (("cpu_loader_alone_images_per_s", {}), ("device_resize_loader_alone_images_per_s", {"device_resize": True, "device": dev})):
             tr, _ = get_dataloaders(a, b, a, b, batch_size=16, num_workers=args.workers, image_size=256, **kw)
@@ -77,6 +95,7 @@ def main():
                     last = r_.to(dev, non_blocking=True)
             torch.cuda.synchronize()
             out[name] = n / (time.perf_counter() - t0)
+    out["host_time"] = HOST
     print(json.dumps(out), flush=True)
 
 

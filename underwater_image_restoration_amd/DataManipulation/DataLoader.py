@@ -30,8 +30,8 @@ def get_dataloaders(raw_dir, ref_dir, test_raw_dir, test_ref_dir, batch_size=16,
         persistent_workers = num_workers > 0
     extra = {"persistent_workers": persistent_workers} if num_workers > 0 else {}
     if device_resize:
-        from .device_resize import DevicePrefetchLoader, collate_decoded
-        extra["collate_fn"] = collate_decoded
+        from .device_resize import DevicePrefetchLoader, collate_packed
+        extra["collate_fn"] = collate_packed
         pin_memory = False                 # items are variable-size byte arrays; the resizer owns the pinned staging
     train_loader = DataLoader(train_ds, batch_size=batch_size, shuffle=(shuffle and sampler is None), sampler=sampler,
                               num_workers=num_workers, pin_memory=pin_memory, drop_last=sampler is not None, **extra)

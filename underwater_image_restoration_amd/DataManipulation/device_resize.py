@@ -62,6 +62,8 @@ class DeviceResizer:
         self.dev = torch.device(device)
         if self.dev.type != "cuda":
             raise RuntimeError("DeviceResizer needs the GPU; there is no CPU fallback")
+        if self.dev.index is None:
+            self.dev = torch.device("cuda", torch.cuda.current_device())
         self._axis: Dict[Tuple[int, int], Tuple[int, np.ndarray, np.ndarray]] = {}
         # byte -> fp32 exactly as torchvision: ToTensor = uint8.to(float32).div(255); Normalize = sub(0.5).div(0.5)
         self.lut = torch.arange(256, dtype=torch.uint8).to(torch.float32).div(255).sub_(0.5).div_(0.5).to(self.dev)
@@ -76,12 +78,34 @@ class DeviceResizer:
         return self._axis[key]
 
     def __call__(self, images: Sequence[np.ndarray], want_u8: bool = False, stream=None):
-        """Enqueue copy + resize on ``stream`` (default: the resizer's side stream).  Returns (out, event) -- the
-        consumer's stream must wait on ``event`` -- or (out, out_u8, event) with ``want_u8``."""
-        images = [a.numpy() if torch.is_tensor(a) else a for a in images]      # shared-memory tensors from the workers: views
-        n = len(images)
-        if n == 0:
+        """Enqueue copy + resize of a list of uint8 [h][w][3] images on ``stream`` (default: the resizer's side stream).
+        Returns (out, event) -- the consumer's stream must wait on ``event`` -- or (out, out_u8, event) with ``want_u8``."""
+        images = [a.numpy() if torch.is_tensor(a) else a for a in images]
+        if len(images) == 0:
             raise ValueError("empty batch")
+        for a in images:
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3 or a.shape[0] < 1 or a.shape[1] < 1:
+                raise ValueError("images must be uint8 [h][w][3]")
+        shapes = [(a.shape[0], a.shape[1]) for a in images]
+
+        def fill(src_np, offsets):
+            for a, o in zip(images, offsets):
+                src_np[o:o + a.size] = np.ascontiguousarray(a).reshape(-1)
+        return self._submit(shapes, fill, want_u8, stream)
+
+    def submit_packed(self, packed: torch.Tensor, shapes, want_u8: bool = False, stream=None):
+        """Same, for a batch a DataLoader worker has already packed (``collate_packed``): ``packed`` = the images' bytes back
+        to back (1-D uint8, shared memory), ``shapes`` = their (h, w): one host copy into the pinned staging buffer."""
+        shapes = [(int(h), int(w)) for h, w in (shapes.tolist() if torch.is_tensor(shapes) else shapes)]
+        if len(shapes) == 0 or packed.dtype != torch.uint8 or packed.numel() != sum(3 * h * w for h, w in shapes):
+            raise ValueError("packed batch does not match its shapes")
+
+        def fill(src_np, offsets):
+            src_np[:packed.numel()] = packed.numpy()
+        return self._submit(shapes, fill, want_u8, stream)
+
+    def _submit(self, shapes, fill, want_u8, stream):
+        n = len(shapes)
         st = self.sets[self.turn]
         self.turn ^= 1
         # plan: tables de-duplicated per (source extent, axis), descriptors, byte offsets
@@ -90,10 +114,9 @@ class DeviceResizer:
         cur = 0
         descs = (L.ResizeImage * n)()
         src_off = 0
-        for i, a in enumerate(images):
-            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3 or a.shape[0] < 1 or a.shape[1] < 1:
+        for i, (h, w) in enumerate(shapes):
+            if h < 1 or w < 1:
                 raise ValueError("images must be uint8 [h][w][3]")
-            h, w = a.shape[:2]
             for axis, in_size, out_size in (("h", w, self.out_w), ("v", h, self.out_h)):
                 if (axis, in_size) not in off:
                     ks, b, k = self._table(in_size, out_size)
@@ -108,10 +131,7 @@ class DeviceResizer:
         if st.done is not None:
             st.done.synchronize()                 # the launch that last read this staging set has finished
         st.fit(src_off + L.RESIZE_SRC_SLACK, cur, n)
-        src_np = st.src_h.numpy()
-        for i, a in enumerate(images):
-            o = descs[i].src_off
-            src_np[o:o + a.size] = np.ascontiguousarray(a).reshape(-1)
+        fill(st.src_h.numpy(), [descs[i].src_off for i in range(n)])
         st.tab_h.numpy()[:cur] = np.concatenate(tabs)
         C.memmove(st.img_h.data_ptr(), descs, C.sizeof(descs))
 
@@ -141,18 +161,26 @@ class DeviceResizer:
         return out, ev
 
 
-def collate_decoded(items):
-    """DataLoader collate for decode-only items: keeps the per-image uint8 tensors (sizes differ)."""
-    return [r for r, _ in items], [f for _, f in items]
+def collate_packed(items):
+    """DataLoader collate for decode-only items, run in the worker: the batch's bytes back to back in ONE uint8 tensor
+    (raw images first, then ref) plus the (h, w) of each image -- the training process maps one shared-memory block and
+    does one copy per batch instead of 2*B of each."""
+    imgs = [r for r, _ in items] + [f for _, f in items]
+    shapes = torch.tensor([[t.shape[0], t.shape[1]] for t in imgs], dtype=torch.int32)
+    packed = torch.cat([t.reshape(-1) for t in imgs])
+    return packed, shapes, len(items)
 
 
 class DevicePrefetchLoader:
-    """Wraps a decode-only DataLoader: yields (raw, ref) fp32 ``[B,3,S,S]`` device tensors, resized on the GPU, with
-    the next batch's copy + resize enqueued on a side stream before the current one is handed out."""
+    """Wraps a decode-only DataLoader: yields (raw, ref) fp32 ``[B,3,S,S]`` device tensors, resized on the GPU.  A
+    background thread takes the packed batches from the workers, copies them into the pinned staging buffer and enqueues
+    H2D + resize on the resizer's side stream, up to two batches ahead of the consumer: the ~18 ms of host work per
+    batch (mapping the shared-memory block, the 40 MB copy; both release the GIL) overlaps the train step's launch loop."""
 
-    def __init__(self, loader, size, device="cuda"):
+    def __init__(self, loader, size, device="cuda", ahead: int = 2):
         self.loader = loader
         self.resizer = DeviceResizer(size, device)
+        self.ahead = max(1, int(ahead))
 
     def __len__(self):
         return len(self.loader)
@@ -162,22 +190,47 @@ class DevicePrefetchLoader:
         return self.loader.dataset
 
     def _submit(self, batch):
-        raws, refs = batch
-        out, ev = self.resizer(list(raws) + list(refs))
-        return out, ev, len(raws)
+        packed, shapes, nb = batch
+        out, ev = self.resizer.submit_packed(packed, shapes)
+        return out, ev, int(nb)
 
     def __iter__(self):
-        it = iter(self.loader)
-        try:
-            nxt = self._submit(next(it))
-        except StopIteration:
-            return
-        while nxt is not None:
-            out, ev, nb = nxt
+        import queue
+        import threading
+        dev = self.resizer.dev
+        q: "queue.Queue" = queue.Queue(maxsize=self.ahead)
+        stop = threading.Event()
+
+        def producer():
             try:
-                nxt = self._submit(next(it))
-            except StopIteration:
-                nxt = None
-            torch.cuda.current_stream(self.resizer.dev).wait_event(ev)
-            out.record_stream(torch.cuda.current_stream(self.resizer.dev))
-            yield out[:nb], out[nb:]
+                torch.cuda.set_device(dev)
+                for batch in self.loader:
+                    if stop.is_set():
+                        return
+                    q.put(self._submit(batch))
+                q.put(None)
+            except BaseException as e:          # surfaces in the consumer
+                q.put(e)
+
+        th = threading.Thread(target=producer, name="uir-input-stage", daemon=True)
+        th.start()
+        try:
+            while True:
+                item = q.get()
+                if item is None:
+                    break
+                if isinstance(item, BaseException):
+                    raise item
+                out, ev, nb = item
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_event(ev)
+                out.record_stream(cur)
+                yield out[:nb], out[nb:]
+        finally:
+            stop.set()
+            while th.is_alive():                # unblock a producer waiting on a full queue, then let it finish
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
