@@ -407,6 +407,25 @@ typedef struct UirResizeArgs {
 } UirResizeArgs;
 int uir_resize_norm_u8(const UirResizeArgs* args, void* stream);
 
+/* ---------------------------------------------------------------- uir_ssim */
+/* Validation SSIM: torchSSIM(ref, out) = pytorch_msssim.ssim(tar, prd, data_range=1.0, size_average=True)
+ * (src/ModelTrainer.py:16,23-24,149,156).  The package is not vendored in the reference: its published algorithm is
+ * restated (11-tap Gaussian sigma 1.5, separable VALID convolution per channel, K = (0.01, 0.03)); PARITY UNPINNED against
+ * the package itself.  One slab entry per 16 x 32 tile of the valid output of each (sample, channel) plane = the sum of
+ * ssim_map over the tile; SSIM = uir_reduce_slab(slab, nblocks, 1, out, 1, 0, 1 / (planes (H-10) (W-10))).
+ * uir_ssim_nblocks is a host helper (returns -1 if H or W < 11). */
+#define UIR_SSIM_TILE_H 16
+#define UIR_SSIM_TILE_W 32
+typedef struct UirSsimArgs {
+  const float* X; const float* Y;   /* [planes][H][W] each (planes = B * C of two NCHW tensors)                */
+  float* slab; long slab_floats;    /* >= uir_ssim_nblocks(planes, H, W)                                       */
+  int planes, H, W;
+  float C1, C2;                     /* (0.01 * data_range)^2, (0.03 * data_range)^2                            */
+  float win[11];                    /* the normalised Gaussian window (fp32, as _fspecial_gauss_1d(11, 1.5))   */
+} UirSsimArgs;
+long uir_ssim_nblocks(int planes, int H, int W);
+int uir_ssim_partials(const UirSsimArgs* args, void* stream);
+
 /* library self-description (used by the loader test) */
 const char* uir_version(void);
 

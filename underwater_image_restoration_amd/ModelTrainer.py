@@ -78,14 +78,16 @@ class ModelTrainer:
             avg = epoch_loss / max(1, len(train_loader))
             print(f"Epoch {epoch + 1}/{num_epochs} completed in {epoch_time:.2f}s, Avg Loss: {avg:.6f}")
             model.eval()
-            val_loss = psnr = 0.0
+            val_loss = psnr = ssim = 0.0
             for raw_imgs, ref_imgs in test_loader:
-                vl, vp = step.evaluate(raw_imgs.to(dev), ref_imgs.to(dev))
+                vl, vp, vs = step.evaluate(raw_imgs.to(dev), ref_imgs.to(dev), with_ssim=True)   # :148-150
                 val_loss += float(vl)
                 psnr += float(vp)
+                ssim += float(vs)
             avg_val_loss = val_loss / max(1, len(test_loader))
             print(f"Validation Loss: {avg_val_loss:.6f}")
             print(f"Validation PSNR: {psnr / max(1, len(test_loader)):.4f}")
+            print(f"Validation SSIM: {ssim / max(1, len(test_loader)):.4f}")
             if rank0:
                 best_loss = self.SaveModel(avg_val_loss, best_loss, directory, epoch, model, step.opt)
         print("Training completed!")

@@ -134,6 +134,11 @@ class ResizeArgs(C.Structure):
                 ("n_img", C.c_int), ("out_h", C.c_int), ("out_w", C.c_int)]
 
 
+class SsimArgs(C.Structure):
+    _fields_ = [("X", fp), ("Y", fp), ("slab", fp), ("slab_floats", C.c_long), ("planes", C.c_int), ("H", C.c_int), ("W", C.c_int),
+                ("C1", C.c_float), ("C2", C.c_float), ("win", C.c_float * 11)]
+
+
 class AdamArgs(C.Structure):
     _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("sumsq", fp), ("norm_out", fp), ("hyper", fp), ("n", C.c_long),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -182,6 +187,8 @@ SIGNATURES = {
     "uir_resize_ksize": [i32, i32],                      # host-only helpers: return ksize (or -1), not a status
     "uir_resize_coeffs": [i32, i32, fp, fp, i64],
     "uir_resize_norm_u8": [C.POINTER(ResizeArgs), fp],
+    "uir_ssim_nblocks": [i32, i32, i32],                 # host helper: returns a count (c_long), not a status
+    "uir_ssim_partials": [C.POINTER(SsimArgs), fp],
 }
 
 
@@ -195,6 +202,7 @@ def _load() -> C.CDLL:
         fn = getattr(lib, name)  # AttributeError if the symbol is missing
         fn.argtypes = argtypes
         fn.restype = C.c_int
+    lib.uir_ssim_nblocks.restype = C.c_long
     lib.uir_version.restype = C.c_char_p
     lib.uir_version.argtypes = []
     return lib

@@ -41,6 +41,33 @@ def loss_sums(pred: torch.Tensor, truth: torch.Tensor, kind: int) -> torch.Tenso
     return out
 
 
+def ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """0-dim device tensor = pytorch_msssim.ssim(x, y, data_range=data_range, size_average=True), the reference's torchSSIM
+    (src/ModelTrainer.py:23-24): 11-tap Gaussian (sigma 1.5), valid convolution, K = (0.01, 0.03).  [N,C,H,W] fp32, H, W >= 11."""
+    x, y = _req(x, "ssim"), _req(y, "ssim")
+    if x.shape != y.shape or x.dim() != 4:
+        raise ValueError(f"ssim expects matching [N,C,H,W] tensors, got {tuple(x.shape)} / {tuple(y.shape)}")
+    N, Cc, H, W = x.shape
+    nb = lib.uir_ssim_nblocks(N * Cc, H, W)
+    if nb < 0:
+        raise ValueError("ssim needs H, W >= 11 (the Gaussian window)")
+    coords = torch.arange(11, dtype=torch.float32) - 5            # _fspecial_gauss_1d(11, 1.5), fp32 as in the package
+    g = torch.exp(-(coords ** 2) / (2 * 1.5 ** 2))
+    g = g / g.sum()
+    slab = torch.empty(nb, dtype=torch.float32, device=x.device)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    a = L.SsimArgs()
+    a.X, a.Y, a.slab, a.slab_floats = x.data_ptr(), y.data_ptr(), slab.data_ptr(), nb
+    a.planes, a.H, a.W = N * Cc, H, W
+    a.C1, a.C2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    for i in range(11):
+        a.win[i] = float(g[i])
+    st = _stream()
+    L.check(lib.uir_ssim_partials(C.byref(a), st), "uir_ssim_partials")
+    L.check(lib.uir_reduce_slab(slab.data_ptr(), nb, 1, out.data_ptr(), 1, 0, 1.0 / (N * Cc * (H - 10) * (W - 10)), st), "uir_reduce_slab")
+    return out[0]
+
+
 def loss_grad(pred: torch.Tensor, truth: torch.Tensor, gscale: torch.Tensor, kind: int) -> torch.Tensor:
     pred, truth = _req(pred, "loss"), _req(truth, "loss")
     B, _, H, W = pred.shape

@@ -103,10 +103,13 @@ class TrainStep:
         return g
 
     @torch.no_grad()
-    def evaluate(self, raw: torch.Tensor, ref: torch.Tensor):
-        """Validation batch (src/ModelTrainer.py:134-158): -> (loss, PSNR) device tensors."""
+    def evaluate(self, raw: torch.Tensor, ref: torch.Tensor, with_ssim: bool = False):
+        """Validation batch (src/ModelTrainer.py:134-158): -> (loss, PSNR) device tensors, plus torchSSIM(ref, out)
+        (:23-24,149) with ``with_ssim`` (needs H, W >= 11)."""
         plan = self.model._plan_for(raw)
         out = plan.forward(raw)
         self.model._fwd_serial += 1
         res = ops.loss_sums(out, ref, self.kind)
+        if with_ssim:
+            return res[0], res[1], ops.ssim(ref, out, data_range=1.0)
         return res[0], res[1]
