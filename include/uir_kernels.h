@@ -248,9 +248,9 @@ int uir_layernorm_bwd(const UirLnBwdArgs* args, void* stream);
  * uir_attn_fwd: Gram matrix + squared norms -> attn (softmax(normalize(q) normalize(k)^T * T)),
  * WA, WB.  One workgroup per batch. */
 typedef struct UirAttnFwdArgs {
-  const float* G;      /* [B][C][C]   sum_p q_i k_j                                              */
-  const float* sq_q;   /* [B][C]      sum_p q_i^2                                                */
-  const float* sq_k;   /* [B][C]                                                                 */
+  float* G;            /* [B][C][C]   sum_p q_i k_j         (input; OUTPUT - the head blocks - when `slab` is given) */
+  float* sq_q;         /* [B][C]      sum_p q_i^2           (same)                                */
+  float* sq_k;         /* [B][C]                            (same)                                */
   const float* temperature; /* [heads]                                                           */
   const float* P;      /* [C][C]                                                                 */
   const float* Wof;    /* [C][C] project_outf.weight                                             */
@@ -258,6 +258,10 @@ typedef struct UirAttnFwdArgs {
   float* WA;           /* [B][C][C]                                                              */
   float* WB;           /* [B][C][C]                                                              */
   int B, C, heads;
+  /* optional: sum the uir_gram partial rows here instead of a separate uir_reduce_slab launch (the kernel sits on the  */
+  /* forward chain 24 times per step): row c of `slab` holds [G (B*C*C) ... sq_q at sq_q_off (B*C) ... sq_k at sq_k_off];  */
+  /* the reduced head blocks of G and the norms are written to G / sq_q / sq_k for uir_attn_bwd.  NULL: G etc. are inputs */
+  const float* slab; int nch; long slab_stride; long sq_q_off, sq_k_off;
 } UirAttnFwdArgs;
 int uir_attn_fwd(const UirAttnFwdArgs* args, void* stream);
 
@@ -272,6 +276,9 @@ typedef struct UirAttnBwdArgs {
   float* dWof;         /* [B][C][C]                                                              */
   float* dT;           /* [B][heads]                                                             */
   int B, C, heads;
+  /* optional: dWA / dWB as uir_gram partial rows (row c: dWA[b] at dWA_off + b*C*C, dWB[b] at dWB_off + b*C*C), summed   */
+  /* here; `dWA` / `dWB` are then ignored                                                                                 */
+  const float* slab; int nch; long slab_stride; long dWA_off, dWB_off;
 } UirAttnBwdArgs;
 int uir_attn_bwd(const UirAttnBwdArgs* args, void* stream);
 

@@ -526,6 +526,39 @@ def test_attn_fwd_bwd(C, heads):
     dqk = torch.einsum("bnk,bpk->bpn", Mqk, qk)
     assert rel(dqk[..., :C], dq) < 5e-5 and rel(dqk[..., C:], dk) < 5e-5
     assert rel(o["dP"].sum(0), dP) < TOL and rel(o["dWof"].sum(0), dWof) < TOL and rel(o["dT"].sum(0), dT) < 5e-5
+    # same answers when the kernels sum uir_gram partial rows themselves (slab != NULL): 3 rows that add up to the operands
+    nch = 3
+    def split(v):                                   # [nch][numel] partial rows with the right sum
+        parts = rnd(nch, v.numel(), seed=11)
+        parts[0] = v.reshape(-1).cpu() - parts[1:].sum(0)
+        return parts
+    sq, sk = (qd ** 2).sum(1), (kd ** 2).sum(1)
+    gs = dev(torch.cat([split(G), split(sq), split(sk)], 1))            # row: [G | sq_q | sq_k]
+    o2 = {n: torch.zeros_like(v) for n, v in o.items()}
+    Gout, sqo, sko = torch.zeros(B, C, C, device=DEV), torch.zeros(B, C, device=DEV), torch.zeros(B, C, device=DEV)
+    fa.G, fa.sq_q, fa.sq_k = Gout.data_ptr(), sqo.data_ptr(), sko.data_ptr()
+    fa.attn, fa.WA, fa.WB = o2["attn"].data_ptr(), o2["WA"].data_ptr(), o2["WB"].data_ptr()
+    fa.slab, fa.nch, fa.slab_stride, fa.sq_q_off, fa.sq_k_off = gs.data_ptr(), nch, gs.shape[1], B * C * C, B * C * C + B * C
+    assert lib.uir_attn_fwd(ctypes.byref(fa), None) == 0
+    ws = dev(torch.cat([split(dWB), split(dWA)], 1))                    # row: [dWB | dWA]
+    ba.dWA, ba.dWB = None, None
+    ba.G, ba.sq_q, ba.sq_k, ba.attn = Gout.data_ptr(), sqo.data_ptr(), sko.data_ptr(), o2["attn"].data_ptr()
+    ba.Mqk, ba.dP, ba.dWof, ba.dT = o2["Mqk"].data_ptr(), o2["dP"].data_ptr(), o2["dWof"].data_ptr(), o2["dT"].data_ptr()
+    ba.slab, ba.nch, ba.slab_stride, ba.dWB_off, ba.dWA_off = ws.data_ptr(), nch, ws.shape[1], 0, B * C * C
+    assert lib.uir_attn_bwd(ctypes.byref(ba), None) == 0
+    torch.cuda.synchronize()
+    for k in ("attn", "WA", "WB", "dP", "dWof", "dT"):
+        assert rel(o2[k], o[k]) < 2e-5, k
+    m1, m2 = o["Mqk"].double().cpu(), o2["Mqk"].double().cpu()
+    blk = torch.zeros(2 * C, 2 * C, dtype=torch.bool)                   # rows/columns of the heads' blocks (the rest is never written)
+    for h in range(heads):
+        sl = slice(h * d, (h + 1) * d)
+        blk[sl, C + h * d:C + (h + 1) * d] = True
+        blk[C + h * d:C + (h + 1) * d, sl] = True
+    blk |= torch.eye(2 * C, dtype=torch.bool)
+    assert float((m1 - m2)[:, blk].abs().max()) < 2e-5 * float(m1[:, blk].abs().max() + 1e-30)
+    ba.slab_stride = B * C * C                                           # too short for both halves: refused
+    assert lib.uir_attn_bwd(ctypes.byref(ba), None) == 1
 
 
 # -------------------------------------------------------------- uir_spectral

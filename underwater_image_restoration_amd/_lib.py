@@ -100,13 +100,15 @@ class LnBwdArgs(C.Structure):
 
 class AttnFwdArgs(C.Structure):
     _fields_ = [("G", fp), ("sq_q", fp), ("sq_k", fp), ("temperature", fp), ("P", fp), ("Wof", fp),
-                ("attn", fp), ("WA", fp), ("WB", fp), ("B", C.c_int), ("C", C.c_int), ("heads", C.c_int)]
+                ("attn", fp), ("WA", fp), ("WB", fp), ("B", C.c_int), ("C", C.c_int), ("heads", C.c_int),
+                ("slab", fp), ("nch", C.c_int), ("slab_stride", C.c_long), ("sq_q_off", C.c_long), ("sq_k_off", C.c_long)]
 
 
 class AttnBwdArgs(C.Structure):
     _fields_ = [("dWA", fp), ("dWB", fp), ("G", fp), ("sq_q", fp), ("sq_k", fp), ("temperature", fp),
                 ("attn", fp), ("P", fp), ("Wof", fp), ("Mqk", fp), ("dP", fp), ("dWof", fp), ("dT", fp),
-                ("B", C.c_int), ("C", C.c_int), ("heads", C.c_int)]
+                ("B", C.c_int), ("C", C.c_int), ("heads", C.c_int),
+                ("slab", fp), ("nch", C.c_int), ("slab_stride", C.c_long), ("dWA_off", C.c_long), ("dWB_off", C.c_long)]
 
 
 class DftArgs(C.Structure):

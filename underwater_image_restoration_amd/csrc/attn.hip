@@ -40,14 +40,40 @@ __global__ __launch_bounds__(1024) void uir_attn_fwd_kernel(const UirAttnFwdArgs
     Ps[e] = a.P[(long)r * C + hd + i];
     Ws[e] = a.Wof[(long)r * C + hd + i];
   }
-  if (tid < d) {
+  if (a.slab) {                       // sum the Gram partial rows here: norms first (needed by every logit)
+    if (tid < 2 * d) {
+      const int isk = tid >= d, t = hd + tid - isk * d;
+      const float* sp = a.slab + (isk ? a.sq_k_off : a.sq_q_off) + (long)b * C + t;
+      float sv = 0.f;
+#pragma unroll 4
+      for (int c = 0; c < a.nch; ++c) sv += sp[(long)c * a.slab_stride];
+      (isk ? a.sq_k : a.sq_q)[(long)b * C + t] = sv;
+      (isk ? nk : nq)[tid - isk * d] = fmaxf(sqrtf(sv), NORM_EPS);
+    }
+  } else if (tid < d) {
     nq[tid] = fmaxf(sqrtf(a.sq_q[(long)b * C + hd + tid]), NORM_EPS);
     nk[tid] = fmaxf(sqrtf(a.sq_k[(long)b * C + hd + tid]), NORM_EPS);
   }
   __syncthreads();
   for (int e = tid; e < d * d; e += nthr) {
     const int i = e / d, j = e - i * d;
-    at[e] = G[(long)(hd + i) * C + hd + j] / (nq[i] * nk[j]) * T;
+    const long gi = (long)(hd + i) * C + hd + j;
+    float gv;
+    if (a.slab) {
+      const float* sp = a.slab + (long)b * C * C + gi;
+      float s0 = 0.f, s1 = 0.f;
+      int c = 0;
+      for (; c + 1 < a.nch; c += 2) {
+        s0 += sp[(long)c * a.slab_stride];
+        s1 += sp[(long)(c + 1) * a.slab_stride];
+      }
+      if (c < a.nch) s0 += sp[(long)c * a.slab_stride];
+      gv = s0 + s1;
+      a.G[(long)b * C * C + gi] = gv;          // kept for uir_attn_bwd
+    } else {
+      gv = G[gi];
+    }
+    at[e] = gv / (nq[i] * nk[j]) * T;
   }
   __syncthreads();
   {
@@ -108,8 +134,21 @@ __global__ __launch_bounds__(1024) void uir_attn_bwd_kernel(const UirAttnBwdArgs
     const long w = (long)r * C + hd + j;
     Ps[e] = a.P[w];
     Ws[e] = a.Wof[w];
-    wA[e] = a.dWA[(long)b * C * C + w];
-    wB[e] = a.dWB[(long)b * C * C + w];
+    if (a.slab) {                     // dWA / dWB arrive as uir_gram partial rows: summed here, no reduction launch
+      const float* pa = a.slab + a.dWA_off + (long)b * C * C + w;
+      const float* pb = a.slab + a.dWB_off + (long)b * C * C + w;
+      float sa = 0.f, sb = 0.f;
+#pragma unroll 4
+      for (int c = 0; c < a.nch; ++c) {
+        sa += pa[(long)c * a.slab_stride];
+        sb += pb[(long)c * a.slab_stride];
+      }
+      wA[e] = sa;
+      wB[e] = sb;
+    } else {
+      wA[e] = a.dWA[(long)b * C * C + w];
+      wB[e] = a.dWB[(long)b * C * C + w];
+    }
   }
   if (tid < d) {
     nqs[tid] = fmaxf(sqrtf(a.sq_q[(long)b * C + hd + tid]), NORM_EPS);
@@ -212,6 +251,8 @@ __global__ __launch_bounds__(1024) void uir_attn_bwd_kernel(const UirAttnBwdArgs
 extern "C" int uir_attn_fwd(const UirAttnFwdArgs* p, void* stream) {
   const UirAttnFwdArgs& a = *p;
   UIR_REQUIRE(a.G && a.sq_q && a.sq_k && a.temperature && a.P && a.Wof && a.attn && a.WA && a.WB);
+  if (a.slab) UIR_REQUIRE(a.nch >= 1 && a.sq_q_off >= (long)a.B * a.C * a.C && a.sq_k_off >= (long)a.B * a.C * a.C &&
+                          a.slab_stride >= a.sq_q_off + (long)a.B * a.C && a.slab_stride >= a.sq_k_off + (long)a.B * a.C);
   UIR_REQUIRE(a.B > 0 && a.C > 0 && a.heads > 0 && a.C % a.heads == 0 && a.C <= 128);
   UIR_REQUIRE(a.C / a.heads <= 32);
   const int d = a.C / a.heads;
@@ -224,7 +265,9 @@ extern "C" int uir_attn_fwd(const UirAttnFwdArgs* p, void* stream) {
 
 extern "C" int uir_attn_bwd(const UirAttnBwdArgs* p, void* stream) {
   const UirAttnBwdArgs& a = *p;
-  UIR_REQUIRE(a.dWA && a.dWB && a.G && a.sq_q && a.sq_k && a.temperature && a.attn && a.P && a.Wof);
+  UIR_REQUIRE((a.slab || (a.dWA && a.dWB)) && a.G && a.sq_q && a.sq_k && a.temperature && a.attn && a.P && a.Wof);
+  if (a.slab) UIR_REQUIRE(a.nch >= 1 && a.dWA_off >= 0 && a.dWB_off >= 0 && a.slab_stride >= a.dWA_off + (long)a.B * a.C * a.C &&
+                          a.slab_stride >= a.dWB_off + (long)a.B * a.C * a.C);
   UIR_REQUIRE(a.Mqk && a.dP && a.dWof && a.dT);
   UIR_REQUIRE(a.B > 0 && a.C > 0 && a.heads > 0 && a.C % a.heads == 0 && a.C <= 128);
   UIR_REQUIRE(a.C / a.heads <= 32);

@@ -513,7 +513,7 @@ class Recorder:
             # (tensor, column offset, chunk stride): several Grams write side by side into one slab and the caller issues
             # ONE reduction launch for all of them; returns nch so the caller can check that the chunking agrees
             slab_t, col0, cstride = shared_slab
-            assert not extras and fused_out is None and col0 + stride <= cstride and nch * cstride <= slab_t.numel()
+            assert fused_out is None and col0 + stride <= cstride and nch * cstride <= slab_t.numel()
             a.slab = slab_t.data_ptr() + 4 * col0
             a.slab_stride = cstride
             self._hold(slab_t)
@@ -828,10 +828,24 @@ class Plan(Recorder):
         # P = W_kv[vf] @ W_o depends on weights only: side lane, joined right before its first use
         with self.side():
             self.gemm(n + ".P", Wkvf, Wo, Pm, N=C_, K=C_, w_sn=1, w_sk=C_)
-        self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
-                  out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, fused_out=gbuf)
-        self.join(n + ".P.join")
+        # the per-sample Gram partials (and, in the backward, the dWA | dWB partials) are summed inside the attention kernels:
+        # two ~7 us reduction launches less on the chain per block, but 16-128 workgroups walking 64 partial rows take longer than that
+        inred = os.environ.get("UIR_ATTN_INRED", "0") == "1"     # opt-in: measured 43.33 vs 42.9 ms/step
         fa = L.AttnFwdArgs()
+        if inred:
+            tn_ = (C_ + 31) // 32
+            nch_g, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B)
+            gstride = B * C_ * C_ + 2 * B * C_
+            gslab = self.alloc(nch_g * gstride)
+            got = self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
+                            out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, shared_slab=(gslab, 0, gstride))
+            assert got == nch_g
+            fa.slab, fa.nch, fa.slab_stride = _ptr(gslab), nch_g, gstride
+            fa.sq_q_off, fa.sq_k_off = B * C_ * C_, B * C_ * C_ + B * C_
+        else:
+            self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
+                      out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, fused_out=gbuf)
+        self.join(n + ".P.join")
         fa.G, fa.sq_q, fa.sq_k, fa.temperature, fa.P, fa.Wof = _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp), _ptr(Pm), _ptr(Wof)
         fa.attn, fa.WA, fa.WB = _ptr(attn), _ptr(WA), _ptr(WB)
         fa.B, fa.C, fa.heads = B, C_, heads
@@ -942,7 +956,8 @@ class Plan(Recorder):
                 got = self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
                                 shared_slab=(slab_ab, nab, 2 * nab))
                 assert got == nch_ab
-                self._op(n + ".dWAB.red", lib.uir_reduce_slab, _ptr(slab_ab), nch_ab, 2 * nab, _ptr(dWB), 2 * nab, 0, 1.0)
+                if not inred:
+                    self._op(n + ".dWAB.red", lib.uir_reduce_slab, _ptr(slab_ab), nch_ab, 2 * nab, _ptr(dWB), 2 * nab, 0, 1.0)
             self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
             if side_grams:
                 self.join(n + ".dWAB.join")
@@ -951,6 +966,8 @@ class Plan(Recorder):
             ba.attn, ba.P, ba.Wof = _ptr(attn), _ptr(Pm), _ptr(Wof)
             ba.Mqk, ba.dP, ba.dWof, ba.dT = _ptr(Mqk), _ptr(dPb), _ptr(dWofb), _ptr(dTb)
             ba.B, ba.C, ba.heads = B, C_, heads
+            if inred and not side_grams:
+                ba.slab, ba.nch, ba.slab_stride, ba.dWB_off, ba.dWA_off = _ptr(slab_ab), nch_ab, 2 * nab, 0, nab
             self.keep.append(ba)
             self._op(n + ".attn_bwd", lib.uir_attn_bwd, C.byref(ba))
             with self.bulk():
