@@ -807,7 +807,8 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     const bool combo_ok = (a.pro == UIR_PRO_NONE) || (a.epi == UIR_EPI_PLAIN && !(a.pro == UIR_PRO_LN && a.R));
     if (lds <= 100 * 1024 && combo_ok) {
       const int rtiles = (a.M + 127) / 128;
-      int gx = 1536 / (groups1 * a.batches);
+      static const int gx_total = getenv("UIR_GEMM_GX") ? atoi(getenv("UIR_GEMM_GX")) : 768;   // = the resident workgroups at 3 per CU (1536: +0.15 ms/step)
+      int gx = gx_total / (groups1 * a.batches);
       if (gx < 1) gx = 1;
       // the variants with fused reductions run 2 workgroups per CU (launch bounds): 512 resident workgroups take all
       // the tiles, and every workgroup writes one slab row for uir_reduce_slab - no point in more rows than that
