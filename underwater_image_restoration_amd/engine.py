@@ -119,6 +119,7 @@ def twiddles(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     return _TWIDDLE_CACHE[key]
 
 
+_GRAM_WGS = int(os.environ.get("UIR_GRAM_WGS", 1024))           # workgroups (= partial rows x column groups) per Gram launch; tuning aid
 GEMM_SLAB_ROWS = int(os.environ.get("UIR_GEMM_ROWS", 512))      # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
 _DFT2_CACHE: dict = {}
 
@@ -465,7 +466,7 @@ class Recorder:
         self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps)
 
     def _chunks(self, M, ngroups, batches):
-        nch = max(1, min(M // 256, 1024 // max(1, ngroups * batches)))
+        nch = max(1, min(M // 256, _GRAM_WGS // max(1, ngroups * batches)))
         rpc = ((M + nch - 1) // nch + 7) & ~7
         nch = (M + rpc - 1) // rpc
         return nch, rpc
