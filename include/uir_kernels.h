@@ -371,11 +371,17 @@ int uir_sumsq_partials(const float* g, long n, float* slab, int nblocks, void* s
 typedef struct UirAdamArgs {
   float* p; const float* g; float* m; float* v;
   const float* sumsq; float* norm_out;
-  const float* hyper;  /* optional device float[4] = {lr, bc1, bc2, gscale}: overrides the by-value fields (hipGraph replay) */
+  const float* hyper;  /* NULL in the eager path (the by-value fields below are used: kernel arguments are copied at launch,
+                        * so an un-synchronised host can never overwrite a queued step's scalars).  hipGraph replay only:
+                        * device float[4] = {lr, bc1, bc2, gscale}, stored by uir_adam_set_hyper on the replay stream. */
   long n;
   float lr, beta1, beta2, eps, bc1, bc2, max_norm, gscale;
+  float weight_decay;  /* 0 = torch.optim.Adam (ModelTrainer.py:199); > 0 = torch.optim.AdamW's decoupled decay (:201) */
+  int _pad;
 } UirAdamArgs;
 int uir_clip_adam_step(const UirAdamArgs* args, void* stream);
+/* hyper[0..4) = {lr, bc1, bc2, gscale}, passed BY VALUE and written by a one-thread kernel in stream order */
+int uir_adam_set_hyper(float* hyper, float lr, float bc1, float bc2, float gscale, void* stream);
 
 /* -------------------------------------------------------------- uir_resize */
 /* Input stage.  Replaces transforms.Resize((1024,1024), BILINEAR) -> ToTensor ->
@@ -435,6 +441,10 @@ int uir_ssim_partials(const UirSsimArgs* args, void* stream);
 
 /* library self-description (used by the loader test) */
 const char* uir_version(void);
+/* Layout of an argument struct as the compiler built it: out[0] = sizeof, out[1 + i] = offsetof(field i) in declaration
+ * order; returns 1 + number of fields, -1 for an unknown name / too small a buffer.  A host binding (ctypes, cgo, JNI)
+ * checks its mirror of each struct against this at load time (csrc/abi_layout.hip is generated from this header). */
+long uir_abi_layout(const char* struct_name, long* out, int cap);
 
 #ifdef __cplusplus
 }

@@ -381,7 +381,9 @@ class AdamClipState:
         self.v = {n: torch.zeros_like(P[n]) for n in live_names(P)}
         self.t = 0
 
-    def step(self, P: Params, grads: Params, lr: float, max_norm: float = 1.0) -> float:
+    def step(self, P: Params, grads: Params, lr: float, max_norm: float = 1.0, weight_decay: float = 0.0) -> float:
+        """weight_decay > 0: torch.optim.AdamW (src/ModelTrainer.py:201) - decoupled decay `p *= 1 - lr * wd` before the
+        Adam update (torch/optim/adam.py, decoupled_weight_decay branch)."""
         total = torch.sqrt(sum((g.double() ** 2).sum() for g in grads.values())).to(next(iter(grads.values())).dtype)
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
         self.t += 1
@@ -392,7 +394,7 @@ class AdamClipState:
             self.m[n].mul_(b1).add_(g, alpha=1 - b1)
             self.v[n].mul_(b2).addcmul_(g, g, value=1 - b2)
             denom = (self.v[n].sqrt() / math.sqrt(bc2)).add_(eps)
-            P[n] = P[n] - (lr / bc1) * self.m[n] / denom
+            P[n] = P[n] * (1 - lr * weight_decay) - (lr / bc1) * self.m[n] / denom
         return float(total)
 
 

@@ -29,22 +29,102 @@ def test_library_exports_every_declared_symbol():
     assert L.lib.uir_version().decode().startswith("uir_hip")
 
 
-def test_struct_layouts_match_header_field_order():
-    """ctypes mirrors must list the same fields in the same order as the C structs."""
+def test_struct_layouts_match_the_compiled_library():
+    """Every argument struct of the header (all of them, not a sample): the ctypes mirror lists the same fields in the
+    same order, and its size and every field offset equal what the COMPILED library reports (uir_abi_layout, generated
+    from the header by tools/gen_abi.py)."""
+    import ctypes as C
     from underwater_image_restoration_amd import _lib as L
-    hdr = _header()
-    for cname, cls in (("UirGemmArgs", L.GemmArgs), ("UirGramArgs", L.GramArgs), ("UirDwArgs", L.DwArgs),
-                       ("UirDwWgradArgs", L.DwWgradArgs), ("UirLnBwdArgs", L.LnBwdArgs), ("UirAttnFwdArgs", L.AttnFwdArgs),
-                       ("UirAttnBwdArgs", L.AttnBwdArgs), ("UirDftArgs", L.DftArgs), ("UirAdamArgs", L.AdamArgs)):
-        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (cname, cname), hdr, flags=re.S).group(1)
-        fields = []
-        for decl in body.split(";"):
-            decl = decl.strip()
-            if not decl:
-                continue
-            decl = re.sub(r"^(const\s+)?(float|int|long)\s*\*?", "", decl)
-            fields += [f.strip().lstrip("*").strip() for f in decl.split(",")]
-        assert fields == [f[0] for f in cls._fields_], cname
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_abi
+    structs = gen_abi.parse_structs(open(os.path.join(ROOT, "include", "uir_kernels.h")).read())
+    assert len(structs) == 18 and {n for n, _ in structs} == set(L.STRUCTS)
+    for cname, fields in structs:
+        cls = L.STRUCTS[cname]
+        assert [f for f, _, _ in fields] == [f[0] for f in cls._fields_], cname
+        size, offs = L.abi_layout(L.lib, cname)
+        assert size == C.sizeof(cls), (cname, size, C.sizeof(cls))
+        assert offs == [getattr(cls, f[0]).offset for f in cls._fields_], cname
+        for (f, ctype, arr), (_, ct) in zip(fields, cls._fields_):          # and the types
+            if ctype.endswith("*"):
+                assert ct is L.fp, (cname, f)
+            else:
+                want = {"int": C.c_int, "long": C.c_long, "float": C.c_float}[ctype.replace("const ", "")]
+                assert ct is (want * arr if arr else want) or (arr and ct._type_ is want and ct._length_ == arr), (cname, f)
+    assert L.lib.uir_abi_layout(b"NoSuchStruct", (C.c_long * 4)(), 4) == -1
+    # the generated source is the header's: regenerate and compare
+    assert gen_abi.emit_hip(structs) == open(gen_abi.OUT).read(), "run `python tools/gen_abi.py`"
+    # INTEGRATION.md shows exactly the generated ctypes mirror
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for line in gen_abi.emit_ctypes(structs).splitlines():
+        if line.strip():
+            assert line in doc, f"INTEGRATION.md is stale: missing `{line.strip()}` (python tools/gen_abi.py --ctypes)"
+
+
+def test_trainer_reads_args_like_the_reference(golden_dir, monkeypatch):
+    """`python main.py` with NO flags: the namespace recorded from the reference's own argparse (args.py:6-279).  The
+    reference trains at 1024 x 1024 whatever --height/--width say (DataLoader.py:14), batch 2, L1, Adam 3e-4; so must
+    ModelTrainer.train - checked on the actual call into get_dataloaders / TrainStep."""
+    import json
+    import types
+    from underwater_image_restoration_amd import ModelTrainer as MT
+    ns = types.SimpleNamespace(**json.load(open(os.path.join(golden_dir, "ref_args_defaults.json"))))
+    assert (ns.height, ns.width, ns.train_batch_size, ns.lossf, ns.optim, ns.lr, ns.use_dwt) == (128, 256, 2, "L1", "adam", 3e-4, "Fourier")
+    cfg = MT.run_config(ns, ns.lr)
+    assert cfg == {"batch_size": 2, "image_size": 1024, "num_workers": 4, "device_resize": True, "use_dwt": "Fourier",
+                   "lossf": "L1", "lr": 3e-4, "weight_decay": 0.0}
+    ns.image_size = 256                      # the build's explicit override (bench configuration)
+    assert MT.run_config(ns, ns.lr)["image_size"] == 256
+    del ns.image_size
+    ns.optim = "adamw"
+    assert MT.run_config(ns, ns.lr)["weight_decay"] == 0.01          # torch.optim.AdamW default (ModelTrainer.py:201)
+    ns.optim = "sgd"
+    with pytest.raises(ValueError, match="Unsupported optimizer"):
+        MT.run_config(ns, ns.lr)
+    ns.optim = "adam"
+    seen = {}
+
+    class Stop(Exception):
+        pass
+
+    def fake_loaders(*a, **k):
+        seen["a"], seen["k"] = a, k
+        raise Stop()
+    monkeypatch.setattr(MT, "get_dataloaders", fake_loaders)
+    monkeypatch.setattr(MT, "resolve_device", lambda d: torch.device("cpu"))
+    with pytest.raises(Stop):
+        MT.ModelTrainer("a", "b", "ta", "tb").train(ns, ns.arch, ns.max_epoch, ns.lr, "cuda")
+    assert seen["a"] == ("a", "b", "ta", "tb", 2) and seen["k"]["image_size"] == 1024 and seen["k"]["num_workers"] == 4
+    assert MT.multistep_lr(3e-4, 0) == 3e-4 and MT.multistep_lr(3e-4, 1) == 7.5e-5 and abs(MT.multistep_lr(3e-4, 100) - 1.875e-5) < 1e-12
+
+
+def test_resolve_device_uses_local_rank(monkeypatch):
+    from underwater_image_restoration_amd import ModelTrainer as MT
+    picked = []
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: picked.append(d))
+    monkeypatch.setenv("LOCAL_RANK", "3")
+    assert MT.resolve_device("cuda") == torch.device("cuda", 3) and picked[-1] == torch.device("cuda", 3)
+    assert MT.resolve_device("cuda:1") == torch.device("cuda", 1)           # an explicit index wins
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        MT.resolve_device("cpu")
+
+
+def test_plan_memory_estimate_and_loss_names():
+    """plan_bytes_estimate (what TrainStep sizes micro-batches with, and what _plan_for refuses on) bounds the real
+    Plan.bytes from above by < 4 %; the reference's default run (16 x 1024 x 1024) needs micro-batches on 288 GB."""
+    from underwater_image_restoration_amd import Models, engine as E, _lib as L
+    m = Models.init_model("SpectralTransformer")
+    fp = m._ensure_flat("cpu")
+    for shape in ((1, 64, 64), (2, 64, 128), (1, 128, 128)):
+        for wb in (True, False):
+            plan = E.Plan(fp, *shape, want_backward=wb)
+            est = E.plan_bytes_estimate(*shape, wb)
+            assert plan.bytes <= est <= 1.04 * plan.bytes + (64 << 20), (shape, wb, plan.bytes, est)
+            assert (len(plan.bwd) > 0) == wb
+            del plan
+    gib = 2 ** 30
+    assert E.plan_bytes_estimate(16, 1024, 1024) > 288 * gib > E.plan_bytes_estimate(4, 1024, 1024)
+    assert L.LOSS_KINDS["L1ColorLum"] == L.LOSS_KINDS["L1withColor"]            # same formula, losses.py:59-66 / :67-75
 
 
 def test_factory_and_loss_surface():
@@ -166,3 +246,83 @@ def test_shard_indices_without_process_group():
     assert parallel.world_size() == 1 and parallel.rank() == 0
     assert parallel.shard_indices(5) == [0, 1, 2, 3, 4]
     assert parallel.allreduce_flat_grads(torch.ones(4), 4) == 1.0
+
+
+class _FakeStep:
+    """evaluate() of a validation batch = (loss, PSNR, SSIM) derived from the batch itself (no GPU needed)."""
+
+    def evaluate(self, raw, ref, with_ssim=False):
+        v = raw.double().mean()
+        return v, v * 10, v * 0.1
+
+
+def _val_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from underwater_image_restoration_amd.ModelTrainer import ModelTrainer
+    from torch.utils.data import TensorDataset
+    from torch.utils.data.distributed import DistributedSampler
+    batches = [(torch.full((2, 3, 4, 4), float(i + 1)), torch.zeros(2, 3, 4, 4)) for i in range(5)]
+    got = ModelTrainer.validate(_FakeStep(), batches, torch.device("cpu"), world)
+    # the train sampler reshuffles per epoch only when set_epoch is called - which train() now does
+    ds = TensorDataset(torch.arange(16))
+    s = DistributedSampler(ds, shuffle=True, drop_last=True)
+    orders = []
+    for epoch in range(2):
+        s.set_epoch(epoch)
+        orders.append(list(iter(s)))
+    torch.save({"val": got, "orders": orders}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_validation_means_are_all_reduced_over_ranks(tmp_path):
+    """validation means = rank-local sums all-reduced.  2 gloo ranks split 5 batches 3 / 2; both must report
+    the global per-batch means (src/ModelTrainer.py:148-157 divides the sums by len(test_loader))."""
+    out = str(tmp_path / "val")
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_val_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0", weights_only=False), torch.load(out + ".1", weights_only=False)
+    want = sum(range(1, 6)) / 5.0
+    for r in (r0, r1):
+        assert abs(r["val"][0] - want) < 1e-12 and abs(r["val"][1] - 10 * want) < 1e-12 and abs(r["val"][2] - 0.1 * want) < 1e-12
+    assert r0["orders"][0] != r0["orders"][1]                         # a new shuffle each epoch
+    assert not set(r0["orders"][0]) & set(r1["orders"][0])             # disjoint shards
+
+
+def test_trainer_calls_set_epoch(monkeypatch):
+    """ModelTrainer.train must call sampler.set_epoch(epoch) on the (possibly wrapped) train loader every epoch."""
+    import types
+    from underwater_image_restoration_amd import ModelTrainer as MT
+    calls = []
+
+    class Sampler:
+        def set_epoch(self, e):
+            calls.append(e)
+
+    class Loader(list):
+        sampler = Sampler()
+
+    class Wrapped(list):            # DevicePrefetchLoader keeps the DataLoader under .loader
+        loader = Loader()
+
+    class Step:
+        opt = None
+
+        def __init__(self, *a, **k):
+            pass
+
+        def check_memory(self, *a):
+            return 1
+
+        def evaluate(self, *a, **k):
+            raise AssertionError("no validation batches")
+    monkeypatch.setattr(MT, "resolve_device", lambda d: torch.device("cpu"))
+    monkeypatch.setattr(MT, "get_dataloaders", lambda *a, **k: (Wrapped(), []))
+    monkeypatch.setattr(MT, "TrainStep", Step)
+    monkeypatch.setattr(MT.Models, "init_model", lambda **k: torch.nn.Linear(1, 1))
+    monkeypatch.setattr(MT.ModelTrainer, "SaveModel", lambda self, *a: 0.0)
+    args = types.SimpleNamespace(train_batch_size=2, lossf="L1", lr=3e-4, arch="SpectralTransformer", use_dwt="Fourier", optim="adam")
+    MT.ModelTrainer("a", "b", "c", "d").train(args, "SpectralTransformer", 3, 3e-4, "cuda")
+    assert calls == [0, 1, 2]

@@ -79,7 +79,8 @@ class DeviceResizer:
 
     def __call__(self, images: Sequence[np.ndarray], want_u8: bool = False, stream=None):
         """Enqueue copy + resize of a list of uint8 [h][w][3] images on ``stream`` (default: the resizer's side stream).
-        Returns (out, event) -- the consumer's stream must wait on ``event`` -- or (out, out_u8, event) with ``want_u8``."""
+        Returns (out, event) -- the consumer's stream must wait on ``event`` and, if it is another stream, call
+        ``out.record_stream(consumer_stream)`` -- or (out, out_u8, event) with ``want_u8``."""
         images = [a.numpy() if torch.is_tensor(a) else a for a in images]
         if len(images) == 0:
             raise ValueError("empty batch")
@@ -136,9 +137,12 @@ class DeviceResizer:
         C.memmove(st.img_h.data_ptr(), descs, C.sizeof(descs))
 
         stream = stream or self.stream
-        out = torch.empty(n, 3, self.out_h, self.out_w, dtype=torch.float32, device=self.dev)
-        out_u8 = torch.empty(n, self.out_h, self.out_w, 3, dtype=torch.uint8, device=self.dev) if want_u8 else None
         with torch.cuda.stream(stream):
+            # allocated UNDER the launch stream: the block comes from that stream's pool of the caching allocator, so it
+            # cannot be memory the train step freed on its own stream while kernels that still use it are queued there
+            # (the consumer's record_stream only covers the hand-over and the later free, not this first use)
+            out = torch.empty(n, 3, self.out_h, self.out_w, dtype=torch.float32, device=self.dev)
+            out_u8 = torch.empty(n, self.out_h, self.out_w, 3, dtype=torch.uint8, device=self.dev) if want_u8 else None
             st.src_d[:src_off].copy_(st.src_h[:src_off], non_blocking=True)
             st.tab_d[:cur].copy_(st.tab_h[:cur], non_blocking=True)
             st.img_d[:C.sizeof(descs)].copy_(st.img_h[:C.sizeof(descs)], non_blocking=True)
@@ -154,9 +158,7 @@ class DeviceResizer:
             ev = torch.cuda.Event()
             ev.record(stream)
         st.done = ev
-        out.record_stream(stream)
         if want_u8:
-            out_u8.record_stream(stream)
             return out, out_u8, ev
         return out, ev
 

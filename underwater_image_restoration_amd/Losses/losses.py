@@ -9,6 +9,7 @@ truth)`` (src/Losses/losses.py:30-160), for the loss names on the SpectralTransf
                 reference raises AttributeError there (it never builds self.luminanceLoss for this
                 name, :49), so this is the evident intent, without the
                 four `print(loss.item())` host syncs.
+  L1ColorLum    the same formula (:67-75; in the reference it raises the same AttributeError as L1withColor)
 
 Forward and backward are HIP reductions (uir_loss_*).  Other reference loss names need
 third-party packages / pretrained VGG weights that are outside this build's scope.
@@ -22,7 +23,7 @@ from .. import ops
 
 _REFERENCE_OTHER = ("perceptual", "gradient", "ms_ssim", "ffl", "mix", "fflMixTV", "bigMix", "fflCharbonnier", "fflMix",
                     "LuminanceCharbonnier", "AdaptiveLuminanceCharbonnier", "AdaptiveLuminanceFFL", "LuminanceFFL",
-                    "ssimFFLCharbonnier", "L1ColorLum")
+                    "ssimFFLCharbonnier")
 
 
 class _LossFn(torch.autograd.Function):

@@ -14,7 +14,7 @@ from typing import Dict, Tuple
 import torch
 import torch.nn as nn
 
-from ..engine import FlatParams, Plan, hidden_of, is_dead_param
+from ..engine import FlatParams, Plan, hidden_of, is_dead_param, plan_bytes_estimate, device_bytes_available
 
 
 class _Holder(nn.Module):
@@ -135,7 +135,8 @@ class SpectralTransformer(nn.Module):
         self._plans: Dict[Tuple[int, int, int], Plan] = {}
         self._live_names = [n for n, _ in self.named_parameters() if not is_dead_param(n)]
         self._fwd_serial = 0
-        self.max_cached_plans = 2
+        # a real epoch sees four shapes (train full / tail batch, validation full / tail): keep them all
+        self.max_cached_plans = 4
 
     # ------------------------------------------------------------ flat storage
     def _flatten(self, device) -> None:
@@ -165,15 +166,33 @@ class SpectralTransformer(nn.Module):
         dev = next(self.parameters()).device
         return self._ensure_flat(dev)
 
-    def _plan_for(self, x: torch.Tensor) -> Plan:
+    def _plan_for(self, x: torch.Tensor, want_backward: bool = True) -> Plan:
+        """Launch plan for x's (B, H, W).  want_backward=False (validation) builds a forward-only plan - no backward
+        list, no gradient buffers - unless a training plan of that shape already exists, which then serves both."""
         fp = self._ensure_flat(x.device)
-        key = (x.shape[0], x.shape[2], x.shape[3])
-        plan = self._plans.get(key)
+        shape = (x.shape[0], x.shape[2], x.shape[3])
+        plan = self._plans.get(shape + (True,))
+        if plan is None and not want_backward:
+            plan = self._plans.get(shape + (False,))
         if plan is None:
             while len(self._plans) >= self.max_cached_plans:
-                self._plans.pop(next(iter(self._plans)))
-            plan = Plan(fp, *key)
-            self._plans[key] = plan
+                self._plans.pop(next(iter(self._plans)))      # oldest first; a hipGraph captured from it dies with it
+            if fp.device.type == "cuda":
+                # one plan holds every activation (no re-materialisation): make room by dropping cached plans, and fail
+                # here with the numbers rather than somewhere inside the build with an allocator error
+                need = plan_bytes_estimate(*shape, want_backward)
+                while self._plans and need > device_bytes_available(fp.device):
+                    self._plans.pop(next(iter(self._plans)))
+                    torch.cuda.empty_cache()
+                have = device_bytes_available(fp.device)
+                if need > have:
+                    raise RuntimeError(
+                        f"SpectralTransformer(HIP): a {'train' if want_backward else 'forward-only'} plan for batch {shape[0]} at "
+                        f"{shape[1]}x{shape[2]} needs ~{need / 2**30:.1f} GiB of HBM ({have / 2**30:.1f} GiB available): every "
+                        f"activation is kept for the backward pass.  Use a smaller batch, or TrainStep(micro_batch=...) "
+                        f"(gradient accumulation over micro-batches; TrainStep picks one automatically).")
+            plan = Plan(fp, *shape, want_backward=want_backward)
+            self._plans[shape + (want_backward,)] = plan
         return plan
 
     # ----------------------------------------------------------------- forward
@@ -191,6 +210,6 @@ class SpectralTransformer(nn.Module):
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             live = [p for n, p in self.named_parameters() if not is_dead_param(n)]
             return _PlanFunction.apply(x, self, *live)
-        plan = self._plan_for(x)
+        plan = self._plan_for(x, want_backward=False)
         self._fwd_serial += 1
         return plan.forward(x).clone()

@@ -17,7 +17,8 @@ fp = C.c_void_p  # device pointers travel as integers
 PRO_NONE, PRO_LN, PRO_GATE = 0, 1, 2
 EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW, EPI_LN_BWD = 0, 1, 2, 3, 4
 ACT_NONE, ACT_LEAKY = 0, 1
-LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4}
+# L1ColorLum has the same formula as L1withColor in the reference (src/Losses/losses.py:59-66 vs :67-75)
+LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4}
 
 
 class GemmArgs(C.Structure):
@@ -144,7 +145,8 @@ class SsimArgs(C.Structure):
 class AdamArgs(C.Structure):
     _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("sumsq", fp), ("norm_out", fp), ("hyper", fp), ("n", C.c_long),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
-                ("bc1", C.c_float), ("bc2", C.c_float), ("max_norm", C.c_float), ("gscale", C.c_float)]
+                ("bc1", C.c_float), ("bc2", C.c_float), ("max_norm", C.c_float), ("gscale", C.c_float),
+                ("weight_decay", C.c_float), ("_pad", C.c_int)]
 
 
 i32, i64, f32 = C.c_int, C.c_long, C.c_float
@@ -186,12 +188,41 @@ SIGNATURES = {
     "uir_loss_bwd": [fp, fp, fp, fp, i32, i32, i32, fp],
     "uir_sumsq_partials": [fp, i64, fp, i32, fp],
     "uir_clip_adam_step": [C.POINTER(AdamArgs), fp],
+    "uir_adam_set_hyper": [fp, f32, f32, f32, f32, fp],
     "uir_resize_ksize": [i32, i32],                      # host-only helpers: return ksize (or -1), not a status
     "uir_resize_coeffs": [i32, i32, fp, fp, i64],
     "uir_resize_norm_u8": [C.POINTER(ResizeArgs), fp],
     "uir_ssim_nblocks": [i32, i32, i32],                 # host helper: returns a count (c_long), not a status
     "uir_ssim_partials": [C.POINTER(SsimArgs), fp],
+    "uir_abi_layout": [C.c_char_p, C.POINTER(C.c_long), i32],   # host helper: returns a count (c_long)
 }
+
+# C struct name -> ctypes mirror (every argument struct of include/uir_kernels.h)
+STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirDwArgs": DwArgs, "UirDwWgradArgs": DwWgradArgs,
+           "UirDwBwdArgs": DwBwdArgs, "UirGdfnFwdArgs": GdfnFwdArgs, "UirQkvFwdArgs": QkvFwdArgs,
+           "UirAttnvFwdArgs": AttnvFwdArgs, "UirGdfnBwdArgs": GdfnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
+           "UirAttnFwdArgs": AttnFwdArgs, "UirAttnBwdArgs": AttnBwdArgs, "UirDftArgs": DftArgs, "UirDft2Args": Dft2Args,
+           "UirAdamArgs": AdamArgs, "UirResizeImage": ResizeImage, "UirResizeArgs": ResizeArgs, "UirSsimArgs": SsimArgs}
+
+
+def abi_layout(lib_, cname: str):
+    """(sizeof, [offsetof ...]) of a C struct as the library was compiled."""
+    buf = (C.c_long * 96)()
+    n = lib_.uir_abi_layout(cname.encode(), buf, 96)
+    if n < 1:
+        raise ImportError(f"libuir_hip.so does not know struct {cname}")
+    return buf[0], list(buf[1:n])
+
+
+def _verify_structs(lib_) -> None:
+    """Refuse to run with a ctypes mirror that disagrees with the compiled structs (a silent mismatch would hand the
+    kernels garbage pointers)."""
+    for cname, cls in STRUCTS.items():
+        size, offs = abi_layout(lib_, cname)
+        mine = [getattr(cls, f[0]).offset for f in cls._fields_]
+        if size != C.sizeof(cls) or offs != mine:
+            raise ImportError(f"ctypes mirror of {cname} does not match libuir_hip.so: sizeof {C.sizeof(cls)} vs {size}, "
+                              f"offsets {mine} vs {offs}")
 
 
 def _load() -> C.CDLL:
@@ -205,6 +236,8 @@ def _load() -> C.CDLL:
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.uir_ssim_nblocks.restype = C.c_long
+    lib.uir_abi_layout.restype = C.c_long
+    _verify_structs(lib)
     lib.uir_version.restype = C.c_char_p
     lib.uir_version.argtypes = []
     return lib

@@ -16,7 +16,20 @@ OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libuir_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-SOURCES = ["gemm", "gram", "dwconv", "gdfn", "layernorm", "attn", "spectral", "shuffle", "resize", "colsum", "loss", "ssim", "optim"]
+SOURCES = ["gemm", "gram", "dwconv", "gdfn", "layernorm", "attn", "spectral", "shuffle", "resize", "colsum", "loss", "ssim", "optim", "abi_layout"]
+
+
+def source_sha() -> str:
+    """sha256 (16 hex) over everything that decides which kernels a train step runs and how: csrc/*.hip, *.h, the C header and
+    the launch-plan compiler.  Measurement files (profiles/*pmc_traffic*.json) carry it; bench.py refuses a stale one."""
+    import hashlib
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files += [os.path.join(HERE, "..", "include", "uir_kernels.h"), os.path.join(HERE, "engine.py")]
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def _deps():

@@ -25,8 +25,14 @@ __global__ __launch_bounds__(256) void sumsq_partials_kernel(const float* __rest
   if (threadIdx.x == 0) slab[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
+// Per-step scalars for a captured hipGraph: written by VALUE (kernel arguments are copied at launch time, so the host may
+// run any number of steps ahead), read by the replayed clip_adam_kernel through `hyper`.  No host staging buffer exists.
+__global__ void adam_hyper_kernel(float* hyper, float lr, float bc1, float bc2, float gscale) {
+  if (threadIdx.x == 0) { hyper[0] = lr; hyper[1] = bc1; hyper[2] = bc2; hyper[3] = gscale; }
+}
+
 __global__ __launch_bounds__(256) void clip_adam_kernel(UirAdamArgs a) {
-  if (a.hyper) {  // per-step values live in device memory so a captured hipGraph replays with fresh ones
+  if (a.hyper) {  // hipGraph replay only: the values uir_adam_set_hyper stored on this stream before the replay
     a.lr = a.hyper[0]; a.bc1 = a.hyper[1]; a.bc2 = a.hyper[2]; a.gscale = a.hyper[3];
   }
   const float total = sqrtf(a.sumsq[0]) * a.gscale;
@@ -36,13 +42,14 @@ __global__ __launch_bounds__(256) void clip_adam_kernel(UirAdamArgs a) {
   const float gmul = a.gscale * coef;
   const float step = a.lr / a.bc1;
   const float rs2 = rsqrtf(a.bc2);
+  const float decay = 1.f - a.lr * a.weight_decay;   // AdamW (decoupled): p *= 1 - lr * wd before the update; 1 for Adam
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < a.n; i += (long)gridDim.x * blockDim.x) {
     const float g = a.g[i] * gmul;
     const float m = a.beta1 * a.m[i] + (1.f - a.beta1) * g;
     const float v = a.beta2 * a.v[i] + (1.f - a.beta2) * g * g;
     a.m[i] = m;
     a.v[i] = v;
-    a.p[i] -= step * m / (sqrtf(v) * rs2 + a.eps);
+    a.p[i] = a.p[i] * decay - step * m / (sqrtf(v) * rs2 + a.eps);
   }
 }
 
@@ -58,9 +65,16 @@ extern "C" int uir_clip_adam_step(const UirAdamArgs* p, void* stream) {
   const UirAdamArgs& a = *p;
   UIR_REQUIRE(a.p && a.g && a.m && a.v && a.sumsq && a.n > 0);
   UIR_REQUIRE(a.hyper || (a.bc1 > 0.f && a.bc2 > 0.f));
+  UIR_REQUIRE(a.weight_decay >= 0.f);
   long blocks = (a.n + 255) / 256;
   if (blocks > 2048) blocks = 2048;
   hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return uir_launch_status();
+}
+
+extern "C" int uir_adam_set_hyper(float* hyper, float lr, float bc1, float bc2, float gscale, void* stream) {
+  UIR_REQUIRE(hyper && bc1 > 0.f && bc2 > 0.f);
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), hyper, lr, bc1, bc2, gscale);
   return uir_launch_status();
 }
 

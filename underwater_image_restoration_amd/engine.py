@@ -50,6 +50,25 @@ _GDFN_BWD_FUSED = set(filter(None, os.environ.get("UIR_GDFN_BWD_FUSED", "").spli
 SCRATCH_FLOATS = 96 * 1024 * 1024  # 384 MB of slab scratch shared by every reduction
 
 
+# Plan memory model: every activation / gradient buffer lives for the plan's lifetime and is linear in B*H*W
+# (measured by building plans of several shapes: 59.2-60.4 KB per pixel with the backward list, 28.8-29.2 KB forward only;
+# tests/test_cpu_surface.py holds the estimate to the real Plan.bytes), plus two slab scratch areas.
+PLAN_BYTES_PER_PIXEL_TRAIN = 60_500
+PLAN_BYTES_PER_PIXEL_EVAL = 29_300
+
+
+def plan_bytes_estimate(B: int, H: int, W: int, want_backward: bool = True) -> int:
+    """Upper estimate of the device memory one Plan(B, H, W) allocates (bytes)."""
+    per = PLAN_BYTES_PER_PIXEL_TRAIN if want_backward else PLAN_BYTES_PER_PIXEL_EVAL
+    return B * H * W * per + 2 * SCRATCH_FLOATS * 4 + (64 << 20)
+
+
+def device_bytes_available(device) -> int:
+    """Bytes a new plan can still get on `device`: free HBM plus what torch's caching allocator holds unused."""
+    free, _total = torch.cuda.mem_get_info(device)
+    return int(free + torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device))
+
+
 def hidden_of(c: int) -> int:
     return int(c * EXPANSION)
 
@@ -187,6 +206,8 @@ class Recorder:
         self.keep: List[object] = []  # ctypes structs / tensors referenced by raw pointer
         self.bytes = 0
         self.meta: Dict[int, list] = {id(self.fwd): [], id(self.bwd): []}
+        # per launch: the device kernel its arguments select ("uir_gemm<taps=1,pro=1,epi=0>" ...), for per-kernel reports
+        self.variants: Dict[int, list] = {id(self.fwd): [], id(self.bwd): []}
         self.scratch = self.alloc(scratch_floats)
         # lane 0 = the critical dX chain (current stream); lane 1 = weight-gradient work that nothing
         # on the chain waits for, run on a second HIP stream with its own slab scratch
@@ -211,12 +232,13 @@ class Recorder:
         return self.fp.gview(name)
 
     # --------------------------------------------------------------- recording
-    def _op(self, name: str, fn, *args, nbytes: int = 0, flops: int = 0):
+    def _op(self, name: str, fn, *args, nbytes: int = 0, flops: int = 0, variant: "str | None" = None):
         """Record one launch.  nbytes/flops = ALGORITHMIC HBM bytes / flops of that launch
         (each operand counted once; used by the roofline report, never by the launch)."""
         self.cur.append((fn, args, name))
         self.meta[id(self.cur)].append((name, fn.__name__, nbytes, flops))
         self.lanes[id(self.cur)].append(self.lane)
+        self.variants[id(self.cur)].append(variant or fn.__name__)
 
     class _Side:
         def __init__(self, rec):
@@ -252,12 +274,14 @@ class Recorder:
         self.cur.append((None, (), name))
         self.meta[id(self.cur)].append((name, "mark", 0, 0))
         self.lanes[id(self.cur)].append(3)
+        self.variants[id(self.cur)].append(None)
 
     def join(self, name: str = "join") -> None:
         """Mid-list join: the main lane waits for everything recorded so far on the side lane."""
         self.cur.append((None, (), name))
         self.meta[id(self.cur)].append((name, "join", 0, 0))
         self.lanes[id(self.cur)].append(2)
+        self.variants[id(self.cur)].append(None)
 
     def _slab(self) -> torch.Tensor:
         return self.scratch_side if self.lane in (1, 4) else self.scratch
@@ -463,7 +487,8 @@ class Recorder:
         nreal = n_grp[0] * (N // n_grp[1]) if n_grp[1] else N
         nb = 4 * rows * (K * (2 if pro == L.PRO_GATE else 1) + N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1)
                          + (N if R is not None else 0) + (N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1) if G is not None else 0))
-        self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps)
+        self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps,
+                 variant=f"uir_gemm<taps={taps},pro={pro},epi={epi}>" + ("[tap groups]" if taps == 9 and K > 80 else ""))
 
     def _chunks(self, M, ngroups, batches):
         nch = max(1, min(M // 256, _GRAM_WGS // max(1, ngroups * batches)))
@@ -538,7 +563,7 @@ class Recorder:
         self.keep.append(a)
         rows = M * batches
         self._op(name, lib.uir_gram, C.byref(a), nbytes=4 * rows * (N + K * (2 if pro_b == L.PRO_GATE else 1)),
-                 flops=2 * rows * N * K * taps)
+                 flops=2 * rows * N * K * taps, variant=f"uir_gram<taps={taps},pro_b={pro_b}>")
         if shared_slab is not None:
             return nch
         sp = slab_t.data_ptr()
@@ -1275,7 +1300,7 @@ class Plan(Recorder):
         the bandwidth idle.  Legal because every plan buffer is written exactly once per step."""
         if os.environ.get("UIR_DEFER", "0") != "1":      # opt-in: A/B measured +0.6 ms/step (contention moves to L1)
             return
-        lanes, meta = self.lanes[id(ops)], self.meta[id(ops)]
+        lanes, meta, variants = self.lanes[id(ops)], self.meta[id(ops)], self.variants[id(ops)]
         names = [o[2] for o in ops]
         if marker not in names:
             return
@@ -1286,6 +1311,7 @@ class Plan(Recorder):
         ops[:] = [ops[i] for i in order]
         lanes[:] = [lanes[i] for i in order]
         meta[:] = [meta[i] for i in order]
+        variants[:] = [variants[i] for i in order]
 
     # ------------------------------------------------------------------- run
     def forward(self, x_nchw: torch.Tensor, serial: bool = False) -> torch.Tensor:

@@ -78,13 +78,20 @@ def loss_grad(pred: torch.Tensor, truth: torch.Tensor, gscale: torch.Tensor, kin
 
 
 class FusedClipAdam:
-    """clip_grad_norm_(max_norm) + Adam(lr, betas=(0.9,0.999), eps=1e-8, no weight decay) - the step
-    tail of src/ModelTrainer.py:87-88,199 - as two kernels over the flat live-parameter buffer."""
+    """clip_grad_norm_(max_norm) + Adam(lr, betas=(0.9,0.999), eps=1e-8) - the step tail of
+    src/ModelTrainer.py:87-88,199 - as two kernels over the flat live-parameter buffer.
+    ``weight_decay > 0`` selects torch.optim.AdamW's decoupled decay (:201, default 0.01 there).
 
-    def __init__(self, flat, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0):
+    Per-step scalars {lr, bc1, bc2, gscale} travel BY VALUE in the launch arguments (copied at launch time), so a host
+    that runs many steps ahead of the GPU can never change a queued step.  Only hipGraph replay reads them from device
+    memory, where ``uir_adam_set_hyper`` (again by-value arguments, stream ordered) stores them before each replay."""
+
+    def __init__(self, flat, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0,
+                 weight_decay: float = 0.0):
         self.flat = flat
         self.n = flat.n_live
-        self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
+        self.lr, self.betas, self.eps, self.max_norm, self.weight_decay = lr, betas, eps, max_norm, weight_decay
+        self.initial_lr = lr
         dev = flat.device
         self.m = torch.zeros(self.n, dtype=torch.float32, device=dev)
         self.v = torch.zeros(self.n, dtype=torch.float32, device=dev)
@@ -93,43 +100,99 @@ class FusedClipAdam:
         self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.t = 0
         self.args = L.AdamArgs()
-        # per-step scalars {lr, bc1, bc2, gscale} live in device memory (written from a pinned host
-        # staging buffer on the launch stream), so the kernels can be captured once in a hipGraph
-        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)
-        self._hyper_host = torch.zeros(4, dtype=torch.float32).pin_memory() if dev.type == "cuda" else torch.zeros(4)
+        self.hyper = torch.zeros(4, dtype=torch.float32, device=dev)      # hipGraph replay only
 
-    def advance(self, lr: float | None = None, grad_scale: float = 1.0) -> None:
-        """Host side of one step: bump the step count and stage this step's scalars (async H2D, 16 bytes)."""
+    def _scalars(self, lr, grad_scale):
         if lr is not None:
             self.lr = lr
         self.t += 1
-        h = self._hyper_host
-        h[0], h[1], h[2], h[3] = self.lr, 1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t, grad_scale
-        self.hyper.copy_(h, non_blocking=True)
+        return self.lr, 1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t, grad_scale
 
-    def launch(self) -> torch.Tensor:
-        """Device side: sum of squares -> reduce -> clip + Adam.  Capturable (no host values baked in)."""
+    def advance(self, lr: float | None = None, grad_scale: float = 1.0) -> None:
+        """hipGraph path: bump the step count and store this step's scalars in `hyper` with a by-value launch on the
+        current stream (ordered before the replay that follows; no host buffer the host could overwrite early)."""
+        lr_, bc1, bc2, gs = self._scalars(lr, grad_scale)
+        L.check(lib.uir_adam_set_hyper(self.hyper.data_ptr(), lr_, bc1, bc2, gs, _stream()), "uir_adam_set_hyper")
+
+    def launch(self, scalars=None, grad: "torch.Tensor | None" = None) -> torch.Tensor:
+        """Device side: sum of squares -> reduce -> clip + Adam.  scalars=None: read them from `hyper` (capturable).
+        grad: the flat gradient to consume (default: the plan's bucket; the micro-batch accumulator otherwise)."""
         fp, st = self.flat, _stream()
-        L.check(lib.uir_sumsq_partials(fp.grad.data_ptr(), self.n, self.slab.data_ptr(), _SUMSQ_BLOCKS, st), "uir_sumsq_partials")
+        grad = fp.grad if grad is None else grad
+        L.check(lib.uir_sumsq_partials(grad.data_ptr(), self.n, self.slab.data_ptr(), _SUMSQ_BLOCKS, st), "uir_sumsq_partials")
         L.check(lib.uir_reduce_slab(self.slab.data_ptr(), _SUMSQ_BLOCKS, 1, self.sumsq.data_ptr(), 1, 0, 1.0, st), "uir_reduce_slab")
         a = self.args
-        a.p, a.g, a.m, a.v = fp.flat.data_ptr(), fp.grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
+        a.p, a.g, a.m, a.v = fp.flat.data_ptr(), grad.data_ptr(), self.m.data_ptr(), self.v.data_ptr()
         a.sumsq, a.norm_out, a.n = self.sumsq.data_ptr(), self.norm.data_ptr(), self.n
-        a.hyper = self.hyper.data_ptr()
         a.beta1, a.beta2, a.eps, a.max_norm = self.betas[0], self.betas[1], self.eps, self.max_norm
+        a.weight_decay = self.weight_decay
+        if scalars is None:
+            a.hyper = self.hyper.data_ptr()
+            a.lr, a.bc1, a.bc2, a.gscale = self.lr, 1.0, 1.0, 1.0
+        else:
+            a.hyper = None
+            a.lr, a.bc1, a.bc2, a.gscale = scalars
         L.check(lib.uir_clip_adam_step(C.byref(a), st), "uir_clip_adam_step")
         return self.norm
 
-    def step(self, lr: float | None = None, grad_scale: float = 1.0) -> torch.Tensor:
-        """Returns the (pre-clip) total gradient norm as a device tensor [1]; no host sync."""
-        self.advance(lr, grad_scale)
-        return self.launch()
+    def step(self, lr: float | None = None, grad_scale: float = 1.0, grad: "torch.Tensor | None" = None) -> torch.Tensor:
+        """Returns the (pre-clip) total gradient norm as a device tensor [1]; no host sync, no host staging."""
+        return self.launch(self._scalars(lr, grad_scale), grad)
 
+
+def flat_accumulate(src: torch.Tensor, dst: torch.Tensor, n: int, accumulate: bool) -> None:
+    """dst[:n] (+)= src[:n] over flat fp32 buffers (n a multiple of 4), through uir_copy_cols on rows of 4 floats."""
+    assert n % 4 == 0 and src.numel() >= n and dst.numel() >= n
+    L.check(lib.uir_copy_cols(src.data_ptr(), 4, 0, dst.data_ptr(), 4, 0, n // 4, 4, 1 if accumulate else 0, _stream()), "uir_copy_cols")
+
+
+def axpy_scalar(dst: torch.Tensor, src: torch.Tensor, w: float, first: bool) -> None:
+    """dst[0] = (0 if first else dst[0]) + w * src[0] on the device (loss bookkeeping of micro-batched steps)."""
+    if first:
+        torch.mul(src.reshape(1), w, out=dst)
+    else:
+        dst.add_(src.reshape(1), alpha=w)
+
+    # ---- checkpoint: the layout torch.optim.Adam.state_dict() writes (src/ModelTrainer.py:176-181 saves exactly that) ----
     def state_dict(self):
-        return {"step": self.t, "exp_avg": self.m, "exp_avg_sq": self.v, "lr": self.lr}
+        """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} with i = index in model.parameters()
+        order; the 63 parameters the reference never uses have no state entry (torch creates state lazily, on first grad)."""
+        fp = self.flat
+        state = {}
+        for i, name in enumerate(fp.shapes):
+            o, n = fp.slots[name]
+            if o + n > self.n or self.t == 0:
+                continue
+            state[i] = {"step": torch.tensor(float(self.t)),
+                        "exp_avg": self.m[o:o + n].view(fp.shapes[name]).clone(),
+                        "exp_avg_sq": self.v[o:o + n].view(fp.shapes[name]).clone()}
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay,
+                 "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+                 "fused": None, "decoupled_weight_decay": self.weight_decay > 0, "initial_lr": self.initial_lr,
+                 "params": list(range(len(fp.shapes)))}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.t = int(sd["step"])
-        self.m.copy_(sd["exp_avg"])
-        self.v.copy_(sd["exp_avg_sq"])
-        self.lr = float(sd.get("lr", self.lr))
+        fp = self.flat
+        if "param_groups" not in sd:
+            raise ValueError("expected a torch.optim.Adam-style state_dict ({'state', 'param_groups'})")
+        g = sd["param_groups"][0]
+        self.lr = float(g["lr"])
+        self.initial_lr = float(g.get("initial_lr", self.initial_lr))
+        self.betas, self.eps = tuple(g.get("betas", self.betas)), float(g.get("eps", self.eps))
+        self.weight_decay = float(g.get("weight_decay", self.weight_decay))
+        names = list(fp.shapes)
+        steps = set()
+        self.m.zero_()
+        self.v.zero_()
+        for i, st in sd["state"].items():
+            name = names[int(i)]
+            o, n = fp.slots[name]
+            if o + n > self.n:
+                raise ValueError(f"optimizer state for '{name}', which is not on the live path")
+            self.m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a state this optimizer can resume")
+        self.t = steps.pop() if steps else 0

@@ -16,21 +16,28 @@ from . import parallel
 
 
 class TrainStep:
-    def __init__(self, model, loss_name: str = "L1", lr: float = 3e-4, max_norm: float = 1.0, process_group=None):
+    def __init__(self, model, loss_name: str = "L1", lr: float = 3e-4, max_norm: float = 1.0, process_group=None,
+                 weight_decay: float = 0.0, micro_batch: "int | None" = None):
         if loss_name not in L.LOSS_KINDS:
             raise ValueError(f"Unsupported loss: {loss_name}")
         self.model = model
         self.kind = L.LOSS_KINDS[loss_name]
         self.flat = model.flat_params()
-        self.opt = ops.FusedClipAdam(self.flat, lr=lr, max_norm=max_norm)
+        if self.flat.device.type == "cuda" and self.flat.device.index not in (None, torch.cuda.current_device()):
+            # every launch goes to torch.cuda.current_stream(): it must belong to the device that owns the buffers
+            raise RuntimeError(f"model lives on {self.flat.device} but the current device is cuda:{torch.cuda.current_device()}: "
+                               "call torch.cuda.set_device(...) first (one process per GPU)")
+        self.opt = ops.FusedClipAdam(self.flat, lr=lr, max_norm=max_norm, weight_decay=weight_decay)
         self.pg = process_group
+        self.micro_batch = micro_batch          # None: the largest divisor of the batch whose plan fits in HBM
+        self._acc = None                        # flat gradient accumulator of micro-batched steps
         self.world = parallel.world_size(process_group)
         if self.world > 1:
             parallel.broadcast_flat_params(self.flat.flat, process_group)
         self._one = torch.ones(1, dtype=torch.float32, device=self.flat.device)
         self._graph_on = os.environ.get("UIR_GRAPH", "0") == "1" and self.flat.device.type == "cuda"
         # opt-in (UIR_GRAPH=1): on ROCm 7.2 replaying the ~1400-node graph measured 62.2 ms/step vs 57.9 eager
-        self._graphs, self._eager_calls = {}, {}
+        # a captured graph is stored ON its plan (plan._graph): it can never outlive the buffers it was recorded over
         # optional (UIR_MAIN_HIPRIO=1): critical chain on a high-priority stream; measured neutral on MI355X
         self._hp = None
         if self.flat.device.type == "cuda" and os.environ.get("UIR_MAIN_HIPRIO", "0") == "1":
@@ -51,15 +58,76 @@ class TrainStep:
             return res, norm
         return self._step(raw, ref, lr)
 
+    # ---- memory: one plan keeps every activation of its batch (62 GB at 16 x 256 x 256); the reference's own default run
+    # (16 x 1024 x 1024, DataLoader.py:14) is ~1 TB that way, so large batches run as micro-batches of the SAME plan with
+    # gradient accumulation.  Exact: the network has no cross-sample statistics (no BatchNorm; attention is per sample).
+    def micro_batch_for(self, B: int, H: int, W: int) -> int:
+        if self.micro_batch is not None:
+            mb = int(self.micro_batch)
+            if mb < 1 or B % mb:
+                raise ValueError(f"micro_batch={mb} must divide the batch size {B}")
+            return mb
+        if self.flat.device.type != "cuda":
+            return B
+        from .engine import plan_bytes_estimate, device_bytes_available
+        shape_cached = any(k[:3] == (B, H, W) and k[3] for k in self.model._plans)
+        if shape_cached:
+            return B
+        have = device_bytes_available(self.flat.device) + sum(p.bytes for p in self.model._plans.values())
+        for mb in sorted((d for d in range(1, B + 1) if B % d == 0), reverse=True):
+            if plan_bytes_estimate(mb, H, W) <= 0.95 * have:
+                return mb
+        raise RuntimeError(f"SpectralTransformer(HIP): even one {H}x{W} image needs ~{plan_bytes_estimate(1, H, W) / 2**30:.1f} GiB "
+                           f"of HBM for its train plan ({have / 2**30:.1f} GiB available)")
+
+    def check_memory(self, B: int, H: int, W: int) -> int:
+        """Fail before the first batch, with the numbers, if the configuration cannot run; returns the micro-batch."""
+        mb = self.micro_batch_for(B, H, W)
+        if mb != B and parallel.rank() == 0:
+            print(f"[uir] batch {B} at {H}x{W} runs as {B // mb} micro-batches of {mb} (gradient accumulation; one plan keeps "
+                  f"every activation of its micro-batch in HBM)")
+        return mb
+
+    def _weights(self, mb: int, B: int) -> float:
+        """Weight of one micro-batch's loss in the full-batch loss: b/B for plain means; (b/B)^2 for the losses the
+        reference also divides by the batch size (L1, L2, L1withColor / L1ColorLum: src/Losses/losses.py:57,65,74,78)."""
+        f = mb / B
+        return f * f if self.kind in (0, 1, 4) else f
+
+    def _step_micro(self, raw, ref, lr, mb):
+        B = raw.shape[0]
+        n = self.flat.n_live
+        if self._acc is None:
+            self._acc = torch.zeros(self.flat.total, dtype=torch.float32, device=self.flat.device)
+            self._wdev = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
+            self._loss_acc = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
+        w = self._weights(mb, B)
+        self._wdev.fill_(w)
+        for i, o in enumerate(range(0, B, mb)):
+            r, f = raw[o:o + mb], ref[o:o + mb]
+            plan = self.model._plan_for(r)
+            out = plan.forward(r)
+            res = ops.loss_sums(out, f, self.kind)
+            dout = ops.loss_grad(out, f, self._wdev, self.kind)
+            plan.backward(dout)
+            self.model._fwd_serial += 1
+            ops.flat_accumulate(self.flat.grad, self._acc, n, accumulate=i > 0)
+            ops.axpy_scalar(self._loss_acc, res[0], w, first=i == 0)
+        scale = parallel.allreduce_flat_grads(self._acc, n, self.pg)
+        norm = self.opt.step(lr=lr, grad_scale=scale, grad=self._acc)
+        return self._loss_acc[0].clone(), norm[0]
+
     def _step(self, raw, ref, lr):
+        mb = self.micro_batch_for(raw.shape[0], raw.shape[2], raw.shape[3])
+        if mb != raw.shape[0]:
+            return self._step_micro(raw, ref, lr, mb)
         plan = self.model._plan_for(raw)
-        key = (id(plan), tuple(raw.shape))
         if self._graph_on and self.world == 1:
-            g = self._graphs.get(key)
+            g = getattr(plan, "_graph", None)
             if g is None:
-                self._eager_calls[key] = self._eager_calls.get(key, 0) + 1
-                if self._eager_calls[key] > 2:          # plan, streams and allocator pools are warm: capture
-                    g = self._capture(plan, ref, key)
+                plan._eager_calls = getattr(plan, "_eager_calls", 0) + 1
+                if plan._eager_calls > 2:               # plan, streams and allocator pools are warm: capture
+                    g = self._capture(plan, ref)
             if g is not None:
                 plan.in_nchw.copy_(raw)
                 g["ref"].copy_(ref)
@@ -77,7 +145,7 @@ class TrainStep:
         norm = self.opt.step(lr=lr, grad_scale=scale)
         return res[0], norm[0]
 
-    def _capture(self, plan, ref, key):
+    def _capture(self, plan, ref):
         """Capture forward list + loss + backward list (+ their side/bulk stream forks and joins) + clip/Adam
         into ONE hipGraph.  Inputs are the plan's static image buffer and a static reference buffer; the
         per-step scalars come from `opt.hyper` in device memory."""
@@ -99,17 +167,50 @@ class TrainStep:
             self._graph_on = False
             torch.cuda.synchronize()
             return None
-        self._graphs[key] = g
+        plan._graph = g
         return g
 
     @torch.no_grad()
     def evaluate(self, raw: torch.Tensor, ref: torch.Tensor, with_ssim: bool = False):
         """Validation batch (src/ModelTrainer.py:134-158): -> (loss, PSNR) device tensors, plus torchSSIM(ref, out)
-        (:23-24,149) with ``with_ssim`` (needs H, W >= 11)."""
-        plan = self.model._plan_for(raw)
-        out = plan.forward(raw)
-        self.model._fwd_serial += 1
-        res = ops.loss_sums(out, ref, self.kind)
-        if with_ssim:
-            return res[0], res[1], ops.ssim(ref, out, data_range=1.0)
-        return res[0], res[1]
+        (:23-24,149) with ``with_ssim`` (needs H, W >= 11).  A batch whose forward plan does not fit in HBM is evaluated in
+        micro-batches: the loss recombines as in training, PSNR through the mean squared error it is a function of
+        (20 log10(1/rmse) over the whole batch, :17-21), SSIM is a mean over samples."""
+        B = raw.shape[0]
+        mb = self._eval_micro_batch(B, raw.shape[2], raw.shape[3])
+        if mb == B:
+            plan = self.model._plan_for(raw, want_backward=False)
+            out = plan.forward(raw)
+            self.model._fwd_serial += 1
+            res = ops.loss_sums(out, ref, self.kind)
+            if with_ssim:
+                return res[0], res[1], ops.ssim(ref, out, data_range=1.0)
+            return res[0], res[1]
+        w = self._weights(mb, B)
+        loss = mse = ss = None
+        for o in range(0, B, mb):
+            r, f = raw[o:o + mb], ref[o:o + mb]
+            plan = self.model._plan_for(r, want_backward=False)
+            out = plan.forward(r)
+            self.model._fwd_serial += 1
+            res = ops.loss_sums(out, f, self.kind)
+            l_i, m_i = res[0] * w, torch.pow(10.0, -res[1] / 10.0) * (mb / B)
+            loss = l_i if loss is None else loss + l_i
+            mse = m_i if mse is None else mse + m_i
+            if with_ssim:
+                s_i = ops.ssim(f, out, data_range=1.0) * (mb / B)
+                ss = s_i if ss is None else ss + s_i
+        psnr = -10.0 * torch.log10(mse)
+        return (loss, psnr, ss) if with_ssim else (loss, psnr)
+
+    def _eval_micro_batch(self, B: int, H: int, W: int) -> int:
+        if self.micro_batch is not None:
+            return min(B, self.micro_batch) if B % min(B, self.micro_batch) == 0 else 1
+        if self.flat.device.type != "cuda" or any(k[:3] == (B, H, W) for k in self.model._plans):
+            return B
+        from .engine import plan_bytes_estimate, device_bytes_available
+        have = device_bytes_available(self.flat.device) + sum(p.bytes for p in self.model._plans.values())
+        for mb in sorted((d for d in range(1, B + 1) if B % d == 0), reverse=True):
+            if any(k[:3] == (mb, H, W) for k in self.model._plans) or plan_bytes_estimate(mb, H, W, False) <= 0.95 * have:
+                return mb
+        raise RuntimeError(f"SpectralTransformer(HIP): one {H}x{W} image does not fit in HBM for evaluation")
