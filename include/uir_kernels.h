@@ -439,6 +439,11 @@ typedef struct UirSsimArgs {
 long uir_ssim_nblocks(int planes, int H, int W);
 int uir_ssim_partials(const UirSsimArgs* args, void* stream);
 
+/* Host helpers: a stream restricted to n_enabled compute units (hipExtStreamCreateWithCUMask; the driver spreads the enabled
+ * bits over the 8 XCDs), for the weight-gradient lane of the train step.  The caller owns the stream. */
+int uir_stream_create_cu_masked(int n_enabled, void** out_stream);
+int uir_stream_destroy(void* stream);
+
 /* library self-description (used by the loader test) */
 const char* uir_version(void);
 /* Layout of an argument struct as the compiler built it: out[0] = sizeof, out[1 + i] = offsetof(field i) in declaration

@@ -579,8 +579,9 @@ def test_adamw_and_optimizer_state_layout():
     assert len(sd["state"]) == 380 and all(set(v) == {"step", "exp_avg", "exp_avg_sq"} for v in sd["state"].values())
     cpu_params = [torch.nn.Parameter(p.detach().cpu().clone()) for p in model.parameters()]
     topt = torch.optim.Adam(cpu_params, lr=3e-4)
-    topt.load_state_dict({"state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
-                          "param_groups": sd["param_groups"]})
+    import copy
+    topt.load_state_dict(copy.deepcopy({"state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                                        "param_groups": sd["param_groups"]}))      # torch steps `step` in place: give it its own copy
     # one more step on both sides from the same (clipped) gradients
     names = [n for n, _ in model.named_parameters()]
     Pn = {n: p.detach().cpu().clone() for n, p in model.named_parameters()}

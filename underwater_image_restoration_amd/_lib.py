@@ -194,6 +194,8 @@ SIGNATURES = {
     "uir_resize_norm_u8": [C.POINTER(ResizeArgs), fp],
     "uir_ssim_nblocks": [i32, i32, i32],                 # host helper: returns a count (c_long), not a status
     "uir_ssim_partials": [C.POINTER(SsimArgs), fp],
+    "uir_stream_create_cu_masked": [i32, C.POINTER(C.c_void_p)],
+    "uir_stream_destroy": [fp],
     "uir_abi_layout": [C.c_char_p, C.POINTER(C.c_long), i32],   # host helper: returns a count (c_long)
 }
 

@@ -78,4 +78,28 @@ extern "C" int uir_adam_set_hyper(float* hyper, float lr, float bc1, float bc2, 
   return uir_launch_status();
 }
 
+// A HIP stream whose kernels may only occupy `n_enabled` of the device's compute units (bits spread over the XCDs by the
+// driver's symmetric mapping).  Used for the weight-gradient ("bulk") lane: its HBM-bound Gram kernels keep filling the
+// bandwidth the latency-bound deep-level chain kernels leave idle, without taking every CU from them.
+extern "C" int uir_stream_create_cu_masked(int n_enabled, void** out) {
+  UIR_REQUIRE(out && n_enabled > 0);
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return UIR_ELAUNCH;
+  const int total = prop.multiProcessorCount;
+  if (n_enabled > total) n_enabled = total;
+  uint32_t mask[16] = {0};
+  UIR_REQUIRE(total <= 512);
+  for (int i = 0; i < n_enabled; ++i) mask[i >> 5] |= 1u << (i & 31);
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)((total + 31) / 32), mask) != hipSuccess) return UIR_ELAUNCH;
+  *out = st;
+  return UIR_OK;
+}
+
+extern "C" int uir_stream_destroy(void* stream) {
+  UIR_REQUIRE(stream);
+  return hipStreamDestroy(static_cast<hipStream_t>(stream)) == hipSuccess ? UIR_OK : UIR_ELAUNCH;
+}
+
 extern "C" const char* uir_version(void) { return "uir_hip 0.1 gfx950"; }

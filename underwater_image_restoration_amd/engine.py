@@ -329,7 +329,14 @@ class Recorder:
         side = self._side_stream
         st1 = C.c_void_p(side.cuda_stream)
         if self._bulk_stream is None:
-            self._bulk_stream = torch.cuda.Stream(device=self.dev)
+            ncu = int(os.environ.get("UIR_BULK_CUS", "0"))
+            if ncu > 0:      # weight-gradient lane confined to `ncu` compute units (uir_stream_create_cu_masked)
+                h = C.c_void_p()
+                L.check(lib.uir_stream_create_cu_masked(ncu, C.byref(h)), "uir_stream_create_cu_masked")
+                self._bulk_stream = torch.cuda.ExternalStream(h.value, device=self.dev)
+                self._bulk_handle = h          # lives as long as the plan
+            else:
+                self._bulk_stream = torch.cuda.Stream(device=self.dev)
         bulk = self._bulk_stream
         st4 = C.c_void_p(bulk.cuda_stream)
         nev = 0

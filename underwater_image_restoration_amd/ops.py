@@ -139,20 +139,6 @@ class FusedClipAdam:
         """Returns the (pre-clip) total gradient norm as a device tensor [1]; no host sync, no host staging."""
         return self.launch(self._scalars(lr, grad_scale), grad)
 
-
-def flat_accumulate(src: torch.Tensor, dst: torch.Tensor, n: int, accumulate: bool) -> None:
-    """dst[:n] (+)= src[:n] over flat fp32 buffers (n a multiple of 4), through uir_copy_cols on rows of 4 floats."""
-    assert n % 4 == 0 and src.numel() >= n and dst.numel() >= n
-    L.check(lib.uir_copy_cols(src.data_ptr(), 4, 0, dst.data_ptr(), 4, 0, n // 4, 4, 1 if accumulate else 0, _stream()), "uir_copy_cols")
-
-
-def axpy_scalar(dst: torch.Tensor, src: torch.Tensor, w: float, first: bool) -> None:
-    """dst[0] = (0 if first else dst[0]) + w * src[0] on the device (loss bookkeeping of micro-batched steps)."""
-    if first:
-        torch.mul(src.reshape(1), w, out=dst)
-    else:
-        dst.add_(src.reshape(1), alpha=w)
-
     # ---- checkpoint: the layout torch.optim.Adam.state_dict() writes (src/ModelTrainer.py:176-181 saves exactly that) ----
     def state_dict(self):
         """{'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} with i = index in model.parameters()
@@ -196,3 +182,17 @@ def axpy_scalar(dst: torch.Tensor, src: torch.Tensor, w: float, first: bool) -> 
         if len(steps) > 1:
             raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a state this optimizer can resume")
         self.t = steps.pop() if steps else 0
+
+
+def flat_accumulate(src: torch.Tensor, dst: torch.Tensor, n: int, accumulate: bool) -> None:
+    """dst[:n] (+)= src[:n] over flat fp32 buffers (n a multiple of 4), through uir_copy_cols on rows of 4 floats."""
+    assert n % 4 == 0 and src.numel() >= n and dst.numel() >= n
+    L.check(lib.uir_copy_cols(src.data_ptr(), 4, 0, dst.data_ptr(), 4, 0, n // 4, 4, 1 if accumulate else 0, _stream()), "uir_copy_cols")
+
+
+def axpy_scalar(dst: torch.Tensor, src: torch.Tensor, w: float, first: bool) -> None:
+    """dst[0] = (0 if first else dst[0]) + w * src[0] on the device (loss bookkeeping of micro-batched steps)."""
+    if first:
+        torch.mul(src.reshape(1), w, out=dst)
+    else:
+        dst.add_(src.reshape(1), alpha=w)
