@@ -439,6 +439,24 @@ typedef struct UirSsimArgs {
 long uir_ssim_nblocks(int planes, int H, int W);
 int uir_ssim_partials(const UirSsimArgs* args, void* stream);
 
+/* ---------------------------------------------------------------- uir_uiqm */
+/* Evaluation metric UIQM.  Replaces getUIQM of uqim_utils.py:176-190 (with _uicm :36-48, mu_a :10-28,
+ * s_a :30-34, sobel :50-54, eme :57-86, _uism :88-113, _uiconm :141-174) for a batch of N images of one size, HWC, either
+ * float32 (the reference's x.astype(np.float32)) or the uint8 bytes eval.ipynb reads (cv2.imread + resize).
+ * out[n] = (uiqm, uicm, uism, uiconm) in double, like the reference's Python floats.  flags[n] != 0: a window's max/min ratio
+ * was <= 0 (signed image) - the reference raises ValueError("math domain error") there; the host mirror does the same.
+ * work: uir_uiqm_work_doubles(N, H, W) doubles of scratch (-1 if H or W < 10, one 10 x 10 window). */
+typedef struct UirUiqmArgs {
+  const float* img_f32;
+  const unsigned char* img_u8;   /* exactly one of img_f32 / img_u8 is non-NULL */
+  double* work;
+  double* out;                   /* [N][4] */
+  int* flags;                    /* [N] */
+  int N, H, W;
+} UirUiqmArgs;
+long uir_uiqm_work_doubles(int N, int H, int W);
+int uir_uiqm(const UirUiqmArgs* args, void* stream);
+
 /* Host helpers: a stream restricted to n_enabled compute units (hipExtStreamCreateWithCUMask; the driver spreads the enabled
  * bits over the 8 XCDs), for the weight-gradient lane of the train step.  The caller owns the stream. */
 int uir_stream_create_cu_masked(int n_enabled, void** out_stream);

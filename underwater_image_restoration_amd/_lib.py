@@ -142,6 +142,11 @@ class SsimArgs(C.Structure):
                 ("C1", C.c_float), ("C2", C.c_float), ("win", C.c_float * 11)]
 
 
+class UiqmArgs(C.Structure):
+    _fields_ = [("img_f32", fp), ("img_u8", fp), ("work", fp), ("out", fp), ("flags", fp),
+                ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
+
+
 class AdamArgs(C.Structure):
     _fields_ = [("p", fp), ("g", fp), ("m", fp), ("v", fp), ("sumsq", fp), ("norm_out", fp), ("hyper", fp), ("n", C.c_long),
                 ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
@@ -194,6 +199,8 @@ SIGNATURES = {
     "uir_resize_norm_u8": [C.POINTER(ResizeArgs), fp],
     "uir_ssim_nblocks": [i32, i32, i32],                 # host helper: returns a count (c_long), not a status
     "uir_ssim_partials": [C.POINTER(SsimArgs), fp],
+    "uir_uiqm_work_doubles": [i32, i32, i32],            # host helper: returns a count (c_long) or -1
+    "uir_uiqm": [C.POINTER(UiqmArgs), fp],
     "uir_stream_create_cu_masked": [i32, C.POINTER(C.c_void_p)],
     "uir_stream_destroy": [fp],
     "uir_abi_layout": [C.c_char_p, C.POINTER(C.c_long), i32],   # host helper: returns a count (c_long)
@@ -204,7 +211,8 @@ STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirDwArgs": DwArgs
            "UirDwBwdArgs": DwBwdArgs, "UirGdfnFwdArgs": GdfnFwdArgs, "UirQkvFwdArgs": QkvFwdArgs,
            "UirAttnvFwdArgs": AttnvFwdArgs, "UirGdfnBwdArgs": GdfnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
            "UirAttnFwdArgs": AttnFwdArgs, "UirAttnBwdArgs": AttnBwdArgs, "UirDftArgs": DftArgs, "UirDft2Args": Dft2Args,
-           "UirAdamArgs": AdamArgs, "UirResizeImage": ResizeImage, "UirResizeArgs": ResizeArgs, "UirSsimArgs": SsimArgs}
+           "UirAdamArgs": AdamArgs, "UirResizeImage": ResizeImage, "UirResizeArgs": ResizeArgs, "UirSsimArgs": SsimArgs,
+           "UirUiqmArgs": UiqmArgs}
 
 
 def abi_layout(lib_, cname: str):
@@ -239,6 +247,7 @@ def _load() -> C.CDLL:
         fn.restype = C.c_int
     lib.uir_ssim_nblocks.restype = C.c_long
     lib.uir_abi_layout.restype = C.c_long
+    lib.uir_uiqm_work_doubles.restype = C.c_long
     _verify_structs(lib)
     lib.uir_version.restype = C.c_char_p
     lib.uir_version.argtypes = []
