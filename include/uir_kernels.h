@@ -104,6 +104,21 @@ int uir_gram(const UirGramArgs* args, void* stream);
 /* out[i] = (accumulate ? out[i] : 0) + scale * sum_c slab[c*stride + i], i < n */
 int uir_reduce_slab(const float* slab, int nchunks, long stride, float* out, long n, int accumulate,
                     float scale, void* stream);
+/* The same reduction for MANY tensors in one launch: descs[d] (device memory) describes one uir_reduce_slab call,
+ * first_block[d] (device, ascending, first_block[0] = 0) is the first workgroup of descriptor d (64 outputs per workgroup),
+ * total_blocks their sum.  Summation order per output is exactly uir_reduce_slab's: results are bit-identical.  The train
+ * step batches the weight-gradient reductions of one network stage this way (~380 launches per step -> ~75). */
+typedef struct UirReduceDesc {
+  const float* slab;
+  float* out;
+  long stride;
+  long n;
+  int nchunks;
+  int accumulate;
+  float scale;
+  int _pad;
+} UirReduceDesc;
+int uir_reduce_slab_batch(const UirReduceDesc* descs_dev, const int* first_block_dev, int ndesc, int total_blocks, void* stream);
 
 /* -------------------------------------------------------------- uir_dwconv */
 /* Depthwise 3x3, pad 1, no bias, on HWC rows; C (padded) % 4 == 0.  flip=1 gives the

@@ -142,6 +142,11 @@ class SsimArgs(C.Structure):
                 ("C1", C.c_float), ("C2", C.c_float), ("win", C.c_float * 11)]
 
 
+class ReduceDesc(C.Structure):
+    _fields_ = [("slab", fp), ("out", fp), ("stride", C.c_long), ("n", C.c_long), ("nchunks", C.c_int),
+                ("accumulate", C.c_int), ("scale", C.c_float), ("_pad", C.c_int)]
+
+
 class UiqmArgs(C.Structure):
     _fields_ = [("img_f32", fp), ("img_u8", fp), ("work", fp), ("out", fp), ("flags", fp),
                 ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
@@ -161,6 +166,7 @@ SIGNATURES = {
     "uir_gemm": [C.POINTER(GemmArgs), fp],
     "uir_gram": [C.POINTER(GramArgs), fp],
     "uir_reduce_slab": [fp, i32, i64, fp, i64, i32, f32, fp],
+    "uir_reduce_slab_batch": [fp, fp, i32, i32, fp],
     "uir_dwconv": [C.POINTER(DwArgs), fp],
     "uir_dwconv_wgrad": [C.POINTER(DwWgradArgs), fp],
     "uir_dwconv_bwd_fused": [C.POINTER(DwBwdArgs), fp],
@@ -212,7 +218,7 @@ STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirDwArgs": DwArgs
            "UirAttnvFwdArgs": AttnvFwdArgs, "UirGdfnBwdArgs": GdfnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
            "UirAttnFwdArgs": AttnFwdArgs, "UirAttnBwdArgs": AttnBwdArgs, "UirDftArgs": DftArgs, "UirDft2Args": Dft2Args,
            "UirAdamArgs": AdamArgs, "UirResizeImage": ResizeImage, "UirResizeArgs": ResizeArgs, "UirSsimArgs": SsimArgs,
-           "UirUiqmArgs": UiqmArgs}
+           "UirUiqmArgs": UiqmArgs, "UirReduceDesc": ReduceDesc}
 
 
 def abi_layout(lib_, cname: str):

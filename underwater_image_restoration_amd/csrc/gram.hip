@@ -514,6 +514,50 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
   return uir_launch_status();
 }
 
+// Many slab reductions in ONE launch (the ~380 per-tensor launches of a train step were the #1 symbol of a rocprofv3 trace:
+// 7-30 us each for kilobytes of data).  Every workgroup finds its descriptor by binary search over the block prefix table
+// and then runs exactly uir_reduce_slab_kernel's summation (same 64-output blocks, same chunk split over the 4 waves, same
+// combination order): results are bit-identical to the per-tensor launches.
+__global__ __launch_bounds__(256) void uir_reduce_slab_batch_kernel(const UirReduceDesc* __restrict__ descs,
+                                                                    const int* __restrict__ first_block, int ndesc) {
+  __shared__ float red[4][64];
+  int lo = 0, hi = ndesc - 1;
+  const int bid = blockIdx.x;
+  while (lo < hi) {                       // last d with first_block[d] <= bid
+    const int mid = (lo + hi + 1) >> 1;
+    if (first_block[mid] <= bid) lo = mid; else hi = mid - 1;
+  }
+  const UirReduceDesc d = descs[lo];
+  const int lane = threadIdx.x & 63, cl = threadIdx.x >> 6;
+  const long i = (long)(bid - first_block[lo]) * 64 + lane;
+  float s[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) s[k] = 0.f;
+  if (i < d.n) {
+    const float* p = d.slab + i;
+    int c = cl;
+    for (; c + 28 < d.nchunks; c += 32) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += p[(long)(c + 4 * k) * d.stride];
+    }
+    for (; c < d.nchunks; c += 4) s[0] += p[(long)c * d.stride];
+  }
+  red[cl][lane] = ((s[0] + s[1]) + (s[2] + s[3])) + ((s[4] + s[5]) + (s[6] + s[7]));
+  __syncthreads();
+  if (cl == 0 && i < d.n) {
+    const float t = ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane])) * d.scale;
+    d.out[i] = d.accumulate ? d.out[i] + t : t;
+  }
+}
+
+extern "C" int uir_reduce_slab_batch(const UirReduceDesc* descs_dev, const int* first_block_dev, int ndesc, int total_blocks,
+                                     void* stream) {
+  UIR_REQUIRE(descs_dev && first_block_dev && ndesc > 0 && total_blocks > 0);
+  hipLaunchKernelGGL(uir_reduce_slab_batch_kernel, dim3((unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     descs_dev, first_block_dev, ndesc);
+  return uir_launch_status();
+}
+
 extern "C" int uir_reduce_slab(const float* slab, int nchunks, long stride, float* out, long n, int accumulate,
                                float scale, void* stream) {
   UIR_REQUIRE(slab && out && nchunks > 0 && n > 0);

@@ -138,6 +138,7 @@ def twiddles(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     return _TWIDDLE_CACHE[key]
 
 
+_RED_BATCH = os.environ.get("UIR_RED_BATCH", "1") == "1"       # one batched slab-reduction launch per stage on the bulk lane
 _GRAM_WGS = int(os.environ.get("UIR_GRAM_WGS", 1024))           # workgroups (= partial rows x column groups) per Gram launch; tuning aid
 GEMM_SLAB_ROWS = int(os.environ.get("UIR_GEMM_ROWS", 512))      # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
 _DFT2_CACHE: dict = {}
@@ -217,6 +218,7 @@ class Recorder:
         self._side_stream = None
         self._bulk_stream = None
         self._events: List[object] = []
+        self._pending: List[tuple] = []        # bulk-lane slab reductions waiting for the stage's batched launch
 
     # ------------------------------------------------------------------ memory
     def alloc(self, *shape, zero: bool = False) -> torch.Tensor:
@@ -239,6 +241,41 @@ class Recorder:
         self.meta[id(self.cur)].append((name, fn.__name__, nbytes, flops))
         self.lanes[id(self.cur)].append(self.lane)
         self.variants[id(self.cur)].append(variant or fn.__name__)
+
+    # ---- slab reductions.  On the weight-gradient (bulk) lane nothing reads a reduced gradient before the optimizer, so they
+    # are collected and issued as ONE uir_reduce_slab_batch launch per network stage (flushed at every stage mark): ~380
+    # launches of 7-30 us per step become ~75.  Bit-identical to the per-tensor launches (same summation order).
+    def _batching(self) -> bool:
+        return _RED_BATCH and self.lane == 4
+
+    def _reduce(self, name: str, src: int, rows: int, stride: int, dst: int, n: int, immediate: bool = False):
+        if self._batching() and not immediate:
+            self._pending.append((name, int(src), int(rows), int(stride), int(dst), int(n)))
+            return
+        self._op(name, lib.uir_reduce_slab, src, rows, stride, dst, n, 0, 1.0)
+
+    def _private_slab(self, floats: int) -> torch.Tensor:
+        """Partial-slab buffer that stays intact until the stage's batched reduction has run (the shared scratch of a lane
+        is overwritten by that lane's next kernel)."""
+        return self.alloc(floats)
+
+    def flush_reductions(self, tag: str = "stage") -> None:
+        if not self._pending:
+            return
+        pend, self._pending = self._pending, []
+        descs = (L.ReduceDesc * len(pend))()
+        first, tot = [], 0
+        for d, (name, src, rows, stride, dst, n) in zip(descs, pend):
+            d.slab, d.out, d.stride, d.n, d.nchunks, d.accumulate, d.scale = src, dst, stride, n, rows, 0, 1.0
+            first.append(tot)
+            tot += (n + 63) // 64
+        dt = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
+        ft = torch.tensor(first, dtype=torch.int32).to(self.dev)
+        self.keep += [dt, ft]
+        prev, self.lane = self.lane, 4
+        self._op(tag + ".red_batch", lib.uir_reduce_slab_batch, dt.data_ptr(), ft.data_ptr(), len(pend), tot,
+                 variant=f"uir_reduce_slab_batch")
+        self.lane = prev
 
     class _Side:
         def __init__(self, rec):
@@ -271,6 +308,7 @@ class Recorder:
     def mark(self, name: str) -> None:
         """Stage marker: `run(ops, marks=[])` records an event on the main stream here (timeline of
         the real, overlapped execution; nothing is serialised)."""
+        self.flush_reductions(name)
         self.cur.append((None, (), name))
         self.meta[id(self.cur)].append((name, "mark", 0, 0))
         self.lanes[id(self.cur)].append(3)
@@ -302,6 +340,8 @@ class Recorder:
         order): the reference schedule the overlapped execution must reproduce bit for bit.
         timed=[]: a HIP event pair is recorded around every launch ON THE STREAM IT IS LAUNCHED ON, in the real
         three-lane execution (nothing is serialised across lanes); entries (op index, start event, end event)."""
+        if self._pending:              # a recorder driven op by op (unit tests): nothing may stay un-reduced
+            self.flush_reductions("auto")
         if self.dev.type != "cuda":
             st = C.c_void_p(0)
             for fn, args, name in ops:
@@ -550,8 +590,8 @@ class Recorder:
             a.slab = slab_t.data_ptr() + 4 * col0
             a.slab_stride = cstride
             self._hold(slab_t)
-        elif own_slab:     # private partial-slab buffer: the launch may run on a lane that shares its scratch with another
-            slab_t = self.alloc(nch * stride)
+        elif own_slab or self._batching():     # private partial-slab buffer: the launch may run on a lane that shares its
+            slab_t = self.alloc(nch * stride)  # scratch with another / its reduction is deferred to the stage's batch
             a.slab = _ptr(slab_t)
         else:
             slab_t = self._slab()
@@ -578,13 +618,13 @@ class Recorder:
             # `fused_out` = [out | sq_a | sq_b | cs_a] contiguous, i.e. exactly one slab row: one reduction launch
             assert fused_out.numel() == stride and fused_out.data_ptr() == out.data_ptr()
             self._hold(fused_out)
-            self._op(name + ".red", lib.uir_reduce_slab, sp, nch, stride, _ptr(fused_out), stride, 0, 1.0)
+            self._reduce(name + ".red", sp, nch, stride, _ptr(fused_out), stride)
             return
-        self._op(name + ".red", lib.uir_reduce_slab, sp, nch, stride, _ptr(out), out_elems, 0, 1.0)
+        self._reduce(name + ".red", sp, nch, stride, _ptr(out), out_elems)
         for key, off in (("sq_a", a.sq_a_off), ("sq_b", a.sq_b_off), ("cs_a", a.cs_a_off)):
             if key in extras:
                 t = extras[key]
-                self._op(name + ".red." + key, lib.uir_reduce_slab, sp + 4 * off, nch, stride, _ptr(t), t.numel(), 0, 1.0)
+                self._reduce(name + ".red." + key, sp + 4 * off, nch, stride, _ptr(t), t.numel())
 
     def dwconv(self, name, X, Wt, Y, *, C_, dims, grp=(0, 0), flip=0):
         self._hold(X, Wt, Y)
@@ -675,10 +715,10 @@ class Recorder:
                   ln=(gamma, None), R=dRes, dw_slab=slab)
         with self.bulk():
             if dbeta.data_ptr() == dgamma.data_ptr() + 4 * C_:
-                self._op(name + ".dgb", lib.uir_reduce_slab, _ptr(slab), GEMM_SLAB_ROWS, 2 * C_, _ptr(dgamma), 2 * C_, 0, 1.0)
+                self._reduce(name + ".dgb", _ptr(slab), GEMM_SLAB_ROWS, 2 * C_, _ptr(dgamma), 2 * C_)
             else:
-                self._op(name + ".dg", lib.uir_reduce_slab, _ptr(slab), GEMM_SLAB_ROWS, 2 * C_, _ptr(dgamma), C_, 0, 1.0)
-                self._op(name + ".db", lib.uir_reduce_slab, slab.data_ptr() + 4 * C_, GEMM_SLAB_ROWS, 2 * C_, _ptr(dbeta), C_, 0, 1.0)
+                self._reduce(name + ".dg", _ptr(slab), GEMM_SLAB_ROWS, 2 * C_, _ptr(dgamma), C_)
+                self._reduce(name + ".db", slab.data_ptr() + 4 * C_, GEMM_SLAB_ROWS, 2 * C_, _ptr(dbeta), C_)
 
     def dwconv_wgrad(self, name, dY, X, out, *, C_, creal, dims, grp=(0, 0)):
         self._hold(dY, X, out)
@@ -694,11 +734,13 @@ class Recorder:
         items = dims[0] * ((dims[1] + hs - 1) // hs) * ((dims[2] + 3) // 4)   # (strip of hs rows, run of 4 pixels)
         ny = 256 // (C_ // 4)
         a.nblocks = max(1, min(2048, items // max(1, ny)))
-        assert a.nblocks * creal * 9 <= self._slab().numel()
+        slab = self._private_slab(a.nblocks * creal * 9) if self._batching() else self._slab()
+        a.slab = _ptr(slab)
+        assert a.nblocks * creal * 9 <= slab.numel()
         self.keep.append(a)
         rows = dims[0] * dims[1] * dims[2]
         self._op(name, lib.uir_dwconv_wgrad, C.byref(a), nbytes=8 * rows * C_, flops=18 * rows * C_)
-        self._op(name + ".red", lib.uir_reduce_slab, _ptr(self._slab()), a.nblocks, creal * 9, _ptr(out), creal * 9, 0, 1.0)
+        self._reduce(name + ".red", _ptr(slab), a.nblocks, creal * 9, _ptr(out), creal * 9)
 
     def dwconv_bwd(self, name, dY, X, Wt, dX, dW, *, C_, creal, dims, grp=(0, 0)):
         """Fused input-gradient + weight-gradient of a depthwise 3x3 (dY read once)."""
@@ -735,7 +777,7 @@ class Recorder:
         rows = dims[0] * dims[1] * dims[2]
         self._op(name, lib.uir_dwconv_bwd_fused, C.byref(a), nbytes=12 * rows * C_, flops=36 * rows * C_)
         with self.bulk():
-            self._op(name + ".red", lib.uir_reduce_slab, _ptr(slab), a.nblocks, creal * 9, _ptr(dW), creal * 9, 0, 1.0)
+            self._reduce(name + ".red", _ptr(slab), a.nblocks, creal * 9, _ptr(dW), creal * 9)
 
     def ln_bwd(self, name, dT, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_):
         self._hold(dT, X, stats, gamma, dRes, dX, dgamma, dbeta)
@@ -754,18 +796,19 @@ class Recorder:
         sp = slab.data_ptr()
         with self.bulk():
             if dbeta.data_ptr() == dgamma.data_ptr() + 4 * C_:      # weight | bias adjacent in the flat gradient bucket
-                self._op(name + ".dgb", lib.uir_reduce_slab, sp, a.nblocks, 2 * C_, _ptr(dgamma), 2 * C_, 0, 1.0)
+                self._reduce(name + ".dgb", sp, a.nblocks, 2 * C_, _ptr(dgamma), 2 * C_)
             else:
-                self._op(name + ".dg", lib.uir_reduce_slab, sp, a.nblocks, 2 * C_, _ptr(dgamma), C_, 0, 1.0)
-                self._op(name + ".db", lib.uir_reduce_slab, sp + 4 * C_, a.nblocks, 2 * C_, _ptr(dbeta), C_, 0, 1.0)
+                self._reduce(name + ".dg", sp, a.nblocks, 2 * C_, _ptr(dgamma), C_)
+                self._reduce(name + ".db", sp + 4 * C_, a.nblocks, 2 * C_, _ptr(dbeta), C_)
 
     def colsum(self, name, src, col, C_, out):
         self._hold(src, out)
         M = src.shape[0]
         slots = 256 // C_
         nb = max(1, min(512, M // max(1, slots * 8)))
-        self._op(name, lib.uir_colsum_partials, _ptr(src), _ld(src), col, M, C_, _ptr(self._slab()), nb, nbytes=4 * M * C_)
-        self._op(name + ".red", lib.uir_reduce_slab, _ptr(self._slab()), nb, C_, _ptr(out), C_, 0, 1.0)
+        slab = self._private_slab(nb * C_) if self._batching() else self._slab()
+        self._op(name, lib.uir_colsum_partials, _ptr(src), _ld(src), col, M, C_, _ptr(slab), nb, nbytes=4 * M * C_)
+        self._reduce(name + ".red", _ptr(slab), nb, C_, _ptr(out), C_)
 
     def copy_cols(self, name, src, scol, dst, dcol, C_, accumulate=0):
         self._hold(src, dst)
@@ -938,8 +981,8 @@ class Plan(Recorder):
                     self.gemm(n + ".dgate+dWout", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp),
                               epi=L.EPI_GATE_BWD_DW, G=g, g_off=hp, dw_slab=dws)
                     with self.bulk():
-                        self._op(n + ".dWout.red", lib.uir_reduce_slab, _ptr(dws), GEMM_SLAB_ROWS, C_ * h,
-                                 _ptr(Gr(f"{pfx}.ffn.project_out.weight")), C_ * h, 0, 1.0)
+                        self._reduce(n + ".dWout.red", _ptr(dws), GEMM_SLAB_ROWS, C_ * h,
+                                 _ptr(Gr(f"{pfx}.ffn.project_out.weight")), C_ * h)
                 else:
                     self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g,
                               g_off=hp)
@@ -990,7 +1033,7 @@ class Plan(Recorder):
                                 shared_slab=(slab_ab, nab, 2 * nab))
                 assert got == nch_ab
                 if not inred:
-                    self._op(n + ".dWAB.red", lib.uir_reduce_slab, _ptr(slab_ab), nch_ab, 2 * nab, _ptr(dWB), 2 * nab, 0, 1.0)
+                    self._reduce(n + ".dWAB.red", _ptr(slab_ab), nch_ab, 2 * nab, _ptr(dWB), 2 * nab)
             self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
             if side_grams:
                 self.join(n + ".dWAB.join")
@@ -1004,9 +1047,9 @@ class Plan(Recorder):
             self.keep.append(ba)
             self._op(n + ".attn_bwd", lib.uir_attn_bwd, C.byref(ba))
             with self.bulk():
-                self._op(n + ".dWof", lib.uir_reduce_slab, _ptr(dWofb), B, C_ * C_, _ptr(Gr(f"{a}.project_outf.weight")), C_ * C_, 0, 1.0)
-                self._op(n + ".dPsum", lib.uir_reduce_slab, _ptr(dPb), B, C_ * C_, _ptr(dPsum), C_ * C_, 0, 1.0)
-                self._op(n + ".dT", lib.uir_reduce_slab, _ptr(dTb), B, heads, _ptr(Gr(f"{a}.temperature")), heads, 0, 1.0)
+                self._reduce(n + ".dWof", _ptr(dWofb), B, C_ * C_, _ptr(Gr(f"{a}.project_outf.weight")), C_ * C_)
+                self._reduce(n + ".dPsum", _ptr(dPb), B, C_ * C_, _ptr(dPsum), C_ * C_, immediate=True)   # consumed by the next two launches
+                self._reduce(n + ".dT", _ptr(dTb), B, heads, _ptr(Gr(f"{a}.temperature")), heads)
                 # P = Wkvf @ Wo  ->  dWkvf = dP Wo^T ; dWo = Wkvf^T dP
                 self.gemm(n + ".dWkvf", dPsum, Wo, Gr(f"{a}.kv.weight").view(2 * C_, C_)[C_:], N=C_, K=C_, w_sn=C_, w_sk=1)
                 self.gram(n + ".dWo", Wkvf, dPsum, Gr(f"{a}.project_out.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
