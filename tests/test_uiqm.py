@@ -95,8 +95,11 @@ def test_hip_uiqm_batch_and_sizes():
         got = metrics.uiqm(torch.from_numpy(imgs).cuda()).cpu().numpy()
         for i in range(n):
             want = U.get_uiqm(imgs[i])
+            # up to ~2^23 / 255 pixels every float32 partial sum of the reference's trimmed mean is exact; beyond (1024 x 1024)
+            # ITS left-to-right float32 sum rounds (measured 6e-8 relative on UICM) while the kernel sums in double
+            tol = 1e-9 if h * w <= 65536 else 1e-6
             for a, b in zip(got[i], want):
-                assert _close(float(a), float(b), rel=1e-9, abs_=1e-9), (n, h, w, i, got[i], want)
+                assert _close(float(a), float(b), rel=tol, abs_=tol), (n, h, w, i, got[i], want)
     with pytest.raises(ValueError):
         metrics.uiqm(torch.zeros(1, 9, 40, 3).cuda())           # smaller than one window
     with pytest.raises(ValueError):
