@@ -454,6 +454,31 @@ typedef struct UirSsimArgs {
 long uir_ssim_nblocks(int planes, int H, int W);
 int uir_ssim_partials(const UirSsimArgs* args, void* stream);
 
+/* ---------------------------------------------------------------- uir_frfn */
+/* FRFN feed-forward of the NewBigFRFNModel family: src/model/block.py:249-282.  Its contractions are
+ * uir_gemm (Linear C -> 8C with bias :252,273; Linear 4C -> C with bias :254,281; partial 3x3 convolution on the first C/4
+ * channels :259,267-269), uir_dwconv / uir_dwconv_bwd_fused (depthwise 3x3 of the x1 half :253,277) and uir_gram /
+ * uir_colsum_partials (weight and bias gradients).  These four are the element-wise steps in between:
+ *   t = GELU(pre)                    (:252 nn.GELU after linear1)          uir_frfn_act_fwd / _bwd (dpre = dt * GELU'(pre))
+ *   g = GELU(u + bias) * v           (:253 conv bias + nn.GELU, :279 gate) uir_frfn_gate_fwd / _bwd (dU, dV from dG)
+ * rows = tokens (pixels), `cols` / `hid` channels (multiples of 4), ld* = row strides in floats. */
+int uir_frfn_act_fwd(const float* pre, int ldp, float* t, int ldt, long M, int cols, void* stream);
+int uir_frfn_act_bwd(const float* pre, int ldp, const float* dt, int ldt, float* dpre, int ldo, long M, int cols, void* stream);
+typedef struct UirFrfnGateArgs {
+  const float* U;      /* depthwise-conv output without bias [M][ldu] */
+  const float* bias;   /* [hid] */
+  const float* V;      /* the x2 half [M][ldv] */
+  float* G;            /* forward: out [M][ldg] */
+  const float* dG;     /* backward: gradient of G [M][ldg] */
+  float* dU;
+  float* dV;
+  long M;
+  int hid;
+  int ldu, ldv, ldg, lddu, lddv;
+} UirFrfnGateArgs;
+int uir_frfn_gate_fwd(const UirFrfnGateArgs* args, void* stream);
+int uir_frfn_gate_bwd(const UirFrfnGateArgs* args, void* stream);
+
 /* ---------------------------------------------------------------- uir_uiqm */
 /* Evaluation metric UIQM.  Replaces getUIQM of uqim_utils.py:176-190 (with _uicm :36-48, mu_a :10-28,
  * s_a :30-34, sobel :50-54, eme :57-86, _uism :88-113, _uiconm :141-174) for a batch of N images of one size, HWC, either

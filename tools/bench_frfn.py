@@ -1,0 +1,91 @@
+"""Measure the FRFN feed-forward (reference src/model/block.py:249-282) at BASELINE configs[3]'s first
+level: dim 32, hidden 128, 256 x 256 tokens, batch 8 per GPU, forward + backward (input and all parameter gradients).
+ONE JSON line:
+
+  value        images/s (forward + backward of one FRFN over a resident batch)
+  roofline     both ceilings, as the path is composed of HBM-bound passes today:
+               bound "mfma": algorithmic FLOPs (3 x the forward contractions) / time vs the dense fp32 MFMA peak 157.3 TFLOP/s
+               hbm_frac:     the launch plan's algorithmic bytes (every operand of every launch once) / time vs 8 TB/s
+  cpu_baseline the oracle (torch CPU restatement pinned to the reference's own outputs) on the host cores, bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from underwater_image_restoration_amd.model.block import FRFN  # noqa: E402
+
+MFMA_F32_PEAK = 157.3e12
+HBM_PEAK = 8.0e12
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dim", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+    dim, hid, B, S = args.dim, 4 * args.dim, args.batch, args.size
+    torch.manual_seed(0)
+    m = FRFN(dim, hid).cuda()
+    x = torch.randn(B, S * S, dim, device="cuda")
+    dy = torch.randn(B, S * S, dim, device="cuda")
+    plan = m._plan_for(x)
+    xr, dyr = x.view(-1, dim), dy.view(-1, dim)
+
+    def step():
+        plan.forward(xr)
+        plan.backward(dyr)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(args.steps):
+        step()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / args.steps
+    M = B * S * S
+    c4 = dim // 4
+    fwd_flops = M * (2 * dim * 2 * hid + 2 * hid * dim + 2 * 9 * c4 * c4 + 18 * hid)
+    flops = 3 * fwd_flops
+    rows = plan.run_timed(plan.fwd) + plan.run_timed(plan.bwd)
+    top = sorted(rows, key=lambda r: -r[4])[:6]
+    line = {"metric": "FRFN forward+backward images/s (dim 32, hidden 128, 256x256 tokens, bs 8)", "value": B / (ms * 1e-3),
+            "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"FRFN(dim={dim}, hidden={hid}) fwd+bwd on {B} x {S}x{S} tokens"},
+            "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
+                         "frac": flops / (ms * 1e-3) / MFMA_F32_PEAK, "traffic": None,
+                         "hbm_achieved_GBps": plan.alg_bytes() / (ms * 1e-3) / 1e9, "hbm_frac": plan.alg_bytes() / (ms * 1e-3) / HBM_PEAK,
+                         "plan_algorithmic_bytes": plan.alg_bytes(), "algorithmic_flops": flops,
+                         "note": "composed of separate HBM-bound launches this round: the HBM fraction is the binding one",
+                         "top_launches_serial_ms": [[r[0], r[1], round(r[4], 4)] for r in top]}}
+    if not args.no_cpu:
+        from oracle import frfn_ref as R
+        cores = min(16, len(os.sched_getaffinity(0)))
+        torch.set_num_threads(cores)
+        P = {n: p.detach().cpu() for n, p in m.named_parameters()}
+        xb, pb = x[:1].cpu(), dy[:1].cpu()
+        R.out_and_grads(xb, P, pb)
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < 10.0:
+            R.out_and_grads(xb, P, pb)
+            k += 1
+        dt = (time.perf_counter() - t0) / k
+        line["cpu_baseline"] = {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port",
+                                "sample": f"{k} forward+backward passes of one {S}x{S} image through oracle/frfn_ref.py (torch CPU, {cores} threads)"}
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -147,6 +147,11 @@ class ReduceDesc(C.Structure):
                 ("accumulate", C.c_int), ("scale", C.c_float), ("_pad", C.c_int)]
 
 
+class FrfnGateArgs(C.Structure):
+    _fields_ = [("U", fp), ("bias", fp), ("V", fp), ("G", fp), ("dG", fp), ("dU", fp), ("dV", fp), ("M", C.c_long),
+                ("hid", C.c_int), ("ldu", C.c_int), ("ldv", C.c_int), ("ldg", C.c_int), ("lddu", C.c_int), ("lddv", C.c_int)]
+
+
 class UiqmArgs(C.Structure):
     _fields_ = [("img_f32", fp), ("img_u8", fp), ("work", fp), ("out", fp), ("flags", fp),
                 ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
@@ -205,6 +210,10 @@ SIGNATURES = {
     "uir_resize_norm_u8": [C.POINTER(ResizeArgs), fp],
     "uir_ssim_nblocks": [i32, i32, i32],                 # host helper: returns a count (c_long), not a status
     "uir_ssim_partials": [C.POINTER(SsimArgs), fp],
+    "uir_frfn_act_fwd": [fp, i32, fp, i32, i64, i32, fp],
+    "uir_frfn_act_bwd": [fp, i32, fp, i32, fp, i32, i64, i32, fp],
+    "uir_frfn_gate_fwd": [C.POINTER(FrfnGateArgs), fp],
+    "uir_frfn_gate_bwd": [C.POINTER(FrfnGateArgs), fp],
     "uir_uiqm_work_doubles": [i32, i32, i32],            # host helper: returns a count (c_long) or -1
     "uir_uiqm": [C.POINTER(UiqmArgs), fp],
     "uir_stream_create_cu_masked": [i32, C.POINTER(C.c_void_p)],
@@ -218,7 +227,8 @@ STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirDwArgs": DwArgs
            "UirAttnvFwdArgs": AttnvFwdArgs, "UirGdfnBwdArgs": GdfnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
            "UirAttnFwdArgs": AttnFwdArgs, "UirAttnBwdArgs": AttnBwdArgs, "UirDftArgs": DftArgs, "UirDft2Args": Dft2Args,
            "UirAdamArgs": AdamArgs, "UirResizeImage": ResizeImage, "UirResizeArgs": ResizeArgs, "UirSsimArgs": SsimArgs,
-           "UirUiqmArgs": UiqmArgs, "UirReduceDesc": ReduceDesc}
+           "UirUiqmArgs": UiqmArgs, "UirReduceDesc": ReduceDesc,
+           "UirFrfnGateArgs": FrfnGateArgs}
 
 
 def abi_layout(lib_, cname: str):

@@ -1,0 +1,123 @@
+// Element-wise pieces of the FRFN feed-forward of the NewBigFRFNModel family (reference
+// src/model/block.py:249-282).  The contractions of FRFN (Linear C -> 8C, Linear 4C -> C, the partial 3x3 convolution and
+// the depthwise 3x3) run on uir_gemm / uir_gram / uir_dwconv*; what is left between them is
+//   t        = GELU(pre)                          after linear1 (block.py:252: nn.Sequential(nn.Linear, nn.GELU()))
+//   g        = GELU(u + b_dw) * x2                u = depthwise 3x3 of the x1 half WITHOUT its bias (:253 has bias=True:
+//                                                 it is added here), x2 = the other half of t  (:276-279)
+// and their backward passes.  Rows are pixels (the reference's (B, L, C) token layout IS the HWC row layout), float4 along
+// the channels, one pass each: HBM-bound.  GELU = exact-erf form (uir_gelu_pair, |erf error| <= 1.5e-7).
+#include "uir_common.h"
+#include "../../include/uir_kernels.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void frfn_act_fwd_kernel(const float* __restrict__ pre, int ldp, float* __restrict__ t, int ldt,
+                                                           long M, int cols4) {
+  const long total = M * cols4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / cols4;
+    const int c = (int)(e - m * cols4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(pre + m * ldp + c);
+    float4 o;
+    o.x = uir_gelu(v.x); o.y = uir_gelu(v.y); o.z = uir_gelu(v.z); o.w = uir_gelu(v.w);
+    *reinterpret_cast<float4*>(t + m * ldt + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void frfn_act_bwd_kernel(const float* __restrict__ pre, int ldp, const float* __restrict__ dt,
+                                                           int ldt, float* __restrict__ dpre, int ldo, long M, int cols4) {
+  const long total = M * cols4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / cols4;
+    const int c = (int)(e - m * cols4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(pre + m * ldp + c);
+    const float4 d = *reinterpret_cast<const float4*>(dt + m * ldt + c);
+    float4 o;
+    o.x = d.x * uir_gelu_grad(v.x); o.y = d.y * uir_gelu_grad(v.y); o.z = d.z * uir_gelu_grad(v.z); o.w = d.w * uir_gelu_grad(v.w);
+    *reinterpret_cast<float4*>(dpre + m * ldo + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void frfn_gate_fwd_kernel(const UirFrfnGateArgs a) {
+  const int cols4 = a.hid / 4;
+  const long total = a.M * cols4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / cols4;
+    const int c = (int)(e - m * cols4) * 4;
+    const float4 u = *reinterpret_cast<const float4*>(a.U + m * a.ldu + c);
+    const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
+    const float4 v = *reinterpret_cast<const float4*>(a.V + m * a.ldv + c);
+    float4 o;
+    o.x = uir_gelu(u.x + b.x) * v.x; o.y = uir_gelu(u.y + b.y) * v.y; o.z = uir_gelu(u.z + b.z) * v.z; o.w = uir_gelu(u.w + b.w) * v.w;
+    *reinterpret_cast<float4*>(a.G + m * a.ldg + c) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void frfn_gate_bwd_kernel(const UirFrfnGateArgs a) {
+  const int cols4 = a.hid / 4;
+  const long total = a.M * cols4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / cols4;
+    const int c = (int)(e - m * cols4) * 4;
+    const float4 u = *reinterpret_cast<const float4*>(a.U + m * a.ldu + c);
+    const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
+    const float4 v = *reinterpret_cast<const float4*>(a.V + m * a.ldv + c);
+    const float4 d = *reinterpret_cast<const float4*>(a.dG + m * a.ldg + c);
+    float4 du, dv;
+    float g, dg;
+    uir_gelu_pair(u.x + b.x, g, dg); du.x = d.x * v.x * dg; dv.x = d.x * g;
+    uir_gelu_pair(u.y + b.y, g, dg); du.y = d.y * v.y * dg; dv.y = d.y * g;
+    uir_gelu_pair(u.z + b.z, g, dg); du.z = d.z * v.z * dg; dv.z = d.z * g;
+    uir_gelu_pair(u.w + b.w, g, dg); du.w = d.w * v.w * dg; dv.w = d.w * g;
+    *reinterpret_cast<float4*>(a.dU + m * a.lddu + c) = du;
+    *reinterpret_cast<float4*>(a.dV + m * a.lddv + c) = dv;
+  }
+}
+
+inline unsigned grid_for(long total) {
+  long g = (total + 255) / 256;
+  return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int uir_frfn_act_fwd(const float* pre, int ldp, float* t, int ldt, long M, int cols, void* stream) {
+  UIR_REQUIRE(pre && t && M > 0 && cols > 0 && (cols & 3) == 0 && ldp >= cols && ldt >= cols && (ldp & 3) == 0 && (ldt & 3) == 0);
+  UIR_REQUIRE(uir_aligned16(pre) && uir_aligned16(t));
+  hipLaunchKernelGGL(frfn_act_fwd_kernel, dim3(grid_for(M * (cols / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), pre, ldp, t, ldt,
+                     M, cols / 4);
+  return uir_launch_status();
+}
+
+extern "C" int uir_frfn_act_bwd(const float* pre, int ldp, const float* dt, int ldt, float* dpre, int ldo, long M, int cols,
+                                void* stream) {
+  UIR_REQUIRE(pre && dt && dpre && M > 0 && cols > 0 && (cols & 3) == 0 && ldp >= cols && ldt >= cols && ldo >= cols);
+  UIR_REQUIRE((ldp & 3) == 0 && (ldt & 3) == 0 && (ldo & 3) == 0 && uir_aligned16(pre) && uir_aligned16(dt) && uir_aligned16(dpre));
+  hipLaunchKernelGGL(frfn_act_bwd_kernel, dim3(grid_for(M * (cols / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), pre, ldp, dt,
+                     ldt, dpre, ldo, M, cols / 4);
+  return uir_launch_status();
+}
+
+static int frfn_gate_check(const UirFrfnGateArgs& a, bool bwd) {
+  UIR_REQUIRE(a.U && a.bias && a.V && a.M > 0 && a.hid > 0 && (a.hid & 3) == 0);
+  UIR_REQUIRE(a.ldu >= a.hid && a.ldv >= a.hid && a.ldg >= a.hid && ((a.ldu | a.ldv | a.ldg) & 3) == 0);
+  UIR_REQUIRE(uir_aligned16(a.U) && uir_aligned16(a.bias) && uir_aligned16(a.V));
+  if (!bwd) UIR_REQUIRE(a.G && uir_aligned16(a.G));
+  else UIR_REQUIRE(a.dG && a.dU && a.dV && a.lddu >= a.hid && a.lddv >= a.hid && ((a.lddu | a.lddv) & 3) == 0 &&
+                   uir_aligned16(a.dG) && uir_aligned16(a.dU) && uir_aligned16(a.dV));
+  return UIR_OK;
+}
+
+extern "C" int uir_frfn_gate_fwd(const UirFrfnGateArgs* p, void* stream) {
+  const UirFrfnGateArgs& a = *p;
+  if (int rc = frfn_gate_check(a, false)) return rc;
+  hipLaunchKernelGGL(frfn_gate_fwd_kernel, dim3(grid_for(a.M * (a.hid / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return uir_launch_status();
+}
+
+extern "C" int uir_frfn_gate_bwd(const UirFrfnGateArgs* p, void* stream) {
+  const UirFrfnGateArgs& a = *p;
+  if (int rc = frfn_gate_check(a, true)) return rc;
+  hipLaunchKernelGGL(frfn_gate_bwd_kernel, dim3(grid_for(a.M * (a.hid / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return uir_launch_status();
+}
