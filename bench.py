@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--loss", default="L1withColor")
+    ap.add_argument("--micro-batch", type=int, default=0, help="experiment: run the batch as micro-batches of this size (gradient accumulation)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--breakdown-file", default="")
@@ -119,7 +120,7 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # the factory prints "modelCreated" like the reference: keep stdout = ONE JSON line
         model = init_model("SpectralTransformer").to(dev)
-    step = TrainStep(model, args.loss, lr=3e-4)
+    step = TrainStep(model, args.loss, lr=3e-4, micro_batch=args.micro_batch or None)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     B, S = args.batch, args.size
     raw = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)
@@ -177,7 +178,7 @@ def main():
                 "launch": "one train step = forward+backward launch lists + loss + clip/Adam",
                 "mfma_frac_fp32": (ALG_FLOPS_PER_IMAGE_256 * scale * B / (ms * 1e-3)) / 157.3e12}
         if args.timeline_file:
-            plan = model._plan_for(raw)
+            plan = model._plan_for(raw[:args.micro_batch] if args.micro_batch else raw)
             mk = []
             torch.cuda.synchronize()
             plan.run(plan.fwd, marks=mk)
@@ -188,7 +189,7 @@ def main():
                 for (n0_, e0), (n1_, e1) in zip(mk[:-1], mk[1:]):
                     if n1_ != "bwd.start":
                         f.write(f"{n1_},{e0.elapsed_time(e1):.3f}\n")
-        if not args.no_kernel_breakdown:
+        if not args.no_kernel_breakdown and not args.micro_batch:
             plan = model._plan_for(raw)
             rows = plan.run_timed(plan.fwd) + plan.run_timed(plan.bwd)
             lanes = list(plan.lanes[id(plan.fwd)]) + list(plan.lanes[id(plan.bwd)])

@@ -532,22 +532,30 @@ def test_micro_batched_step_equals_full_batch():
     raw, ref = O.closed_form_images(4, 64, 61).to(DEV), O.closed_form_images(4, 64, 62).to(DEV)
     for loss in ("L1withColor", "charbonnier"):
         model, step = _fresh_step(loss)
-        for _ in range(2):
-            l0, n0 = step(raw, ref)
+        l0, n0 = step(raw, ref)
+        torch.cuda.synchronize()
+        g0 = model.flat_params().grad[:model.flat_params().n_live].clone()       # full-batch gradient of step 1
+        l0b, n0b = step(raw, ref)
         v0 = step.evaluate(raw, ref, with_ssim=True)
         torch.cuda.synchronize()
         for mb in (2, 1):
             model2, step2 = _fresh_step(loss, micro_batch=mb)
-            for _ in range(2):
-                l1, n1 = step2(raw, ref)
-            v1 = step2.evaluate(raw, ref, with_ssim=True)
+            l1, n1 = step2(raw, ref)
             torch.cuda.synchronize()
+            g1 = step2._acc[:g0.numel()].clone()                                   # accumulated micro-batch gradients of step 1
+            assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()), (loss, mb)
             assert abs(float(l1) - float(l0)) <= 2e-6 * abs(float(l0)), (loss, mb)
             assert abs(float(n1) - float(n0)) <= 2e-5 * abs(float(n0)), (loss, mb)
+            l1b, n1b = step2(raw, ref)
+            v1 = step2.evaluate(raw, ref, with_ssim=True)
+            torch.cuda.synchronize()
+            assert abs(float(l1b) - float(l0b)) <= 1e-5 * abs(float(l0b)), (loss, mb)
             d = float((model2.flat_params().flat - model.flat_params().flat).abs().max())
-            assert d <= 2e-6, (loss, mb, d)                       # two Adam steps of 3e-4; gradients agree to ~1e-5 relative
-            assert abs(float(v1[0]) - float(v0[0])) <= 1e-5 * abs(float(v0[0]))
-            assert abs(float(v1[1]) - float(v0[1])) <= 1e-3 and abs(float(v1[2]) - float(v0[2])) <= 1e-5
+            # Adam's update is lr * m / sqrt(v) ~ lr * sign(g) in the first steps: a gradient entry near zero can move its
+            # parameter by a visible fraction of lr (3e-4) under 1e-5-level gradient noise; everything else agrees to ~1e-7
+            assert d <= 1e-4, (loss, mb, d)
+            assert abs(float(v1[0]) - float(v0[0])) <= 1e-4 * abs(float(v0[0]))
+            assert abs(float(v1[1]) - float(v0[1])) <= 1e-2 and abs(float(v1[2]) - float(v0[2])) <= 1e-4
     with pytest.raises(ValueError):
         _fresh_step(micro_batch=3)[1](raw, ref)
 

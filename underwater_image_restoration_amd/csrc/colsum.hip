@@ -21,10 +21,54 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ s
     slab[(long)blockIdx.x * C + threadIdx.x] = t;
   }
 }
+// float4 variant (C, col, ld multiples of 4, 16-byte aligned base): lane = one float4 of a row, 256 / (C/4) rows per pass,
+// four independent row loads in flight per thread.  The scalar kernel above moved 1.3 TB/s at C = 256 (one 4-byte load in
+// flight per thread, 512 workgroups); the bias gradients of the FRFN path (256 columns over 0.5 M rows) made it the top kernel.
+__global__ __launch_bounds__(256) void colsum4_kernel(const float* __restrict__ src, int ld, int col, long M, int C4,
+                                                      float* __restrict__ slab) {
+  __shared__ float4 red[256];
+  const int slots = 256 / C4;
+  const int c = threadIdx.x % C4, slot = threadIdx.x / C4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (slot < slots) {
+    const long step = (long)gridDim.x * slots;
+    const float* p = src + col + 4 * c;
+    long m = (long)blockIdx.x * slots + slot;
+    for (; m + 3 * step < M; m += 4 * step) {
+      const float4 a = *reinterpret_cast<const float4*>(p + m * ld);
+      const float4 b = *reinterpret_cast<const float4*>(p + (m + step) * ld);
+      const float4 d = *reinterpret_cast<const float4*>(p + (m + 2 * step) * ld);
+      const float4 e = *reinterpret_cast<const float4*>(p + (m + 3 * step) * ld);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+      s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+      s2.x += d.x; s2.y += d.y; s2.z += d.z; s2.w += d.w;
+      s3.x += e.x; s3.y += e.y; s3.z += e.z; s3.w += e.w;
+    }
+    for (; m < M; m += step) {
+      const float4 a = *reinterpret_cast<const float4*>(p + m * ld);
+      s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+    }
+  }
+  red[threadIdx.x] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z),
+                                 (s0.w + s1.w) + (s2.w + s3.w));
+  __syncthreads();
+  if ((int)threadIdx.x < C4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < slots; ++k) {
+      const float4 v = red[k * C4 + threadIdx.x];
+      t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+    }
+    *reinterpret_cast<float4*>(slab + (long)blockIdx.x * (4 * C4) + 4 * threadIdx.x) = t;
+  }
+}
 }  // namespace
 
 extern "C" int uir_colsum_partials(const float* src, int ld, int col, long M, int C, float* slab, int nblocks, void* stream) {
   UIR_REQUIRE(src && slab && M > 0 && C > 0 && C <= 256 && ld >= col + C && nblocks > 0);
+  if (((C | col | ld) & 3) == 0 && uir_aligned16(src) && uir_aligned16(slab)) {
+    hipLaunchKernelGGL(colsum4_kernel, dim3(nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld, col, M, C / 4, slab);
+    return uir_launch_status();
+  }
   hipLaunchKernelGGL(colsum_kernel, dim3(nblocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, ld, col, M, C, slab);
   return uir_launch_status();
 }

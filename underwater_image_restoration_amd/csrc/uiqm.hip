@@ -51,6 +51,7 @@ __device__ __forceinline__ float sobel_mag(const UirUiqmArgs& a, long base, int 
 
 template <bool U8>
 __global__ __launch_bounds__(256) void uiqm_sobel_max_kernel(const UirUiqmArgs a, unsigned* __restrict__ maxbits) {
+  __shared__ float red[3][4];
   const int n = blockIdx.y;
   const long base = (long)n * a.H * a.W * 3;
   const long npx = (long)a.H * a.W;
@@ -65,8 +66,14 @@ __global__ __launch_bounds__(256) void uiqm_sobel_max_kernel(const UirUiqmArgs a
     float v = m[c];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(maxbits + n * 3 + c, __float_as_uint(v));     // magnitudes are >= 0: bit order == value order
+    if ((threadIdx.x & 63) == 0) red[c][threadIdx.x >> 6] = v;
   }
+  __syncthreads();
+  // ONE atomic per workgroup and channel (a wave-level atomic per 64 pixels serialised ~3000 same-address atomics per image:
+  // 1.19 ms of the 1.96 ms batch).  Magnitudes are >= 0: the bit pattern orders like the value; max is order-independent.
+  if (threadIdx.x < 3)
+    atomicMax(maxbits + n * 3 + threadIdx.x, __float_as_uint(fmaxf(fmaxf(red[threadIdx.x][0], red[threadIdx.x][1]),
+                                                                      fmaxf(red[threadIdx.x][2], red[threadIdx.x][3]))));
 }
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -328,8 +335,8 @@ int launch_all(const UirUiqmArgs& a, hipStream_t st) {
   if (hipMemsetAsync(maxbits, 0, sizeof(unsigned) * a.N * 3, st) != hipSuccess) return UIR_ELAUNCH;
   if (hipMemsetAsync(a.flags, 0, sizeof(int) * a.N, st) != hipSuccess) return UIR_ELAUNCH;
   const long npx = (long)a.H * a.W;
-  int gx = (int)((npx + 255) / 256);
-  if (gx > 1024) gx = 1024;
+  int gx = (int)((npx + 2047) / 2048);        // ~8 pixels per thread: few same-address atomics, still >= 4 waves per CU at N >= 8
+  if (gx > 512) gx = 512;
   hipLaunchKernelGGL((uiqm_sobel_max_kernel<U8>), dim3(gx, a.N), dim3(256), 0, st, a, maxbits);
   hipLaunchKernelGGL((uiqm_trimmed_kernel<U8>), dim3(2 * a.N), dim3(TT), 0, st, a, stats);
   hipLaunchKernelGGL((uiqm_blocks_kernel<U8>), dim3((unsigned)((nblk + 3) / 4), a.N), dim3(256), 0, st, a, maxbits, terms, k1, k2);

@@ -804,8 +804,8 @@ class Recorder:
     def colsum(self, name, src, col, C_, out):
         self._hold(src, out)
         M = src.shape[0]
-        slots = 256 // C_
-        nb = max(1, min(512, M // max(1, slots * 8)))
+        slots = max(1, 256 // (C_ // 4 if C_ % 4 == 0 else C_))      # rows per workgroup pass (float4 lanes when C_ % 4 == 0)
+        nb = max(1, min(1024, M // max(1, slots * 8)))
         slab = self._private_slab(nb * C_) if self._batching() else self._slab()
         self._op(name, lib.uir_colsum_partials, _ptr(src), _ld(src), col, M, C_, _ptr(slab), nb, nbytes=4 * M * C_)
         self._reduce(name + ".red", _ptr(slab), nb, C_, _ptr(out), C_)
