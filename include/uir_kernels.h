@@ -479,6 +479,20 @@ typedef struct UirFrfnGateArgs {
 int uir_frfn_gate_fwd(const UirFrfnGateArgs* args, void* stream);
 int uir_frfn_gate_bwd(const UirFrfnGateArgs* args, void* stream);
 
+/* ------------------------------------------------------------ token-axis ops */
+/* EncoderBlock of the NewBigFRFNModel family (src/model/model.py:57-92).
+ * uir_layernorm_fwd: nn.LayerNorm(C) over token rows (:62-63), Y = (X - mean) * rstd * gamma + beta, eps inside the root;
+ *   stats[m] = (mean, rstd) as uir_layernorm_bwd expects them; C in {16, 32, 64, 128}.
+ * fft.fftn(x, dim=(-2,-1)).real (:72) and fft.ifftn(...).real (:86) over the (L, C) axes of (B, L, C) tokens are one real-
+ * symmetric operator: two uir_gemm against cos / sin matrices for C, and for L = N1 * N2 a two-stage
+ * transform on uir_dft_axis with
+ *   uir_cmul_table      (re, im)[r][c] *= (tab_re, tab_im)[r % P]: the inter-stage twiddle exp(2 pi i k1 n2 / L), P = N1 * N2
+ *   uir_transpose_rows  dst[b][j][i][:] = scale * src[b][i][j][:]: frequency index k1 + N1 k2 back to natural token order. */
+int uir_layernorm_fwd(const float* X, int ldx, const float* gamma, const float* beta, float* Y, int ldy, float* stats, long M, int C,
+                      float eps, void* stream);
+int uir_cmul_table(float* re, float* im, const float* tab_re, const float* tab_im, long rows, long P, int C, void* stream);
+int uir_transpose_rows(const float* src, float* dst, int B, int N1, int N2, int C, float scale, void* stream);
+
 /* ---------------------------------------------------------------- uir_uiqm */
 /* Evaluation metric UIQM.  Replaces getUIQM of uqim_utils.py:176-190 (with _uicm :36-48, mu_a :10-28,
  * s_a :30-34, sobel :50-54, eme :57-86, _uism :88-113, _uiconm :141-174) for a batch of N images of one size, HWC, either

@@ -533,6 +533,7 @@ def test_micro_batched_step_equals_full_batch():
     for loss in ("L1withColor", "charbonnier"):
         model, step = _fresh_step(loss)
         l0, n0 = step(raw, ref)
+        l0, n0 = l0.clone(), n0.clone()            # the norm is a view of the optimizer's persistent buffer: the next step rewrites it
         torch.cuda.synchronize()
         g0 = model.flat_params().grad[:model.flat_params().n_live].clone()       # full-batch gradient of step 1
         l0b, n0b = step(raw, ref)
@@ -541,6 +542,7 @@ def test_micro_batched_step_equals_full_batch():
         for mb in (2, 1):
             model2, step2 = _fresh_step(loss, micro_batch=mb)
             l1, n1 = step2(raw, ref)
+            l1, n1 = l1.clone(), n1.clone()
             torch.cuda.synchronize()
             g1 = step2._acc[:g0.numel()].clone()                                   # accumulated micro-batch gradients of step 1
             assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max()), (loss, mb)

@@ -1,0 +1,121 @@
+// Token-axis pieces of the NewBigFRFNModel EncoderBlock (reference src/model/model.py:57-92):
+//   norm1(x)                                   nn.LayerNorm over C on (B, L, C) tokens  (:63)      uir_layernorm_fwd
+//   fft.fftn(x, dim=(-2, -1)).real             a 2-D DFT over (L, C) - NOT a spatial fft2 (:72)    } Re(sum x e^{i(a+b)}) =
+//   fft.ifftn(y, dim=(-2, -1)).real            the same operator / (L*C) on real input  (:86)       } C_L x C_C - S_L x S_C
+// The C axis (32..128) is a pair of uir_gemm calls against cos / sin matrices; the L axis (L = H*W up to 65 536) is a
+// two-stage Cooley-Tukey transform, L = N1*N2, on uir_dft_axis (MFMA contractions against host-built fp64 tables):
+//   stage A over n1 (stride N2)  ->  uir_cmul_table: A[k1][n2] *= exp(2 pi i k1 n2 / L)  ->  stage B over n2  ->
+//   uir_transpose_rows: frequency k = k1 + N1 k2 back to natural token order.
+// The operator is real-symmetric, so its backward pass is the operator itself.
+#include "uir_common.h"
+#include "../../include/uir_kernels.h"
+
+namespace {
+
+template <int L>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ Y, int ldy,
+                                                     float* __restrict__ stats, long M, float eps) {
+  constexpr int ROWS = 256 / L;
+  const int li = threadIdx.x % L, rl = threadIdx.x / L;
+  const float4 g = *reinterpret_cast<const float4*>(gamma + 4 * li);
+  const float4 b = *reinterpret_cast<const float4*>(beta + 4 * li);
+  const float invc = 1.0f / (float)(4 * L);
+  for (long m0 = (long)blockIdx.x * ROWS; m0 < M; m0 += (long)gridDim.x * ROWS) {
+    const long m = m0 + rl;
+    const bool ok = m < M;
+    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ok) x = *reinterpret_cast<const float4*>(X + m * ldx + 4 * li);
+    float s = (x.x + x.y) + (x.z + x.w);
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s * invc;
+    const float d0 = x.x - mean, d1 = x.y - mean, d2 = x.z - mean, d3 = x.w - mean;
+    float q = (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+#pragma unroll
+    for (int o = L / 2; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q * invc + eps);
+    if (ok) {
+      float4 y;
+      y.x = fmaf(d0 * rstd, g.x, b.x); y.y = fmaf(d1 * rstd, g.y, b.y); y.z = fmaf(d2 * rstd, g.z, b.z); y.w = fmaf(d3 * rstd, g.w, b.w);
+      *reinterpret_cast<float4*>(Y + m * ldy + 4 * li) = y;
+      if (li == 0 && stats) *reinterpret_cast<float2*>(stats + 2 * m) = make_float2(mean, rstd);
+    }
+  }
+}
+
+// (re, im)[b][p][c] *= (tr, ti)[p]  for p < P tokens, c < C channels (float4 along c)
+__global__ __launch_bounds__(256) void cmul_table_kernel(float* __restrict__ re, float* __restrict__ im, const float* __restrict__ tr,
+                                                         const float* __restrict__ ti, long rows, long P, int C4) {
+  const long total = rows * C4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long r = e / C4;
+    const long p = r % P;
+    const float wr = tr[p], wi = ti[p];
+    float4 a = reinterpret_cast<float4*>(re)[e], b = reinterpret_cast<float4*>(im)[e];
+    float4 oa, ob;
+    oa.x = a.x * wr - b.x * wi; ob.x = a.x * wi + b.x * wr;
+    oa.y = a.y * wr - b.y * wi; ob.y = a.y * wi + b.y * wr;
+    oa.z = a.z * wr - b.z * wi; ob.z = a.z * wi + b.z * wr;
+    oa.w = a.w * wr - b.w * wi; ob.w = a.w * wi + b.w * wr;
+    reinterpret_cast<float4*>(re)[e] = oa;
+    reinterpret_cast<float4*>(im)[e] = ob;
+  }
+}
+
+// dst[b][j][i][:] = scale * src[b][i][j][:]   (rows of C floats; i < N1, j < N2)
+__global__ __launch_bounds__(256) void transpose_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int Bn, int N1,
+                                                             int N2, int C4, float scale) {
+  const long total = (long)Bn * N1 * N2 * C4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int c = (int)(e % C4);
+    long r = e / C4;                       // destination row: (b, j, i)
+    const int i = (int)(r % N1);
+    r /= N1;
+    const int j = (int)(r % N2);
+    const long b = r / N2;
+    float4 v = reinterpret_cast<const float4*>(src)[((b * N1 + i) * N2 + j) * C4 + c];
+    v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+    reinterpret_cast<float4*>(dst)[e] = v;
+  }
+}
+
+inline unsigned grid_for(long total) {
+  long g = (total + 255) / 256;
+  return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" int uir_layernorm_fwd(const float* X, int ldx, const float* gamma, const float* beta, float* Y, int ldy, float* stats,
+                                 long M, int C, float eps, void* stream) {
+  UIR_REQUIRE(X && gamma && beta && Y && M > 0 && ldx >= C && ldy >= C && (ldx & 3) == 0 && (ldy & 3) == 0);
+  UIR_REQUIRE(uir_aligned16(X) && uir_aligned16(Y) && uir_aligned16(gamma) && uir_aligned16(beta));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int L = C / 4;
+  long blocks = (M + (256 / (L > 0 ? L : 1)) - 1) / (256 / (L > 0 ? L : 1));
+  if (blocks > 4096) blocks = 4096;
+  switch (C) {
+    case 16: hipLaunchKernelGGL(ln_fwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, gamma, beta, Y, ldy, stats, M, eps); break;
+    case 32: hipLaunchKernelGGL(ln_fwd_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, gamma, beta, Y, ldy, stats, M, eps); break;
+    case 64: hipLaunchKernelGGL(ln_fwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, gamma, beta, Y, ldy, stats, M, eps); break;
+    case 128: hipLaunchKernelGGL(ln_fwd_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, gamma, beta, Y, ldy, stats, M, eps); break;
+    default: return UIR_EINVAL;
+  }
+  return uir_launch_status();
+}
+
+extern "C" int uir_cmul_table(float* re, float* im, const float* tab_re, const float* tab_im, long rows, long P, int C, void* stream) {
+  UIR_REQUIRE(re && im && tab_re && tab_im && rows > 0 && P > 0 && rows % P == 0 && C > 0 && (C & 3) == 0);
+  UIR_REQUIRE(uir_aligned16(re) && uir_aligned16(im));
+  hipLaunchKernelGGL(cmul_table_kernel, dim3(grid_for(rows * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), re, im, tab_re,
+                     tab_im, rows, P, C / 4);
+  return uir_launch_status();
+}
+
+extern "C" int uir_transpose_rows(const float* src, float* dst, int B, int N1, int N2, int C, float scale, void* stream) {
+  UIR_REQUIRE(src && dst && src != dst && B > 0 && N1 > 0 && N2 > 0 && C > 0 && (C & 3) == 0 && uir_aligned16(src) && uir_aligned16(dst));
+  hipLaunchKernelGGL(transpose_rows_kernel, dim3(grid_for((long)B * N1 * N2 * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     src, dst, B, N1, N2, C / 4, scale);
+  return uir_launch_status();
+}

@@ -30,95 +30,109 @@ import ctypes as C
 lib = L.lib
 
 
-class FrfnPlan(Recorder):
-    """Launch lists + buffers of one FRFN for a fixed (B, H, W)."""
+def _act(rec, name, pre, t, cols, bwd_dt=None, dpre=None):
+    rec._hold(pre, t, bwd_dt, dpre)
+    M = pre.shape[0]
+    if bwd_dt is None:
+        rec._op(name, lib.uir_frfn_act_fwd, _ptr(pre), _ld(pre), _ptr(t), _ld(t), M, cols, nbytes=8 * M * cols)
+    else:
+        rec._op(name, lib.uir_frfn_act_bwd, _ptr(pre), _ld(pre), _ptr(bwd_dt), _ld(bwd_dt), _ptr(dpre), _ld(dpre), M, cols,
+                nbytes=12 * M * cols)
 
-    def __init__(self, fp: FlatParams, dim: int, hidden: int, B: int, H: int, W: int, want_backward: bool = True):
+
+def _gate(rec, name, hid, U, bias, V, G=None, dG=None, dU=None, dV=None):
+    rec._hold(U, bias, V, G, dG, dU, dV)
+    a = L.FrfnGateArgs()
+    a.U, a.bias, a.V = _ptr(U), _ptr(bias), _ptr(V)
+    a.M, a.hid = U.shape[0], hid
+    a.ldu, a.ldv = _ld(U), _ld(V)
+    rec.keep.append(a)
+    if dG is None:
+        a.G, a.ldg = _ptr(G), _ld(G)
+        rec._op(name, lib.uir_frfn_gate_fwd, C.byref(a), nbytes=12 * a.M * a.hid)
+    else:
+        a.dG, a.ldg = _ptr(dG), _ld(dG)
+        a.dU, a.dV, a.lddu, a.lddv = _ptr(dU), _ptr(dV), _ld(dU), _ld(dV)
+        rec._op(name, lib.uir_frfn_gate_bwd, C.byref(a), nbytes=20 * a.M * a.hid)
+
+
+def _colsum_wide(rec, name, src, cols, out):
+    """Bias gradient over `cols` columns: uir_colsum_partials handles <= 256 columns per launch."""
+    for c0 in range(0, cols, 256):
+        n = min(256, cols - c0)
+        rec.colsum(f"{name}[{c0}]", src, c0, n, out[c0:c0 + n])
+
+
+def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims):
+    """Record FRFN.forward (block.py:262-282) on token rows x [M, dim] into `rec` (parameters `pfx + name` of rec.fp).
+    Returns (y, backward) with backward(dy) -> dx recording the backward launches."""
+    B, H, W = dims
+    M, C_, c4 = B * H * W, dim, dim // 4
+    P, Gr = (lambda n: rec.P(pfx + n)), (lambda n: rec.Gr(pfx + n))
+    W1, b1 = P("linear1.0.weight"), P("linear1.0.bias")
+    Wdw, bdw = P("dwconv.0.weight"), P("dwconv.0.bias")
+    W2, b2 = P("linear2.0.weight"), P("linear2.0.bias")
+    Wpc = P("partial_conv3.weight")
+    xc, pre, t = rec.alloc(M, C_), rec.alloc(M, 2 * hid), rec.alloc(M, 2 * hid)
+    u, g, y = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
+    n = pfx
+    # partial_conv3 on channels [0, C/4), the rest passes through (block.py:267-270)
+    rec.copy_cols(n + "pc3.pass", x, c4, xc, c4, C_ - c4)
+    rec.gemm(n + "pc3", x[:, :c4], Wpc, xc[:, :c4], N=c4, K=c4, w_sn=c4 * 9, w_sk=9, w_st=1, taps=9, hw=(H, W))
+    rec.gemm(n + "linear1", xc, W1, pre, N=2 * hid, K=C_, w_sn=C_, w_sk=1, bias=b1)
+    _act(rec, n + "linear1.gelu", pre, t, 2 * hid)
+    rec.dwconv(n + "dwconv", t[:, :hid], Wdw, u, C_=hid, dims=dims)
+    _gate(rec, n + "dwconv.gelu*x2", hid, u, bdw, t[:, hid:], G=g)
+    rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
+
+    def backward(dy: torch.Tensor) -> torch.Tensor:
+        dx = rec.alloc(M, C_)
+        dg, du, dt = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, 2 * hid)
+        dpre, dxc = rec.alloc(M, 2 * hid), rec.alloc(M, C_)
+        with rec.bulk():
+            rec.gram(n + "linear2.dW", dy, g, Gr("linear2.0.weight"), N=C_, K=hid, o_sn=hid, o_sk=1)
+            _colsum_wide(rec, n + "linear2.db", dy, C_, Gr("linear2.0.bias"))
+        rec.gemm(n + "linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
+        _gate(rec, n + "gate.bwd", hid, u, bdw, t[:, hid:], dG=dg, dU=du, dV=dt[:, hid:])
+        with rec.bulk():
+            _colsum_wide(rec, n + "dwconv.db", du, hid, Gr("dwconv.0.bias"))
+        rec.dwconv_bwd(n + "dwconv.bwd", du, t[:, :hid], Wdw, dt[:, :hid], Gr("dwconv.0.weight"), C_=hid, creal=hid, dims=dims)
+        _act(rec, n + "linear1.gelu.bwd", pre, None, 2 * hid, bwd_dt=dt, dpre=dpre)
+        with rec.bulk():
+            rec.gram(n + "linear1.dW", dpre, xc, Gr("linear1.0.weight"), N=2 * hid, K=C_, o_sn=C_, o_sk=1)
+            _colsum_wide(rec, n + "linear1.db", dpre, 2 * hid, Gr("linear1.0.bias"))
+        rec.gemm(n + "linear1.dX", dpre, W1, dxc, N=C_, K=2 * hid, w_sn=1, w_sk=C_)
+        rec.copy_cols(n + "pc3.pass.bwd", dxc, c4, dx, c4, C_ - c4)
+        with rec.bulk():
+            rec.gram(n + "pc3.dW", dxc[:, :c4], x[:, :c4], Gr("partial_conv3.weight"), N=c4, K=c4, o_sn=c4 * 9, o_sk=9, o_st=1,
+                     taps=9, hw=(H, W))
+        rec.gemm(n + "pc3.dX", dxc[:, :c4], Wpc, dx[:, :c4], N=c4, K=c4, w_sn=9, w_sk=c4 * 9, w_st=1, taps=9, flip=1, hw=(H, W))
+        return dx
+    return y, backward
+
+
+class TokenPlan(Recorder):
+    """A launch plan over token rows [B*H*W, dim]: input buffer -> recorded forward -> output buffer, and the recorded backward.
+    Subclasses provide ``_record(x) -> (y, backward)``."""
+
+    def __init__(self, fp: FlatParams, dim: int, B: int, H: int, W: int, want_backward: bool = True):
         super().__init__(fp.device, fp, scratch_floats=8 * 1024 * 1024)
-        self.dim, self.hidden, self.B, self.H, self.W = dim, hidden, B, H, W
+        self.dim, self.B, self.H, self.W = dim, B, H, W
         self.want_backward = want_backward
-        self._build()
-
-    def _act(self, name, pre, t, cols, bwd_dt=None, dpre=None):
-        self._hold(pre, t, bwd_dt, dpre)
-        M = pre.shape[0]
-        if bwd_dt is None:
-            self._op(name, lib.uir_frfn_act_fwd, _ptr(pre), _ld(pre), _ptr(t), _ld(t), M, cols, nbytes=8 * M * cols)
-        else:
-            self._op(name, lib.uir_frfn_act_bwd, _ptr(pre), _ld(pre), _ptr(bwd_dt), _ld(bwd_dt), _ptr(dpre), _ld(dpre), M, cols,
-                     nbytes=12 * M * cols)
-
-    def _gate(self, name, U, bias, V, G=None, dG=None, dU=None, dV=None):
-        self._hold(U, bias, V, G, dG, dU, dV)
-        a = L.FrfnGateArgs()
-        a.U, a.bias, a.V = _ptr(U), _ptr(bias), _ptr(V)
-        a.M, a.hid = U.shape[0], self.hidden
-        a.ldu, a.ldv = _ld(U), _ld(V)
-        if dG is None:
-            a.G, a.ldg = _ptr(G), _ld(G)
-            self.keep.append(a)
-            self._op(name, lib.uir_frfn_gate_fwd, C.byref(a), nbytes=12 * a.M * a.hid)
-        else:
-            a.dG, a.ldg = _ptr(dG), _ld(dG)
-            a.dU, a.dV, a.lddu, a.lddv = _ptr(dU), _ptr(dV), _ld(dU), _ld(dV)
-            self.keep.append(a)
-            self._op(name, lib.uir_frfn_gate_bwd, C.byref(a), nbytes=20 * a.M * a.hid)
-
-    def _colsum_wide(self, name, src, cols, out):
-        """Bias gradient over `cols` columns: uir_colsum_partials handles <= 256 columns per launch."""
-        for c0 in range(0, cols, 256):
-            n = min(256, cols - c0)
-            self.colsum(f"{name}[{c0}]", src, c0, n, out[c0:c0 + n])
-
-    def _build(self):
-        C_, hid, B, H, W = self.dim, self.hidden, self.B, self.H, self.W
-        M, dims, c4 = B * H * W, (B, H, W), self.dim // 4
-        P, Gr = self.P, self.Gr
-        W1, b1 = P("linear1.0.weight"), P("linear1.0.bias")
-        Wdw, bdw = P("dwconv.0.weight"), P("dwconv.0.bias")
-        W2, b2 = P("linear2.0.weight"), P("linear2.0.bias")
-        Wpc = P("partial_conv3.weight")
-        self.x_in, self.y_out = self.alloc(M, C_), self.alloc(M, C_)
-        x = self.x_in
-        xc, pre, t = self.alloc(M, C_), self.alloc(M, 2 * hid), self.alloc(M, 2 * hid)
-        u, g = self.alloc(M, hid), self.alloc(M, hid)
+        M = B * H * W
+        self.x_in = self.alloc(M, dim)
         self.cur = self.fwd
-        # partial_conv3 on channels [0, C/4), the rest passes through (block.py:267-270)
-        self.copy_cols("pc3.pass", x, c4, xc, c4, C_ - c4)
-        self.gemm("pc3", x[:, :c4], Wpc, xc[:, :c4], N=c4, K=c4, w_sn=c4 * 9, w_sk=9, w_st=1, taps=9, hw=(H, W))
-        self.gemm("linear1", xc, W1, pre, N=2 * hid, K=C_, w_sn=C_, w_sk=1, bias=b1)
-        self._act("linear1.gelu", pre, t, 2 * hid)
-        self.dwconv("dwconv", t[:, :hid], Wdw, u, C_=hid, dims=dims)
-        self._gate("dwconv.gelu*x2", u, bdw, t[:, hid:], G=g)
-        self.gemm("linear2", g, W2, self.y_out, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
+        self.y_out, bw = self._record(self.x_in)
         self.mark("fwd.end")
-        if not self.want_backward:
-            return
-        self.cur = self.bwd
-        self.dy_in, self.dx_out = self.alloc(M, C_), self.alloc(M, C_)
-        dy = self.dy_in
-        dg, du, dt = self.alloc(M, hid), self.alloc(M, hid), self.alloc(M, 2 * hid)
-        dpre, dxc = self.alloc(M, 2 * hid), self.alloc(M, C_)
-        with self.bulk():
-            self.gram("linear2.dW", dy, g, Gr("linear2.0.weight"), N=C_, K=hid, o_sn=hid, o_sk=1)
-            self._colsum_wide("linear2.db", dy, C_, Gr("linear2.0.bias"))
-        self.gemm("linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
-        self._gate("gate.bwd", u, bdw, t[:, hid:], dG=dg, dU=du, dV=dt[:, hid:])
-        with self.bulk():
-            self._colsum_wide("dwconv.db", du, hid, Gr("dwconv.0.bias"))
-        self.dwconv_bwd("dwconv.bwd", du, t[:, :hid], Wdw, dt[:, :hid], Gr("dwconv.0.weight"), C_=hid, creal=hid, dims=dims)
-        self._act("linear1.gelu.bwd", pre, None, 2 * hid, bwd_dt=dt, dpre=dpre)
-        with self.bulk():
-            self.gram("linear1.dW", dpre, xc, Gr("linear1.0.weight"), N=2 * hid, K=C_, o_sn=C_, o_sk=1)
-            self._colsum_wide("linear1.db", dpre, 2 * hid, Gr("linear1.0.bias"))
-        self.gemm("linear1.dX", dpre, W1, dxc, N=C_, K=2 * hid, w_sn=1, w_sk=C_)
-        self.copy_cols("pc3.pass.bwd", dxc, c4, self.dx_out, c4, C_ - c4)
-        with self.bulk():
-            self.gram("pc3.dW", dxc[:, :c4], x[:, :c4], Gr("partial_conv3.weight"), N=c4, K=c4, o_sn=c4 * 9, o_sk=9, o_st=1, taps=9,
-                      hw=(H, W))
-        self.gemm("pc3.dX", dxc[:, :c4], Wpc, self.dx_out[:, :c4], N=c4, K=c4, w_sn=9, w_sk=c4 * 9, w_st=1, taps=9, flip=1, hw=(H, W))
-        self.mark("bwd.end")
+        if want_backward:
+            self.cur = self.bwd
+            self.dy_in = self.alloc(M, dim)
+            self.dx_out = bw(self.dy_in)
+            self.mark("bwd.end")
         self.cur = self.fwd
+
+    def _record(self, x):
+        raise NotImplementedError
 
     def forward(self, x_rows: torch.Tensor) -> torch.Tensor:
         self.x_in.copy_(x_rows)
@@ -130,7 +144,7 @@ class FrfnPlan(Recorder):
         self.run(self.bwd)
         return self.dx_out
 
-    # algorithmic work of one forward + backward (for the bench): every leaf op's operands once
+    # algorithmic work of one forward + backward (for the bench tools): every launch's operands once
     def flops(self) -> int:
         return sum(m[3] for m in self.meta[id(self.fwd)]) + sum(m[3] for m in self.meta[id(self.bwd)])
 
@@ -138,7 +152,20 @@ class FrfnPlan(Recorder):
         return sum(m[2] for m in self.meta[id(self.fwd)]) + sum(m[2] for m in self.meta[id(self.bwd)])
 
 
-class _FrfnFunction(torch.autograd.Function):
+class FrfnPlan(TokenPlan):
+    """Launch lists + buffers of one FRFN for a fixed (B, H, W)."""
+
+    def __init__(self, fp: FlatParams, dim: int, hidden: int, B: int, H: int, W: int, want_backward: bool = True):
+        self.hidden = hidden
+        super().__init__(fp, dim, B, H, W, want_backward)
+
+    def _record(self, x):
+        return record_frfn(self, "", x, self.dim, self.hidden, (self.B, self.H, self.W))
+
+
+class _TokenFunction(torch.autograd.Function):
+    """One autograd node for a whole token-plan module: forward and backward are launch lists."""
+
     @staticmethod
     def forward(ctx, x, module, *params):
         B, Ltok, C_ = x.shape
@@ -152,14 +179,76 @@ class _FrfnFunction(torch.autograd.Function):
     def backward(ctx, dy):
         m = ctx.module
         if ctx.serial != m._serial:
-            raise RuntimeError("FRFN(HIP): a later forward overwrote the saved activations; call backward before the next forward")
+            raise RuntimeError(f"{type(m).__name__}(HIP): a later forward overwrote the saved activations; call backward before "
+                               "the next forward")
         B, Ltok, C_ = ctx.shape
         dx = ctx.plan.backward(dy.contiguous().view(B * Ltok, C_)).clone().view(B, Ltok, C_)
         fp = m._flat
-        return (dx, None) + tuple(fp.gview(n).clone() for n in m._names)
+        return (dx, None) + tuple(None if n in m._dead else fp.gview(n).clone() for n in m._names)
 
 
-class FRFN(nn.Module):
+class TokenModule(nn.Module):
+    """Shared host plumbing of the token-plan modules: parameters as views of one flat buffer, one plan per (B, H, W),
+    the reference's ``forward(x: (B, L, C))`` contract with L = H*H."""
+
+    _dead: frozenset = frozenset()        # parameters the reference never uses (their .grad stays None, as there)
+
+    def _init_plumbing(self):
+        self._flat: "FlatParams | None" = None
+        self._plans: Dict[Tuple[int, int, int], TokenPlan] = {}
+        self._names = [n for n, _ in self.named_parameters()]
+        self._serial = 0
+
+    def _make_plan(self, fp, B, H, W, want_backward) -> TokenPlan:
+        raise NotImplementedError
+
+    def _ensure_flat(self, device) -> FlatParams:
+        named = list(self.named_parameters())
+        ok = self._flat is not None and self._flat.device == torch.device(device) and \
+            all(p.data_ptr() == self._flat.view(n).data_ptr() for n, p in named)
+        if not ok:
+            fp = FlatParams({n: tuple(p.shape) for n, p in named}, device)
+            with torch.no_grad():
+                for n, p in named:
+                    v = fp.view(n)
+                    v.copy_(p.data.to(device=device, dtype=torch.float32))
+                    p.data = v
+            self._flat = fp
+            self._plans.clear()
+        return self._flat
+
+    def _plan_for(self, x: torch.Tensor, want_backward: bool = True) -> TokenPlan:
+        fp = self._ensure_flat(x.device)
+        B, Ltok, _ = x.shape
+        hh = int(math.sqrt(Ltok))
+        key = (B, hh, hh)
+        plan = self._plans.get(key)
+        if plan is None or (want_backward and not plan.want_backward):
+            while len(self._plans) >= 2:
+                self._plans.pop(next(iter(self._plans)))
+            plan = self._make_plan(fp, B, hh, hh, want_backward)
+            self._plans[key] = plan
+        return plan
+
+    def forward(self, x: torch.Tensor, mask=None) -> torch.Tensor:
+        if x.dim() != 3 or x.shape[2] != self.dim:
+            raise ValueError(f"expected (B, L, {self.dim}) tokens, got {tuple(x.shape)}")
+        hh = int(math.sqrt(x.shape[1]))
+        if hh * hh != x.shape[1]:
+            raise ValueError("needs a square token grid (L = H*H), like the reference's int(math.sqrt(hw))")
+        if x.device.type != "cuda":
+            raise RuntimeError(f"{type(self).__name__}(HIP) runs on an AMD GPU ('cuda' device in PyTorch-ROCm); there is no CPU fallback")
+        x = x.contiguous().float()
+        self._ensure_flat(x.device)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return _TokenFunction.apply(x, self, *self.parameters())
+        B, Ltok, C_ = x.shape
+        plan = self._plan_for(x, want_backward=False)
+        self._serial += 1
+        return plan.forward(x.reshape(B * Ltok, C_)).clone().view(B, Ltok, C_)
+
+
+class FRFN(TokenModule):
     """Drop-in for ``src.model.block.FRFN`` (block.py:249-282)."""
 
     def __init__(self, dim=32, hidden_dim=128, act_layer=nn.GELU, drop=0., use_eca=False):
@@ -177,52 +266,7 @@ class FRFN(nn.Module):
         self.dim_conv = self.dim // 4
         self.dim_untouched = self.dim - self.dim_conv
         self.partial_conv3 = nn.Conv2d(self.dim_conv, self.dim_conv, 3, padding=1, stride=1, bias=False)
-        self._flat: "FlatParams | None" = None
-        self._plans: Dict[Tuple[int, int, int], FrfnPlan] = {}
-        self._names = [n for n, _ in self.named_parameters()]
-        self._serial = 0
+        self._init_plumbing()
 
-    def _ensure_flat(self, device) -> FlatParams:
-        named = list(self.named_parameters())
-        ok = self._flat is not None and self._flat.device == torch.device(device) and \
-            all(p.data_ptr() == self._flat.view(n).data_ptr() for n, p in named)
-        if not ok:
-            fp = FlatParams({n: tuple(p.shape) for n, p in named}, device)
-            with torch.no_grad():
-                for n, p in named:
-                    v = fp.view(n)
-                    v.copy_(p.data.to(device=device, dtype=torch.float32))
-                    p.data = v
-            self._flat = fp
-            self._plans.clear()
-        return self._flat
-
-    def _plan_for(self, x: torch.Tensor, want_backward: bool = True) -> FrfnPlan:
-        fp = self._ensure_flat(x.device)
-        B, Ltok, _ = x.shape
-        hh = int(math.sqrt(Ltok))
-        key = (B, hh, hh)
-        plan = self._plans.get(key)
-        if plan is None or (want_backward and not plan.want_backward):
-            while len(self._plans) >= 2:
-                self._plans.pop(next(iter(self._plans)))
-            plan = FrfnPlan(fp, self.dim, self.hidden_dim, B, hh, hh, want_backward)
-            self._plans[key] = plan
-        return plan
-
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
-        if x.dim() != 3 or x.shape[2] != self.dim:
-            raise ValueError(f"expected (B, L, {self.dim}) tokens, got {tuple(x.shape)}")
-        hh = int(math.sqrt(x.shape[1]))
-        if hh * hh != x.shape[1]:
-            raise ValueError("FRFN needs a square token grid (L = H*H), like the reference's int(math.sqrt(hw))")
-        if x.device.type != "cuda":
-            raise RuntimeError("FRFN(HIP) runs on an AMD GPU ('cuda' device in PyTorch-ROCm); there is no CPU fallback")
-        x = x.contiguous().float()
-        self._ensure_flat(x.device)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            return _FrfnFunction.apply(x, self, *self.parameters())
-        B, Ltok, C_ = x.shape
-        plan = self._plan_for(x, want_backward=False)
-        self._serial += 1
-        return plan.forward(x.reshape(B * Ltok, C_)).clone().view(B, Ltok, C_)
+    def _make_plan(self, fp, B, H, W, want_backward):
+        return FrfnPlan(fp, self.dim, self.hidden_dim, B, H, W, want_backward)

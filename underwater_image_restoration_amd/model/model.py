@@ -1,0 +1,148 @@
+"""``EncoderBlock`` of the NewBigFRFNModel family on MI355X behind the reference's surface
+(src/model/model.py:16-93): same constructor arguments, same ``state_dict`` names in the same registration order
+(``norm1.*``, ``mlp.*``, ``norm2.*``, ``freq_mlp.*``), ``forward(x: (B, L, C), mask=None) -> (B, L, C)``.
+
+Built for the configuration MyBigFRFNModel uses for its first level (model.py:481-489): ``token_mlp = freq_mlp = "frfn"``,
+``use_dwt = "Fourier"``, ``drop_path = 0``.  In that mode the reference computes
+
+    x1 = mlp(norm1(x));  f = Re fftn(x1, dims (L, C));  f = freq_mlp(f);  f = Re ifftn(f, dims (L, C));  out = x + f + x1
+
+(``norm2`` is evaluated and discarded, :62,72: its parameters keep ``grad = None`` here too).  ``Re fftn`` over the (L, C) axes
+of a real tensor is the real-symmetric operator  T(x) = C_L x C_C - S_L x S_C  (cos / sin DFT matrices), and ``Re ifftn`` is
+T / (L*C): one operator, also its own backward pass.  T runs as two uir_gemm (C axis) and a two-stage length-L transform
+(L = H*W = N1*N2: uir_dft_axis over n1, uir_cmul_table twiddles, uir_dft_axis over n2, uir_transpose_rows); the two FRFNs
+are ``block.record_frfn``; LayerNorm is uir_layernorm_fwd / uir_layernorm_bwd.  No CPU / eager fallback.
+
+Not built yet (raise NotImplementedError): ``token_mlp="leff"``, the Wavelet mode, ``drop_path > 0`` (stochastic depth of the
+deeper encoder levels), DecoderBlock / MDASSA / FDFP - SURVEY.md 8(f)-2, next.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib as L
+from ..engine import FlatParams, _ptr
+from .block import FRFN, TokenModule, TokenPlan, record_frfn
+
+lib = L.lib
+_TABLES: dict = {}
+
+
+def _axis_tables(C: int, device):
+    """cos / sin(2 pi c' c / C), [C][C], fp64-built on exact residues."""
+    key = ("C", C, str(device))
+    if key not in _TABLES:
+        r = (np.arange(C, dtype=np.int64)[:, None] * np.arange(C, dtype=np.int64)[None, :]) % C
+        ang = 2.0 * np.pi * r.astype(np.float64) / C
+        c, s = np.cos(ang), np.sin(ang)
+        q = (4 * r) % C == 0
+        c[q], s[q] = np.round(c[q]), np.round(s[q])
+        _TABLES[key] = (torch.from_numpy(c.astype(np.float32)).to(device).contiguous(),
+                        torch.from_numpy(s.astype(np.float32)).to(device).contiguous())
+    return _TABLES[key]
+
+
+def _twiddle_tables(N1: int, N2: int, device):
+    """exp(+2 pi i k1 n2 / (N1*N2)) at p = k1*N2 + n2."""
+    key = ("tw", N1, N2, str(device))
+    if key not in _TABLES:
+        Ltok = N1 * N2
+        r = (np.arange(N1, dtype=np.int64)[:, None] * np.arange(N2, dtype=np.int64)[None, :]) % Ltok
+        ang = 2.0 * np.pi * r.astype(np.float64) / Ltok
+        c, s = np.cos(ang), np.sin(ang)
+        q = (4 * r) % Ltok == 0
+        c[q], s[q] = np.round(c[q]), np.round(s[q])
+        _TABLES[key] = (torch.from_numpy(c.astype(np.float32).reshape(-1)).to(device).contiguous(),
+                        torch.from_numpy(s.astype(np.float32).reshape(-1)).to(device).contiguous())
+    return _TABLES[key]
+
+
+def record_token_fft(rec, name: str, x: torch.Tensor, dims, C_: int, scale: float) -> torch.Tensor:
+    """y = scale * Re(sum_{l,c} x[l,c] exp(i 2 pi (k l / L + c' c / C))) = scale * (C_L x C_C - S_L x S_C) on token rows."""
+    B, N1, N2 = dims                       # token l = n1 * N2 + n2
+    M, Ltok = B * N1 * N2, N1 * N2
+    Cc, Sc = _axis_tables(C_, rec.dev)
+    twr, twi = _twiddle_tables(N1, N2, rec.dev)
+    rec._hold(Cc, Sc, twr, twi)
+    zr, zi, ar, ai = rec.alloc(M, C_), rec.alloc(M, C_), rec.alloc(M, C_), rec.alloc(M, C_)
+    rec.gemm(name + ".cosC", x, Cc, zr, N=C_, K=C_, w_sn=C_, w_sk=1)
+    rec.gemm(name + ".sinC", x, Sc, zi, N=C_, K=C_, w_sn=C_, w_sk=1)
+    rec.dft(name + ".n1", zr, zi, ar, ai, O=B, N=N1, I=N2, C_=C_, sign=1.0, scale=1.0)
+    rec._op(name + ".twiddle", lib.uir_cmul_table, _ptr(ar), _ptr(ai), _ptr(twr), _ptr(twi), M, Ltok, C_, nbytes=16 * M * C_)
+    br, y = rec.alloc(M, C_), rec.alloc(M, C_)
+    rec.dft(name + ".n2", ar, ai, br, None, O=B * N1, N=N2, I=1, C_=C_, sign=1.0, scale=1.0)
+    rec._op(name + ".natural", lib.uir_transpose_rows, _ptr(br), _ptr(y), B, N1, N2, C_, scale, nbytes=8 * M * C_)
+    return y
+
+
+class EncoderPlan(TokenPlan):
+    def __init__(self, fp: FlatParams, dim: int, hidden: int, B: int, H: int, W: int, want_backward: bool = True):
+        self.hidden = hidden
+        super().__init__(fp, dim, B, H, W, want_backward)
+
+    def _record(self, x):
+        C_, dims = self.dim, (self.B, self.H, self.W)
+        M, Ltok = self.B * self.H * self.W, self.H * self.W
+        g1, b1 = self.P("norm1.weight"), self.P("norm1.bias")
+        xn, stats = self.alloc(M, C_), self.alloc(M, 2)
+        self._hold(g1, b1)
+        self._op("norm1", lib.uir_layernorm_fwd, _ptr(x), C_, _ptr(g1), _ptr(b1), _ptr(xn), C_, _ptr(stats), M, C_, 1e-5,
+                 nbytes=8 * M * C_)
+        x1, bw1 = record_frfn(self, "mlp.", xn, C_, self.hidden, dims)
+        f1 = record_token_fft(self, "fftn", x1, dims, C_, 1.0)
+        f2, bw2 = record_frfn(self, "freq_mlp.", f1, C_, self.hidden, dims)
+        y = record_token_fft(self, "ifftn", f2, dims, C_, 1.0 / (Ltok * C_))
+        self.copy_cols("out+=x", x, 0, y, 0, C_, accumulate=1)          # shortcut + freq_x + x  (model.py:91)
+        self.copy_cols("out+=x1", x1, 0, y, 0, C_, accumulate=1)
+
+        def backward(dy):
+            g2 = record_token_fft(self, "ifftn.bwd", dy, dims, C_, 1.0 / (Ltok * C_))     # T is symmetric: its own adjoint
+            df1 = bw2(g2)
+            dx1 = record_token_fft(self, "fftn.bwd", df1, dims, C_, 1.0)
+            self.copy_cols("dx1+=dy", dy, 0, dx1, 0, C_, accumulate=1)
+            dxn = bw1(dx1)
+            dx = self.alloc(M, C_)
+            self.ln_bwd("norm1.bwd", dxn, x, stats, g1, dy, dx, self.Gr("norm1.weight"), self.Gr("norm1.bias"), C_=C_)
+            return dx
+        return y, backward
+
+
+class EncoderBlock(TokenModule):
+    """Drop-in for ``src.model.model.EncoderBlock`` (model.py:16-93) in the mode MyBigFRFNModel's first level uses."""
+
+    _dead = frozenset(("norm2.weight", "norm2.bias"))
+
+    def __init__(self, dim, input_resolution, num_heads, mlp_ratio=4, token_mlp="leff", drop_path=0.0, norm_layer=nn.LayerNorm,
+                 act_layer=nn.GELU, drop=0.0, freq_mlp="leff", use_dwt="Fourier"):
+        super().__init__()
+        if token_mlp != "frfn" or freq_mlp != "frfn":
+            if token_mlp not in ("leff", "frfn"):
+                raise ValueError(f"Unknown token_mlp type: {token_mlp}")                 # the reference's errors (model.py:38,48)
+            if freq_mlp not in ("leff", "frfn"):
+                raise ValueError(f"Unknown freq_mlp type: {freq_mlp}")
+            raise NotImplementedError("the HIP EncoderBlock is built for token_mlp = freq_mlp = 'frfn' (MyBigFRFNModel); LeFF is next")
+        if use_dwt != "Fourier" or drop_path > 0.0 or norm_layer is not nn.LayerNorm or act_layer is not nn.GELU:
+            raise NotImplementedError("the HIP EncoderBlock is built for use_dwt='Fourier', drop_path=0, LayerNorm, GELU "
+                                      "(encoder_0 / encoder_0_1 of MyBigFRFNModel, model.py:481-489)")
+        if dim not in (32, 64, 128):
+            raise NotImplementedError("dim in {32, 64, 128} this round (the LayerNorm kernels' channel counts)")
+        self.dim = dim
+        self.input_resolution = input_resolution
+        self.num_heads = num_heads
+        self.mlp_ratio = mlp_ratio
+        self.token_mlp = token_mlp
+        self.drop_path = nn.Identity()
+        self.norm1 = norm_layer(dim)
+        self.use_dwt = use_dwt
+        mlp_hidden_dim = int(dim * mlp_ratio)
+        self.hidden_dim = mlp_hidden_dim
+        self.mlp = FRFN(dim, mlp_hidden_dim, act_layer=act_layer, drop=drop)          # parameter containers in the reference's
+        self.norm2 = norm_layer(dim)                                                    # registration order (model.py:28-52)
+        self.freq_mlp = FRFN(dim, mlp_hidden_dim, act_layer=act_layer, drop=drop)
+        self.drop_path2 = nn.Identity()
+        self._init_plumbing()
+
+    def _make_plan(self, fp, B, H, W, want_backward):
+        return EncoderPlan(fp, self.dim, self.hidden_dim, B, H, W, want_backward)
