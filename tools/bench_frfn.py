@@ -18,6 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from underwater_image_restoration_amd.model.block import FRFN  # noqa: E402
+from underwater_image_restoration_amd.model.model import EncoderBlock  # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12
 HBM_PEAK = 8.0e12
@@ -31,10 +32,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--what", default="frfn", choices=("frfn", "encoder"),
+                    help="frfn: one FRFN (block.py:249-282); encoder: one EncoderBlock = LN + 2 FRFN + 2 (L,C) transforms (model.py:16-93)")
     args = ap.parse_args()
     dim, hid, B, S = args.dim, 4 * args.dim, args.batch, args.size
     torch.manual_seed(0)
-    m = FRFN(dim, hid).cuda()
+    enc = args.what == "encoder"
+    m = (EncoderBlock(dim, (S, S), 4, token_mlp="frfn", freq_mlp="frfn") if enc else FRFN(dim, hid)).cuda()
     x = torch.randn(B, S * S, dim, device="cuda")
     dy = torch.randn(B, S * S, dim, device="cuda")
     plan = m._plan_for(x)
@@ -57,19 +61,46 @@ def main():
     c4 = dim // 4
     fwd_flops = M * (2 * dim * 2 * hid + 2 * hid * dim + 2 * 9 * c4 * c4 + 18 * hid)
     flops = 3 * fwd_flops
+    if enc:
+        # 2 FRFNs + LayerNorm (8/elem) + 4 applications of the (L, C) transform per step (2 forward, 2 backward), each counted
+        # as an FFT would be: 5 N log2 N per length-N complex transform (N = L per channel, N = C per token)
+        import math
+        Ltok = S * S
+        fft_flops = B * (dim * 5 * Ltok * math.log2(Ltok) + Ltok * 5 * dim * math.log2(dim))
+        flops = 2 * 3 * fwd_flops + 3 * 8 * M * dim + 4 * fft_flops
     rows = plan.run_timed(plan.fwd) + plan.run_timed(plan.bwd)
     top = sorted(rows, key=lambda r: -r[4])[:6]
-    line = {"metric": "FRFN forward+backward images/s (dim 32, hidden 128, 256x256 tokens, bs 8)", "value": B / (ms * 1e-3),
+    what = "EncoderBlock (Fourier mode, FRFN mlps)" if enc else "FRFN"
+    line = {"metric": f"{what} forward+backward images/s (dim {dim}, hidden {hid}, {S}x{S} tokens, bs {B})", "value": B / (ms * 1e-3),
             "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"FRFN(dim={dim}, hidden={hid}) fwd+bwd on {B} x {S}x{S} tokens"},
+            "config": {"workload": f"{what}(dim={dim}, hidden={hid}) fwd+bwd on {B} x {S}x{S} tokens"},
             "roofline": {"bound": "mfma", "achieved": flops / (ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK / 1e12, "unit": "TFLOP/s",
                          "frac": flops / (ms * 1e-3) / MFMA_F32_PEAK, "traffic": None,
                          "hbm_achieved_GBps": plan.alg_bytes() / (ms * 1e-3) / 1e9, "hbm_frac": plan.alg_bytes() / (ms * 1e-3) / HBM_PEAK,
                          "plan_algorithmic_bytes": plan.alg_bytes(), "algorithmic_flops": flops,
                          "note": "composed of separate HBM-bound launches this round: the HBM fraction is the binding one",
                          "top_launches_serial_ms": [[r[0], r[1], round(r[4], 4)] for r in top]}}
-    if not args.no_cpu:
+    if enc:
+        line["roofline"]["executed_flops"] = plan.flops()
+        line["roofline"]["note"] = ("algorithmic flops count the (L,C) transforms as FFTs (5 N log2 N); the plan executes the length-L "
+                                    "transform as two dense 256-point MFMA contractions: executed_flops is what the launches do")
+    if not args.no_cpu and enc:
+        from oracle import encoder_ref as E
+        cores = min(16, len(os.sched_getaffinity(0)))
+        torch.set_num_threads(cores)
+        P = {n: p.detach().cpu() for n, p in m.named_parameters()}
+        xb, pb = x[:1].cpu(), dy[:1].cpu()
+        E.out_and_grads(xb, P, pb)
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < 10.0:
+            E.out_and_grads(xb, P, pb)
+            k += 1
+        dt = (time.perf_counter() - t0) / k
+        line["cpu_baseline"] = {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port",
+                                "sample": f"{k} forward+backward passes of one {S}x{S} image through oracle/encoder_ref.py (torch CPU, {cores} threads)"}
+    elif not args.no_cpu:
         from oracle import frfn_ref as R
         cores = min(16, len(os.sched_getaffinity(0)))
         torch.set_num_threads(cores)

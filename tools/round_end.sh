@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-end evidence set on one MI355X (run through gpurun from the repo root):  tools/round_end.sh <tag>
+#   gpurun_out/<tag>/  bench.json (+ op breakdown, stage timeline), frfn / encoder / uiqm bench lines, rocprofv3 kernel stats of the
+#   bench command, PMC traffic (tools/profile_round.sh), smoke
+T=${1:-r02x}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$T; mkdir -p $O
+cd $R
+python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 && echo smoke-ok
+python bench.py --breakdown-file $O/op_breakdown.csv --timeline-file $O/stage_timeline.csv > $O/bench.json 2> $O/bench.err && echo bench-ok
+python tools/bench_frfn.py > $O/frfn_bench.json 2> $O/frfn.err && echo frfn-ok
+python tools/bench_frfn.py --what encoder > $O/encoder_bench.json 2> $O/encoder.err && echo encoder-ok
+python tools/bench_uiqm.py > $O/uiqm_bench.json 2> $O/uiqm.err && echo uiqm-ok
+bash tools/profile_round.sh gpurun_out/$T/prof 3
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/uiqm -- python3 $R/tools/bench_uiqm.py --no-cpu > $O/prof/uiqm.log 2>&1 && echo uiqm-prof-ok
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof/encoder -- python3 $R/tools/bench_frfn.py --what encoder --no-cpu > $O/prof/encoder.log 2>&1 && echo encoder-prof-ok
+find $O/prof -name "*kernel_trace.csv" -delete; find $O/prof -name "*counter_collection.csv" -delete
