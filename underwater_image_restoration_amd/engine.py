@@ -535,7 +535,7 @@ class Recorder:
         nb = 4 * rows * (K * (2 if pro == L.PRO_GATE else 1) + N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1)
                          + (N if R is not None else 0) + (N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1) if G is not None else 0))
         self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps,
-                 variant=f"uir_gemm<taps={taps},pro={pro},epi={epi}>" + ("[tap groups]" if taps == 9 and K > 80 else ""))
+                 variant=f"uir_gemm1x1_kernel<*,{pro},{epi},*>")     # the rocprofv3 symbol family (NT and HAS_R vary per call)
 
     def _chunks(self, M, ngroups, batches):
         nch = max(1, min(M // 256, _GRAM_WGS // max(1, ngroups * batches)))
@@ -610,7 +610,7 @@ class Recorder:
         self.keep.append(a)
         rows = M * batches
         self._op(name, lib.uir_gram, C.byref(a), nbytes=4 * rows * (N + K * (2 if pro_b == L.PRO_GATE else 1)),
-                 flops=2 * rows * N * K * taps, variant=f"uir_gram<taps={taps},pro_b={pro_b}>")
+                 flops=2 * rows * N * K * taps, variant="uir_gram_kernel<*>" if taps == 1 or pro_b or extras else "uir_gram_taps9*")
         if shared_slab is not None:
             return nch
         sp = slab_t.data_ptr()
