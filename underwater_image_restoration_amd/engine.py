@@ -351,6 +351,10 @@ class Recorder:
                 if rc:
                     L.check(rc, name)
             return
+        if self.dev.index is not None and torch.cuda.current_device() != self.dev.index:
+            # raw device pointers + the CURRENT device's stream: a mismatch would run kernels on another GPU's queue
+            raise RuntimeError(f"plan lives on {self.dev} but the current device is cuda:{torch.cuda.current_device()}: "
+                               "call torch.cuda.set_device(...) first (one process per GPU)")
         main = torch.cuda.current_stream()
         st0 = C.c_void_p(main.cuda_stream)
         lanes = self.lanes[id(ops)]
