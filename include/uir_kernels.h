@@ -463,18 +463,23 @@ int uir_ssim_partials(const UirSsimArgs* args, void* stream);
  *   g = GELU(u + bias) * v           (:253 conv bias + nn.GELU, :279 gate) uir_frfn_gate_fwd / _bwd (dU, dV from dG)
  * rows = tokens (pixels), `cols` / `hid` channels (multiples of 4), ld* = row strides in floats. */
 int uir_frfn_act_fwd(const float* pre, int ldp, float* t, int ldt, long M, int cols, void* stream);
-int uir_frfn_act_bwd(const float* pre, int ldp, const float* dt, int ldt, float* dpre, int ldo, long M, int cols, void* stream);
+/* db_slab != NULL: also per-workgroup column sums of dpre (= the bias gradient of linear1), slab[nblocks][cols], the launch
+ * uses exactly nblocks workgroups; needs 256 % (cols/4) == 0.  Summed by uir_reduce_slab(_batch). */
+int uir_frfn_act_bwd(const float* pre, int ldp, const float* dt, int ldt, float* dpre, int ldo, long M, int cols, float* db_slab,
+                     int nblocks, void* stream);
 typedef struct UirFrfnGateArgs {
   const float* U;      /* depthwise-conv output without bias [M][ldu] */
   const float* bias;   /* [hid] */
-  const float* V;      /* the x2 half [M][ldv] */
+  const float* V;      /* the x2 half [M][ldv]; NULL: no gate (v = 1), G = GELU(U + bias) - LeFF's depthwise stage (block.py:228,240) */
   float* G;            /* forward: out [M][ldg] */
   const float* dG;     /* backward: gradient of G [M][ldg] */
   float* dU;
-  float* dV;
+  float* dV;           /* NULL iff V is NULL */
+  float* db_slab;      /* backward, optional: per-workgroup column sums of dU (= the depthwise bias gradient), [db_blocks][hid] */
   long M;
   int hid;
   int ldu, ldv, ldg, lddu, lddv;
+  int db_blocks;       /* workgroups of the backward launch when db_slab is given (256 % (hid/4) == 0 required) */
 } UirFrfnGateArgs;
 int uir_frfn_gate_fwd(const UirFrfnGateArgs* args, void* stream);
 int uir_frfn_gate_bwd(const UirFrfnGateArgs* args, void* stream);

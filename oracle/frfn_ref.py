@@ -47,6 +47,42 @@ def closed_form_params(dim: int, hidden: int, dtype=torch.float32) -> Params:
     return P
 
 
+def leff_param_shapes(dim: int, hidden: int) -> "Dict[str, tuple]":
+    """LeFF.__init__ (block.py:224-232)."""
+    return {"linear1.0.weight": (hidden, dim), "linear1.0.bias": (hidden,),
+            "dwconv.0.weight": (hidden, 1, 3, 3), "dwconv.0.bias": (hidden,),
+            "linear2.0.weight": (dim, hidden), "linear2.0.bias": (dim,)}
+
+
+def closed_form_leff_params(dim: int, hidden: int, dtype=torch.float32) -> Params:
+    P = {}
+    for n, shp in leff_param_shapes(dim, hidden).items():
+        numel = int(np.prod(shp))
+        fan_in = int(np.prod(shp[1:])) if len(shp) > 1 else 1
+        scale = fan_in ** -0.5 if len(shp) > 1 else 0.1
+        P[n] = torch.from_numpy(_hash_uniform(numel, _salt("leff." + n) + dim).reshape(shp) * scale).to(dtype)
+    return P
+
+
+def leff(x: torch.Tensor, P: Params) -> torch.Tensor:
+    """LeFF.forward (block.py:234-247): Linear + GELU -> depthwise 3x3 (+ bias) + GELU on the token image -> Linear."""
+    B, L, C = x.shape
+    H = W = int(math.sqrt(L))
+    hidden = P["dwconv.0.weight"].shape[0]
+    t = F.gelu(F.linear(x, P["linear1.0.weight"], P["linear1.0.bias"]))
+    u = F.conv2d(t.reshape(B, H, W, hidden).permute(0, 3, 1, 2), P["dwconv.0.weight"], P["dwconv.0.bias"], padding=1, groups=hidden)
+    g = F.gelu(u).permute(0, 2, 3, 1).reshape(B, L, hidden)
+    return F.linear(g, P["linear2.0.weight"], P["linear2.0.bias"])
+
+
+def leff_out_and_grads(x: torch.Tensor, P: Params, probe: torch.Tensor):
+    x = x.detach().clone().requires_grad_(True)
+    leaves = {n: v.detach().clone().requires_grad_(True) for n, v in P.items()}
+    y = leff(x, leaves)
+    (y * probe).sum().backward()
+    return y.detach(), x.grad, {n: v.grad for n, v in leaves.items()}
+
+
 def closed_form_input(b: int, l: int, c: int, salt: int, dtype=torch.float32) -> torch.Tensor:
     return torch.from_numpy(_hash_uniform(b * l * c, 7000 + salt).reshape(b, l, c)).to(dtype)
 

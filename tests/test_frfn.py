@@ -94,3 +94,41 @@ def test_hip_frfn_full_size_properties_and_surface():
         m(torch.zeros(1, 15, dim).cuda())                                  # not a square token grid
     with pytest.raises(RuntimeError):
         FRFN(32, 128)(torch.zeros(1, 16, 32))                              # CPU tensor: no fallback
+
+
+# ---------------------------------------------------------------------------------------------- LeFF (block.py:223-247)
+LEFF_CASES = {"leff_d32_b2_s16": (32, 2, 16), "leff_d64_b1_s8": (64, 1, 8)}
+
+
+@pytest.mark.parametrize("case", list(LEFF_CASES))
+def test_oracle_matches_reference_leff(case):
+    g = np.load(GOLDEN)
+    dim, B, S = LEFF_CASES[case]
+    assert list(g["leff_names"]) == list(R.leff_param_shapes(32, 128).keys())
+    P = {k: v.double() for k, v in R.closed_form_leff_params(dim, 4 * dim).items()}
+    x, probe = R.closed_form_input(B, S * S, dim, 19).double(), R.closed_form_input(B, S * S, dim, 29).double()
+    y, dx, grads = R.leff_out_and_grads(x, P, probe)
+    assert _rel(y, g[case + ".y"]) < 1e-6 and _rel(dx, g[case + ".dx"]) < 1e-6
+    for n, gw in grads.items():
+        assert _rel(gw, g[case + ".grad." + n]) < 1e-6, n
+
+
+@gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("case", list(LEFF_CASES))
+def test_hip_leff_matches_reference(case):
+    from underwater_image_restoration_amd.model.block import LeFF
+    g = np.load(GOLDEN)
+    dim, B, S = LEFF_CASES[case]
+    m = LeFF(dim, 4 * dim)
+    assert list(m.state_dict().keys()) == list(g["leff_names"])
+    m.load_state_dict(R.closed_form_leff_params(dim, 4 * dim))
+    m = m.cuda()
+    x = R.closed_form_input(B, S * S, dim, 19).cuda().requires_grad_(True)
+    probe = R.closed_form_input(B, S * S, dim, 29).cuda()
+    y = m(x)
+    (y * probe).sum().backward()
+    torch.cuda.synchronize()
+    worst = max(_rel(p.grad, g[case + ".grad." + n]) for n, p in m.named_parameters())
+    print(f"{case}: y {_rel(y, g[case + '.y']):.2e} dx {_rel(x.grad, g[case + '.dx']):.2e} worst param grad {worst:.2e}")
+    assert _rel(y, g[case + ".y"]) < 2e-5 and _rel(x.grad, g[case + ".dx"]) < 2e-5 and worst < 1e-4

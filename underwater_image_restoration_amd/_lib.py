@@ -148,8 +148,9 @@ class ReduceDesc(C.Structure):
 
 
 class FrfnGateArgs(C.Structure):
-    _fields_ = [("U", fp), ("bias", fp), ("V", fp), ("G", fp), ("dG", fp), ("dU", fp), ("dV", fp), ("M", C.c_long),
-                ("hid", C.c_int), ("ldu", C.c_int), ("ldv", C.c_int), ("ldg", C.c_int), ("lddu", C.c_int), ("lddv", C.c_int)]
+    _fields_ = [("U", fp), ("bias", fp), ("V", fp), ("G", fp), ("dG", fp), ("dU", fp), ("dV", fp), ("db_slab", fp), ("M", C.c_long),
+                ("hid", C.c_int), ("ldu", C.c_int), ("ldv", C.c_int), ("ldg", C.c_int), ("lddu", C.c_int), ("lddv", C.c_int),
+                ("db_blocks", C.c_int)]
 
 
 class UiqmArgs(C.Structure):
@@ -211,7 +212,7 @@ SIGNATURES = {
     "uir_ssim_nblocks": [i32, i32, i32],                 # host helper: returns a count (c_long), not a status
     "uir_ssim_partials": [C.POINTER(SsimArgs), fp],
     "uir_frfn_act_fwd": [fp, i32, fp, i32, i64, i32, fp],
-    "uir_frfn_act_bwd": [fp, i32, fp, i32, fp, i32, i64, i32, fp],
+    "uir_frfn_act_bwd": [fp, i32, fp, i32, fp, i32, i64, i32, fp, i32, fp],
     "uir_frfn_gate_fwd": [C.POINTER(FrfnGateArgs), fp],
     "uir_frfn_gate_bwd": [C.POINTER(FrfnGateArgs), fp],
     "uir_layernorm_fwd": [fp, i32, fp, fp, fp, i32, fp, i64, i32, f32, fp],

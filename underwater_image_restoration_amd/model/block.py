@@ -30,30 +30,57 @@ import ctypes as C
 lib = L.lib
 
 
-def _act(rec, name, pre, t, cols, bwd_dt=None, dpre=None):
+_DB_BLOCKS = 1024      # workgroups (= slab rows) of the element-wise backward passes that also sum the bias gradient
+
+
+def _fused_db(cols: int) -> bool:
+    return cols <= 1024 and cols % 4 == 0 and 256 % (cols // 4) == 0
+
+
+def _act(rec, name, pre, t, cols, bwd_dt=None, dpre=None, dbias=None):
     rec._hold(pre, t, bwd_dt, dpre)
     M = pre.shape[0]
     if bwd_dt is None:
         rec._op(name, lib.uir_frfn_act_fwd, _ptr(pre), _ld(pre), _ptr(t), _ld(t), M, cols, nbytes=8 * M * cols)
-    else:
-        rec._op(name, lib.uir_frfn_act_bwd, _ptr(pre), _ld(pre), _ptr(bwd_dt), _ld(bwd_dt), _ptr(dpre), _ld(dpre), M, cols,
-                nbytes=12 * M * cols)
+        return
+    slab = rec.alloc(_DB_BLOCKS, cols) if dbias is not None and _fused_db(cols) else None
+    rec._op(name, lib.uir_frfn_act_bwd, _ptr(pre), _ld(pre), _ptr(bwd_dt), _ld(bwd_dt), _ptr(dpre), _ld(dpre), M, cols,
+            _ptr(slab), _DB_BLOCKS if slab is not None else 0, nbytes=12 * M * cols)
+    if dbias is not None:
+        with rec.bulk():
+            if slab is not None:      # the bias gradient came out of the same pass: only its (batched) slab reduction is left
+                rec._reduce(name + ".db", _ptr(slab), _DB_BLOCKS, cols, _ptr(dbias), cols)
+            else:
+                _colsum_wide(rec, name + ".db", dpre, cols, dbias)
 
 
-def _gate(rec, name, hid, U, bias, V, G=None, dG=None, dU=None, dV=None):
+def _gate(rec, name, hid, U, bias, V, G=None, dG=None, dU=None, dV=None, dbias=None):
+    """V = None: no gate (LeFF): G = GELU(U + bias)."""
     rec._hold(U, bias, V, G, dG, dU, dV)
     a = L.FrfnGateArgs()
-    a.U, a.bias, a.V = _ptr(U), _ptr(bias), _ptr(V)
+    a.U, a.bias = _ptr(U), _ptr(bias)
+    a.V = _ptr(V) if V is not None else None
     a.M, a.hid = U.shape[0], hid
-    a.ldu, a.ldv = _ld(U), _ld(V)
+    a.ldu, a.ldv = _ld(U), (_ld(V) if V is not None else 0)
     rec.keep.append(a)
     if dG is None:
         a.G, a.ldg = _ptr(G), _ld(G)
-        rec._op(name, lib.uir_frfn_gate_fwd, C.byref(a), nbytes=12 * a.M * a.hid)
-    else:
-        a.dG, a.ldg = _ptr(dG), _ld(dG)
-        a.dU, a.dV, a.lddu, a.lddv = _ptr(dU), _ptr(dV), _ld(dU), _ld(dV)
-        rec._op(name, lib.uir_frfn_gate_bwd, C.byref(a), nbytes=20 * a.M * a.hid)
+        rec._op(name, lib.uir_frfn_gate_fwd, C.byref(a), nbytes=(12 if V is not None else 8) * a.M * a.hid)
+        return
+    a.dG, a.ldg = _ptr(dG), _ld(dG)
+    a.dU, a.lddu = _ptr(dU), _ld(dU)
+    if dV is not None:
+        a.dV, a.lddv = _ptr(dV), _ld(dV)
+    slab = rec.alloc(_DB_BLOCKS, hid) if dbias is not None and _fused_db(hid) else None
+    if slab is not None:
+        a.db_slab, a.db_blocks = _ptr(slab), _DB_BLOCKS
+    rec._op(name, lib.uir_frfn_gate_bwd, C.byref(a), nbytes=(20 if V is not None else 12) * a.M * a.hid)
+    if dbias is not None:
+        with rec.bulk():
+            if slab is not None:
+                rec._reduce(name + ".db", _ptr(slab), _DB_BLOCKS, hid, _ptr(dbias), hid)
+            else:
+                _colsum_wide(rec, name + ".db", dU, hid, dbias)
 
 
 def _colsum_wide(rec, name, src, cols, out):
@@ -93,20 +120,49 @@ def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
             rec.gram(n + "linear2.dW", dy, g, Gr("linear2.0.weight"), N=C_, K=hid, o_sn=hid, o_sk=1)
             _colsum_wide(rec, n + "linear2.db", dy, C_, Gr("linear2.0.bias"))
         rec.gemm(n + "linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
-        _gate(rec, n + "gate.bwd", hid, u, bdw, t[:, hid:], dG=dg, dU=du, dV=dt[:, hid:])
-        with rec.bulk():
-            _colsum_wide(rec, n + "dwconv.db", du, hid, Gr("dwconv.0.bias"))
+        _gate(rec, n + "gate.bwd", hid, u, bdw, t[:, hid:], dG=dg, dU=du, dV=dt[:, hid:], dbias=Gr("dwconv.0.bias"))
         rec.dwconv_bwd(n + "dwconv.bwd", du, t[:, :hid], Wdw, dt[:, :hid], Gr("dwconv.0.weight"), C_=hid, creal=hid, dims=dims)
-        _act(rec, n + "linear1.gelu.bwd", pre, None, 2 * hid, bwd_dt=dt, dpre=dpre)
+        _act(rec, n + "linear1.gelu.bwd", pre, None, 2 * hid, bwd_dt=dt, dpre=dpre, dbias=Gr("linear1.0.bias"))
         with rec.bulk():
             rec.gram(n + "linear1.dW", dpre, xc, Gr("linear1.0.weight"), N=2 * hid, K=C_, o_sn=C_, o_sk=1)
-            _colsum_wide(rec, n + "linear1.db", dpre, 2 * hid, Gr("linear1.0.bias"))
         rec.gemm(n + "linear1.dX", dpre, W1, dxc, N=C_, K=2 * hid, w_sn=1, w_sk=C_)
         rec.copy_cols(n + "pc3.pass.bwd", dxc, c4, dx, c4, C_ - c4)
         with rec.bulk():
             rec.gram(n + "pc3.dW", dxc[:, :c4], x[:, :c4], Gr("partial_conv3.weight"), N=c4, K=c4, o_sn=c4 * 9, o_sk=9, o_st=1,
                      taps=9, hw=(H, W))
         rec.gemm(n + "pc3.dX", dxc[:, :c4], Wpc, dx[:, :c4], N=c4, K=c4, w_sn=9, w_sk=c4 * 9, w_st=1, taps=9, flip=1, hw=(H, W))
+        return dx
+    return y, backward
+
+
+def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims):
+    """Record LeFF.forward (block.py:234-247): Linear C -> hidden + GELU, depthwise 3x3 + bias + GELU, Linear hidden -> C."""
+    B, H, W = dims
+    M, C_ = B * H * W, dim
+    P, Gr = (lambda n: rec.P(pfx + n)), (lambda n: rec.Gr(pfx + n))
+    W1, b1 = P("linear1.0.weight"), P("linear1.0.bias")
+    Wdw, bdw = P("dwconv.0.weight"), P("dwconv.0.bias")
+    W2, b2 = P("linear2.0.weight"), P("linear2.0.bias")
+    pre, t, u, g, y = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
+    n = pfx
+    rec.gemm(n + "linear1", x, W1, pre, N=hid, K=C_, w_sn=C_, w_sk=1, bias=b1)
+    _act(rec, n + "linear1.gelu", pre, t, hid)
+    rec.dwconv(n + "dwconv", t, Wdw, u, C_=hid, dims=dims)
+    _gate(rec, n + "dwconv.gelu", hid, u, bdw, None, G=g)
+    rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
+
+    def backward(dy: torch.Tensor) -> torch.Tensor:
+        dg, du, dt, dpre, dx = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
+        with rec.bulk():
+            rec.gram(n + "linear2.dW", dy, g, Gr("linear2.0.weight"), N=C_, K=hid, o_sn=hid, o_sk=1)
+            _colsum_wide(rec, n + "linear2.db", dy, C_, Gr("linear2.0.bias"))
+        rec.gemm(n + "linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
+        _gate(rec, n + "dwconv.gelu.bwd", hid, u, bdw, None, dG=dg, dU=du, dbias=Gr("dwconv.0.bias"))
+        rec.dwconv_bwd(n + "dwconv.bwd", du, t, Wdw, dt, Gr("dwconv.0.weight"), C_=hid, creal=hid, dims=dims)
+        _act(rec, n + "linear1.gelu.bwd", pre, None, hid, bwd_dt=dt, dpre=dpre, dbias=Gr("linear1.0.bias"))
+        with rec.bulk():
+            rec.gram(n + "linear1.dW", dpre, x, Gr("linear1.0.weight"), N=hid, K=C_, o_sn=C_, o_sk=1)
+        rec.gemm(n + "linear1.dX", dpre, W1, dx, N=C_, K=hid, w_sn=1, w_sk=C_)
         return dx
     return y, backward
 
@@ -161,6 +217,15 @@ class FrfnPlan(TokenPlan):
 
     def _record(self, x):
         return record_frfn(self, "", x, self.dim, self.hidden, (self.B, self.H, self.W))
+
+
+class LeffPlan(TokenPlan):
+    def __init__(self, fp: FlatParams, dim: int, hidden: int, B: int, H: int, W: int, want_backward: bool = True):
+        self.hidden = hidden
+        super().__init__(fp, dim, B, H, W, want_backward)
+
+    def _record(self, x):
+        return record_leff(self, "", x, self.dim, self.hidden, (self.B, self.H, self.W))
 
 
 class _TokenFunction(torch.autograd.Function):
@@ -270,3 +335,24 @@ class FRFN(TokenModule):
 
     def _make_plan(self, fp, B, H, W, want_backward):
         return FrfnPlan(fp, self.dim, self.hidden_dim, B, H, W, want_backward)
+
+
+class LeFF(TokenModule):
+    """Drop-in for ``src.model.block.LeFF`` (block.py:223-247), the default feed-forward of EncoderBlock / AST."""
+
+    def __init__(self, dim=32, hidden_dim=128, act_layer=nn.GELU, drop=0., use_eca=False):
+        super().__init__()
+        if act_layer is not nn.GELU:
+            raise NotImplementedError("the HIP LeFF implements the reference's configuration (act_layer=nn.GELU)")
+        if dim % 4 or hidden_dim % 4:
+            raise NotImplementedError("dim and hidden_dim must be multiples of 4 (float4 channel groups)")
+        self.linear1 = nn.Sequential(nn.Linear(dim, hidden_dim), act_layer())
+        self.dwconv = nn.Sequential(nn.Conv2d(hidden_dim, hidden_dim, groups=hidden_dim, kernel_size=3, stride=1, padding=1), act_layer())
+        self.linear2 = nn.Sequential(nn.Linear(hidden_dim, dim))
+        self.dim = dim
+        self.hidden_dim = hidden_dim
+        self.eca = nn.Identity()
+        self._init_plumbing()
+
+    def _make_plan(self, fp, B, H, W, want_backward):
+        return LeffPlan(fp, self.dim, self.hidden_dim, B, H, W, want_backward)

@@ -2,8 +2,8 @@
 (src/model/model.py:16-93): same constructor arguments, same ``state_dict`` names in the same registration order
 (``norm1.*``, ``mlp.*``, ``norm2.*``, ``freq_mlp.*``), ``forward(x: (B, L, C), mask=None) -> (B, L, C)``.
 
-Built for the configuration MyBigFRFNModel uses for its first level (model.py:481-489): ``token_mlp = freq_mlp = "frfn"``,
-``use_dwt = "Fourier"``, ``drop_path = 0``.  In that mode the reference computes
+Built for the configuration MyBigFRFNModel uses for its first level (model.py:481-489): ``token_mlp = freq_mlp = "frfn"``
+(or "leff", the class default), ``use_dwt = "Fourier"``, ``drop_path = 0``.  In that mode the reference computes
 
     x1 = mlp(norm1(x));  f = Re fftn(x1, dims (L, C));  f = freq_mlp(f);  f = Re ifftn(f, dims (L, C));  out = x + f + x1
 
@@ -13,7 +13,8 @@ T / (L*C): one operator, also its own backward pass.  T runs as two uir_gemm (C 
 (L = H*W = N1*N2: uir_dft_axis over n1, uir_cmul_table twiddles, uir_dft_axis over n2, uir_transpose_rows); the two FRFNs
 are ``block.record_frfn``; LayerNorm is uir_layernorm_fwd / uir_layernorm_bwd.  No CPU / eager fallback.
 
-Not built yet (raise NotImplementedError): ``token_mlp="leff"``, the Wavelet mode, ``drop_path > 0`` (stochastic depth of the
+``token_mlp`` / ``freq_mlp`` may each be "frfn" or "leff" (the reference's default).  Not built yet (raise
+NotImplementedError): the Wavelet mode, ``drop_path > 0`` (stochastic depth of the
 deeper encoder levels), DecoderBlock / MDASSA / FDFP - SURVEY.md 8(f)-2, next.
 """
 from __future__ import annotations
@@ -24,7 +25,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from ..engine import FlatParams, _ptr
-from .block import FRFN, TokenModule, TokenPlan, record_frfn
+from .block import FRFN, LeFF, TokenModule, TokenPlan, record_frfn, record_leff
 
 lib = L.lib
 _TABLES: dict = {}
@@ -77,9 +78,13 @@ def record_token_fft(rec, name: str, x: torch.Tensor, dims, C_: int, scale: floa
     return y
 
 
+_MLP_RECORDERS = {"frfn": record_frfn, "leff": record_leff}
+
+
 class EncoderPlan(TokenPlan):
-    def __init__(self, fp: FlatParams, dim: int, hidden: int, B: int, H: int, W: int, want_backward: bool = True):
-        self.hidden = hidden
+    def __init__(self, fp: FlatParams, dim: int, hidden: int, B: int, H: int, W: int, want_backward: bool = True,
+                 token_mlp: str = "frfn", freq_mlp: str = "frfn"):
+        self.hidden, self.token_mlp, self.freq_mlp = hidden, token_mlp, freq_mlp
         super().__init__(fp, dim, B, H, W, want_backward)
 
     def _record(self, x):
@@ -90,9 +95,9 @@ class EncoderPlan(TokenPlan):
         self._hold(g1, b1)
         self._op("norm1", lib.uir_layernorm_fwd, _ptr(x), C_, _ptr(g1), _ptr(b1), _ptr(xn), C_, _ptr(stats), M, C_, 1e-5,
                  nbytes=8 * M * C_)
-        x1, bw1 = record_frfn(self, "mlp.", xn, C_, self.hidden, dims)
+        x1, bw1 = _MLP_RECORDERS[self.token_mlp](self, "mlp.", xn, C_, self.hidden, dims)
         f1 = record_token_fft(self, "fftn", x1, dims, C_, 1.0)
-        f2, bw2 = record_frfn(self, "freq_mlp.", f1, C_, self.hidden, dims)
+        f2, bw2 = _MLP_RECORDERS[self.freq_mlp](self, "freq_mlp.", f1, C_, self.hidden, dims)
         y = record_token_fft(self, "ifftn", f2, dims, C_, 1.0 / (Ltok * C_))
         self.copy_cols("out+=x", x, 0, y, 0, C_, accumulate=1)          # shortcut + freq_x + x  (model.py:91)
         self.copy_cols("out+=x1", x1, 0, y, 0, C_, accumulate=1)
@@ -117,12 +122,10 @@ class EncoderBlock(TokenModule):
     def __init__(self, dim, input_resolution, num_heads, mlp_ratio=4, token_mlp="leff", drop_path=0.0, norm_layer=nn.LayerNorm,
                  act_layer=nn.GELU, drop=0.0, freq_mlp="leff", use_dwt="Fourier"):
         super().__init__()
-        if token_mlp != "frfn" or freq_mlp != "frfn":
-            if token_mlp not in ("leff", "frfn"):
-                raise ValueError(f"Unknown token_mlp type: {token_mlp}")                 # the reference's errors (model.py:38,48)
-            if freq_mlp not in ("leff", "frfn"):
-                raise ValueError(f"Unknown freq_mlp type: {freq_mlp}")
-            raise NotImplementedError("the HIP EncoderBlock is built for token_mlp = freq_mlp = 'frfn' (MyBigFRFNModel); LeFF is next")
+        if token_mlp not in ("leff", "frfn"):
+            raise ValueError(f"Unknown token_mlp type: {token_mlp}")                     # the reference's errors (model.py:38,48)
+        if freq_mlp not in ("leff", "frfn"):
+            raise ValueError(f"Unknown freq_mlp type: {freq_mlp}")
         if use_dwt != "Fourier" or drop_path > 0.0 or norm_layer is not nn.LayerNorm or act_layer is not nn.GELU:
             raise NotImplementedError("the HIP EncoderBlock is built for use_dwt='Fourier', drop_path=0, LayerNorm, GELU "
                                       "(encoder_0 / encoder_0_1 of MyBigFRFNModel, model.py:481-489)")
@@ -138,11 +141,13 @@ class EncoderBlock(TokenModule):
         self.use_dwt = use_dwt
         mlp_hidden_dim = int(dim * mlp_ratio)
         self.hidden_dim = mlp_hidden_dim
-        self.mlp = FRFN(dim, mlp_hidden_dim, act_layer=act_layer, drop=drop)          # parameter containers in the reference's
-        self.norm2 = norm_layer(dim)                                                    # registration order (model.py:28-52)
-        self.freq_mlp = FRFN(dim, mlp_hidden_dim, act_layer=act_layer, drop=drop)
+        mlps = {"frfn": FRFN, "leff": LeFF}                                             # parameter containers in the reference's
+        self.mlp = mlps[token_mlp](dim, mlp_hidden_dim, act_layer=act_layer, drop=drop)  # registration order (model.py:28-52)
+        self.norm2 = norm_layer(dim)
+        self.freq_mlp = mlps[freq_mlp](dim, mlp_hidden_dim, act_layer=act_layer, drop=drop)
+        self.freq_mlp_kind = freq_mlp
         self.drop_path2 = nn.Identity()
         self._init_plumbing()
 
     def _make_plan(self, fp, B, H, W, want_backward):
-        return EncoderPlan(fp, self.dim, self.hidden_dim, B, H, W, want_backward)
+        return EncoderPlan(fp, self.dim, self.hidden_dim, B, H, W, want_backward, self.token_mlp, self.freq_mlp_kind)
