@@ -130,8 +130,8 @@ def test_hip_encoder_block_leff_vs_oracle():
         m = EncoderBlock(dim, (S, S), 4, token_mlp=tok, freq_mlp=frq)
         P = {}
         for n, p in m.named_parameters():
-            base = R.closed_form_leff_params(dim, 4 * dim) if (n.startswith("mlp.") and tok == "leff") or (n.startswith("freq_mlp.") and frq == "leff") \\
-                else R.closed_form_params(dim, 4 * dim)
+            is_leff = (n.startswith("mlp.") and tok == "leff") or (n.startswith("freq_mlp.") and frq == "leff")
+            base = R.closed_form_leff_params(dim, 4 * dim) if is_leff else R.closed_form_params(dim, 4 * dim)
             key = n.split(".", 1)[1] if n.startswith(("mlp.", "freq_mlp.")) else None
             P[n] = base[key].clone() if key else E.closed_form_params(dim, 4 * dim)[n].clone()
         m.load_state_dict(P)
