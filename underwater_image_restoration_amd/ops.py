@@ -196,3 +196,8 @@ def axpy_scalar(dst: torch.Tensor, src: torch.Tensor, w: float, first: bool) -> 
         torch.mul(src.reshape(1), w, out=dst)
     else:
         dst.add_(src.reshape(1), alpha=w)
+
+
+def flat_accumulate_add(src: torch.Tensor, dst: torch.Tensor, n: int) -> None:
+    """dst[:n] += src[:n] (flat fp32 buffers, n a multiple of 4)."""
+    flat_accumulate(src, dst, n, accumulate=True)

@@ -17,7 +17,7 @@ from . import parallel
 
 class TrainStep:
     def __init__(self, model, loss_name: str = "L1", lr: float = 3e-4, max_norm: float = 1.0, process_group=None,
-                 weight_decay: float = 0.0, micro_batch: "int | None" = None):
+                 weight_decay: float = 0.0, micro_batch: "int | None" = None, lanes: "int | None" = None):
         if loss_name not in L.LOSS_KINDS:
             raise ValueError(f"Unsupported loss: {loss_name}")
         self.model = model
@@ -29,6 +29,12 @@ class TrainStep:
                                "call torch.cuda.set_device(...) first (one process per GPU)")
         self.opt = ops.FusedClipAdam(self.flat, lr=lr, max_norm=max_norm, weight_decay=weight_decay)
         self.pg = process_group
+        # Sample lanes: the batch is split into `lanes` equal parts, each with its OWN plan and HIP stream, running concurrently.
+        # The deep U-Net levels are latency-bound (a few hundred workgroups per kernel) and the full-resolution stages are
+        # HBM-bound: with the lanes out of phase (the host enqueues lane 0's lists first) one lane's deep levels fill the idle
+        # CUs / bandwidth under the other lane's full-resolution kernels.  Exact (no cross-sample statistics).
+        self.lanes = int(lanes if lanes is not None else os.environ.get("UIR_LANES", "1"))
+        self._lane_state = {}
         self.micro_batch = micro_batch          # None: the largest divisor of the batch whose plan fits in HBM
         self._acc = None                        # flat gradient accumulator of micro-batched steps
         self.world = parallel.world_size(process_group)
@@ -117,7 +123,62 @@ class TrainStep:
         norm = self.opt.step(lr=lr, grad_scale=scale, grad=self._acc)
         return self._loss_acc[0].clone(), norm[0]
 
+    def _lanes_for(self, shape):
+        """Per (shape) state of the concurrent sample lanes: per lane a FlatParams view (shared weights, own gradient
+        bucket), a Plan built on it, a stream."""
+        import copy
+        from .engine import Plan
+        key = tuple(shape)
+        st = self._lane_state.get(key)
+        if st is None:
+            B, _, H, W = shape
+            b = B // self.lanes
+            st = []
+            for i in range(self.lanes):
+                fp = self.flat if i == 0 else copy.copy(self.flat)
+                if i > 0:
+                    fp.grad = torch.zeros_like(self.flat.grad)       # weights (fp.flat) stay shared; gradients are per lane
+                st.append({"fp": fp, "plan": Plan(fp, b, H, W), "stream": torch.cuda.Stream(device=self.flat.device),
+                           "done": torch.cuda.Event()})
+            self._lane_state = {key: st}                              # one shape at a time (plans are large)
+            self._wdev = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
+            self._loss_parts = torch.zeros(self.lanes, dtype=torch.float32, device=self.flat.device)
+        return st
+
+    def _step_lanes(self, raw, ref, lr):
+        B = raw.shape[0]
+        n = self.flat.n_live
+        st = self._lanes_for(raw.shape)
+        b = B // self.lanes
+        w = self._weights(b, B)
+        cur = torch.cuda.current_stream()
+        self._wdev.fill_(w)
+        start = torch.cuda.Event()
+        start.record(cur)
+        for i, lane in enumerate(st):
+            s_ = lane["stream"]
+            s_.wait_event(start)                       # the previous optimizer step and this step's inputs are visible
+            with torch.cuda.stream(s_):
+                r, f = raw[i * b:(i + 1) * b], ref[i * b:(i + 1) * b]
+                plan = lane["plan"]
+                out = plan.forward(r)
+                res = ops.loss_sums(out, f, self.kind)
+                dout = ops.loss_grad(out, f, self._wdev, self.kind)
+                plan.backward(dout)
+                self._loss_parts[i:i + 1].copy_(res[0:1])
+                lane["done"].record(s_)
+        for lane in st:
+            cur.wait_event(lane["done"])
+        self.model._fwd_serial += 1
+        for i, lane in enumerate(st[1:]):              # lane 0 writes the main bucket; the others are added to it
+            ops.flat_accumulate_add(lane["fp"].grad, self.flat.grad, n)
+        scale = parallel.allreduce_flat_grads(self.flat.grad, n, self.pg)
+        norm = self.opt.step(lr=lr, grad_scale=scale)
+        return (self._loss_parts.sum() * w), norm[0]
+
     def _step(self, raw, ref, lr):
+        if self.lanes > 1 and raw.shape[0] % self.lanes == 0 and self.flat.device.type == "cuda":
+            return self._step_lanes(raw, ref, lr)
         mb = self.micro_batch_for(raw.shape[0], raw.shape[2], raw.shape[3])
         if mb != raw.shape[0]:
             return self._step_micro(raw, ref, lr, mb)
