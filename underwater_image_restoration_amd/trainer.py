@@ -161,10 +161,11 @@ class TrainStep:
             with torch.cuda.stream(s_):
                 r, f = raw[i * b:(i + 1) * b], ref[i * b:(i + 1) * b]
                 plan = lane["plan"]
-                out = plan.forward(r)
+                ser = os.environ.get("UIR_LANE_SERIAL", "0") == "1"      # experiment: one stream per lane (no side / bulk streams)
+                out = plan.forward(r, serial=ser)
                 res = ops.loss_sums(out, f, self.kind)
                 dout = ops.loss_grad(out, f, self._wdev, self.kind)
-                plan.backward(dout)
+                plan.backward(dout, serial=ser)
                 self._loss_parts[i:i + 1].copy_(res[0:1])
                 lane["done"].record(s_)
         for lane in st:
