@@ -138,6 +138,7 @@ def twiddles(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     return _TWIDDLE_CACHE[key]
 
 
+_NO_SIDE_STREAM = os.environ.get("UIR_NO_SIDE_STREAM", "0") == "1"
 _RED_BATCH = os.environ.get("UIR_RED_BATCH", "1") == "1"       # one batched slab-reduction launch per stage on the bulk lane
 _GRAM_WGS = int(os.environ.get("UIR_GRAM_WGS", 1024))           # workgroups (= partial rows x column groups) per Gram launch; tuning aid
 GEMM_SLAB_ROWS = int(os.environ.get("UIR_GEMM_ROWS", 512))      # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
@@ -358,6 +359,8 @@ class Recorder:
         main = torch.cuda.current_stream()
         st0 = C.c_void_p(main.cuda_stream)
         lanes = self.lanes[id(ops)]
+        if _NO_SIDE_STREAM:          # experiment: side-lane work in list order on the main stream (weight-gradient lane kept)
+            lanes = [0 if l == 1 else (3 if l == 2 else l) for l in lanes]
         if serial or (1 not in lanes and 4 not in lanes):
             for fn, args, name in ops:
                 if fn is None:
