@@ -492,11 +492,12 @@ int uir_frfn_gate_bwd(const UirFrfnGateArgs* args, void* stream);
  * symmetric operator: two uir_gemm against cos / sin matrices for C, and for L = N1 * N2 a two-stage
  * transform on uir_dft_axis with
  *   uir_cmul_table      (re, im)[r][c] *= (tab_re, tab_im)[r % P]: the inter-stage twiddle exp(2 pi i k1 n2 / L), P = N1 * N2
- *   uir_transpose_rows  dst[b][j][i][:] = scale * src[b][i][j][:]: frequency index k1 + N1 k2 back to natural token order. */
+ *   uir_transpose_rows  dst[b][k3][k2][k1][:] = scale * src[b][k1][k2][k3][:]: the stage-ordered frequency index
+ *                       k1 + N1 (k2 + N2 k3) back to natural token order (N3 = 1 or N2 = 1: the two-stage transpose). */
 int uir_layernorm_fwd(const float* X, int ldx, const float* gamma, const float* beta, float* Y, int ldy, float* stats, long M, int C,
                       float eps, void* stream);
 int uir_cmul_table(float* re, float* im, const float* tab_re, const float* tab_im, long rows, long P, int C, void* stream);
-int uir_transpose_rows(const float* src, float* dst, int B, int N1, int N2, int C, float scale, void* stream);
+int uir_transpose_rows(const float* src, float* dst, int B, int N1, int N2, int N3, int C, float scale, void* stream);
 
 /* ---------------------------------------------------------------- uir_uiqm */
 /* Evaluation metric UIQM.  Replaces getUIQM of uqim_utils.py:176-190 (with _uicm :36-48, mu_a :10-28,

@@ -87,12 +87,23 @@ def test_hip_encoder_block_matches_reference(case):
 def test_hip_encoder_block_full_size_and_surface():
     """cfg4's first level (dim 32) at 256 x 256 (L = 65 536: the two-stage 256 x 256 token transform), B = 2, vs the fp64 oracle;
     bitwise determinism; the reference's constructor errors."""
-    from underwater_image_restoration_amd.model.model import EncoderBlock
-    dim, B, S = 32, 2, 256
-    m = EncoderBlock(dim, (S, S), 4, token_mlp="frfn", freq_mlp="frfn")
+    from underwater_image_restoration_amd.model.model import EncoderBlock, token_factors
+    assert token_factors(256, 256) == (64, 32, 32) and token_factors(64, 64) == (128, 32) and token_factors(16, 16) == (16, 16)
+    dim, B = 32, 2
+    m = EncoderBlock(dim, (64, 64), 4, token_mlp="frfn", freq_mlp="frfn")
     P = E.closed_form_params(dim, 4 * dim)
     m.load_state_dict(P)
     m = m.cuda()
+    # 64 x 64 tokens: the two-stage (128, 32) transform on the MFMA DFT kernel
+    xs, ps = R.closed_form_input(B, 64 * 64, dim, 53), R.closed_form_input(B, 64 * 64, dim, 54)
+    ys64, dxs64, gs64 = E.out_and_grads(xs.double(), {k: v.double() for k, v in P.items()}, ps.double())
+    xg = xs.cuda().requires_grad_(True)
+    ys = m(xg)
+    (ys * ps.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert _rel(ys, ys64) < 5e-5 and _rel(xg.grad, dxs64) < 1e-4
+    assert max(_rel(p.grad, gs64[n]) for n, p in m.named_parameters() if p.grad is not None) < 5e-4
+    S = 256                                                  # 65 536 tokens: three stages (64, 32, 32)
     x = R.closed_form_input(B, S * S, dim, 51)
     probe = R.closed_form_input(B, S * S, dim, 52)
     torch.set_num_threads(8)

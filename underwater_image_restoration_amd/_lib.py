@@ -217,7 +217,7 @@ SIGNATURES = {
     "uir_frfn_gate_bwd": [C.POINTER(FrfnGateArgs), fp],
     "uir_layernorm_fwd": [fp, i32, fp, fp, fp, i32, fp, i64, i32, f32, fp],
     "uir_cmul_table": [fp, fp, fp, fp, i64, i64, i32, fp],
-    "uir_transpose_rows": [fp, fp, i32, i32, i32, i32, f32, fp],
+    "uir_transpose_rows": [fp, fp, i32, i32, i32, i32, i32, f32, fp],
     "uir_uiqm_work_doubles": [i32, i32, i32],            # host helper: returns a count (c_long) or -1
     "uir_uiqm": [C.POINTER(UiqmArgs), fp],
     "uir_stream_create_cu_masked": [i32, C.POINTER(C.c_void_p)],

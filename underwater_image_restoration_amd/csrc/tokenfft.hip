@@ -5,7 +5,8 @@
 // The C axis (32..128) is a pair of uir_gemm calls against cos / sin matrices; the L axis (L = H*W up to 65 536) is a
 // two-stage Cooley-Tukey transform, L = N1*N2, on uir_dft_axis (MFMA contractions against host-built fp64 tables):
 //   stage A over n1 (stride N2)  ->  uir_cmul_table: A[k1][n2] *= exp(2 pi i k1 n2 / L)  ->  stage B over n2  ->
-//   uir_transpose_rows: frequency k = k1 + N1 k2 back to natural token order.
+//   uir_transpose_rows: frequency k = k1 + N1 k2 back to natural token order
+// (three stages, L = N1*N2*N3, when that puts every stage on the two-stage MFMA DFT of csrc/spectral.hip: 65 536 = 64*32*32).
 // The operator is real-symmetric, so its backward pass is the operator itself.
 #include "uir_common.h"
 #include "../../include/uir_kernels.h"
@@ -63,18 +64,21 @@ __global__ __launch_bounds__(256) void cmul_table_kernel(float* __restrict__ re,
   }
 }
 
-// dst[b][j][i][:] = scale * src[b][i][j][:]   (rows of C floats; i < N1, j < N2)
+// dst[b][k3][k2][k1][:] = scale * src[b][k1][k2][k3][:]   (rows of C floats; index reversal of a 2- or 3-stage transform:
+// N2 = 1 gives the plain transpose dst[b][j][i] = src[b][i][j])
 __global__ __launch_bounds__(256) void transpose_rows_kernel(const float* __restrict__ src, float* __restrict__ dst, int Bn, int N1,
-                                                             int N2, int C4, float scale) {
-  const long total = (long)Bn * N1 * N2 * C4;
+                                                             int N2, int N3, int C4, float scale) {
+  const long total = (long)Bn * N1 * N2 * N3 * C4;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const int c = (int)(e % C4);
-    long r = e / C4;                       // destination row: (b, j, i)
-    const int i = (int)(r % N1);
+    long r = e / C4;                       // destination row: (b, k3, k2, k1)
+    const int k1 = (int)(r % N1);
     r /= N1;
-    const int j = (int)(r % N2);
-    const long b = r / N2;
-    float4 v = reinterpret_cast<const float4*>(src)[((b * N1 + i) * N2 + j) * C4 + c];
+    const int k2 = (int)(r % N2);
+    r /= N2;
+    const int k3 = (int)(r % N3);
+    const long b = r / N3;
+    float4 v = reinterpret_cast<const float4*>(src)[(((b * N1 + k1) * N2 + k2) * N3 + k3) * C4 + c];
     v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
     reinterpret_cast<float4*>(dst)[e] = v;
   }
@@ -113,9 +117,10 @@ extern "C" int uir_cmul_table(float* re, float* im, const float* tab_re, const f
   return uir_launch_status();
 }
 
-extern "C" int uir_transpose_rows(const float* src, float* dst, int B, int N1, int N2, int C, float scale, void* stream) {
-  UIR_REQUIRE(src && dst && src != dst && B > 0 && N1 > 0 && N2 > 0 && C > 0 && (C & 3) == 0 && uir_aligned16(src) && uir_aligned16(dst));
-  hipLaunchKernelGGL(transpose_rows_kernel, dim3(grid_for((long)B * N1 * N2 * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
-                     src, dst, B, N1, N2, C / 4, scale);
+extern "C" int uir_transpose_rows(const float* src, float* dst, int B, int N1, int N2, int N3, int C, float scale, void* stream) {
+  UIR_REQUIRE(src && dst && src != dst && B > 0 && N1 > 0 && N2 > 0 && N3 > 0 && C > 0 && (C & 3) == 0);
+  UIR_REQUIRE(uir_aligned16(src) && uir_aligned16(dst));
+  hipLaunchKernelGGL(transpose_rows_kernel, dim3(grid_for((long)B * N1 * N2 * N3 * (C / 4))), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), src, dst, B, N1, N2, N3, C / 4, scale);
   return uir_launch_status();
 }

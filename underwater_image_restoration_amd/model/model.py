@@ -19,6 +19,8 @@ deeper encoder levels), DecoderBlock / MDASSA / FDFP - SURVEY.md 8(f)-2, next.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -45,12 +47,12 @@ def _axis_tables(C: int, device):
     return _TABLES[key]
 
 
-def _twiddle_tables(N1: int, N2: int, device):
-    """exp(+2 pi i k1 n2 / (N1*N2)) at p = k1*N2 + n2."""
-    key = ("tw", N1, N2, str(device))
+def _twiddle_tables(N1: int, Mrest: int, device):
+    """exp(+2 pi i k1 m / (N1*Mrest)) at p = k1*Mrest + m: the twiddle between a stage of length N1 and the rest."""
+    key = ("tw", N1, Mrest, str(device))
     if key not in _TABLES:
-        Ltok = N1 * N2
-        r = (np.arange(N1, dtype=np.int64)[:, None] * np.arange(N2, dtype=np.int64)[None, :]) % Ltok
+        Ltok = N1 * Mrest
+        r = (np.arange(N1, dtype=np.int64)[:, None] * np.arange(Mrest, dtype=np.int64)[None, :]) % Ltok
         ang = 2.0 * np.pi * r.astype(np.float64) / Ltok
         c, s = np.cos(ang), np.sin(ang)
         q = (4 * r) % Ltok == 0
@@ -60,21 +62,51 @@ def _twiddle_tables(N1: int, N2: int, device):
     return _TABLES[key]
 
 
+_FAST = (128, 64, 32)          # lengths the two-stage MFMA DFT kernel (uir_dft_axis2) handles; anything else is a dense contraction
+
+
+def token_factors(H: int, W: int):
+    """Stage lengths (N1, N2[, N3]) with product H*W.  Prefer factors the fast DFT kernel handles (65 536 = 64*32*32,
+    4096 = 64*64); otherwise the two dense stages (H, W)."""
+    Ltok = H * W
+    if os.environ.get("UIR_TOKEN_FFT_DENSE", "0") != "1":
+        for a in _FAST:
+            if Ltok % a == 0 and Ltok // a in _FAST:
+                return (a, Ltok // a)
+        for a in _FAST:
+            for b in _FAST:
+                if Ltok % (a * b) == 0 and Ltok // (a * b) in _FAST and a >= b >= Ltok // (a * b):
+                    return (a, b, Ltok // (a * b))
+    return (H, W)
+
+
 def record_token_fft(rec, name: str, x: torch.Tensor, dims, C_: int, scale: float) -> torch.Tensor:
     """y = scale * Re(sum_{l,c} x[l,c] exp(i 2 pi (k l / L + c' c / C))) = scale * (C_L x C_C - S_L x S_C) on token rows."""
-    B, N1, N2 = dims                       # token l = n1 * N2 + n2
-    M, Ltok = B * N1 * N2, N1 * N2
+    B, H, W = dims
+    M, Ltok = B * H * W, H * W
+    f = token_factors(H, W)                # token l = (n1 * N2 + n2) * N3 + n3
     Cc, Sc = _axis_tables(C_, rec.dev)
-    twr, twi = _twiddle_tables(N1, N2, rec.dev)
-    rec._hold(Cc, Sc, twr, twi)
-    zr, zi, ar, ai = rec.alloc(M, C_), rec.alloc(M, C_), rec.alloc(M, C_), rec.alloc(M, C_)
+    rec._hold(Cc, Sc)
+    zr, zi = rec.alloc(M, C_), rec.alloc(M, C_)
     rec.gemm(name + ".cosC", x, Cc, zr, N=C_, K=C_, w_sn=C_, w_sk=1)
     rec.gemm(name + ".sinC", x, Sc, zi, N=C_, K=C_, w_sn=C_, w_sk=1)
-    rec.dft(name + ".n1", zr, zi, ar, ai, O=B, N=N1, I=N2, C_=C_, sign=1.0, scale=1.0)
-    rec._op(name + ".twiddle", lib.uir_cmul_table, _ptr(ar), _ptr(ai), _ptr(twr), _ptr(twi), M, Ltok, C_, nbytes=16 * M * C_)
-    br, y = rec.alloc(M, C_), rec.alloc(M, C_)
-    rec.dft(name + ".n2", ar, ai, br, None, O=B * N1, N=N2, I=1, C_=C_, sign=1.0, scale=1.0)
-    rec._op(name + ".natural", lib.uir_transpose_rows, _ptr(br), _ptr(y), B, N1, N2, C_, scale, nbytes=8 * M * C_)
+    outer, rest = B, Ltok
+    for si, n in enumerate(f):
+        rest //= n
+        last = si == len(f) - 1
+        ar = rec.alloc(M, C_)
+        ai = None if last else rec.alloc(M, C_)
+        rec.dft(f"{name}.n{si + 1}", zr, zi, ar, ai, O=outer, N=n, I=rest, C_=C_, sign=1.0, scale=1.0)
+        if not last:       # twiddle between this stage and the remaining length-(n * rest) ... (rest) transform
+            twr, twi = _twiddle_tables(n, rest, rec.dev)
+            rec._hold(twr, twi)
+            rec._op(f"{name}.twiddle{si + 1}", lib.uir_cmul_table, _ptr(ar), _ptr(ai), _ptr(twr), _ptr(twi), M, n * rest, C_,
+                    nbytes=16 * M * C_)
+        zr, zi = ar, ai
+        outer *= n
+    y = rec.alloc(M, C_)
+    n1, n2, n3 = (f[0], 1, f[1]) if len(f) == 2 else f            # stage-ordered frequency index -> natural order
+    rec._op(name + ".natural", lib.uir_transpose_rows, _ptr(zr), _ptr(y), B, n1, n2, n3, C_, scale, nbytes=8 * M * C_)
     return y
 
 
