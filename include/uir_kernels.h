@@ -24,7 +24,7 @@ extern "C" {
 enum { UIR_PRO_NONE = 0, UIR_PRO_LN = 1, UIR_PRO_GATE = 2 };
 #define UIR_GEMM_SLAB_ROWS 512   /* max workgroups (= slab rows) of the GEMM variants with fused reductions */
 enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2, UIR_EPI_GATE_BWD_DW = 3, UIR_EPI_LN_BWD = 4 };
-enum { UIR_ACT_NONE = 0, UIR_ACT_LEAKY = 1 };
+enum { UIR_ACT_NONE = 0, UIR_ACT_LEAKY = 1, UIR_ACT_GELU = 2 };   /* GELU: exact-erf form; plain epilogue only */
 
 /* Dense channel contraction over HWC rows, 1 or 9 (3x3, pad 1) taps:
  *   Y[z][m][n] = epi( sum_tap sum_k pro(X[z][nbr(m,tap)][k]) * W[z][n][k][tap] + bias[n] ) + R[z][m][n]
@@ -66,6 +66,9 @@ typedef struct UirGemmArgs {
   int tap0, ntap;      /* taps == 9 only: contract taps [tap0, tap0 + ntap) (ntap <= 0: all nine).  uir_gemm  */
                        /* itself uses this to run a 3x3 convolution whose weight panel exceeds LDS as a few   */
                        /* launches over tap groups that accumulate into Y (R = Y)                             */
+  float* pre_out;      /* UIR_ACT_GELU only, optional: the pre-activation X.W^T + bias is ALSO stored here (row stride */
+  long ldpre;          /* ldpre) - what the GELU backward needs; one pass instead of GEMM + element-wise (FRFN / LeFF  */
+                       /* linear1, block.py:252,273).  batches == 1                                                   */
 } UirGemmArgs;
 int uir_gemm(const UirGemmArgs* args, void* stream);
 

@@ -16,7 +16,7 @@ fp = C.c_void_p  # device pointers travel as integers
 # enums (mirror include/uir_kernels.h)
 PRO_NONE, PRO_LN, PRO_GATE = 0, 1, 2
 EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW, EPI_LN_BWD = 0, 1, 2, 3, 4
-ACT_NONE, ACT_LEAKY = 0, 1
+ACT_NONE, ACT_LEAKY, ACT_GELU = 0, 1, 2
 # L1ColorLum has the same formula as L1withColor in the reference (src/Losses/losses.py:59-66 vs :67-75)
 LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4}
 
@@ -32,7 +32,7 @@ class GemmArgs(C.Structure):
                 ("n_grp_real", C.c_int), ("n_grp_pad", C.c_int), ("k_grp_real", C.c_int), ("k_grp_pad", C.c_int),
                 ("pro", C.c_int), ("gate_off", C.c_int), ("epi", C.c_int), ("g_off", C.c_int), ("act", C.c_int),
                 ("slope", C.c_float), ("ln_eps", C.c_float), ("dw_slab", fp), ("dw_stride", C.c_long),
-                ("tap0", C.c_int), ("ntap", C.c_int)]
+                ("tap0", C.c_int), ("ntap", C.c_int), ("pre_out", fp), ("ldpre", C.c_long)]
 
 
 class GramArgs(C.Structure):

@@ -37,6 +37,10 @@ __device__ __forceinline__ void uir_gemm_epilogue(const UirGemmArgs& a, const f3
       if (mm >= a.M) continue;
       float v = acc[nt][reg] + bias;
       if (a.act == UIR_ACT_LEAKY) v = v > 0.f ? v : v * a.slope;
+      if (a.act == UIR_ACT_GELU) {
+        if (a.pre_out) a.pre_out[(long)mm * a.ldpre + n] = v;
+        v = uir_gelu(v);
+      }
       if (a.epi == UIR_EPI_PLAIN) {
         if (a.R) v += a.R[(long)z * a.r_bs + (long)mm * a.ldr + n];
         Y[(long)mm * a.ldy + n] = v;
@@ -231,6 +235,7 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
                                                   const float (&rv)[HAS_R ? NT : 1][16], int z, int m0, int n0, int r, int h2) {
   float* __restrict__ Y = a.Y + (long)z * a.y_bs;
   const float slope = (a.act == UIR_ACT_LEAKY) ? a.slope : 1.0f;
+  const bool gelu = (a.act == UIR_ACT_GELU);
   const bool full = (m0 + 32 <= a.M);
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -240,11 +245,16 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
     const long row0 = (long)m0 + 4 * h2;
     float* yp = Y + row0 * a.ldy + n;
     const float* gp = (EPI != UIR_EPI_PLAIN) ? a.G + (long)z * a.g_bs + row0 * a.ldg + n : nullptr;
+    float* pp = (EPI == UIR_EPI_PLAIN && gelu && a.pre_out) ? a.pre_out + row0 * a.ldpre + n : nullptr;
     auto put = [&](int reg) {
       const int dr = (reg & 3) + 8 * (reg >> 2);   // row offset inside the tile (compile-time)
       float v = acc[nt][reg] + bias;
       v = v > 0.f ? v : v * slope;
       if constexpr (EPI == UIR_EPI_PLAIN) {
+        if (gelu) {                                // uniform over the launch
+          if (pp) pp[(long)dr * a.ldpre] = v;
+          v = uir_gelu(v);
+        }
         if constexpr (HAS_R) v += rv[nt][reg];
         yp[(long)dr * a.ldy] = v;
       } else if constexpr (EPI == UIR_EPI_GATE_BWD) {
@@ -760,6 +770,8 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     UIR_REQUIRE((a.M & 127) == 0 && a.pro == UIR_PRO_NONE && (a.n_grp_pad <= 0 || a.n_grp_pad == a.N));
   }
   if (a.R) UIR_REQUIRE(a.ldr >= a.N);
+  if (a.act == UIR_ACT_GELU) UIR_REQUIRE(a.epi == UIR_EPI_PLAIN && (!a.pre_out || (a.batches == 1 && a.ldpre >= a.N)));
+  else UIR_REQUIRE(!a.pre_out);
   UIR_REQUIRE(a.ntap <= 0 || (a.taps == 9 && a.tap0 >= 0 && a.tap0 + a.ntap <= 9));
   UIR_REQUIRE(a.ntap > 0 || a.tap0 == 0);
   const int tiles = (a.N + 31) / 32;

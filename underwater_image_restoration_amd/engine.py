@@ -499,7 +499,7 @@ class Recorder:
     # ---------------------------------------------------------------- kernels
     def gemm(self, name, X, W, Y, *, N, K, w_sn, w_sk, w_st=0, w_bs=0, batches=1, bias=None, R=None,
              taps=1, flip=0, hw=None, n_grp=(0, 0), k_grp=(0, 0), pro=L.PRO_NONE, gate_off=0, ln=None, stats=None,
-             epi=L.EPI_PLAIN, G=None, g_off=0, act=L.ACT_NONE, dw_slab=None):
+             epi=L.EPI_PLAIN, G=None, g_off=0, act=L.ACT_NONE, dw_slab=None, pre_out=None, slope=0.1):
         M_total = X.shape[0]
         assert M_total % batches == 0 and Y.shape[0] == M_total
         M = M_total // batches
@@ -529,7 +529,11 @@ class Recorder:
         if G is not None:
             a.G, a.ldg = _ptr(G), _ld(G)
             a.g_bs = M * a.ldg
-        a.slope, a.ln_eps = 0.1, LN_EPS
+        a.slope, a.ln_eps = slope, LN_EPS
+        if pre_out is not None:       # ACT_GELU: the pre-activation is stored too (needed by the GELU backward)
+            assert act == L.ACT_GELU and batches == 1 and pre_out.shape[0] == M_total
+            self._hold(pre_out)
+            a.pre_out, a.ldpre = _ptr(pre_out), _ld(pre_out)
         if dw_slab is not None:
             self._hold(dw_slab)
             a.dw_slab, a.dw_stride = _ptr(dw_slab), dw_slab.stride(0)
@@ -540,7 +544,8 @@ class Recorder:
         kreal = k_grp[0] * (K // k_grp[1]) if k_grp[1] else K
         nreal = n_grp[0] * (N // n_grp[1]) if n_grp[1] else N
         nb = 4 * rows * (K * (2 if pro == L.PRO_GATE else 1) + N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1)
-                         + (N if R is not None else 0) + (N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1) if G is not None else 0))
+                         + (N if R is not None else 0) + (N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1) if G is not None else 0)
+                         + (N if pre_out is not None else 0))
         self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps,
                  variant=f"uir_gemm1x1_kernel<*,{pro},{epi},*>")     # the rocprofv3 symbol family (NT and HAS_R vary per call)
 

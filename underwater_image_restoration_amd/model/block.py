@@ -106,8 +106,8 @@ def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     # partial_conv3 on channels [0, C/4), the rest passes through (block.py:267-270)
     rec.copy_cols(n + "pc3.pass", x, c4, xc, c4, C_ - c4)
     rec.gemm(n + "pc3", x[:, :c4], Wpc, xc[:, :c4], N=c4, K=c4, w_sn=c4 * 9, w_sk=9, w_st=1, taps=9, hw=(H, W))
-    rec.gemm(n + "linear1", xc, W1, pre, N=2 * hid, K=C_, w_sn=C_, w_sk=1, bias=b1)
-    _act(rec, n + "linear1.gelu", pre, t, 2 * hid)
+    # Linear + bias + GELU in one pass: the GEMM epilogue stores the pre-activation (for the backward) and GELU of it
+    rec.gemm(n + "linear1+gelu", xc, W1, t, N=2 * hid, K=C_, w_sn=C_, w_sk=1, bias=b1, act=L.ACT_GELU, pre_out=pre)
     rec.dwconv(n + "dwconv", t[:, :hid], Wdw, u, C_=hid, dims=dims)
     _gate(rec, n + "dwconv.gelu*x2", hid, u, bdw, t[:, hid:], G=g)
     rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
@@ -145,8 +145,7 @@ def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     W2, b2 = P("linear2.0.weight"), P("linear2.0.bias")
     pre, t, u, g, y = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
     n = pfx
-    rec.gemm(n + "linear1", x, W1, pre, N=hid, K=C_, w_sn=C_, w_sk=1, bias=b1)
-    _act(rec, n + "linear1.gelu", pre, t, hid)
+    rec.gemm(n + "linear1+gelu", x, W1, t, N=hid, K=C_, w_sn=C_, w_sk=1, bias=b1, act=L.ACT_GELU, pre_out=pre)
     rec.dwconv(n + "dwconv", t, Wdw, u, C_=hid, dims=dims)
     _gate(rec, n + "dwconv.gelu", hid, u, bdw, None, G=g)
     rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
