@@ -632,3 +632,38 @@ def test_concurrent_sample_lanes_equal_one_lane():
         la, _ = step(raw, ref)
         lb, _ = step2(raw, ref)
     assert abs(float(la) - float(lb)) <= 1e-4 * abs(float(la))
+
+
+def test_reference_default_resolution_fits_through_micro_batches():
+    """The reference's own default run resizes every image to 1024 x 1024 (DataLoader.py:14); a plan keeps ~63 GB of
+    activations per such image, so a batch of 8 cannot be one plan on 288 GB.  TrainStep must pick a micro-batch by itself,
+    take a finite step, and agree with an explicitly micro-batched step; an impossible size must fail up front with the numbers."""
+    from underwater_image_restoration_amd.engine import plan_bytes_estimate, device_bytes_available
+    B, S = 8, 1024
+    assert plan_bytes_estimate(B, S, S) > device_bytes_available(torch.device(DEV, torch.cuda.current_device()))
+    g = torch.Generator().manual_seed(5)
+    raw = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
+    ref = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
+    model, step = _fresh_step("L1")
+    mb = step.check_memory(B, S, S)
+    assert 1 <= mb < B and B % mb == 0
+    loss, norm = step(raw, ref)
+    loss, norm = float(loss), float(norm)
+    assert np.isfinite(loss) and np.isfinite(norm) and loss > 0 and norm > 0
+    vl, vp = step.evaluate(raw, ref)
+    assert np.isfinite(float(vl)) and np.isfinite(float(vp))
+    del model, step
+    torch.cuda.empty_cache()
+    model2, step2 = _fresh_step("L1", micro_batch=1)
+    loss2, norm2 = step2(raw, ref)
+    assert abs(float(loss2) - loss) <= 1e-5 * loss and abs(float(norm2) - norm) <= 1e-4 * norm
+    with pytest.raises(RuntimeError, match="GiB"):
+        model2._plan_for(torch.empty(1, 3, 8192, 8192, device="meta") if False else _FakeShape((1, 3, 8192, 8192)))
+
+
+class _FakeShape:
+    """Stands in for a tensor where only .shape / .device are read (_plan_for of a size that must be refused)."""
+
+    def __init__(self, shape):
+        self.shape = shape
+        self.device = torch.device(DEV, torch.cuda.current_device())
