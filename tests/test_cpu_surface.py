@@ -122,6 +122,9 @@ def test_plan_memory_estimate_and_loss_names():
             assert plan.bytes <= est <= 1.04 * plan.bytes + (64 << 20), (shape, wb, plan.bytes, est)
             assert (len(plan.bwd) > 0) == wb
             del plan
+    assert E.plan_fits_addressing(16, 256, 256) and E.plan_fits_addressing(5, 1024, 1024) and not E.plan_fits_addressing(6, 1024, 1024)
+    with pytest.raises(RuntimeError, match="32-bit offsets"):
+        E.Plan(fp, 6, 1024, 1024)
     gib = 2 ** 30
     assert E.plan_bytes_estimate(16, 1024, 1024) > 288 * gib > E.plan_bytes_estimate(4, 1024, 1024)
     assert L.LOSS_KINDS["L1ColorLum"] == L.LOSS_KINDS["L1withColor"]            # same formula, losses.py:59-66 / :67-75

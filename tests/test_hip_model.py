@@ -658,7 +658,10 @@ def test_reference_default_resolution_fits_through_micro_batches():
     loss2, norm2 = step2(raw, ref)
     assert abs(float(loss2) - loss) <= 1e-5 * loss and abs(float(norm2) - norm) <= 1e-4 * norm
     with pytest.raises(RuntimeError, match="GiB"):
-        model2._plan_for(torch.empty(1, 3, 8192, 8192, device="meta") if False else _FakeShape((1, 3, 8192, 8192)))
+        model2._plan_for(_FakeShape((1, 3, 4096, 4096)))            # ~1 TB of activations for one image
+    with pytest.raises(RuntimeError, match="32-bit offsets"):
+        model2._plan_for(_FakeShape((6, 3, 1024, 1024)), want_backward=False)   # fits in HBM forward-only, but 6.3 M pixels are
+                                                                                 # beyond one plan's 32-bit addressing
 
 
 class _FakeShape:

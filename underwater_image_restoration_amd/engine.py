@@ -63,6 +63,16 @@ def plan_bytes_estimate(B: int, H: int, W: int, want_backward: bool = True) -> i
     return B * H * W * per + 2 * SCRATCH_FLOATS * 4 + (64 << 20)
 
 
+# The tile kernels address a tensor with 32-bit byte offsets: rows * row stride must stay below 2^30 floats.  The widest
+# full-resolution rows are the GDFN tensors of the C = 32 stages (2 * hp = 192 floats), so one plan holds at most this many
+# full-resolution pixels (5 images of 1024 x 1024, 85 of 256 x 256); larger batches run as micro-batches (TrainStep).
+PLAN_MAX_PIXELS = (1 << 30) // 192 - 1
+
+
+def plan_fits_addressing(B: int, H: int, W: int) -> bool:
+    return B * H * W <= PLAN_MAX_PIXELS
+
+
 def device_bytes_available(device) -> int:
     """Bytes a new plan can still get on `device`: free HBM plus what torch's caching allocator holds unused."""
     free, _total = torch.cuda.mem_get_info(device)
@@ -863,6 +873,9 @@ class Plan(Recorder):
 
     def __init__(self, fp: FlatParams, B: int, H: int, W: int, want_backward: bool = True):
         assert H % 8 == 0 and W % 8 == 0, "H and W must be divisible by 8 (three 2x down-samplings)"
+        if not plan_fits_addressing(B, H, W):
+            raise RuntimeError(f"a plan for batch {B} at {H}x{W} has {B * H * W} full-resolution pixels; the kernels' 32-bit offsets "
+                               f"allow {PLAN_MAX_PIXELS} per plan - use micro-batches (TrainStep does so by itself)")
         super().__init__(fp.device, fp)
         self.B, self.H, self.W = B, H, W
         self.want_backward = want_backward

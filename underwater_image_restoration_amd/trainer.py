@@ -75,13 +75,13 @@ class TrainStep:
             return mb
         if self.flat.device.type != "cuda":
             return B
-        from .engine import plan_bytes_estimate, device_bytes_available
+        from .engine import plan_bytes_estimate, device_bytes_available, plan_fits_addressing
         shape_cached = any(k[:3] == (B, H, W) and k[3] for k in self.model._plans)
         if shape_cached:
             return B
         have = device_bytes_available(self.flat.device) + sum(p.bytes for p in self.model._plans.values())
         for mb in sorted((d for d in range(1, B + 1) if B % d == 0), reverse=True):
-            if plan_bytes_estimate(mb, H, W) <= 0.95 * have:
+            if plan_fits_addressing(mb, H, W) and plan_bytes_estimate(mb, H, W) <= 0.95 * have:
                 return mb
         raise RuntimeError(f"SpectralTransformer(HIP): even one {H}x{W} image needs ~{plan_bytes_estimate(1, H, W) / 2**30:.1f} GiB "
                            f"of HBM for its train plan ({have / 2**30:.1f} GiB available)")
@@ -268,11 +268,17 @@ class TrainStep:
     def _eval_micro_batch(self, B: int, H: int, W: int) -> int:
         if self.micro_batch is not None:
             return min(B, self.micro_batch) if B % min(B, self.micro_batch) == 0 else 1
-        if self.flat.device.type != "cuda" or any(k[:3] == (B, H, W) for k in self.model._plans):
+        if any(k[:3] == (B, H, W) for k in self.model._plans):
             return B
-        from .engine import plan_bytes_estimate, device_bytes_available
+        if self.flat.device.type != "cuda":
+            return B
+        from .engine import plan_bytes_estimate, device_bytes_available, plan_fits_addressing
         have = device_bytes_available(self.flat.device) + sum(p.bytes for p in self.model._plans.values())
-        for mb in sorted((d for d in range(1, B + 1) if B % d == 0), reverse=True):
-            if any(k[:3] == (mb, H, W) for k in self.model._plans) or plan_bytes_estimate(mb, H, W, False) <= 0.95 * have:
+        divisors = sorted((d for d in range(1, B + 1) if B % d == 0), reverse=True)
+        for mb in divisors:                    # a plan of this batch's shape that already exists (e.g. the training plan) first
+            if any(k[:3] == (mb, H, W) for k in self.model._plans):
+                return mb
+        for mb in divisors:
+            if plan_fits_addressing(mb, H, W) and plan_bytes_estimate(mb, H, W, False) <= 0.95 * have:
                 return mb
         raise RuntimeError(f"SpectralTransformer(HIP): one {H}x{W} image does not fit in HBM for evaluation")
