@@ -83,6 +83,37 @@ def leff_out_and_grads(x: torch.Tensor, P: Params, probe: torch.Tensor):
     return y.detach(), x.grad, {n: v.grad for n, v in leaves.items()}
 
 
+def fdfp_param_shapes(dim: int, hidden: int) -> "Dict[str, tuple]":
+    """FDFP.__init__ with use_dwt="Fourier" (block.py:519-530): no DWT sub-modules, two 1x1 convolutions with bias."""
+    return {"conv1.weight": (hidden, dim, 1, 1), "conv1.bias": (hidden,), "conv2.weight": (dim, hidden, 1, 1), "conv2.bias": (dim,)}
+
+
+def closed_form_fdfp_params(dim: int, hidden: int, dtype=torch.float32) -> Params:
+    P = {}
+    for n, shp in fdfp_param_shapes(dim, hidden).items():
+        numel = int(np.prod(shp))
+        scale = int(np.prod(shp[1:])) ** -0.5 if len(shp) > 1 else 0.1
+        P[n] = torch.from_numpy(_hash_uniform(numel, _salt("fdfp." + n) + dim).reshape(shp) * scale).to(dtype)
+    return P
+
+
+def fdfp(x: torch.Tensor, P: Params) -> torch.Tensor:
+    """FDFP.forward, Fourier mode (block.py:532-554): x (B, H, W, C)."""
+    v = x.permute(0, 3, 1, 2)
+    v = torch.fft.fftn(v, dim=(-2, -1)).real
+    v = F.conv2d(F.gelu(F.conv2d(v, P["conv1.weight"], P["conv1.bias"])), P["conv2.weight"], P["conv2.bias"])
+    v = torch.fft.ifftn(v, dim=(-2, -1)).real
+    return v.permute(0, 2, 3, 1)
+
+
+def fdfp_out_and_grads(x: torch.Tensor, P: Params, probe: torch.Tensor):
+    x = x.detach().clone().requires_grad_(True)
+    leaves = {n: v.detach().clone().requires_grad_(True) for n, v in P.items()}
+    y = fdfp(x, leaves)
+    (y * probe).sum().backward()
+    return y.detach(), x.grad, {n: v.grad for n, v in leaves.items()}
+
+
 def closed_form_input(b: int, l: int, c: int, salt: int, dtype=torch.float32) -> torch.Tensor:
     return torch.from_numpy(_hash_uniform(b * l * c, 7000 + salt).reshape(b, l, c)).to(dtype)
 

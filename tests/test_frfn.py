@@ -132,3 +132,65 @@ def test_hip_leff_matches_reference(case):
     worst = max(_rel(p.grad, g[case + ".grad." + n]) for n, p in m.named_parameters())
     print(f"{case}: y {_rel(y, g[case + '.y']):.2e} dx {_rel(x.grad, g[case + '.dx']):.2e} worst param grad {worst:.2e}")
     assert _rel(y, g[case + ".y"]) < 2e-5 and _rel(x.grad, g[case + ".dx"]) < 2e-5 and worst < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------- FDFP (block.py:518-556)
+FDFP_CASES = {"fdfp_d32_b2_s16": (32, 2, 16), "fdfp_d64_b1_s8": (64, 1, 8)}
+
+
+@pytest.mark.parametrize("case", list(FDFP_CASES))
+def test_oracle_matches_reference_fdfp(case):
+    g = np.load(GOLDEN)
+    dim, B, S = FDFP_CASES[case]
+    P = {k: v.double() for k, v in R.closed_form_fdfp_params(dim, 2 * dim).items()}
+    x = R.closed_form_input(B, S * S, dim, 37).double().reshape(B, S, S, dim)
+    probe = R.closed_form_input(B, S * S, dim, 39).double().reshape(B, S, S, dim)
+    y, dx, grads = R.fdfp_out_and_grads(x, P, probe)
+    assert _rel(y, g[case + ".y"]) < 1e-6 and _rel(dx, g[case + ".dx"]) < 1e-6
+    for n, gw in grads.items():
+        assert _rel(gw, g[case + ".grad." + n]) < 1e-6, n
+
+
+def test_fdfp_state_dict_is_the_references():
+    """Keys in the reference's order, including the Haar buffers its constructor registers even in Fourier mode, bit for bit."""
+    from underwater_image_restoration_amd.model.block import FDFP
+    g = np.load(GOLDEN)
+    sd = FDFP(32, 64).state_dict()
+    assert list(sd.keys()) == list(g["fdfp_state_keys"])
+    for k, v in sd.items():
+        if k.startswith(("dwt.", "idwt.")):
+            assert np.array_equal(v.numpy(), g["fdfp_buffer." + k]), k
+
+
+@gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("case", list(FDFP_CASES))
+def test_hip_fdfp_matches_reference(case):
+    from underwater_image_restoration_amd.model.block import FDFP
+    g = np.load(GOLDEN)
+    dim, B, S = FDFP_CASES[case]
+    m = FDFP(dim, 2 * dim)
+    m.load_state_dict(R.closed_form_fdfp_params(dim, 2 * dim), strict=False)
+    m = m.cuda()
+    x = R.closed_form_input(B, S * S, dim, 37).reshape(B, S, S, dim).cuda().requires_grad_(True)
+    probe = R.closed_form_input(B, S * S, dim, 39).reshape(B, S, S, dim).cuda()
+    y = m(x)
+    assert y.shape == x.shape
+    (y * probe).sum().backward()
+    torch.cuda.synchronize()
+    worst = max(_rel(p.grad, g[case + ".grad." + n]) for n, p in m.named_parameters())
+    print(f"{case}: y {_rel(y, g[case + '.y']):.2e} dx {_rel(x.grad, g[case + '.dx']):.2e} worst param grad {worst:.2e}")
+    assert _rel(y, g[case + ".y"]) < 2e-5 and _rel(x.grad, g[case + ".dx"]) < 5e-5 and worst < 2e-4
+    # a 64 x 64 token image (the two-stage MFMA DFT path) vs the fp64 oracle
+    if dim == 32:
+        P = R.closed_form_fdfp_params(dim, 2 * dim)
+        xb = R.closed_form_input(2, 64 * 64, dim, 47).reshape(2, 64, 64, dim)
+        pb = R.closed_form_input(2, 64 * 64, dim, 49).reshape(2, 64, 64, dim)
+        y64, dx64, g64 = R.fdfp_out_and_grads(xb.double(), {k: v.double() for k, v in P.items()}, pb.double())
+        xg = xb.cuda().requires_grad_(True)
+        for p in m.parameters():
+            p.grad = None
+        yb = m(xg)
+        (yb * pb.cuda()).sum().backward()
+        assert _rel(yb, y64) < 5e-5 and _rel(xg.grad, dx64) < 1e-4
+        assert max(_rel(p.grad, g64[n]) for n, p in m.named_parameters()) < 5e-4

@@ -166,6 +166,46 @@ def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     return y, backward
 
 
+def record_spatial_refft(rec: Recorder, name: str, x: torch.Tensor, dims, C_: int, scale: float) -> torch.Tensor:
+    """y = scale * Re(fft2 over (H, W)) per channel of token-image rows x [B*H*W, C] = scale * (C_H x C_W - S_H x S_W):
+    `fft.fftn(x, dim=(-2,-1)).real` of FDFP on NCHW (block.py:538) and, divided by H*W, its `ifftn(...).real` (:549) - the
+    operator is real-symmetric, so it is also its own backward pass.  Two uir_dft_axis passes (W, then H: real part only)."""
+    B, H, W = dims
+    M = B * H * W
+    ar, ai, y = rec.alloc(M, C_), rec.alloc(M, C_), rec.alloc(M, C_)
+    rec.dft(name + ".W", x, None, ar, ai, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0)
+    rec.dft(name + ".H", ar, ai, y, None, O=B, N=H, I=W, C_=C_, sign=1.0, scale=scale)
+    return y
+
+
+def record_fdfp(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims):
+    """Record FDFP.forward in Fourier mode (block.py:532-554): Re fft2 -> conv1x1 + bias -> GELU -> conv1x1 + bias -> Re ifft2."""
+    B, H, W = dims
+    M, C_ = B * H * W, dim
+    P, Gr = (lambda n: rec.P(pfx + n)), (lambda n: rec.Gr(pfx + n))
+    W1, b1, W2, b2 = P("conv1.weight"), P("conv1.bias"), P("conv2.weight"), P("conv2.bias")
+    n = pfx
+    f = record_spatial_refft(rec, n + "fft2", x, dims, C_, 1.0)
+    pre, t, z = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
+    rec.gemm(n + "conv1+gelu", f, W1, t, N=hid, K=C_, w_sn=C_, w_sk=1, bias=b1, act=L.ACT_GELU, pre_out=pre)
+    rec.gemm(n + "conv2", t, W2, z, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
+    y = record_spatial_refft(rec, n + "ifft2", z, dims, C_, 1.0 / (H * W))
+
+    def backward(dy: torch.Tensor) -> torch.Tensor:
+        dz = record_spatial_refft(rec, n + "ifft2.bwd", dy, dims, C_, 1.0 / (H * W))
+        dt, dpre, df = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
+        with rec.bulk():
+            rec.gram(n + "conv2.dW", dz, t, Gr("conv2.weight"), N=C_, K=hid, o_sn=hid, o_sk=1)
+            _colsum_wide(rec, n + "conv2.db", dz, C_, Gr("conv2.bias"))
+        rec.gemm(n + "conv2.dX", dz, W2, dt, N=hid, K=C_, w_sn=1, w_sk=hid)
+        _act(rec, n + "gelu.bwd", pre, None, hid, bwd_dt=dt, dpre=dpre, dbias=Gr("conv1.bias"))
+        with rec.bulk():
+            rec.gram(n + "conv1.dW", dpre, f, Gr("conv1.weight"), N=hid, K=C_, o_sn=C_, o_sk=1)
+        rec.gemm(n + "conv1.dX", dpre, W1, df, N=C_, K=hid, w_sn=1, w_sk=C_)
+        return record_spatial_refft(rec, n + "fft2.bwd", df, dims, C_, 1.0)
+    return y, backward
+
+
 class TokenPlan(Recorder):
     """A launch plan over token rows [B*H*W, dim]: input buffer -> recorded forward -> output buffer, and the recorded backward.
     Subclasses provide ``_record(x) -> (y, backward)``."""
@@ -225,6 +265,15 @@ class LeffPlan(TokenPlan):
 
     def _record(self, x):
         return record_leff(self, "", x, self.dim, self.hidden, (self.B, self.H, self.W))
+
+
+class FdfpPlan(TokenPlan):
+    def __init__(self, fp: FlatParams, dim: int, hidden: int, B: int, H: int, W: int, want_backward: bool = True):
+        self.hidden = hidden
+        super().__init__(fp, dim, B, H, W, want_backward)
+
+    def _record(self, x):
+        return record_fdfp(self, "", x, self.dim, self.hidden, (self.B, self.H, self.W))
 
 
 class _TokenFunction(torch.autograd.Function):
@@ -355,3 +404,51 @@ class LeFF(TokenModule):
 
     def _make_plan(self, fp, B, H, W, want_backward):
         return LeffPlan(fp, self.dim, self.hidden_dim, B, H, W, want_backward)
+
+
+class FDFP(TokenModule):
+    """Drop-in for ``src.model.block.FDFP`` (block.py:518-556) in the mode the reference ships (``use_dwt="Fourier"``):
+    ``forward(x: (B, H, W, C)) -> (B, H, W, C)``.  Parameters ``conv1.{weight,bias}`` [hidden, C, 1, 1], ``conv2.*`` [C, hidden, 1, 1]
+    (no DWT_2D / IDWT_2D sub-modules: those are only constructed for a truthy non-"Fourier" flag and hold no parameters the
+    Fourier mode uses)."""
+
+    def __init__(self, in_channels, hidden_channels, act_layer=nn.GELU, use_dwt="Fourier"):
+        super().__init__()
+        if use_dwt != "Fourier" or act_layer is not nn.GELU:
+            raise NotImplementedError("the HIP FDFP implements the reference's shipped mode (use_dwt='Fourier', GELU)")
+        if in_channels % 4 or hidden_channels % 4:
+            raise NotImplementedError("channel counts must be multiples of 4")
+        self.use_dwt = use_dwt
+        # The reference builds DWT_2D / IDWT_2D for any truthy flag (block.py:522-524); in Fourier mode they are never called,
+        # but their Haar buffers are part of the state_dict: kept, built like wave_modules.py:122-134,159-171 from PyWavelets'
+        # published Haar filter bank (float32 products of 1/sqrt(2)).
+        r = 0.7071067811865476
+        lo, hi = torch.Tensor([r, r]), torch.Tensor([r, -r])            # dec_lo[::-1], dec_hi[::-1]
+        self.dwt = nn.Module()
+        for nm, (a, b) in (("w_ll", (lo, lo)), ("w_hl", (hi, lo)), ("w_lh", (lo, hi)), ("w_hh", (hi, hi))):
+            self.dwt.register_buffer(nm, a.unsqueeze(0) * b.unsqueeze(1))
+        rlo, rhi = torch.Tensor([r, r]), torch.Tensor([r, -r])           # rec_lo, rec_hi
+        self.idwt = nn.Module()
+        self.idwt.register_buffer("filters", torch.stack([rlo.unsqueeze(0) * rlo.unsqueeze(1), rlo.unsqueeze(0) * rhi.unsqueeze(1),
+                                                          rhi.unsqueeze(0) * rlo.unsqueeze(1), rhi.unsqueeze(0) * rhi.unsqueeze(1)], dim=0))
+        self.conv1 = nn.Conv2d(in_channels, hidden_channels, kernel_size=1, stride=1)
+        self.conv2 = nn.Conv2d(hidden_channels, in_channels, kernel_size=1, stride=1)
+        self.act = act_layer()
+        self.in_channels = in_channels
+        self.hidden_channels = hidden_channels
+        self.dim = in_channels
+        self._init_plumbing()
+
+    def _make_plan(self, fp, B, H, W, want_backward):
+        return FdfpPlan(fp, self.in_channels, self.hidden_channels, B, H, W, want_backward)
+
+    def _plan_for(self, x, want_backward=True):            # x arrives as (B, L, C) tokens from forward() below
+        return super()._plan_for(x, want_backward)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 4 or x.shape[3] != self.in_channels:
+            raise ValueError(f"expected (B, H, W, {self.in_channels}), got {tuple(x.shape)}")
+        B, H, W, C_ = x.shape
+        if H != W:
+            raise NotImplementedError("square token images (the reference's H = W = sqrt(L))")
+        return super().forward(x.reshape(B, H * W, C_)).view(B, H, W, C_)
