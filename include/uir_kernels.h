@@ -502,6 +502,33 @@ int uir_layernorm_fwd(const float* X, int ldx, const float* gamma, const float* 
 int uir_cmul_table(float* re, float* im, const float* tab_re, const float* tab_im, long rows, long P, int C, void* stream);
 int uir_transpose_rows(const float* src, float* dst, int B, int N1, int N2, int N3, int C, float scale, void* stream);
 
+/* -------------------------------------------------------------- uir_winattn */
+/* Attention core of WindowAttention_Sparse (src/model/block.py:336-370) on 8 x 8 non-shifted windows of an HWC token image
+ * (what every DecoderBlock / MDASSA of NewBigFRFNModel uses: win_size 8, shift_size 0, mask None):
+ *   attn = (Q scale) K^T + table[relative_position_index]; attn = softmax(attn) w1 + relu(attn)^2 w2, (w1, w2) = softmax(w);
+ *   O = attn V, heads along the channels (head h = columns [h C/heads, (h+1) C/heads)).
+ * Q, K, V, O are token rows (the outputs of to_q / to_kv / the input of proj, which are uir_gemm calls).  Backward: dQ, dK, dV rows
+ * from dO, plus per-window partials dtable_slab[window][(2 ws - 1)^2 * heads] (same layout as the table) and
+ * dw_slab[window * heads + h][2] = gradients w.r.t. (w1, w2); uir_winattn_wgrad maps their sum to the gradient of `w`.
+ * C / heads in {16, 32, 64}; ws = 8; H, W multiples of 8. */
+typedef struct UirWinAttnArgs {
+  const float* Q; const float* K; const float* V;
+  const float* table;      /* relative_position_bias_table [(2 ws - 1)^2][heads] */
+  const float* w;          /* [2] */
+  float* O;
+  const float* dO;
+  float* dQ; float* dK; float* dV;
+  float* dtable_slab;
+  float* dw_slab;
+  int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
+  int B, H, W, C, heads, ws;
+  float scale;             /* qk_scale or head_dim^-0.5 (:291) */
+  int _pad;
+} UirWinAttnArgs;
+int uir_winattn_fwd(const UirWinAttnArgs* args, void* stream);
+int uir_winattn_bwd(const UirWinAttnArgs* args, void* stream);
+int uir_winattn_wgrad(const float* w, const float* dsum, float* dw, void* stream);
+
 /* ---------------------------------------------------------------- uir_uiqm */
 /* Evaluation metric UIQM.  Replaces getUIQM of uqim_utils.py:176-190 (with _uicm :36-48, mu_a :10-28,
  * s_a :30-34, sobel :50-54, eme :57-86, _uism :88-113, _uiconm :141-174) for a batch of N images of one size, HWC, either

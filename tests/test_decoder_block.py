@@ -1,0 +1,148 @@
+"""Window attention, MDASSA and DecoderBlock of the NewBigFRFNModel family (reference src/model/block.py:284-515,
+src/model/model.py:96-160).  CPU: the oracle (oracle/decoder_ref.py) against outputs and gradients recorded from the reference's own
+classes (tests/golden/decoder_ref.npz <- make_decoder_vectors.py), and the state_dict surface.  GPU: the HIP launch plans."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_ref as D, frfn_ref as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "decoder_ref.npz")
+S = 16
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _params(g, tag, salt, dtype=torch.float32):
+    shapes = {n: ast.literal_eval(s) for n, s in zip(g[tag + ".param_names"], g[tag + ".param_shapes"])}
+    return D.closed_form_params(shapes, salt, dtype)
+
+
+CASES = {"mdassa_d64": ("mdassa64", 64), "dec_d32_enc": ("dec32", 32), "dec_d64_noenc": ("dec64", 64)}
+
+
+def _inputs(tag):
+    if tag == "dec_d32_enc":
+        return [R.closed_form_input(1, S * S, 32, 73), R.closed_form_input(1, S * S, 32, 74)], R.closed_form_input(1, S * S, 32, 75)
+    return [R.closed_form_input(1, S * S, 64, 71)], R.closed_form_input(1, S * S, 64, 72)
+
+
+def _oracle_fn(tag):
+    if tag == "mdassa_d64":
+        return lambda x, P: D.mdassa(x, P, "", 4)
+    if tag == "dec_d32_enc":
+        return lambda x, e, P: D.decoder_block(x, e, P, 4)
+    return lambda x, P: D.decoder_block(x, None, P, 4)
+
+
+@pytest.mark.parametrize("tag", list(CASES))
+def test_oracle_matches_reference(tag):
+    g = np.load(GOLDEN)
+    P = {k: v.double() for k, v in _params(g, tag, CASES[tag][0]).items()}
+    xs, probe = _inputs(tag)
+    want_y = g[tag + ".y"]
+    y, dxs, grads = D.grads(_oracle_fn(tag), [t.double() for t in xs], P, probe.double().reshape(want_y.shape))
+    assert _rel(y, want_y) < 1e-6
+    for i, dx in enumerate(dxs):
+        assert _rel(dx, g[f"{tag}.dx{i}"]) < 1e-6
+    dead = set(g[tag + ".dead"])
+    for n in g[tag + ".param_names"]:
+        if n in dead:
+            assert n not in grads, n
+        else:
+            assert _rel(grads[n], g[tag + ".grad." + n]) < 2e-6, n
+
+
+def test_state_dict_surface_is_the_references():
+    from underwater_image_restoration_amd.model.block import MDASSA
+    from underwater_image_restoration_amd.model.model import DecoderBlock
+    g = np.load(GOLDEN)
+    m = MDASSA(64, win_size=8, shift_size=0, num_heads=4, enc_out=True, use_dwt="Fourier")
+    assert list(m.state_dict().keys()) == list(g["mdassa_d64.keys"])
+    assert torch.equal(m.attn.relative_position_index, D.relative_position_index())
+    d = DecoderBlock(dim=32, input_resolution=(S, S), num_heads=4, token_mlp="frfn", enc_out=True, use_dwt="Fourier")
+    assert list(d.state_dict().keys()) == list(g["dec_d32_enc.keys"])
+    d2 = DecoderBlock(dim=64, input_resolution=(S, S), num_heads=4, token_mlp="frfn", enc_out=False, use_dwt="Fourier")
+    assert list(d2.state_dict().keys()) == list(g["dec_d64_noenc.keys"])
+    with pytest.raises(ValueError, match="Unknown token_mlp"):
+        DecoderBlock(32, (S, S), 4, token_mlp="nope")
+
+
+gpu = pytest.mark.gpu
+
+
+def _module(tag):
+    from underwater_image_restoration_amd.model.block import MDASSA
+    from underwater_image_restoration_amd.model.model import DecoderBlock
+    if tag == "mdassa_d64":
+        return MDASSA(64, win_size=8, shift_size=0, num_heads=4, enc_out=True, use_dwt="Fourier")
+    if tag == "dec_d32_enc":
+        return DecoderBlock(dim=32, input_resolution=(S, S), num_heads=4, token_mlp="frfn", enc_out=True, use_dwt="Fourier")
+    return DecoderBlock(dim=64, input_resolution=(S, S), num_heads=4, token_mlp="frfn", enc_out=False, use_dwt="Fourier")
+
+
+@gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("tag", list(CASES))
+def test_hip_matches_reference(tag):
+    """Output, every input gradient and every parameter gradient (window-attention bias tables and mixing weights included) vs the
+    reference's own; parameters the reference never uses keep grad None."""
+    g = np.load(GOLDEN)
+    m = _module(tag)
+    m.load_state_dict(_params(g, tag, CASES[tag][0]), strict=False)
+    m = m.cuda()
+    xs, probe = _inputs(tag)
+    xs = [t.cuda().requires_grad_(True) for t in xs]
+    y = m(*xs)
+    want_y = g[tag + ".y"]
+    assert tuple(y.shape) == want_y.shape
+    (y * probe.cuda().reshape(y.shape)).sum().backward()
+    torch.cuda.synchronize()
+    e_y = _rel(y, want_y)
+    e_dx = max(_rel(t.grad, g[f"{tag}.dx{i}"]) for i, t in enumerate(xs))
+    dead = set(g[tag + ".dead"])
+    worst = ("", 0.0)
+    for n, p in m.named_parameters():
+        if n in dead:
+            assert p.grad is None, n
+            continue
+        e = _rel(p.grad, g[tag + ".grad." + n])
+        worst = max(worst, (n, e), key=lambda t: t[1])
+    print(f"{tag}: y {e_y:.2e} dx {e_dx:.2e} worst param grad {worst}")
+    assert e_y < 5e-5 and e_dx < 1e-4 and worst[1] < 5e-4
+
+
+@gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_hip_decoder_block_larger_vs_oracle():
+    """DecoderBlock(dim 32, enc_out) on 64 x 64 tokens, B = 2 (64 windows per image; FDFP on the two-stage MFMA DFT) vs the fp64
+    oracle; bitwise run-to-run."""
+    g = np.load(GOLDEN)
+    m = _module("dec_d32_enc")
+    P = _params(g, "dec_d32_enc", "dec32")
+    m.load_state_dict(P, strict=False)
+    m = m.cuda()
+    B, S2 = 2, 64
+    x, e, probe = R.closed_form_input(B, S2 * S2, 32, 81), R.closed_form_input(B, S2 * S2, 32, 82), R.closed_form_input(B, S2 * S2, 32, 83)
+    y64, dxs64, g64 = D.grads(lambda a, b, Pp: D.decoder_block(a, b, Pp, 4), [x.double(), e.double()],
+                              {k: v.double() for k, v in P.items()}, probe.double())
+    outs = []
+    for _ in range(2):
+        xg, eg = x.cuda().requires_grad_(True), e.cuda().requires_grad_(True)
+        for p in m.parameters():
+            p.grad = None
+        y = m(xg, eg)
+        (y * probe.cuda()).sum().backward()
+        torch.cuda.synchronize()
+        outs.append((y.detach().clone(), xg.grad.clone(), eg.grad.clone(), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    assert all(torch.equal(a, b) for a, b in zip(outs[0][:3], outs[1][:3])) and all(torch.equal(outs[0][3][n], outs[1][3][n]) for n in outs[0][3])
+    assert _rel(outs[0][0], y64) < 1e-4 and _rel(outs[0][1], dxs64[0]) < 2e-4 and _rel(outs[0][2], dxs64[1]) < 2e-4
+    worst = max(((n, _rel(gw, g64[n])) for n, gw in outs[0][3].items()), key=lambda t: t[1])
+    print("64x64 decoder block: worst param grad", worst)
+    assert worst[1] < 1e-3

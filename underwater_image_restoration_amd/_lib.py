@@ -153,6 +153,14 @@ class FrfnGateArgs(C.Structure):
                 ("db_blocks", C.c_int)]
 
 
+class WinAttnArgs(C.Structure):
+    _fields_ = [("Q", fp), ("K", fp), ("V", fp), ("table", fp), ("w", fp), ("O", fp), ("dO", fp), ("dQ", fp), ("dK", fp), ("dV", fp),
+                ("dtable_slab", fp), ("dw_slab", fp),
+                ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int), ("lddq", C.c_int), ("lddk", C.c_int),
+                ("lddv", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("heads", C.c_int),
+                ("ws", C.c_int), ("scale", C.c_float), ("_pad", C.c_int)]
+
+
 class UiqmArgs(C.Structure):
     _fields_ = [("img_f32", fp), ("img_u8", fp), ("work", fp), ("out", fp), ("flags", fp),
                 ("N", C.c_int), ("H", C.c_int), ("W", C.c_int)]
@@ -218,6 +226,9 @@ SIGNATURES = {
     "uir_layernorm_fwd": [fp, i32, fp, fp, fp, i32, fp, i64, i32, f32, fp],
     "uir_cmul_table": [fp, fp, fp, fp, i64, i64, i32, fp],
     "uir_transpose_rows": [fp, fp, i32, i32, i32, i32, i32, f32, fp],
+    "uir_winattn_fwd": [C.POINTER(WinAttnArgs), fp],
+    "uir_winattn_bwd": [C.POINTER(WinAttnArgs), fp],
+    "uir_winattn_wgrad": [fp, fp, fp, fp],
     "uir_uiqm_work_doubles": [i32, i32, i32],            # host helper: returns a count (c_long) or -1
     "uir_uiqm": [C.POINTER(UiqmArgs), fp],
     "uir_stream_create_cu_masked": [i32, C.POINTER(C.c_void_p)],
@@ -232,7 +243,7 @@ STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirDwArgs": DwArgs
            "UirAttnFwdArgs": AttnFwdArgs, "UirAttnBwdArgs": AttnBwdArgs, "UirDftArgs": DftArgs, "UirDft2Args": Dft2Args,
            "UirAdamArgs": AdamArgs, "UirResizeImage": ResizeImage, "UirResizeArgs": ResizeArgs, "UirSsimArgs": SsimArgs,
            "UirUiqmArgs": UiqmArgs, "UirReduceDesc": ReduceDesc,
-           "UirFrfnGateArgs": FrfnGateArgs}
+           "UirFrfnGateArgs": FrfnGateArgs, "UirWinAttnArgs": WinAttnArgs}
 
 
 def abi_layout(lib_, cname: str):

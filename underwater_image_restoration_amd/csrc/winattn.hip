@@ -1,0 +1,269 @@
+// Window attention core of WindowAttention_Sparse (reference src/model/block.py:284-370), forward and
+// backward, for the 8 x 8 non-shifted windows every DecoderBlock / MDASSA of NewBigFRFNModel uses (model.py:517-...: win_size 8,
+// shift_size 0, mask None):
+//   attn = (q * scale) k^T + relative_position_bias            [heads, 64, 64] per window          (:340-352)
+//   attn = softmax(attn) * w1 + relu(attn)^2 * w2,  (w1, w2) = softmax(self.w)                      (:361-367)
+//   out  = attn v, heads concatenated along the channels                                             (:370)
+// The Linear projections around it (to_q / to_kv / proj, :322,327,371) are uir_gemm calls on the token rows: a window is just a
+// set of 64 rows of the HWC token image, gathered here by address - window_partition / window_reverse (:16-41) never move data.
+// One 64-lane workgroup per (window, head); lane i owns query token i: its score row, softmax and output row live in registers,
+// K / V (and, backward, Q / dO and the two 64 x 64 matrices P and dS) are staged in LDS.  relative_position_index (:302-311) is
+// evaluated from the token coordinates.  Backward writes dQ / dK / dV rows and per-workgroup partials of the bias-table and
+// mixing-weight gradients (summed in fixed order by uir_reduce_slab(_batch); no float atomics).
+#include "uir_common.h"
+#include "../../include/uir_kernels.h"
+
+namespace {
+
+constexpr int WS = 8, NT = WS * WS, RP = 2 * WS - 1;   // window side, tokens per window, relative positions per axis
+
+__device__ __forceinline__ long token_row(const UirWinAttnArgs& a, int win, int t) {
+  const int wpr = a.W / WS, wpi = (a.H / WS) * wpr;
+  const int b = win / wpi, r = win - b * wpi;
+  const int wy = r / wpr, wx = r - wy * wpr;
+  return ((long)b * a.H + wy * WS + (t >> 3)) * a.W + wx * WS + (t & 7);
+}
+
+template <int HD>
+__device__ __forceinline__ void stage_rows(const float* __restrict__ base, int ld, int col0, const UirWinAttnArgs& a, int win,
+                                           float (*dst)[HD + 1]) {
+  // 64 lanes x (HD/4) float4 columns: lane = token
+  const int t = threadIdx.x;
+  const float* p = base + token_row(a, win, t) * ld + col0;
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(p + c);
+    dst[t][c] = v.x; dst[t][c + 1] = v.y; dst[t][c + 2] = v.z; dst[t][c + 3] = v.w;
+  }
+}
+
+// scores of query token i against all 64 keys -> p0 (softmax), r (relu^2), and the mixed attention row
+template <int HD>
+__device__ __forceinline__ void score_row(const UirWinAttnArgs& a, int h, int i, const float (&q)[HD], const float (*Ks)[HD + 1],
+                                          float (&s)[NT], float (&p0)[NT]) {
+  const int yi = i >> 3, xi = i & 7;
+  float mx = -__builtin_huge_valf();
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) d = fmaf(q[c], Ks[j][c], d);
+    const int idx = (yi - (j >> 3) + WS - 1) * RP + (xi - (j & 7) + WS - 1);
+    s[j] = fmaf(d, a.scale, a.table[idx * a.heads + h]);
+    mx = fmaxf(mx, s[j]);
+  }
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    p0[j] = __expf(s[j] - mx);
+    sum += p0[j];
+  }
+  const float inv = 1.0f / sum;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) p0[j] *= inv;
+}
+
+__device__ __forceinline__ void mix_weights(const float* w, float& w1, float& w2) {
+  const float m = fmaxf(w[0], w[1]);
+  const float e0 = __expf(w[0] - m), e1 = __expf(w[1] - m);
+  w1 = e0 / (e0 + e1);
+  w2 = e1 / (e0 + e1);
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void winattn_fwd_kernel(const UirWinAttnArgs a) {
+  __shared__ float Ks[NT][HD + 1], Vs[NT][HD + 1];
+  const int win = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c0 = h * HD;
+  stage_rows<HD>(a.K, a.ldk, c0, a, win, Ks);
+  stage_rows<HD>(a.V, a.ldv, c0, a, win, Vs);
+  const long row = token_row(a, win, i);
+  float q[HD];
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    const float4 v = *reinterpret_cast<const float4*>(a.Q + row * a.ldq + c0 + c);
+    q[c] = v.x; q[c + 1] = v.y; q[c + 2] = v.z; q[c + 3] = v.w;
+  }
+  __syncthreads();
+  float s[NT], p0[NT];
+  score_row<HD>(a, h, i, q, Ks, s, p0);
+  float w1, w2;
+  mix_weights(a.w, w1, w2);
+  float o[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) o[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const float r = fmaxf(s[j], 0.f);
+    const float p = fmaf(w1, p0[j], w2 * r * r);
+#pragma unroll
+    for (int c = 0; c < HD; ++c) o[c] = fmaf(p, Vs[j][c], o[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < HD; c += 4)
+    *reinterpret_cast<float4*>(a.O + row * a.ldo + c0 + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+}
+
+template <int HD>
+__global__ __launch_bounds__(64) void winattn_bwd_kernel(const UirWinAttnArgs a) {
+  extern __shared__ float smem[];
+  float (*Ks)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem);
+  float (*Vs)[HD + 1] = Ks + NT;
+  float (*Qs)[HD + 1] = Vs + NT;
+  float (*Gs)[HD + 1] = Qs + NT;                                   // dO
+  float (*Pm)[NT + 1] = reinterpret_cast<float (*)[NT + 1]>(smem + 4 * NT * (HD + 1));
+  float (*Dm)[NT + 1] = Pm + NT;                                   // dS
+  const int win = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c0 = h * HD;
+  stage_rows<HD>(a.K, a.ldk, c0, a, win, Ks);
+  stage_rows<HD>(a.V, a.ldv, c0, a, win, Vs);
+  stage_rows<HD>(a.Q, a.ldq, c0, a, win, Qs);
+  stage_rows<HD>(a.dO, a.ldo, c0, a, win, Gs);
+  __syncthreads();
+  const long row = token_row(a, win, i);
+  float q[HD], g[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) { q[c] = Qs[i][c]; g[c] = Gs[i][c]; }
+  float s[NT], p0[NT];
+  score_row<HD>(a, h, i, q, Ks, s, p0);
+  float w1, w2;
+  mix_weights(a.w, w1, w2);
+  // dP_j = dO_i . v_j ; the three row sums
+  float dp[NT];
+  float sp = 0.f, dw1 = 0.f, dw2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    float d = 0.f;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) d = fmaf(g[c], Vs[j][c], d);
+    dp[j] = d;
+    const float r = fmaxf(s[j], 0.f);
+    sp = fmaf(d, p0[j], sp);
+    dw2 = fmaf(d, r * r, dw2);
+  }
+  dw1 = sp;
+  float dq[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) dq[c] = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const float r = fmaxf(s[j], 0.f);
+    const float ds = fmaf(w1 * p0[j], dp[j] - sp, w2 * dp[j] * 2.f * r);   // softmax backward + relu^2 backward
+    Pm[i][j] = fmaf(w1, p0[j], w2 * r * r);
+    Dm[i][j] = ds;
+#pragma unroll
+    for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, Ks[j][c], dq[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < HD; c += 4)
+    *reinterpret_cast<float4*>(a.dQ + row * a.lddq + c0 + c) =
+        make_float4(dq[c] * a.scale, dq[c + 1] * a.scale, dq[c + 2] * a.scale, dq[c + 3] * a.scale);
+  // mixing-weight partials: sum over the 64 query rows of this (window, head)
+  dw1 = uir_wave_sum(dw1);
+  dw2 = uir_wave_sum(dw2);
+  if (i == 0) {
+    float* o = a.dw_slab + ((long)win * a.heads + h) * 2;
+    o[0] = dw1;
+    o[1] = dw2;
+  }
+  __syncthreads();
+  // lane j: dK_j = scale * sum_i dS[i][j] q_i ;  dV_j = sum_i P[i][j] dO_i
+  float dk[HD], dv[HD];
+#pragma unroll
+  for (int c = 0; c < HD; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+#pragma unroll 4
+  for (int r = 0; r < NT; ++r) {
+    const float ds = Dm[r][i], p = Pm[r][i];
+#pragma unroll
+    for (int c = 0; c < HD; ++c) {
+      dk[c] = fmaf(ds, Qs[r][c], dk[c]);
+      dv[c] = fmaf(p, Gs[r][c], dv[c]);
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < HD; c += 4) {
+    *reinterpret_cast<float4*>(a.dK + row * a.lddk + c0 + c) =
+        make_float4(dk[c] * a.scale, dk[c + 1] * a.scale, dk[c + 2] * a.scale, dk[c + 3] * a.scale);
+    *reinterpret_cast<float4*>(a.dV + row * a.lddv + c0 + c) = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+  }
+  // relative-position-bias table: entry t = (dy + 7) * 15 + (dx + 7) collects dS[i][j] over the pairs with that offset
+  float* tb = a.dtable_slab + (long)win * (RP * RP * a.heads);
+  for (int t = i; t < RP * RP; t += 64) {
+    const int dy = t / RP - (WS - 1), dx = t % RP - (WS - 1);
+    float acc = 0.f;
+    for (int yi = (dy > 0 ? dy : 0); yi < (dy < 0 ? WS + dy : WS); ++yi)
+      for (int xi = (dx > 0 ? dx : 0); xi < (dx < 0 ? WS + dx : WS); ++xi)
+        acc += Dm[yi * WS + xi][(yi - dy) * WS + (xi - dx)];
+    tb[t * a.heads + h] = acc;
+  }
+}
+
+// d(self.w): (w1, w2) = softmax(w), dsum = sum over (window, head) partials already reduced into g[2]
+__global__ void winattn_wgrad_kernel(const float* __restrict__ w, const float* __restrict__ g, float* __restrict__ dw) {
+  if (threadIdx.x == 0) {
+    float w1, w2;
+    mix_weights(w, w1, w2);
+    const float dot = w1 * g[0] + w2 * g[1];
+    dw[0] = w1 * (g[0] - dot);
+    dw[1] = w2 * (g[1] - dot);
+  }
+}
+
+int check(const UirWinAttnArgs& a, bool bwd) {
+  UIR_REQUIRE(a.Q && a.K && a.V && a.table && a.w && a.B > 0 && a.heads > 0 && a.C > 0 && a.C % a.heads == 0);
+  UIR_REQUIRE(a.ws == WS && a.H % WS == 0 && a.W % WS == 0);
+  const int hd = a.C / a.heads;
+  UIR_REQUIRE(hd == 16 || hd == 32 || hd == 64);
+  UIR_REQUIRE(a.ldq >= a.C && a.ldk >= a.C && a.ldv >= a.C && ((a.ldq | a.ldk | a.ldv) & 3) == 0);
+  UIR_REQUIRE(uir_aligned16(a.Q) && uir_aligned16(a.K) && uir_aligned16(a.V));
+  if (!bwd) UIR_REQUIRE(a.O && a.ldo >= a.C && (a.ldo & 3) == 0 && uir_aligned16(a.O));
+  else {
+    UIR_REQUIRE(a.dO && a.dQ && a.dK && a.dV && a.dtable_slab && a.dw_slab && a.ldo >= a.C && (a.ldo & 3) == 0);
+    UIR_REQUIRE(a.lddq >= a.C && a.lddk >= a.C && a.lddv >= a.C && ((a.lddq | a.lddk | a.lddv) & 3) == 0);
+    UIR_REQUIRE(uir_aligned16(a.dO) && uir_aligned16(a.dQ) && uir_aligned16(a.dK) && uir_aligned16(a.dV));
+  }
+  return UIR_OK;
+}
+
+}  // namespace
+
+extern "C" int uir_winattn_fwd(const UirWinAttnArgs* p, void* stream) {
+  const UirWinAttnArgs& a = *p;
+  if (int rc = check(a, false)) return rc;
+  const dim3 grid(a.B * (a.H / WS) * (a.W / WS), a.heads);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  switch (a.C / a.heads) {
+    case 16: hipLaunchKernelGGL(winattn_fwd_kernel<16>, grid, dim3(64), 0, st, a); break;
+    case 32: hipLaunchKernelGGL(winattn_fwd_kernel<32>, grid, dim3(64), 0, st, a); break;
+    default: hipLaunchKernelGGL(winattn_fwd_kernel<64>, grid, dim3(64), 0, st, a); break;
+  }
+  return uir_launch_status();
+}
+
+extern "C" int uir_winattn_bwd(const UirWinAttnArgs* p, void* stream) {
+  const UirWinAttnArgs& a = *p;
+  if (int rc = check(a, true)) return rc;
+  const dim3 grid(a.B * (a.H / WS) * (a.W / WS), a.heads);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int hd = a.C / a.heads;
+  const size_t lds = ((size_t)4 * NT * (hd + 1) + (size_t)2 * NT * (NT + 1)) * sizeof(float);
+  // 51 / 67 / 100 KB of LDS per 64-lane workgroup: above the 64 KB default for head dims 32 and 64
+#define UIR_WA_BWD(HDV)                                                                                                     \
+  do {                                                                                                                      \
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(winattn_bwd_kernel<HDV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                            (int)lds) != hipSuccess)                                                                        \
+      return UIR_ELAUNCH;                                                                                                   \
+    hipLaunchKernelGGL(winattn_bwd_kernel<HDV>, grid, dim3(64), lds, st, a);                                                \
+  } while (0)
+  switch (hd) {
+    case 16: UIR_WA_BWD(16); break;
+    case 32: UIR_WA_BWD(32); break;
+    default: UIR_WA_BWD(64); break;
+  }
+#undef UIR_WA_BWD
+  return uir_launch_status();
+}
+
+extern "C" int uir_winattn_wgrad(const float* w, const float* dsum, float* dw, void* stream) {
+  UIR_REQUIRE(w && dsum && dw);
+  hipLaunchKernelGGL(winattn_wgrad_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), w, dsum, dw);
+  return uir_launch_status();
+}

@@ -206,22 +206,185 @@ def record_fdfp(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     return y, backward
 
 
+def _winattn_args(q, k, v, table, w, dims, C_, heads):
+    a = L.WinAttnArgs()
+    a.Q, a.K, a.V, a.table, a.w = _ptr(q), _ptr(k), _ptr(v), _ptr(table), _ptr(w)
+    a.ldq, a.ldk, a.ldv = _ld(q), _ld(k), _ld(v)
+    a.B, a.H, a.W = dims
+    a.C, a.heads, a.ws = C_, heads, 8
+    a.scale = (C_ // heads) ** -0.5
+    return a
+
+
+def record_window_attention(rec: Recorder, pfx: str, xq: torch.Tensor, xkv: "torch.Tensor | None", dims, C_: int, heads: int):
+    """Record WindowAttention_Sparse.forward (block.py:336-373) applied to every 8 x 8 window of a token image, mask None.
+    xq rows [M, C]; xkv None: keys / values from xq through ``to_qkv.to_kv_from_q`` (:169-174); xkv rows [M, 2C]: through
+    ``to_qkv.to_kv`` (:176-187, the frequency cross attention of MDASSA).  Returns (y rows [M, C], backward) where
+    backward(dy) -> (d xq, d xkv or None)."""
+    B, H, W = dims
+    M, nwin = B * H * W, B * (H // 8) * (W // 8)
+    P, Gr = (lambda n: rec.P(pfx + n)), (lambda n: rec.Gr(pfx + n))
+    table, wmix = P("relative_position_bias_table"), P("w")
+    Wq, bq = P("to_qkv.to_q.weight"), P("to_qkv.to_q.bias")
+    kvn = "to_qkv.to_kv" if xkv is not None else "to_qkv.to_kv_from_q"
+    Wkv, bkv = P(kvn + ".weight"), P(kvn + ".bias")
+    Wp, bp = P("proj.weight"), P("proj.bias")
+    src = xkv if xkv is not None else xq
+    Kin = 2 * C_ if xkv is not None else C_
+    n = pfx
+    q, kv, o, y = rec.alloc(M, C_), rec.alloc(M, 2 * C_), rec.alloc(M, C_), rec.alloc(M, C_)
+    rec.gemm(n + "to_q", xq, Wq, q, N=C_, K=C_, w_sn=C_, w_sk=1, bias=bq)
+    rec.gemm(n + kvn.split(".")[-1], src, Wkv, kv, N=2 * C_, K=Kin, w_sn=Kin, w_sk=1, bias=bkv)
+    k_, v_ = kv[:, :C_], kv[:, C_:]
+    fa = _winattn_args(q, k_, v_, table, wmix, dims, C_, heads)
+    fa.O, fa.ldo = _ptr(o), _ld(o)
+    rec._hold(q, kv, o, table, wmix)
+    rec.keep.append(fa)
+    hd = C_ // heads
+    rec._op(n + "attention", lib.uir_winattn_fwd, C.byref(fa), nbytes=16 * M * C_, flops=M * heads * (4 * 64 * hd))
+    rec.gemm(n + "proj", o, Wp, y, N=C_, K=C_, w_sn=C_, w_sk=1, bias=bp)
+
+    def backward(dy: torch.Tensor):
+        do, dq, dkv, dxq = rec.alloc(M, C_), rec.alloc(M, C_), rec.alloc(M, 2 * C_), rec.alloc(M, C_)
+        with rec.bulk():
+            rec.gram(n + "proj.dW", dy, o, Gr("proj.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
+            _colsum_wide(rec, n + "proj.db", dy, C_, Gr("proj.bias"))
+        rec.gemm(n + "proj.dX", dy, Wp, do, N=C_, K=C_, w_sn=1, w_sk=C_)
+        tslab, wslab, wsum = rec.alloc(nwin, 225 * heads), rec.alloc(nwin * heads, 2), rec.alloc(2)
+        ba = _winattn_args(q, k_, v_, table, wmix, dims, C_, heads)
+        ba.dO, ba.ldo = _ptr(do), _ld(do)
+        ba.dQ, ba.dK, ba.dV = _ptr(dq), _ptr(dkv[:, :C_]), _ptr(dkv[:, C_:])
+        ba.lddq, ba.lddk, ba.lddv = _ld(dq), _ld(dkv), _ld(dkv)
+        ba.dtable_slab, ba.dw_slab = _ptr(tslab), _ptr(wslab)
+        rec._hold(do, dq, dkv)
+        rec.keep.append(ba)
+        rec._op(n + "attention.bwd", lib.uir_winattn_bwd, C.byref(ba), nbytes=28 * M * C_, flops=M * heads * (10 * 64 * hd))
+        with rec.bulk():
+            rec._reduce(n + "dtable", _ptr(tslab), nwin, 225 * heads, _ptr(Gr("relative_position_bias_table")), 225 * heads)
+            rec._reduce(n + "dw.sum", _ptr(wslab), nwin * heads, 2, _ptr(wsum), 2, immediate=True)
+            rec._op(n + "dw", lib.uir_winattn_wgrad, _ptr(wmix), _ptr(wsum), _ptr(Gr("w")))
+            rec.gram(n + "to_q.dW", dq, xq, Gr("to_qkv.to_q.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
+            _colsum_wide(rec, n + "to_q.db", dq, C_, Gr("to_qkv.to_q.bias"))
+            rec.gram(n + "kv.dW", dkv, src, Gr(kvn + ".weight"), N=2 * C_, K=Kin, o_sn=Kin, o_sk=1)
+            _colsum_wide(rec, n + "kv.db", dkv, 2 * C_, Gr(kvn + ".bias"))
+        rec.gemm(n + "to_q.dX", dq, Wq, dxq, N=C_, K=C_, w_sn=1, w_sk=C_)
+        if xkv is None:              # keys / values came from the same rows: their input gradient adds to d xq
+            dxq2 = rec.alloc(M, C_)
+            rec.gemm(n + "kv.dX", dkv, Wkv, dxq2, N=C_, K=2 * C_, w_sn=1, w_sk=C_, R=dxq)
+            return dxq2, None
+        dxkv = rec.alloc(M, 2 * C_)
+        rec.gemm(n + "kv.dX", dkv, Wkv, dxkv, N=2 * C_, K=2 * C_, w_sn=1, w_sk=2 * C_)
+        return dxq, dxkv
+    return y, backward
+
+
+def record_layernorm(rec: Recorder, pfx: str, x: torch.Tensor, C_: int):
+    """nn.LayerNorm(C) over token rows; returns (y, backward(dy, dres) -> dx = LN'(dy) + dres)."""
+    M = x.shape[0]
+    g_, b_ = rec.P(pfx + "weight"), rec.P(pfx + "bias")
+    y, stats = rec.alloc(M, C_), rec.alloc(M, 2)
+    rec._hold(g_, b_)
+    rec._op(pfx + "fwd", lib.uir_layernorm_fwd, _ptr(x), _ld(x), _ptr(g_), _ptr(b_), _ptr(y), C_, _ptr(stats), M, C_, 1e-5,
+            nbytes=8 * M * C_)
+
+    def backward(dy, dres=None):
+        dx = rec.alloc(M, C_)
+        rec.ln_bwd(pfx + "bwd", dy, x, stats, g_, dres, dx, rec.Gr(pfx + "weight"), rec.Gr(pfx + "bias"), C_=C_)
+        return dx
+    return y, backward
+
+
+def _add_rows(rec: Recorder, name: str, a: torch.Tensor, b: torch.Tensor, C_: int) -> torch.Tensor:
+    out = rec.alloc(a.shape[0], C_)
+    rec.copy_cols(name + ".copy", a, 0, out, 0, C_)
+    rec.copy_cols(name + ".add", b, 0, out, 0, C_, accumulate=1)
+    return out
+
+
+def record_mdassa(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, heads: int, dims):
+    """Record MDASSA.forward (block.py:409-515) for shift_size 0, mask None, Fourier FDFP: norm1 -> window self-attention
+    (+ shortcut) -> conv1x1 to (k, v); FDFP(norm1(x)) as the query image; frequency cross window attention; + FDFP shortcut.
+    (norm_q / norm_kv are constructed but commented out in the reference, :471,481: dead parameters.)"""
+    M, C_ = x.shape[0], dim
+    n = pfx
+    xn, ln_bw = record_layernorm(rec, n + "norm1.", x, C_)
+    a1, a1_bw = record_window_attention(rec, n + "attn.", xn, None, dims, C_, heads)
+    xs = _add_rows(rec, n + "spatial", xn, a1, C_)                       # shortcut + attention (:465)
+    fq, f_bw = record_fdfp(rec, n + "fdfp.", xn, C_, 2 * C_, dims)
+    Wc, bc = rec.P(n + "conv1x1.weight"), rec.P(n + "conv1x1.bias")
+    kv = rec.alloc(M, 2 * C_)
+    rec.gemm(n + "conv1x1", xs, Wc, kv, N=2 * C_, K=C_, w_sn=C_, w_sk=1, bias=bc)
+    a2, a2_bw = record_window_attention(rec, n + "freq_attn.", fq, kv, dims, C_, heads)
+    out = _add_rows(rec, n + "freq", fq, a2, C_)                          # freq_shortcut + freq_attn (:514)
+
+    def backward(dout: torch.Tensor) -> torch.Tensor:
+        dfq2, dkv = a2_bw(dout)
+        dfq = _add_rows(rec, n + "dfq", dout, dfq2, C_)
+        with rec.bulk():
+            rec.gram(n + "conv1x1.dW", dkv, xs, rec.Gr(n + "conv1x1.weight"), N=2 * C_, K=C_, o_sn=C_, o_sk=1)
+            _colsum_wide(rec, n + "conv1x1.db", dkv, 2 * C_, rec.Gr(n + "conv1x1.bias"))
+        dxs = rec.alloc(M, C_)
+        rec.gemm(n + "conv1x1.dX", dkv, Wc, dxs, N=C_, K=2 * C_, w_sn=1, w_sk=C_)
+        dxn_f = f_bw(dfq)
+        dxn_a, _ = a1_bw(dxs)
+        dxn = rec.alloc(M, C_)
+        rec.copy_cols(n + "dxn.copy", dxs, 0, dxn, 0, C_)
+        rec.copy_cols(n + "dxn.add1", dxn_f, 0, dxn, 0, C_, accumulate=1)
+        rec.copy_cols(n + "dxn.add2", dxn_a, 0, dxn, 0, C_, accumulate=1)
+        return ln_bw(dxn, None)
+    return out, backward
+
+
+MDASSA_DEAD = ("norm_q.", "norm_kv.", "attn.to_qkv.to_kv.", "freq_attn.to_qkv.to_kv_from_q.")
+
+
+def record_decoder_block(rec: Recorder, pfx: str, xcat: torch.Tensor, dim: int, mdim: int, heads: int, token_mlp: str, dims):
+    """Record DecoderBlock.forward (model.py:142-160) after the optional torch.cat with enc_out (xcat rows [M, mdim]):
+    shortcut = x; x = mdassa(norm1(x)); y = x + shortcut; x = y + mlp(norm2(y)); return mlp_proj(x)."""
+    M = xcat.shape[0]
+    n = pfx
+    x1, n1_bw = record_layernorm(rec, n + "norm1.", xcat, mdim)
+    m, m_bw = record_mdassa(rec, n + "mdassa.", x1, mdim, heads, dims)
+    y = _add_rows(rec, n + "res1", m, xcat, mdim)
+    x2, n2_bw = record_layernorm(rec, n + "norm2.", y, mdim)
+    mlp = record_frfn if token_mlp == "frfn" else record_leff
+    x3, mlp_bw = mlp(rec, n + "mlp.", x2, mdim, 4 * mdim, dims)
+    x4 = _add_rows(rec, n + "res2", y, x3, mdim)
+    Wp, bp = rec.P(n + "mlp_proj.weight"), rec.P(n + "mlp_proj.bias")
+    out = rec.alloc(M, dim)
+    rec.gemm(n + "mlp_proj", x4, Wp, out, N=dim, K=mdim, w_sn=mdim, w_sk=1, bias=bp)
+
+    def backward(dout: torch.Tensor) -> torch.Tensor:
+        with rec.bulk():
+            rec.gram(n + "mlp_proj.dW", dout, x4, rec.Gr(n + "mlp_proj.weight"), N=dim, K=mdim, o_sn=mdim, o_sk=1)
+            _colsum_wide(rec, n + "mlp_proj.db", dout, dim, rec.Gr(n + "mlp_proj.bias"))
+        dx4 = rec.alloc(M, mdim)
+        rec.gemm(n + "mlp_proj.dX", dout, Wp, dx4, N=mdim, K=dim, w_sn=1, w_sk=mdim)
+        dx2 = mlp_bw(dx4)
+        dy = n2_bw(dx2, dx4)                          # y feeds norm2 -> mlp and the residual
+        dx1 = m_bw(dy)
+        return n1_bw(dx1, dy)                         # xcat feeds norm1 -> mdassa and the shortcut
+    return out, backward
+
+
 class TokenPlan(Recorder):
     """A launch plan over token rows [B*H*W, dim]: input buffer -> recorded forward -> output buffer, and the recorded backward.
     Subclasses provide ``_record(x) -> (y, backward)``."""
 
-    def __init__(self, fp: FlatParams, dim: int, B: int, H: int, W: int, want_backward: bool = True):
+    def __init__(self, fp: FlatParams, dim: int, B: int, H: int, W: int, want_backward: bool = True, out_dim: "int | None" = None):
         super().__init__(fp.device, fp, scratch_floats=8 * 1024 * 1024)
         self.dim, self.B, self.H, self.W = dim, B, H, W
+        self.out_dim = out_dim or dim
         self.want_backward = want_backward
         M = B * H * W
         self.x_in = self.alloc(M, dim)
         self.cur = self.fwd
         self.y_out, bw = self._record(self.x_in)
+        assert self.y_out.shape == (M, self.out_dim)
         self.mark("fwd.end")
         if want_backward:
             self.cur = self.bwd
-            self.dy_in = self.alloc(M, dim)
+            self.dy_in = self.alloc(M, self.out_dim)
             self.dx_out = bw(self.dy_in)
             self.mark("bwd.end")
         self.cur = self.fwd
@@ -283,7 +446,7 @@ class _TokenFunction(torch.autograd.Function):
     def forward(ctx, x, module, *params):
         B, Ltok, C_ = x.shape
         plan = module._plan_for(x)
-        y = plan.forward(x.reshape(B * Ltok, C_)).clone().view(B, Ltok, C_)
+        y = plan.forward(x.reshape(B * Ltok, C_)).clone().view(B, Ltok, plan.out_dim)
         module._serial += 1
         ctx.module, ctx.plan, ctx.serial, ctx.shape = module, plan, module._serial, (B, Ltok, C_)
         return y
@@ -295,7 +458,7 @@ class _TokenFunction(torch.autograd.Function):
             raise RuntimeError(f"{type(m).__name__}(HIP): a later forward overwrote the saved activations; call backward before "
                                "the next forward")
         B, Ltok, C_ = ctx.shape
-        dx = ctx.plan.backward(dy.contiguous().view(B * Ltok, C_)).clone().view(B, Ltok, C_)
+        dx = ctx.plan.backward(dy.contiguous().view(B * Ltok, ctx.plan.out_dim)).clone().view(B, Ltok, C_)
         fp = m._flat
         return (dx, None) + tuple(None if n in m._dead else fp.gview(n).clone() for n in m._names)
 
@@ -358,7 +521,7 @@ class TokenModule(nn.Module):
         B, Ltok, C_ = x.shape
         plan = self._plan_for(x, want_backward=False)
         self._serial += 1
-        return plan.forward(x.reshape(B * Ltok, C_)).clone().view(B, Ltok, C_)
+        return plan.forward(x.reshape(B * Ltok, C_)).clone().view(B, Ltok, plan.out_dim)
 
 
 class FRFN(TokenModule):
@@ -452,3 +615,73 @@ class FDFP(TokenModule):
         if H != W:
             raise NotImplementedError("square token images (the reference's H = W = sqrt(L))")
         return super().forward(x.reshape(B, H * W, C_)).view(B, H, W, C_)
+
+
+class MdassaPlan(TokenPlan):
+    def __init__(self, fp, dim, heads, B, H, W, want_backward=True):
+        self.heads = heads
+        super().__init__(fp, dim, B, H, W, want_backward)
+
+    def _record(self, x):
+        return record_mdassa(self, "", x, self.dim, self.heads, (self.B, self.H, self.W))
+
+
+class _WindowAttentionParams(nn.Module):
+    """Parameter container with WindowAttention_Sparse's names and registration order (block.py:285-334)."""
+
+    def __init__(self, dim, num_heads, win=8):
+        super().__init__()
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * win - 1) * (2 * win - 1), num_heads))
+        c = torch.stack(torch.meshgrid([torch.arange(win), torch.arange(win)], indexing="ij")).flatten(1)
+        rel = (c[:, :, None] - c[:, None, :]).permute(1, 2, 0).contiguous()
+        rel[:, :, 0] += win - 1
+        rel[:, :, 1] += win - 1
+        rel[:, :, 0] *= 2 * win - 1
+        self.register_buffer("relative_position_index", rel.sum(-1))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=.02)
+        qkv = nn.Module()
+        qkv.to_q = nn.Linear(dim, dim, bias=True)
+        qkv.to_kv_from_q = nn.Linear(dim, dim * 2, bias=True)
+        qkv.to_kv = nn.Linear(dim * 2, dim * 2, bias=True)
+        self.to_qkv = qkv
+        self.proj = nn.Linear(dim, dim)
+        self.w = nn.Parameter(torch.ones(2))
+
+
+class MDASSA(TokenModule):
+    """Drop-in for ``src.model.block.MDASSA`` (block.py:373-515) as every DecoderBlock of MyBigFRFNModel builds it: win_size 8,
+    shift_size 0, token_projection 'linear', qkv_bias True, no dropout / DropPath, Fourier FDFP.  ``forward(x: (B, L, C), mask=None)
+    -> (B, H, W, C)`` like the reference."""
+
+    _dead = frozenset(n + s for n in MDASSA_DEAD for s in ("weight", "bias"))
+
+    def __init__(self, dim, win_size, shift_size, num_heads, qk_scale=None, qkv_bias=True, token_projection='linear', attn_drop=0.,
+                 proj_drop=0., drop_path=0., norm_layer=nn.LayerNorm, act_layer=nn.GELU, enc_out=True, freq_attn_win_ratio=2,
+                 use_dwt="Fourier"):
+        super().__init__()
+        if (win_size, shift_size, qk_scale, qkv_bias, token_projection, attn_drop, proj_drop, drop_path) != (8, 0, None, True, 'linear', 0., 0., 0.) \
+                or use_dwt != "Fourier" or norm_layer is not nn.LayerNorm or act_layer is not nn.GELU:
+            raise NotImplementedError("the HIP MDASSA is built for MyBigFRFNModel's configuration: win_size 8, shift_size 0, linear "
+                                      "projection with bias, no dropout / DropPath, use_dwt='Fourier'")
+        if dim % num_heads or dim // num_heads not in (16, 32, 64) or dim not in (32, 64, 128):
+            raise NotImplementedError("dim in {32, 64, 128} with head dims 16 / 32 / 64 this round")
+        self.dim, self.win_size, self.shift_size, self.num_heads = dim, win_size, shift_size, num_heads
+        self.norm1 = norm_layer(dim)
+        self.norm_q = norm_layer(dim)
+        self.norm_kv = norm_layer(dim * 2)
+        self.attn = _WindowAttentionParams(dim, num_heads)
+        self.conv1x1 = nn.Conv2d(dim, dim * 2, kernel_size=1, stride=1, padding=0)
+        self.fdfp = FDFP(dim, dim * 2, act_layer=act_layer, use_dwt=use_dwt)
+        self.enc_out = enc_out
+        self.freq_attn = _WindowAttentionParams(dim, num_heads)
+        self._init_plumbing()
+
+    def _make_plan(self, fp, B, H, W, want_backward):
+        return MdassaPlan(fp, self.dim, self.num_heads, B, H, W, want_backward)
+
+    def forward(self, x: torch.Tensor, mask=None) -> torch.Tensor:
+        if mask is not None:
+            raise NotImplementedError("mask=None (what DecoderBlock passes, model.py:151)")
+        y = super().forward(x)
+        hh = int(math.sqrt(x.shape[1]))
+        return y.view(x.shape[0], hh, hh, self.dim)

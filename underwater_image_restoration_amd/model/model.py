@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from ..engine import FlatParams, _ptr
-from .block import FRFN, LeFF, TokenModule, TokenPlan, record_frfn, record_leff
+from .block import FRFN, LeFF, MDASSA, MDASSA_DEAD, TokenModule, TokenPlan, record_decoder_block, record_frfn, record_leff
 
 lib = L.lib
 _TABLES: dict = {}
@@ -183,3 +183,57 @@ class EncoderBlock(TokenModule):
 
     def _make_plan(self, fp, B, H, W, want_backward):
         return EncoderPlan(fp, self.dim, self.hidden_dim, B, H, W, want_backward, self.token_mlp, self.freq_mlp_kind)
+
+
+class DecoderPlan(TokenPlan):
+    def __init__(self, fp: FlatParams, dim: int, mdim: int, heads: int, token_mlp: str, B: int, H: int, W: int, want_backward: bool = True):
+        self.out_width, self.heads, self.token_mlp = dim, heads, token_mlp
+        super().__init__(fp, mdim, B, H, W, want_backward, out_dim=dim)
+
+    def _record(self, x):
+        return record_decoder_block(self, "", x, self.out_width, self.dim, self.heads, self.token_mlp, (self.B, self.H, self.W))
+
+
+class DecoderBlock(TokenModule):
+    """Drop-in for ``src.model.model.DecoderBlock`` (model.py:96-160) as MyBigFRFNModel builds it (win_size 8, shift_size 0,
+    drop_path 0, Fourier): ``forward(x: (B, L, dim), enc_out: (B, L, dim) | None) -> (B, L, dim)``.  With ``enc_out=True`` the
+    block works on the concatenation (2*dim channels) and projects back to dim (``mlp_proj``)."""
+
+    def __init__(self, dim, input_resolution, num_heads, win_size=8, shift_size=0, mlp_ratio=4, token_mlp="leff", drop_path=0.0,
+                 norm_layer=nn.LayerNorm, act_layer=nn.GELU, drop=0.0, token_projection="linear", enc_out=True, freq_attn_win_ratio=2,
+                 use_dwt="Fourier"):
+        super().__init__()
+        if token_mlp not in ("leff", "frfn"):
+            raise ValueError(f"Unknown token_mlp type: {token_mlp}")                     # model.py:136
+        if drop_path > 0.0 or shift_size != 0 or mlp_ratio != 4:
+            raise NotImplementedError("the HIP DecoderBlock is built for drop_path 0, shift_size 0, mlp_ratio 4 (MyBigFRFNModel)")
+        self.dim, self.input_resolution, self.num_heads, self.mlp_ratio = dim, input_resolution, num_heads, mlp_ratio
+        self.token_mlp, self.enc_out, self.win_size, self.shift_size = token_mlp, enc_out, win_size, shift_size
+        if min(self.input_resolution) <= self.win_size:
+            raise NotImplementedError("token images larger than one 8 x 8 window")
+        self.drop_path = nn.Identity()
+        mdim = dim * 2 if enc_out else dim
+        self.mdim = mdim
+        self.norm1 = norm_layer(mdim)                                                    # registration order: model.py:119-139
+        self.norm2 = norm_layer(mdim)
+        self.mdassa = MDASSA(mdim, num_heads=num_heads, win_size=win_size, shift_size=shift_size, token_projection=token_projection,
+                             qkv_bias=True, qk_scale=None, attn_drop=0., proj_drop=0., norm_layer=norm_layer, enc_out=enc_out,
+                             freq_attn_win_ratio=freq_attn_win_ratio, use_dwt=use_dwt)
+        self.mlp = (FRFN if token_mlp == "frfn" else LeFF)(mdim, int(mdim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.mlp_proj = nn.Linear(mdim, dim)
+        self._dead = frozenset("mdassa." + n + s for n in MDASSA_DEAD for s in ("weight", "bias"))
+        self._init_plumbing()
+
+    def _make_plan(self, fp, B, H, W, want_backward):
+        return DecoderPlan(fp, self.dim, self.mdim, self.num_heads, self.token_mlp, B, H, W, want_backward)
+
+    def forward(self, x: torch.Tensor, enc_out=None) -> torch.Tensor:
+        if (enc_out is not None) != bool(self.enc_out):
+            raise ValueError("enc_out must be given exactly when the block was built with enc_out=True")
+        if enc_out is not None:
+            x = torch.cat([x, enc_out], dim=2)                                           # model.py:146
+        d, self.dim = self.dim, self.mdim                                                # TokenModule.forward checks the input width
+        try:
+            return super().forward(x)
+        finally:
+            self.dim = d
