@@ -213,7 +213,7 @@ class DecoderBlock(TokenModule):
             raise NotImplementedError("token images larger than one 8 x 8 window")
         self.drop_path = nn.Identity()
         mdim = dim * 2 if enc_out else dim
-        self.mdim = mdim
+        self.mdim, self._out_width = mdim, dim
         self.norm1 = norm_layer(mdim)                                                    # registration order: model.py:119-139
         self.norm2 = norm_layer(mdim)
         self.mdassa = MDASSA(mdim, num_heads=num_heads, win_size=win_size, shift_size=shift_size, token_projection=token_projection,
@@ -225,7 +225,7 @@ class DecoderBlock(TokenModule):
         self._init_plumbing()
 
     def _make_plan(self, fp, B, H, W, want_backward):
-        return DecoderPlan(fp, self.dim, self.mdim, self.num_heads, self.token_mlp, B, H, W, want_backward)
+        return DecoderPlan(fp, self._out_width, self.mdim, self.num_heads, self.token_mlp, B, H, W, want_backward)
 
     def forward(self, x: torch.Tensor, enc_out=None) -> torch.Tensor:
         if (enc_out is not None) != bool(self.enc_out):
