@@ -18,7 +18,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from underwater_image_restoration_amd.model.block import FRFN  # noqa: E402
-from underwater_image_restoration_amd.model.model import EncoderBlock  # noqa: E402
+from underwater_image_restoration_amd.model.model import DecoderBlock, EncoderBlock  # noqa: E402
 
 MFMA_F32_PEAK = 157.3e12
 HBM_PEAK = 8.0e12
@@ -32,17 +32,22 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--what", default="frfn", choices=("frfn", "encoder"),
-                    help="frfn: one FRFN (block.py:249-282); encoder: one EncoderBlock = LN + 2 FRFN + 2 (L,C) transforms (model.py:16-93)")
+    ap.add_argument("--what", default="frfn", choices=("frfn", "encoder", "decoder"),
+                    help="frfn: one FRFN (block.py:249-282); encoder: one EncoderBlock = LN + 2 FRFN + 2 (L,C) transforms (model.py:16-93); "
+                         "decoder: one DecoderBlock(dim, enc_out=True) = 2 LN + MDASSA (2 window attentions + FDFP) + FRFN(2 dim) + proj (model.py:96-160)")
     args = ap.parse_args()
     dim, hid, B, S = args.dim, 4 * args.dim, args.batch, args.size
     torch.manual_seed(0)
-    enc = args.what == "encoder"
-    m = (EncoderBlock(dim, (S, S), 4, token_mlp="frfn", freq_mlp="frfn") if enc else FRFN(dim, hid)).cuda()
-    x = torch.randn(B, S * S, dim, device="cuda")
+    enc, dec = args.what == "encoder", args.what == "decoder"
+    if dec:
+        m = DecoderBlock(dim, (S, S), 4, token_mlp="frfn", enc_out=True).cuda()
+    else:
+        m = (EncoderBlock(dim, (S, S), 4, token_mlp="frfn", freq_mlp="frfn") if enc else FRFN(dim, hid)).cuda()
+    win = dim * 2 if dec else dim                     # the decoder block works on cat([x, enc_out]) (model.py:146)
+    x = torch.randn(B, S * S, win, device="cuda")
     dy = torch.randn(B, S * S, dim, device="cuda")
     plan = m._plan_for(x)
-    xr, dyr = x.view(-1, dim), dy.view(-1, dim)
+    xr, dyr = x.view(-1, win), dy.view(-1, dim)
 
     def step():
         plan.forward(xr)
@@ -70,7 +75,9 @@ def main():
         flops = 2 * 3 * fwd_flops + 3 * 8 * M * dim + 4 * fft_flops
     rows = plan.run_timed(plan.fwd) + plan.run_timed(plan.bwd)
     top = sorted(rows, key=lambda r: -r[4])[:6]
-    what = "EncoderBlock (Fourier mode, FRFN mlps)" if enc else "FRFN"
+    what = "EncoderBlock (Fourier mode, FRFN mlps)" if enc else ("DecoderBlock (enc_out, MDASSA + FRFN)" if dec else "FRFN")
+    if dec:
+        flops = plan.flops()          # the plan's own count: GEMMs, window attention, depthwise convs, dense / two-stage DFT stages
     line = {"metric": f"{what} forward+backward images/s (dim {dim}, hidden {hid}, {S}x{S} tokens, bs {B})", "value": B / (ms * 1e-3),
             "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "dtype": "f32", "data": "synthetic",
@@ -85,7 +92,23 @@ def main():
         line["roofline"]["executed_flops"] = plan.flops()
         line["roofline"]["note"] = ("algorithmic flops count the (L,C) transforms as FFTs (5 N log2 N); the plan executes the length-L "
                                     "transform as two dense 256-point MFMA contractions: executed_flops is what the launches do")
-    if not args.no_cpu and enc:
+    if not args.no_cpu and dec:
+        from oracle import decoder_ref as D
+        cores = min(16, len(os.sched_getaffinity(0)))
+        torch.set_num_threads(cores)
+        P = {n: v.detach().cpu() for n, v in m.state_dict().items()}
+        xb, pb = x[:1].cpu(), dy[:1].cpu()
+        fn = lambda t, Pp: D.decoder_block(t[:, :, :dim], t[:, :, dim:], Pp, 4)          # noqa: E731
+        D.grads(fn, [xb], P, pb)
+        t0 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t0 < 10.0:
+            D.grads(fn, [xb], P, pb)
+            k += 1
+        dt = (time.perf_counter() - t0) / k
+        line["cpu_baseline"] = {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port",
+                                "sample": f"{k} forward+backward passes of one {S}x{S} image through oracle/decoder_ref.py (torch CPU, {cores} threads)"}
+    elif not args.no_cpu and enc:
         from oracle import encoder_ref as E
         cores = min(16, len(os.sched_getaffinity(0)))
         torch.set_num_threads(cores)
