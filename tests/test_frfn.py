@@ -181,11 +181,11 @@ def test_hip_fdfp_matches_reference(case):
     worst = max(_rel(p.grad, g[case + ".grad." + n]) for n, p in m.named_parameters())
     print(f"{case}: y {_rel(y, g[case + '.y']):.2e} dx {_rel(x.grad, g[case + '.dx']):.2e} worst param grad {worst:.2e}")
     assert _rel(y, g[case + ".y"]) < 2e-5 and _rel(x.grad, g[case + ".dx"]) < 5e-5 and worst < 2e-4
-    # a 64 x 64 token image (the two-stage MFMA DFT path) vs the fp64 oracle
-    if dim == 32:
+    # 64 x 64 (one launch of the two-stage MFMA DFT per axis) and 256 x 256 (each axis factored 2 x 128) vs the fp64 oracle
+    for (nb, sz) in (((2, 64), (1, 256)) if dim == 32 else ()):
         P = R.closed_form_fdfp_params(dim, 2 * dim)
-        xb = R.closed_form_input(2, 64 * 64, dim, 47).reshape(2, 64, 64, dim)
-        pb = R.closed_form_input(2, 64 * 64, dim, 49).reshape(2, 64, 64, dim)
+        xb = R.closed_form_input(nb, sz * sz, dim, 47).reshape(nb, sz, sz, dim)
+        pb = R.closed_form_input(nb, sz * sz, dim, 49).reshape(nb, sz, sz, dim)
         y64, dx64, g64 = R.fdfp_out_and_grads(xb.double(), {k: v.double() for k, v in P.items()}, pb.double())
         xg = xb.cuda().requires_grad_(True)
         for p in m.parameters():

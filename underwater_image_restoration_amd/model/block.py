@@ -166,15 +166,74 @@ def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     return y, backward
 
 
+_AXIS_TW: dict = {}
+_FAST_DFT = (128, 64, 32)            # lengths of the two-stage MFMA DFT kernel (uir_dft_axis2)
+
+
+def _axis_factors(N: int):
+    """(N,) when one launch handles the axis well, else (N1, N2) with N2 on the fast kernel (256 = 2 * 128, 512 = 4 * 128)."""
+    if N in _FAST_DFT or N < 2 * _FAST_DFT[-1]:
+        return (N,)
+    for f in _FAST_DFT:
+        if N % f == 0 and N // f <= 16:
+            return (N // f, f)
+    return (N,)
+
+
+def _axis_twiddle(N1: int, N2: int, inner: int, device):
+    """exp(+2 pi i k1 n2 / (N1 N2)) at ((k1 * N2 + n2) * inner + r): one entry per row of an axis with `inner` rows below it."""
+    import numpy as np
+    key = (N1, N2, inner, str(device))
+    if key not in _AXIS_TW:
+        r = (np.arange(N1, dtype=np.int64)[:, None] * np.arange(N2, dtype=np.int64)[None, :]) % (N1 * N2)
+        ang = 2.0 * np.pi * r.astype(np.float64) / (N1 * N2)
+        c, s_ = np.cos(ang), np.sin(ang)
+        q = (4 * r) % (N1 * N2) == 0
+        c[q], s_[q] = np.round(c[q]), np.round(s_[q])
+        c, s_ = np.repeat(c.reshape(-1), inner), np.repeat(s_.reshape(-1), inner)
+        _AXIS_TW[key] = (torch.from_numpy(c.astype(np.float32)).to(device).contiguous(),
+                         torch.from_numpy(s_.astype(np.float32)).to(device).contiguous())
+    return _AXIS_TW[key]
+
+
+def record_axis_dft(rec: Recorder, name: str, in_re, in_im, O: int, N: int, I: int, C_: int, scale: float, real_out: bool):
+    """Complex DFT (sign +) along one axis of rows viewed [O][N][I][C]; in_im may be None (real input).  One uir_dft_axis launch
+    for short / fast lengths, else Cooley-Tukey N = N1 * N2: stage over n1 -> twiddle -> stage over n2 (fast MFMA kernel) ->
+    reorder k1 + N1 k2.  Returns (out_re, out_im or None)."""
+    M = O * N * I
+    f = _axis_factors(N)
+    if len(f) == 1:
+        o_re = rec.alloc(M, C_)
+        o_im = None if real_out else rec.alloc(M, C_)
+        rec.dft(name, in_re, in_im, o_re, o_im, O=O, N=N, I=I, C_=C_, sign=1.0, scale=scale)
+        return o_re, o_im
+    N1, N2 = f
+    ar, ai = rec.alloc(M, C_), rec.alloc(M, C_)
+    rec.dft(name + ".n1", in_re, in_im, ar, ai, O=O, N=N1, I=N2 * I, C_=C_, sign=1.0, scale=1.0)
+    twr, twi = _axis_twiddle(N1, N2, I, rec.dev)
+    rec._hold(twr, twi)
+    rec._op(name + ".twiddle", lib.uir_cmul_table, _ptr(ar), _ptr(ai), _ptr(twr), _ptr(twi), M, N1 * N2 * I, C_, nbytes=16 * M * C_)
+    br = rec.alloc(M, C_)
+    bi = None if real_out else rec.alloc(M, C_)
+    rec.dft(name + ".n2", ar, ai, br, bi, O=O * N1, N=N2, I=I, C_=C_, sign=1.0, scale=1.0)
+    outs = []
+    for t, nm in ((br, "re"), (bi, "im")):
+        if t is None:
+            outs.append(None)
+            continue
+        o = rec.alloc(M, C_)        # [o][k1][k2][inner rows] -> [o][k2][k1][inner rows]: rows of I*C floats
+        rec._op(f"{name}.natural.{nm}", lib.uir_transpose_rows, _ptr(t), _ptr(o), O, N1, 1, N2, I * C_, scale, nbytes=8 * M * C_)
+        outs.append(o)
+    return outs[0], outs[1]
+
+
 def record_spatial_refft(rec: Recorder, name: str, x: torch.Tensor, dims, C_: int, scale: float) -> torch.Tensor:
     """y = scale * Re(fft2 over (H, W)) per channel of token-image rows x [B*H*W, C] = scale * (C_H x C_W - S_H x S_W):
     `fft.fftn(x, dim=(-2,-1)).real` of FDFP on NCHW (block.py:538) and, divided by H*W, its `ifftn(...).real` (:549) - the
-    operator is real-symmetric, so it is also its own backward pass.  Two uir_dft_axis passes (W, then H: real part only)."""
+    operator is real-symmetric, so it is also its own backward pass.  A DFT along W, then along H with the real part only."""
     B, H, W = dims
-    M = B * H * W
-    ar, ai, y = rec.alloc(M, C_), rec.alloc(M, C_), rec.alloc(M, C_)
-    rec.dft(name + ".W", x, None, ar, ai, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0)
-    rec.dft(name + ".H", ar, ai, y, None, O=B, N=H, I=W, C_=C_, sign=1.0, scale=scale)
+    ar, ai = record_axis_dft(rec, name + ".W", x, None, B * H, W, 1, C_, 1.0, real_out=False)
+    y, _ = record_axis_dft(rec, name + ".H", ar, ai, B, H, W, C_, scale, real_out=True)
     return y
 
 
