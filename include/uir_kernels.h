@@ -501,6 +501,12 @@ int uir_layernorm_fwd(const float* X, int ldx, const float* gamma, const float* 
                       float eps, void* stream);
 int uir_cmul_table(float* re, float* im, const float* tab_re, const float* tab_im, long rows, long P, int C, void* stream);
 int uir_transpose_rows(const float* src, float* dst, int B, int N1, int N2, int N3, int C, float scale, void* stream);
+/* Last stage of a length-N = 2 N2 complex DFT (sign +) along an axis of rows [O][N][I][C] whose first stage transformed the two
+ * interleaved sub-sequences n = 2 n2 + n1 (uir_dft_axis2 over n2 with inner extent 2 I): Y rows [o][k2][n1][i], twiddle table
+ * exp(2 pi i k2 / N) [N2];  X[o][k1 N2 + k2][i] = scale (Y[k2][0] + (-1)^k1 tw[k2] Y[k2][1]), natural order; x_im NULL = real part
+ * only.  Used for the 256-long axes of FDFP's fft2 (block.py:538,549). */
+int uir_radix2_combine(const float* y_re, const float* y_im, float* x_re, float* x_im, const float* tab_re, const float* tab_im, long O,
+                       int N2, long I, int C, float scale, void* stream);
 
 /* -------------------------------------------------------------- uir_winattn */
 /* Attention core of WindowAttention_Sparse (src/model/block.py:336-370) on 8 x 8 non-shifted windows of an HWC token image

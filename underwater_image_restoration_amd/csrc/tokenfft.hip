@@ -84,6 +84,38 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(const float* __rest
   }
 }
 
+// Last stage of a length-N = 2*N2 DFT whose first stage ran over the odd / even sub-sequences (n = 2 n2 + n1):
+//   Y rows [o][k2][n1][i][:]  ->  X[o][k1][k2][i][:] = scale * (Y[k2][0] + (-1)^k1 * tw[k2] * Y[k2][1]),  tw[k2] = exp(2 pi i k2 / N)
+// i.e. the radix-2 butterfly with its twiddle, writing straight to natural frequency order (k = k1 N2 + k2).
+__global__ __launch_bounds__(256) void radix2_combine_kernel(const float* __restrict__ yr, const float* __restrict__ yi,
+                                                             float* __restrict__ xr, float* __restrict__ xi,
+                                                             const float* __restrict__ tr, const float* __restrict__ ti, long O, int N2,
+                                                             long IC4, float scale) {
+  const long total = O * N2 * IC4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long c = e % IC4;
+    long r = e / IC4;
+    const int k2 = (int)(r % N2);
+    const long o = r / N2;
+    const long src = ((o * N2 + k2) * 2) * IC4 + c;
+    const float4 ar = reinterpret_cast<const float4*>(yr)[src], ai = reinterpret_cast<const float4*>(yi)[src];
+    const float4 br = reinterpret_cast<const float4*>(yr)[src + IC4], bi = reinterpret_cast<const float4*>(yi)[src + IC4];
+    const float wr = tr[k2], wi = ti[k2];
+    float4 pr, pi;       // tw * b
+    pr.x = br.x * wr - bi.x * wi; pi.x = br.x * wi + bi.x * wr;
+    pr.y = br.y * wr - bi.y * wi; pi.y = br.y * wi + bi.y * wr;
+    pr.z = br.z * wr - bi.z * wi; pi.z = br.z * wi + bi.z * wr;
+    pr.w = br.w * wr - bi.w * wi; pi.w = br.w * wi + bi.w * wr;
+    const long d0 = (o * 2 * N2 + k2) * IC4 + c, d1 = d0 + (long)N2 * IC4;
+    reinterpret_cast<float4*>(xr)[d0] = make_float4((ar.x + pr.x) * scale, (ar.y + pr.y) * scale, (ar.z + pr.z) * scale, (ar.w + pr.w) * scale);
+    reinterpret_cast<float4*>(xr)[d1] = make_float4((ar.x - pr.x) * scale, (ar.y - pr.y) * scale, (ar.z - pr.z) * scale, (ar.w - pr.w) * scale);
+    if (xi) {
+      reinterpret_cast<float4*>(xi)[d0] = make_float4((ai.x + pi.x) * scale, (ai.y + pi.y) * scale, (ai.z + pi.z) * scale, (ai.w + pi.w) * scale);
+      reinterpret_cast<float4*>(xi)[d1] = make_float4((ai.x - pi.x) * scale, (ai.y - pi.y) * scale, (ai.z - pi.z) * scale, (ai.w - pi.w) * scale);
+    }
+  }
+}
+
 inline unsigned grid_for(long total) {
   long g = (total + 255) / 256;
   return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -122,5 +154,16 @@ extern "C" int uir_transpose_rows(const float* src, float* dst, int B, int N1, i
   UIR_REQUIRE(uir_aligned16(src) && uir_aligned16(dst));
   hipLaunchKernelGGL(transpose_rows_kernel, dim3(grid_for((long)B * N1 * N2 * N3 * (C / 4))), dim3(256), 0,
                      static_cast<hipStream_t>(stream), src, dst, B, N1, N2, N3, C / 4, scale);
+  return uir_launch_status();
+}
+
+extern "C" int uir_radix2_combine(const float* y_re, const float* y_im, float* x_re, float* x_im, const float* tab_re,
+                                  const float* tab_im, long O, int N2, long I, int C, float scale, void* stream) {
+  UIR_REQUIRE(y_re && y_im && x_re && tab_re && tab_im && O > 0 && N2 > 0 && I > 0 && C > 0 && (C & 3) == 0);
+  UIR_REQUIRE(uir_aligned16(y_re) && uir_aligned16(y_im) && uir_aligned16(x_re) && (!x_im || uir_aligned16(x_im)));
+  UIR_REQUIRE(x_re != y_re && x_re != y_im && x_im != y_re && x_im != y_im);
+  const long IC4 = I * (C / 4);
+  hipLaunchKernelGGL(radix2_combine_kernel, dim3(grid_for(O * N2 * IC4)), dim3(256), 0, static_cast<hipStream_t>(stream), y_re, y_im, x_re,
+                     x_im, tab_re, tab_im, O, N2, IC4, scale);
   return uir_launch_status();
 }
