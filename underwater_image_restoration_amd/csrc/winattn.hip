@@ -26,20 +26,21 @@ __device__ __forceinline__ long token_row(const UirWinAttnArgs& a, int win, int 
 
 template <int HD>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ base, int ld, int col0, const UirWinAttnArgs& a, int win,
-                                           float (*dst)[HD + 1]) {
+                                           float (*dst)[HD]) {
   // 64 lanes x (HD/4) float4 columns: lane = token
   const int t = threadIdx.x;
   const float* p = base + token_row(a, win, t) * ld + col0;
 #pragma unroll
   for (int c = 0; c < HD; c += 4) {
     const float4 v = *reinterpret_cast<const float4*>(p + c);
-    dst[t][c] = v.x; dst[t][c + 1] = v.y; dst[t][c + 2] = v.z; dst[t][c + 3] = v.w;
+    *reinterpret_cast<float4*>(&dst[t][c]) = v;      // rows unpadded and 16-byte aligned: the hot loops read them as broadcast
+                                                     // ds_read_b128 (every lane the same address); only this one-time store conflicts
   }
 }
 
 // scores of query token i against all 64 keys -> p0 (softmax), r (relu^2), and the mixed attention row
 template <int HD>
-__device__ __forceinline__ void score_row(const UirWinAttnArgs& a, int h, int i, const float (&q)[HD], const float (*Ks)[HD + 1],
+__device__ __forceinline__ void score_row(const UirWinAttnArgs& a, int h, int i, const float (&q)[HD], const float (*Ks)[HD],
                                           float (&s)[NT], float (&p0)[NT]) {
   const int yi = i >> 3, xi = i & 7;
   float mx = -__builtin_huge_valf();
@@ -72,7 +73,7 @@ __device__ __forceinline__ void mix_weights(const float* w, float& w1, float& w2
 
 template <int HD>
 __global__ __launch_bounds__(64) void winattn_fwd_kernel(const UirWinAttnArgs a) {
-  __shared__ float Ks[NT][HD + 1], Vs[NT][HD + 1];
+  __shared__ __align__(16) float Ks[NT][HD], Vs[NT][HD];
   const int win = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c0 = h * HD;
   stage_rows<HD>(a.K, a.ldk, c0, a, win, Ks);
   stage_rows<HD>(a.V, a.ldv, c0, a, win, Vs);
@@ -105,12 +106,12 @@ __global__ __launch_bounds__(64) void winattn_fwd_kernel(const UirWinAttnArgs a)
 
 template <int HD>
 __global__ __launch_bounds__(64) void winattn_bwd_kernel(const UirWinAttnArgs a) {
-  extern __shared__ float smem[];
-  float (*Ks)[HD + 1] = reinterpret_cast<float (*)[HD + 1]>(smem);
-  float (*Vs)[HD + 1] = Ks + NT;
-  float (*Qs)[HD + 1] = Vs + NT;
-  float (*Gs)[HD + 1] = Qs + NT;                                   // dO
-  float (*Pm)[NT + 1] = reinterpret_cast<float (*)[NT + 1]>(smem + 4 * NT * (HD + 1));
+  extern __shared__ __align__(16) float smem[];
+  float (*Ks)[HD] = reinterpret_cast<float (*)[HD]>(smem);
+  float (*Vs)[HD] = Ks + NT;
+  float (*Qs)[HD] = Vs + NT;
+  float (*Gs)[HD] = Qs + NT;                                       // dO
+  float (*Pm)[NT + 1] = reinterpret_cast<float (*)[NT + 1]>(smem + 4 * NT * HD);
   float (*Dm)[NT + 1] = Pm + NT;                                   // dS
   const int win = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c0 = h * HD;
   stage_rows<HD>(a.K, a.ldk, c0, a, win, Ks);
@@ -244,7 +245,7 @@ extern "C" int uir_winattn_bwd(const UirWinAttnArgs* p, void* stream) {
   const dim3 grid(a.B * (a.H / WS) * (a.W / WS), a.heads);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int hd = a.C / a.heads;
-  const size_t lds = ((size_t)4 * NT * (hd + 1) + (size_t)2 * NT * (NT + 1)) * sizeof(float);
+  const size_t lds = ((size_t)4 * NT * hd + (size_t)2 * NT * (NT + 1)) * sizeof(float);
   // 51 / 67 / 100 KB of LDS per 64-lane workgroup: above the 64 KB default for head dims 32 and 64
 #define UIR_WA_BWD(HDV)                                                                                                     \
   do {                                                                                                                      \
