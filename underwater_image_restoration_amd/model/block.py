@@ -308,7 +308,15 @@ def record_window_attention(rec: Recorder, pfx: str, xq: torch.Tensor, xkv: "tor
         rec._op(n + "attention.bwd", lib.uir_winattn_bwd, C.byref(ba), nbytes=28 * M * C_, flops=M * heads * (10 * 64 * hd))
         with rec.bulk():
             rec._reduce(n + "dtable", _ptr(tslab), nwin, 225 * heads, _ptr(Gr("relative_position_bias_table")), 225 * heads)
-            rec._reduce(n + "dw.sum", _ptr(wslab), nwin * heads, 2, _ptr(wsum), 2, immediate=True)
+            # [nwin * heads][2] partials -> [2]: uir_reduce_slab parallelises over outputs only, so two outputs over 32 768 rows
+            # would be one workgroup walking them (0.75 ms per call at 8 x 256 x 256): fold 256 rows into the columns first
+            rows = nwin * heads
+            if rows % 256 == 0 and rows >= 2048:
+                wmid = rec.alloc(512)
+                rec._reduce(n + "dw.sum1", _ptr(wslab), rows // 256, 512, _ptr(wmid), 512, immediate=True)
+                rec._reduce(n + "dw.sum", _ptr(wmid), 256, 2, _ptr(wsum), 2, immediate=True)
+            else:
+                rec._reduce(n + "dw.sum", _ptr(wslab), rows, 2, _ptr(wsum), 2, immediate=True)
             rec._op(n + "dw", lib.uir_winattn_wgrad, _ptr(wmix), _ptr(wsum), _ptr(Gr("w")))
             rec.gram(n + "to_q.dW", dq, xq, Gr("to_qkv.to_q.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
             _colsum_wide(rec, n + "to_q.db", dq, C_, Gr("to_qkv.to_q.bias"))
