@@ -146,3 +146,29 @@ def test_hip_decoder_block_larger_vs_oracle():
     worst = max(((n, _rel(gw, g64[n])) for n, gw in outs[0][3].items()), key=lambda t: t[1])
     print("64x64 decoder block: worst param grad", worst)
     assert worst[1] < 1e-3
+
+
+@gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_hip_mdassa_head_dim_32_vs_oracle():
+    """MDASSA(128, heads 4): head dim 32 (the decoder_1 level of MyBigFRFNModel, mdssa_dim = 2 * 64) - the other template
+    instance of the window-attention kernels - on a 24 x 24 token image (9 windows, sizes the tiles do not divide) vs the fp64 oracle."""
+    from underwater_image_restoration_amd.model.block import MDASSA
+    dim, B, S2 = 128, 2, 24
+    m = MDASSA(dim, win_size=8, shift_size=0, num_heads=4, enc_out=True, use_dwt="Fourier")
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.is_floating_point() and ".dwt." not in k and ".idwt." not in k}
+    P = D.closed_form_params(shapes, "mdassa128")
+    m.load_state_dict(P, strict=False)
+    m = m.cuda()
+    x, probe = R.closed_form_input(B, S2 * S2, dim, 91), R.closed_form_input(B, S2 * S2, dim, 92)
+    y64, dxs64, g64 = D.grads(lambda t, Pp: D.mdassa(t, Pp, "", 4), [x.double()], {k: v.double() for k, v in P.items()},
+                              probe.double().reshape(B, S2, S2, dim))
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    (y * probe.cuda().reshape(y.shape)).sum().backward()
+    torch.cuda.synchronize()
+    assert _rel(y, y64) < 5e-5 and _rel(xg.grad, dxs64[0]) < 1e-4
+    worst = max(((n, _rel(p.grad, g64[n])) for n, p in m.named_parameters() if p.grad is not None), key=lambda t: t[1])
+    print("MDASSA(128): worst param grad", worst)
+    assert worst[1] < 5e-4
+    assert all((p.grad is None) == (n not in g64) for n, p in m.named_parameters())
