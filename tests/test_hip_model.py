@@ -670,3 +670,50 @@ class _FakeShape:
     def __init__(self, shape):
         self.shape = shape
         self.device = torch.device(DEV, torch.cuda.current_device())
+
+
+def _dp_gpu_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)                         # both ranks share the one GPU of this box: gloo moves the bucket (RCCL refuses
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # two ranks on one device); the step itself is the product path
+    from underwater_image_restoration_amd.trainer import TrainStep
+    model = init_model("SpectralTransformer")
+    P = O.closed_form_state()
+    if rank == 1:
+        P = {k: v + 0.25 for k, v in P.items()}       # rank 1 starts elsewhere: TrainStep must broadcast rank 0's weights
+    model.load_state_dict(P)
+    model = model.to(DEV)
+    step = TrainStep(model, "charbonnier", lr=3e-4)
+    raw, ref = O.closed_form_images(2, 32, 95)[rank:rank + 1].to(DEV), O.closed_form_images(2, 32, 96)[rank:rank + 1].to(DEV)
+    losses = []
+    for _ in range(2):
+        loss, norm = step(raw, ref)
+        losses.append((float(loss), float(norm)))
+    torch.cuda.synchronize()
+    torch.save({"flat": model.flat_params().flat.cpu(), "losses": losses}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_two_ranks_real_step(tmp_path):
+    """SURVEY.md 8(e) with the product's own step: 2 processes x 1 image (HIP forward / backward, one all-reduce of the flat
+    bucket, fused clip + Adam with gscale = 1/2) == 1 process x 2 images for a mean-type loss; replicas stay bit-identical;
+    rank 1's different initial weights are overwritten by the broadcast.  (gloo carries the bucket: two ranks cannot share
+    one GPU under RCCL; the RCCL call path itself is test_rccl_allreduce_call_path_world1.)"""
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "dpgpu")
+    port = 30500 + (os.getpid() % 2000)
+    mp.spawn(_dp_gpu_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["flat"], r1["flat"])                                  # replicas identical after two steps
+    model, step = _fresh_step("charbonnier")
+    raw, ref = O.closed_form_images(2, 32, 95).to(DEV), O.closed_form_images(2, 32, 96).to(DEV)
+    for k in range(2):
+        loss, norm = step(raw, ref)
+        # the global-batch loss is the mean of the two per-rank losses; the clip norm is of the averaged gradient
+        assert abs(float(loss) - 0.5 * (r0["losses"][k][0] + r1["losses"][k][0])) <= 1e-5 * float(loss)
+        assert abs(float(norm) - r0["losses"][k][1]) <= 1e-4 * float(norm)
+    torch.cuda.synchronize()
+    d = float((model.flat_params().flat.cpu() - r0["flat"]).abs().max())
+    assert d <= 1e-4, d                               # Adam's sign-like first steps amplify 1e-5 gradient noise (see the micro-batch test)
