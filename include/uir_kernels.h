@@ -252,7 +252,7 @@ typedef struct UirLnBwdArgs {
   const float* dRes;   /* may be NULL                                                            */
   float* dX; float* slab;
   int ldt, ldx, ldr, ldo;
-  int M, C;            /* C in {16,32,64,128}                                                    */
+  int M, C;            /* C in {16,32,64,128,256,512}                                            */
   int nblocks;
 } UirLnBwdArgs;
 int uir_layernorm_bwd(const UirLnBwdArgs* args, void* stream);
@@ -516,7 +516,7 @@ int uir_radix2_combine(const float* y_re, const float* y_im, float* x_re, float*
  * Q, K, V, O are token rows (the outputs of to_q / to_kv / the input of proj, which are uir_gemm calls).  Backward: dQ, dK, dV rows
  * from dO, plus per-window partials dtable_slab[window][(2 ws - 1)^2 * heads] (same layout as the table) and
  * dw_slab[window * heads + h][2] = gradients w.r.t. (w1, w2); uir_winattn_wgrad maps their sum to the gradient of `w`.
- * C / heads in {16, 32, 64}; ws = 8; H, W multiples of 8. */
+ * C / heads in {8, 16, 32, 64, 128} (walked in chunks of <= 32 channels); ws = 8; H, W multiples of 8. */
 typedef struct UirWinAttnArgs {
   const float* Q; const float* K; const float* V;
   const float* table;      /* relative_position_bias_table [(2 ws - 1)^2][heads] */

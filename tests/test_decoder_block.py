@@ -172,3 +172,33 @@ def test_hip_mdassa_head_dim_32_vs_oracle():
     print("MDASSA(128): worst param grad", worst)
     assert worst[1] < 5e-4
     assert all((p.grad is None) == (n not in g64) for n, p in m.named_parameters())
+
+
+@gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("dim,enc", [(256, True), (32, False), (128, True)], ids=["bottleneck-width 512, head dim 128", "width 32, head dim 8",
+                                                                                  "width 256, head dim 64"])
+def test_hip_decoder_block_every_width_vs_oracle(dim, enc):
+    """The widths of the remaining levels of MyBigFRFNModel (model.py:507-580): decoder_3 works on 512 channels (head dim 128,
+    FRFN 512 -> 4096 -> 512, LayerNorm over 512), decoder_0_1 on 32 (head dim 8).  16 x 16 tokens, vs the fp64 oracle."""
+    from underwater_image_restoration_amd.model.model import DecoderBlock
+    S2, B = 16, 1
+    m = DecoderBlock(dim=dim, input_resolution=(S2, S2), num_heads=4, token_mlp="frfn", enc_out=enc, use_dwt="Fourier")
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.is_floating_point() and ".dwt." not in k and ".idwt." not in k}
+    P = D.closed_form_params(shapes, f"decw{dim}")
+    m.load_state_dict(P, strict=False)
+    m = m.cuda()
+    xs = [R.closed_form_input(B, S2 * S2, dim, 101)] + ([R.closed_form_input(B, S2 * S2, dim, 102)] if enc else [])
+    probe = R.closed_form_input(B, S2 * S2, dim, 103)
+    fn = (lambda a, b, Pp: D.decoder_block(a, b, Pp, 4)) if enc else (lambda a, Pp: D.decoder_block(a, None, Pp, 4))
+    torch.set_num_threads(8)
+    y64, dxs64, g64 = D.grads(fn, [t.double() for t in xs], {k: v.double() for k, v in P.items()}, probe.double())
+    xg = [t.cuda().requires_grad_(True) for t in xs]
+    y = m(*xg)
+    (y * probe.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    e_y = _rel(y, y64)
+    e_dx = max(_rel(t.grad, d) for t, d in zip(xg, dxs64))
+    worst = max(((n, _rel(p.grad, g64[n])) for n, p in m.named_parameters() if p.grad is not None), key=lambda t: t[1])
+    print(f"DecoderBlock({dim}, enc_out={enc}): y {e_y:.2e} dx {e_dx:.2e} worst param grad {worst}")
+    assert e_y < 1e-4 and e_dx < 2e-4 and worst[1] < 1e-3

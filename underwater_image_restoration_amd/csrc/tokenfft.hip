@@ -45,6 +45,48 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ X
   }
 }
 
+// C = 256 / 512 (the deep levels of NewBigFRFNModel): one wave per row, VPL float4 per lane
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_fwd_wide_kernel(const float* __restrict__ X, int ldx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, float* __restrict__ Y, int ldy,
+                                                          float* __restrict__ stats, long M, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float invc = 1.0f / (float)(256 * VPL);
+  float4 g[VPL], b[VPL];
+#pragma unroll
+  for (int v = 0; v < VPL; ++v) {
+    g[v] = *reinterpret_cast<const float4*>(gamma + 4 * (lane + 64 * v));
+    b[v] = *reinterpret_cast<const float4*>(beta + 4 * (lane + 64 * v));
+  }
+  for (long m = (long)blockIdx.x * 4 + wave; m < M; m += (long)gridDim.x * 4) {
+    float4 x[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      x[v] = *reinterpret_cast<const float4*>(X + m * ldx + 4 * (lane + 64 * v));
+      s += (x[v].x + x[v].y) + (x[v].z + x[v].w);
+    }
+    s = uir_wave_sum(s);
+    const float mean = s * invc;
+    float q = 0.f;
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      x[v].x -= mean; x[v].y -= mean; x[v].z -= mean; x[v].w -= mean;
+      q += (x[v].x * x[v].x + x[v].y * x[v].y) + (x[v].z * x[v].z + x[v].w * x[v].w);
+    }
+    q = uir_wave_sum(q);
+    const float rstd = rsqrtf(q * invc + eps);
+#pragma unroll
+    for (int v = 0; v < VPL; ++v) {
+      float4 y;
+      y.x = fmaf(x[v].x * rstd, g[v].x, b[v].x); y.y = fmaf(x[v].y * rstd, g[v].y, b[v].y);
+      y.z = fmaf(x[v].z * rstd, g[v].z, b[v].z); y.w = fmaf(x[v].w * rstd, g[v].w, b[v].w);
+      *reinterpret_cast<float4*>(Y + m * ldy + 4 * (lane + 64 * v)) = y;
+    }
+    if (lane == 0 && stats) *reinterpret_cast<float2*>(stats + 2 * m) = make_float2(mean, rstd);
+  }
+}
+
 // (re, im)[b][p][c] *= (tr, ti)[p]  for p < P tokens, c < C channels (float4 along c)
 __global__ __launch_bounds__(256) void cmul_table_kernel(float* __restrict__ re, float* __restrict__ im, const float* __restrict__ tr,
                                                          const float* __restrict__ ti, long rows, long P, int C4) {
@@ -136,6 +178,8 @@ extern "C" int uir_layernorm_fwd(const float* X, int ldx, const float* gamma, co
     case 32: hipLaunchKernelGGL(ln_fwd_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, gamma, beta, Y, ldy, stats, M, eps); break;
     case 64: hipLaunchKernelGGL(ln_fwd_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, gamma, beta, Y, ldy, stats, M, eps); break;
     case 128: hipLaunchKernelGGL(ln_fwd_kernel<32>, dim3((unsigned)blocks), dim3(256), 0, st, X, ldx, gamma, beta, Y, ldy, stats, M, eps); break;
+    case 256: hipLaunchKernelGGL(ln_fwd_wide_kernel<1>, dim3((unsigned)((M + 3) / 4 > 4096 ? 4096 : (M + 3) / 4)), dim3(256), 0, st, X, ldx, gamma, beta, Y, ldy, stats, M, eps); break;
+    case 512: hipLaunchKernelGGL(ln_fwd_wide_kernel<2>, dim3((unsigned)((M + 3) / 4 > 4096 ? 4096 : (M + 3) / 4)), dim3(256), 0, st, X, ldx, gamma, beta, Y, ldy, stats, M, eps); break;
     default: return UIR_EINVAL;
   }
   return uir_launch_status();

@@ -24,33 +24,60 @@ __device__ __forceinline__ long token_row(const UirWinAttnArgs& a, int win, int 
   return ((long)b * a.H + wy * WS + (t >> 3)) * a.W + wx * WS + (t & 7);
 }
 
-template <int HD>
-__device__ __forceinline__ void stage_rows(const float* __restrict__ base, int ld, int col0, const UirWinAttnArgs& a, int win,
-                                           float (*dst)[HD]) {
-  // 64 lanes x (HD/4) float4 columns: lane = token
+// One channel chunk (CH <= 32 floats of head h, starting at column c0) of the 64 window tokens -> LDS rows, unpadded and 16-byte
+// aligned: the hot loops read them as broadcast ds_read_b128 (every lane the same address); only this one store conflicts.
+template <int CH>
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ base, int ld, int c0, const UirWinAttnArgs& a, int win,
+                                            float (*dst)[CH]) {
   const int t = threadIdx.x;
-  const float* p = base + token_row(a, win, t) * ld + col0;
+  const float* p = base + token_row(a, win, t) * ld + c0;
 #pragma unroll
-  for (int c = 0; c < HD; c += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(p + c);
-    *reinterpret_cast<float4*>(&dst[t][c]) = v;      // rows unpadded and 16-byte aligned: the hot loops read them as broadcast
-                                                     // ds_read_b128 (every lane the same address); only this one-time store conflicts
+  for (int c = 0; c < CH; c += 4) *reinterpret_cast<float4*>(&dst[t][c]) = *reinterpret_cast<const float4*>(p + c);
+}
+
+template <int CH>
+__device__ __forceinline__ void load_chunk(const float* __restrict__ row, float (&v)[CH]) {
+#pragma unroll
+  for (int c = 0; c < CH; c += 4) {
+    const float4 t = *reinterpret_cast<const float4*>(row + c);
+    v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
   }
 }
 
-// scores of query token i against all 64 keys -> p0 (softmax), r (relu^2), and the mixed attention row
-template <int HD>
-__device__ __forceinline__ void score_row(const UirWinAttnArgs& a, int h, int i, const float (&q)[HD], const float (*Ks)[HD],
-                                          float (&s)[NT], float (&p0)[NT]) {
+__device__ __forceinline__ void mix_weights(const float* w, float& w1, float& w2) {
+  const float m = fmaxf(w[0], w[1]);
+  const float e0 = __expf(w[0] - m), e1 = __expf(w[1] - m);
+  w1 = e0 / (e0 + e1);
+  w2 = e1 / (e0 + e1);
+}
+
+// scores of query token i against the 64 keys of its window: s = (q . k) scale + bias; p0 = softmax(s).  The head dimension is
+// walked in chunks of CH channels (K chunk staged in LDS, the lane's q chunk in registers): any head dim from 8 to 128.
+template <int HD, int CH>
+__device__ __forceinline__ void score_row(const UirWinAttnArgs& a, int win, int h, int i, long row, float (*T)[CH], float (&s)[NT],
+                                          float (&p0)[NT]) {
+#pragma unroll
+  for (int j = 0; j < NT; ++j) s[j] = 0.f;
+  for (int c0 = 0; c0 < HD; c0 += CH) {
+    stage_chunk<CH>(a.K, a.ldk, h * HD + c0, a, win, T);
+    float q[CH];
+    load_chunk<CH>(a.Q + row * a.ldq + h * HD + c0, q);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float d = s[j];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) d = fmaf(q[c], T[j][c], d);
+      s[j] = d;
+    }
+    __syncthreads();
+  }
   const int yi = i >> 3, xi = i & 7;
   float mx = -__builtin_huge_valf();
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    float d = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD; ++c) d = fmaf(q[c], Ks[j][c], d);
     const int idx = (yi - (j >> 3) + WS - 1) * RP + (xi - (j & 7) + WS - 1);
-    s[j] = fmaf(d, a.scale, a.table[idx * a.heads + h]);
+    s[j] = fmaf(s[j], a.scale, a.table[idx * a.heads + h]);
     mx = fmaxf(mx, s[j]);
   }
   float sum = 0.f;
@@ -64,99 +91,84 @@ __device__ __forceinline__ void score_row(const UirWinAttnArgs& a, int h, int i,
   for (int j = 0; j < NT; ++j) p0[j] *= inv;
 }
 
-__device__ __forceinline__ void mix_weights(const float* w, float& w1, float& w2) {
-  const float m = fmaxf(w[0], w[1]);
-  const float e0 = __expf(w[0] - m), e1 = __expf(w[1] - m);
-  w1 = e0 / (e0 + e1);
-  w2 = e1 / (e0 + e1);
-}
-
 template <int HD>
 __global__ __launch_bounds__(64) void winattn_fwd_kernel(const UirWinAttnArgs a) {
-  __shared__ __align__(16) float Ks[NT][HD], Vs[NT][HD];
-  const int win = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c0 = h * HD;
-  stage_rows<HD>(a.K, a.ldk, c0, a, win, Ks);
-  stage_rows<HD>(a.V, a.ldv, c0, a, win, Vs);
+  constexpr int CH = HD < 32 ? HD : 32;
+  __shared__ __align__(16) float T[NT][CH];
+  const int win = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
   const long row = token_row(a, win, i);
-  float q[HD];
-#pragma unroll
-  for (int c = 0; c < HD; c += 4) {
-    const float4 v = *reinterpret_cast<const float4*>(a.Q + row * a.ldq + c0 + c);
-    q[c] = v.x; q[c + 1] = v.y; q[c + 2] = v.z; q[c + 3] = v.w;
-  }
-  __syncthreads();
   float s[NT], p0[NT];
-  score_row<HD>(a, h, i, q, Ks, s, p0);
+  score_row<HD, CH>(a, win, h, i, row, T, s, p0);
   float w1, w2;
   mix_weights(a.w, w1, w2);
-  float o[HD];
-#pragma unroll
-  for (int c = 0; c < HD; ++c) o[c] = 0.f;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const float r = fmaxf(s[j], 0.f);
-    const float p = fmaf(w1, p0[j], w2 * r * r);
-#pragma unroll
-    for (int c = 0; c < HD; ++c) o[c] = fmaf(p, Vs[j][c], o[c]);
+    p0[j] = fmaf(w1, p0[j], w2 * r * r);            // the mixed attention row
   }
+  for (int c0 = 0; c0 < HD; c0 += CH) {
+    stage_chunk<CH>(a.V, a.ldv, h * HD + c0, a, win, T);
+    __syncthreads();
+    float o[CH];
 #pragma unroll
-  for (int c = 0; c < HD; c += 4)
-    *reinterpret_cast<float4*>(a.O + row * a.ldo + c0 + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+    for (int c = 0; c < CH; ++c) o[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) o[c] = fmaf(p0[j], T[j][c], o[c]);
+#pragma unroll
+    for (int c = 0; c < CH; c += 4)
+      *reinterpret_cast<float4*>(a.O + row * a.ldo + h * HD + c0 + c) = make_float4(o[c], o[c + 1], o[c + 2], o[c + 3]);
+    __syncthreads();
+  }
 }
 
 template <int HD>
 __global__ __launch_bounds__(64) void winattn_bwd_kernel(const UirWinAttnArgs a) {
-  extern __shared__ __align__(16) float smem[];
-  float (*Ks)[HD] = reinterpret_cast<float (*)[HD]>(smem);
-  float (*Vs)[HD] = Ks + NT;
-  float (*Qs)[HD] = Vs + NT;
-  float (*Gs)[HD] = Qs + NT;                                       // dO
-  float (*Pm)[NT + 1] = reinterpret_cast<float (*)[NT + 1]>(smem + 4 * NT * HD);
-  float (*Dm)[NT + 1] = Pm + NT;                                   // dS
-  const int win = blockIdx.x, h = blockIdx.y, i = threadIdx.x, c0 = h * HD;
-  stage_rows<HD>(a.K, a.ldk, c0, a, win, Ks);
-  stage_rows<HD>(a.V, a.ldv, c0, a, win, Vs);
-  stage_rows<HD>(a.Q, a.ldq, c0, a, win, Qs);
-  stage_rows<HD>(a.dO, a.ldo, c0, a, win, Gs);
-  __syncthreads();
+  constexpr int CH = HD < 32 ? HD : 32;
+  __shared__ __align__(16) float T[NT][CH];
+  __shared__ __align__(16) float T2[NT][CH];
+  __shared__ float Pm[NT][NT + 1], Dm[NT][NT + 1];                // P and dS, row = query token
+  const int win = blockIdx.x, h = blockIdx.y, i = threadIdx.x;
   const long row = token_row(a, win, i);
-  float q[HD], g[HD];
-#pragma unroll
-  for (int c = 0; c < HD; ++c) { q[c] = Qs[i][c]; g[c] = Gs[i][c]; }
   float s[NT], p0[NT];
-  score_row<HD>(a, h, i, q, Ks, s, p0);
+  score_row<HD, CH>(a, win, h, i, row, T, s, p0);
   float w1, w2;
   mix_weights(a.w, w1, w2);
-  // dP_j = dO_i . v_j ; the three row sums
+  // dP_j = dO_i . v_j
   float dp[NT];
-  float sp = 0.f, dw1 = 0.f, dw2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < NT; ++j) dp[j] = 0.f;
+  for (int c0 = 0; c0 < HD; c0 += CH) {
+    stage_chunk<CH>(a.V, a.ldv, h * HD + c0, a, win, T);
+    float g[CH];
+    load_chunk<CH>(a.dO + row * a.ldo + h * HD + c0, g);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      float d = dp[j];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) d = fmaf(g[c], T[j][c], d);
+      dp[j] = d;
+    }
+    __syncthreads();
+  }
+  float sp = 0.f, dw2 = 0.f;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
-    float d = 0.f;
-#pragma unroll
-    for (int c = 0; c < HD; ++c) d = fmaf(g[c], Vs[j][c], d);
-    dp[j] = d;
     const float r = fmaxf(s[j], 0.f);
-    sp = fmaf(d, p0[j], sp);
-    dw2 = fmaf(d, r * r, dw2);
+    sp = fmaf(dp[j], p0[j], sp);
+    dw2 = fmaf(dp[j], r * r, dw2);
   }
-  dw1 = sp;
-  float dq[HD];
-#pragma unroll
-  for (int c = 0; c < HD; ++c) dq[c] = 0.f;
+  float dw1 = sp;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const float r = fmaxf(s[j], 0.f);
     const float ds = fmaf(w1 * p0[j], dp[j] - sp, w2 * dp[j] * 2.f * r);   // softmax backward + relu^2 backward
     Pm[i][j] = fmaf(w1, p0[j], w2 * r * r);
     Dm[i][j] = ds;
-#pragma unroll
-    for (int c = 0; c < HD; ++c) dq[c] = fmaf(ds, Ks[j][c], dq[c]);
+    dp[j] = ds;                                                             // keep dS_i in registers for dQ
   }
-#pragma unroll
-  for (int c = 0; c < HD; c += 4)
-    *reinterpret_cast<float4*>(a.dQ + row * a.lddq + c0 + c) =
-        make_float4(dq[c] * a.scale, dq[c + 1] * a.scale, dq[c + 2] * a.scale, dq[c + 3] * a.scale);
   // mixing-weight partials: sum over the 64 query rows of this (window, head)
   dw1 = uir_wave_sum(dw1);
   dw2 = uir_wave_sum(dw2);
@@ -165,25 +177,47 @@ __global__ __launch_bounds__(64) void winattn_bwd_kernel(const UirWinAttnArgs a)
     o[0] = dw1;
     o[1] = dw2;
   }
-  __syncthreads();
-  // lane j: dK_j = scale * sum_i dS[i][j] q_i ;  dV_j = sum_i P[i][j] dO_i
-  float dk[HD], dv[HD];
+  // dQ_i = scale * sum_j dS_ij k_j
+  for (int c0 = 0; c0 < HD; c0 += CH) {
+    stage_chunk<CH>(a.K, a.ldk, h * HD + c0, a, win, T);
+    __syncthreads();
+    float dq[CH];
 #pragma unroll
-  for (int c = 0; c < HD; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
-#pragma unroll 4
-  for (int r = 0; r < NT; ++r) {
-    const float ds = Dm[r][i], p = Pm[r][i];
+    for (int c = 0; c < CH; ++c) dq[c] = 0.f;
 #pragma unroll
-    for (int c = 0; c < HD; ++c) {
-      dk[c] = fmaf(ds, Qs[r][c], dk[c]);
-      dv[c] = fmaf(p, Gs[r][c], dv[c]);
-    }
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int c = 0; c < CH; ++c) dq[c] = fmaf(dp[j], T[j][c], dq[c]);
+#pragma unroll
+    for (int c = 0; c < CH; c += 4)
+      *reinterpret_cast<float4*>(a.dQ + row * a.lddq + h * HD + c0 + c) =
+          make_float4(dq[c] * a.scale, dq[c + 1] * a.scale, dq[c + 2] * a.scale, dq[c + 3] * a.scale);
+    __syncthreads();
   }
+  // lane j: dK_j = scale * sum_i dS[i][j] q_i ;  dV_j = sum_i P[i][j] dO_i   (Pm / Dm were completed before the barriers above)
+  for (int c0 = 0; c0 < HD; c0 += CH) {
+    stage_chunk<CH>(a.Q, a.ldq, h * HD + c0, a, win, T);
+    stage_chunk<CH>(a.dO, a.ldo, h * HD + c0, a, win, T2);
+    __syncthreads();
+    float dk[CH], dv[CH];
 #pragma unroll
-  for (int c = 0; c < HD; c += 4) {
-    *reinterpret_cast<float4*>(a.dK + row * a.lddk + c0 + c) =
-        make_float4(dk[c] * a.scale, dk[c + 1] * a.scale, dk[c + 2] * a.scale, dk[c + 3] * a.scale);
-    *reinterpret_cast<float4*>(a.dV + row * a.lddv + c0 + c) = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+    for (int c = 0; c < CH; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+#pragma unroll 4
+    for (int r = 0; r < NT; ++r) {
+      const float ds = Dm[r][i], p = Pm[r][i];
+#pragma unroll
+      for (int c = 0; c < CH; ++c) {
+        dk[c] = fmaf(ds, T[r][c], dk[c]);
+        dv[c] = fmaf(p, T2[r][c], dv[c]);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < CH; c += 4) {
+      *reinterpret_cast<float4*>(a.dK + row * a.lddk + h * HD + c0 + c) =
+          make_float4(dk[c] * a.scale, dk[c + 1] * a.scale, dk[c + 2] * a.scale, dk[c + 3] * a.scale);
+      *reinterpret_cast<float4*>(a.dV + row * a.lddv + h * HD + c0 + c) = make_float4(dv[c], dv[c + 1], dv[c + 2], dv[c + 3]);
+    }
+    __syncthreads();
   }
   // relative-position-bias table: entry t = (dy + 7) * 15 + (dx + 7) collects dS[i][j] over the pairs with that offset
   float* tb = a.dtable_slab + (long)win * (RP * RP * a.heads);
@@ -212,7 +246,7 @@ int check(const UirWinAttnArgs& a, bool bwd) {
   UIR_REQUIRE(a.Q && a.K && a.V && a.table && a.w && a.B > 0 && a.heads > 0 && a.C > 0 && a.C % a.heads == 0);
   UIR_REQUIRE(a.ws == WS && a.H % WS == 0 && a.W % WS == 0);
   const int hd = a.C / a.heads;
-  UIR_REQUIRE(hd == 16 || hd == 32 || hd == 64);
+  UIR_REQUIRE(hd == 8 || hd == 16 || hd == 32 || hd == 64 || hd == 128);
   UIR_REQUIRE(a.ldq >= a.C && a.ldk >= a.C && a.ldv >= a.C && ((a.ldq | a.ldk | a.ldv) & 3) == 0);
   UIR_REQUIRE(uir_aligned16(a.Q) && uir_aligned16(a.K) && uir_aligned16(a.V));
   if (!bwd) UIR_REQUIRE(a.O && a.ldo >= a.C && (a.ldo & 3) == 0 && uir_aligned16(a.O));
@@ -232,9 +266,11 @@ extern "C" int uir_winattn_fwd(const UirWinAttnArgs* p, void* stream) {
   const dim3 grid(a.B * (a.H / WS) * (a.W / WS), a.heads);
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (a.C / a.heads) {
+    case 8: hipLaunchKernelGGL(winattn_fwd_kernel<8>, grid, dim3(64), 0, st, a); break;
     case 16: hipLaunchKernelGGL(winattn_fwd_kernel<16>, grid, dim3(64), 0, st, a); break;
     case 32: hipLaunchKernelGGL(winattn_fwd_kernel<32>, grid, dim3(64), 0, st, a); break;
-    default: hipLaunchKernelGGL(winattn_fwd_kernel<64>, grid, dim3(64), 0, st, a); break;
+    case 64: hipLaunchKernelGGL(winattn_fwd_kernel<64>, grid, dim3(64), 0, st, a); break;
+    default: hipLaunchKernelGGL(winattn_fwd_kernel<128>, grid, dim3(64), 0, st, a); break;
   }
   return uir_launch_status();
 }
@@ -244,22 +280,13 @@ extern "C" int uir_winattn_bwd(const UirWinAttnArgs* p, void* stream) {
   if (int rc = check(a, true)) return rc;
   const dim3 grid(a.B * (a.H / WS) * (a.W / WS), a.heads);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int hd = a.C / a.heads;
-  const size_t lds = ((size_t)4 * NT * hd + (size_t)2 * NT * (NT + 1)) * sizeof(float);
-  // 51 / 67 / 100 KB of LDS per 64-lane workgroup: above the 64 KB default for head dims 32 and 64
-#define UIR_WA_BWD(HDV)                                                                                                     \
-  do {                                                                                                                      \
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(winattn_bwd_kernel<HDV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                            (int)lds) != hipSuccess)                                                                        \
-      return UIR_ELAUNCH;                                                                                                   \
-    hipLaunchKernelGGL(winattn_bwd_kernel<HDV>, grid, dim3(64), lds, st, a);                                                \
-  } while (0)
-  switch (hd) {
-    case 16: UIR_WA_BWD(16); break;
-    case 32: UIR_WA_BWD(32); break;
-    default: UIR_WA_BWD(64); break;
+  switch (a.C / a.heads) {            // 16 KB of chunk tiles + 33 KB for P and dS: under the 64 KB static limit for every head dim
+    case 8: hipLaunchKernelGGL(winattn_bwd_kernel<8>, grid, dim3(64), 0, st, a); break;
+    case 16: hipLaunchKernelGGL(winattn_bwd_kernel<16>, grid, dim3(64), 0, st, a); break;
+    case 32: hipLaunchKernelGGL(winattn_bwd_kernel<32>, grid, dim3(64), 0, st, a); break;
+    case 64: hipLaunchKernelGGL(winattn_bwd_kernel<64>, grid, dim3(64), 0, st, a); break;
+    default: hipLaunchKernelGGL(winattn_bwd_kernel<128>, grid, dim3(64), 0, st, a); break;
   }
-#undef UIR_WA_BWD
   return uir_launch_status();
 }
 

@@ -718,8 +718,8 @@ class MDASSA(TokenModule):
                 or use_dwt != "Fourier" or norm_layer is not nn.LayerNorm or act_layer is not nn.GELU:
             raise NotImplementedError("the HIP MDASSA is built for MyBigFRFNModel's configuration: win_size 8, shift_size 0, linear "
                                       "projection with bias, no dropout / DropPath, use_dwt='Fourier'")
-        if dim % num_heads or dim // num_heads not in (16, 32, 64) or dim not in (32, 64, 128):
-            raise NotImplementedError("dim in {32, 64, 128} with head dims 16 / 32 / 64 this round")
+        if dim % num_heads or dim // num_heads not in (8, 16, 32, 64, 128) or dim not in (32, 64, 128, 256, 512):
+            raise NotImplementedError("dim in {32, 64, 128, 256, 512} with head dims 8 ... 128 (every level of MyBigFRFNModel)")
         self.dim, self.win_size, self.shift_size, self.num_heads = dim, win_size, shift_size, num_heads
         self.norm1 = norm_layer(dim)
         self.norm_q = norm_layer(dim)

@@ -161,8 +161,8 @@ class EncoderBlock(TokenModule):
         if use_dwt != "Fourier" or drop_path > 0.0 or norm_layer is not nn.LayerNorm or act_layer is not nn.GELU:
             raise NotImplementedError("the HIP EncoderBlock is built for use_dwt='Fourier', drop_path=0, LayerNorm, GELU "
                                       "(encoder_0 / encoder_0_1 of MyBigFRFNModel, model.py:481-489)")
-        if dim not in (32, 64, 128):
-            raise NotImplementedError("dim in {32, 64, 128} this round (the LayerNorm kernels' channel counts)")
+        if dim not in (32, 64, 128, 256, 512):
+            raise NotImplementedError("dim in {32, 64, 128, 256, 512} (the LayerNorm kernels' channel counts)")
         self.dim = dim
         self.input_resolution = input_resolution
         self.num_heads = num_heads
