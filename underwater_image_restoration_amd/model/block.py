@@ -83,6 +83,22 @@ def _gate(rec, name, hid, U, bias, V, G=None, dG=None, dU=None, dV=None, dbias=N
                 _colsum_wide(rec, name + ".db", dU, hid, dbias)
 
 
+_DW_MAX = 1024       # channels per depthwise launch: the kernels keep the 9-tap weights of their channels in LDS (<= 64 KB)
+
+
+def _dwconv_wide(rec, name, X, Wt, Y, C_, dims):
+    for c0 in range(0, C_, _DW_MAX):
+        n = min(_DW_MAX, C_ - c0)
+        rec.dwconv(f"{name}[{c0}]" if C_ > _DW_MAX else name, X[:, c0:c0 + n], Wt[c0:c0 + n], Y[:, c0:c0 + n], C_=n, dims=dims)
+
+
+def _dwconv_bwd_wide(rec, name, dY, X, Wt, dX, dW, C_, dims):
+    for c0 in range(0, C_, _DW_MAX):
+        n = min(_DW_MAX, C_ - c0)
+        rec.dwconv_bwd(f"{name}[{c0}]" if C_ > _DW_MAX else name, dY[:, c0:c0 + n], X[:, c0:c0 + n], Wt[c0:c0 + n], dX[:, c0:c0 + n],
+                       dW[c0:c0 + n], C_=n, creal=n, dims=dims)
+
+
 def _colsum_wide(rec, name, src, cols, out):
     """Bias gradient over `cols` columns: uir_colsum_partials handles <= 256 columns per launch."""
     for c0 in range(0, cols, 256):
@@ -108,7 +124,7 @@ def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     rec.gemm(n + "pc3", x[:, :c4], Wpc, xc[:, :c4], N=c4, K=c4, w_sn=c4 * 9, w_sk=9, w_st=1, taps=9, hw=(H, W))
     # Linear + bias + GELU in one pass: the GEMM epilogue stores the pre-activation (for the backward) and GELU of it
     rec.gemm(n + "linear1+gelu", xc, W1, t, N=2 * hid, K=C_, w_sn=C_, w_sk=1, bias=b1, act=L.ACT_GELU, pre_out=pre)
-    rec.dwconv(n + "dwconv", t[:, :hid], Wdw, u, C_=hid, dims=dims)
+    _dwconv_wide(rec, n + "dwconv", t[:, :hid], Wdw, u, hid, dims)
     _gate(rec, n + "dwconv.gelu*x2", hid, u, bdw, t[:, hid:], G=g)
     rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
 
@@ -121,7 +137,7 @@ def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
             _colsum_wide(rec, n + "linear2.db", dy, C_, Gr("linear2.0.bias"))
         rec.gemm(n + "linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
         _gate(rec, n + "gate.bwd", hid, u, bdw, t[:, hid:], dG=dg, dU=du, dV=dt[:, hid:], dbias=Gr("dwconv.0.bias"))
-        rec.dwconv_bwd(n + "dwconv.bwd", du, t[:, :hid], Wdw, dt[:, :hid], Gr("dwconv.0.weight"), C_=hid, creal=hid, dims=dims)
+        _dwconv_bwd_wide(rec, n + "dwconv.bwd", du, t[:, :hid], Wdw, dt[:, :hid], Gr("dwconv.0.weight"), hid, dims)
         _act(rec, n + "linear1.gelu.bwd", pre, None, 2 * hid, bwd_dt=dt, dpre=dpre, dbias=Gr("linear1.0.bias"))
         with rec.bulk():
             rec.gram(n + "linear1.dW", dpre, xc, Gr("linear1.0.weight"), N=2 * hid, K=C_, o_sn=C_, o_sk=1)
@@ -146,7 +162,7 @@ def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     pre, t, u, g, y = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
     n = pfx
     rec.gemm(n + "linear1+gelu", x, W1, t, N=hid, K=C_, w_sn=C_, w_sk=1, bias=b1, act=L.ACT_GELU, pre_out=pre)
-    rec.dwconv(n + "dwconv", t, Wdw, u, C_=hid, dims=dims)
+    _dwconv_wide(rec, n + "dwconv", t, Wdw, u, hid, dims)
     _gate(rec, n + "dwconv.gelu", hid, u, bdw, None, G=g)
     rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
 
@@ -157,7 +173,7 @@ def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
             _colsum_wide(rec, n + "linear2.db", dy, C_, Gr("linear2.0.bias"))
         rec.gemm(n + "linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
         _gate(rec, n + "dwconv.gelu.bwd", hid, u, bdw, None, dG=dg, dU=du, dbias=Gr("dwconv.0.bias"))
-        rec.dwconv_bwd(n + "dwconv.bwd", du, t, Wdw, dt, Gr("dwconv.0.weight"), C_=hid, creal=hid, dims=dims)
+        _dwconv_bwd_wide(rec, n + "dwconv.bwd", du, t, Wdw, dt, Gr("dwconv.0.weight"), hid, dims)
         _act(rec, n + "linear1.gelu.bwd", pre, None, hid, bwd_dt=dt, dpre=dpre, dbias=Gr("linear1.0.bias"))
         with rec.bulk():
             rec.gram(n + "linear1.dW", dpre, x, Gr("linear1.0.weight"), N=hid, K=C_, o_sn=C_, o_sk=1)
