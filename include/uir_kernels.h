@@ -470,6 +470,8 @@ int uir_frfn_act_fwd(const float* pre, int ldp, float* t, int ldt, long M, int c
  * uses exactly nblocks workgroups; needs 256 % (cols/4) == 0.  Summed by uir_reduce_slab(_batch). */
 int uir_frfn_act_bwd(const float* pre, int ldp, const float* dt, int ldt, float* dpre, int ldo, long M, int cols, float* db_slab,
                      int nblocks, void* stream);
+/* dz = dy * (y > 0 ? 1 : slope): backward of LeakyReLU from its output (InputProjection's nn.LeakyReLU(inplace=True), block.py:50) */
+int uir_leaky_bwd(const float* y, int ldy, const float* dy, int lddy, float* dz, int lddz, long M, int cols, float slope, void* stream);
 typedef struct UirFrfnGateArgs {
   const float* U;      /* depthwise-conv output without bias [M][ldu] */
   const float* bias;   /* [hid] */

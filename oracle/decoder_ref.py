@@ -123,3 +123,40 @@ def grads(fn, inputs: "list[torch.Tensor]", P: Params, probe: torch.Tensor):
     y = fn(*xs, leaves)
     (y * probe).sum().backward()
     return y.detach(), [t.grad for t in xs], {n: v.grad for n, v in leaves.items() if v.is_floating_point() and v.grad is not None}
+
+
+# ---- samplers and projections (src/model/block.py:42-153) ----
+def _img(t: torch.Tensor) -> torch.Tensor:
+    B, Ltok, C = t.shape
+    H = int(round(Ltok ** 0.5))
+    return t.transpose(1, 2).reshape(B, C, H, H)
+
+
+def _tok(img: torch.Tensor) -> torch.Tensor:
+    return img.flatten(2).transpose(1, 2)
+
+
+def downsample(x: torch.Tensor, P: Params, pfx: str = "") -> torch.Tensor:
+    """Downsample.forward (:113-122): conv3x3 C -> C/2 (no bias), PixelUnshuffle(2)."""
+    return _tok(F.pixel_unshuffle(F.conv2d(_img(x), P[pfx + "body.0.weight"], padding=1), 2))
+
+
+def upsample(x: torch.Tensor, P: Params, pfx: str = "") -> torch.Tensor:
+    """Upsample.forward (:144-153): conv3x3 C -> 2C (no bias), PixelShuffle(2)."""
+    return _tok(F.pixel_shuffle(F.conv2d(_img(x), P[pfx + "body.0.weight"], padding=1), 2))
+
+
+def input_projection(img: torch.Tensor, P: Params, pfx: str = "") -> torch.Tensor:
+    """InputProjection.forward (:58-63): conv 3->8, 8->32, 32->C (3x3, bias), LeakyReLU(0.01); NCHW -> tokens."""
+    v = img
+    for i in range(3):
+        v = F.conv2d(v, P[f"{pfx}proj.{i}.weight"], P[f"{pfx}proj.{i}.bias"], padding=1)
+    return _tok(F.leaky_relu(v, 0.01))
+
+
+def output_projection(x: torch.Tensor, P: Params, pfx: str = "") -> torch.Tensor:
+    """OutputProjection.forward (:84-91) on the token image reshaped as model.py:435-437 does: tokens -> NCHW [B, 3, H, W]."""
+    v = _img(x)
+    for i in range(3):
+        v = F.conv2d(v, P[f"{pfx}proj.{i}.weight"], P[f"{pfx}proj.{i}.bias"], padding=1)
+    return v

@@ -49,7 +49,7 @@ for name, mod in (("timm", timm), ("timm.layers", layers), ("pywt", pywt), ("tor
                   ("torchvision.transforms.functional", tvf)):
     sys.modules.setdefault(name, mod)
 
-from src.model.block import MDASSA  # noqa: E402
+from src.model.block import MDASSA, Downsample, Upsample, InputProjection, OutputProjection  # noqa: E402
 from src.model.model import DecoderBlock  # noqa: E402
 from oracle import decoder_ref as D, frfn_ref as R  # noqa: E402
 
@@ -95,5 +95,24 @@ record("dec_d32_enc", DecoderBlock(dim=32, input_resolution=(S, S), num_heads=4,
 record("dec_d64_noenc", DecoderBlock(dim=64, input_resolution=(S, S), num_heads=4, win_size=8, shift_size=0, mlp_ratio=4, token_mlp="frfn",
                                      drop_path=0.0, token_projection="linear", enc_out=False, freq_attn_win_ratio=2, use_dwt="Fourier"),
        [x64], pr64, "dec64")
+# samplers and projections (block.py:42-153).  OutputProjection takes NCHW in the reference: it is fed the token image reshaped
+# as model.py:435-437 does (tokens -> (B, C, H, W)); the recorded input gradient is w.r.t. the tokens.
+record("down_c32", Downsample(32, 64), [x32], R.closed_form_input(1, (S // 2) ** 2, 64, 76), "down32")
+record("up_c64", Upsample(64, 32), [R.closed_form_input(1, (S // 2) ** 2, 64, 77)], R.closed_form_input(1, S * S, 32, 78), "up64")
+img = R.closed_form_input(1, 3, S * S, 79).reshape(1, 3, S, S)
+record("inproj_c32", InputProjection(in_channels=3, out_channels=32), [img], pr32, "inproj32")
+
+
+class _OutOnTokens(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.inner = OutputProjection(in_channels=32, out_channel=3, kernel_size=3, stride=1, norm_layer=None, act_layer=None)
+
+    def forward(self, t):
+        B, Ltok, C = t.shape
+        return self.inner(t.transpose(1, 2).reshape(B, C, S, S))
+
+
+record("outproj_c32", _OutOnTokens(), [x32], R.closed_form_input(1, 3, S * S, 80).reshape(1, 3, S, S), "outproj32")
 np.savez_compressed(os.path.join(HERE, "decoder_ref.npz"), **out)
 print("wrote decoder_ref.npz", os.path.getsize(os.path.join(HERE, "decoder_ref.npz")) // 1024, "KB")

@@ -202,3 +202,55 @@ def test_hip_decoder_block_every_width_vs_oracle(dim, enc):
     worst = max(((n, _rel(p.grad, g64[n])) for n, p in m.named_parameters() if p.grad is not None), key=lambda t: t[1])
     print(f"DecoderBlock({dim}, enc_out={enc}): y {e_y:.2e} dx {e_dx:.2e} worst param grad {worst}")
     assert e_y < 1e-4 and e_dx < 2e-4 and worst[1] < 1e-3
+
+
+# ---------------------------------------------------------------- samplers and projections (block.py:42-153)
+SMALL = {"down_c32": "down32", "up_c64": "up64", "inproj_c32": "inproj32", "outproj_c32": "outproj32"}
+
+
+def _small_setup(tag, g):
+    from underwater_image_restoration_amd.model import block as Bk
+    strip = "inner." if tag == "outproj_c32" else ""
+    P = {k[len(strip):]: v for k, v in _params(g, tag, SMALL[tag]).items()}
+    if tag == "down_c32":
+        return Bk.Downsample(32, 64), P, [R.closed_form_input(1, S * S, 32, 73)], R.closed_form_input(1, (S // 2) ** 2, 64, 76), D.downsample
+    if tag == "up_c64":
+        return Bk.Upsample(64, 32), P, [R.closed_form_input(1, (S // 2) ** 2, 64, 77)], R.closed_form_input(1, S * S, 32, 78), D.upsample
+    if tag == "inproj_c32":
+        return (Bk.InputProjection(3, 32), P, [R.closed_form_input(1, 3, S * S, 79).reshape(1, 3, S, S)], R.closed_form_input(1, S * S, 32, 75),
+                D.input_projection)
+    return (Bk.OutputProjection(32, 3), P, [R.closed_form_input(1, S * S, 32, 73)], R.closed_form_input(1, 3, S * S, 80).reshape(1, 3, S, S),
+            D.output_projection)
+
+
+@pytest.mark.parametrize("tag", list(SMALL))
+def test_oracle_matches_reference_samplers_projections(tag):
+    g = np.load(GOLDEN)
+    m, P, xs, probe, fn = _small_setup(tag, g)
+    strip = "inner." if tag == "outproj_c32" else ""
+    assert list(m.state_dict().keys()) == [k[len(strip):] for k in g[tag + ".keys"]]
+    y, dxs, grads = D.grads(lambda t, Pp: fn(t, Pp), [t.double() for t in xs], {k: v.double() for k, v in P.items()}, probe.double())
+    assert _rel(y, g[tag + ".y"]) < 1e-6 and _rel(dxs[0], g[tag + ".dx0"]) < 1e-6
+    for n, gw in grads.items():
+        assert _rel(gw, g[tag + ".grad." + strip + n]) < 1e-6, n
+
+
+@gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+@pytest.mark.parametrize("tag", list(SMALL))
+def test_hip_samplers_projections_match_reference(tag):
+    g = np.load(GOLDEN)
+    m, P, xs, probe, _ = _small_setup(tag, g)
+    strip = "inner." if tag == "outproj_c32" else ""
+    m.load_state_dict(P)
+    m = m.cuda()
+    xg = xs[0].cuda().requires_grad_(tag != "inproj_c32")
+    y = m(xg)
+    assert tuple(y.shape) == g[tag + ".y"].shape
+    (y * probe.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert _rel(y, g[tag + ".y"]) < 2e-5
+    if tag != "inproj_c32":
+        assert _rel(xg.grad, g[tag + ".dx0"]) < 5e-5
+    for n, p in m.named_parameters():
+        assert _rel(p.grad, g[tag + ".grad." + strip + n]) < 2e-4, n

@@ -221,6 +221,7 @@ SIGNATURES = {
     "uir_ssim_partials": [C.POINTER(SsimArgs), fp],
     "uir_frfn_act_fwd": [fp, i32, fp, i32, i64, i32, fp],
     "uir_frfn_act_bwd": [fp, i32, fp, i32, fp, i32, i64, i32, fp, i32, fp],
+    "uir_leaky_bwd": [fp, i32, fp, i32, fp, i32, i64, i32, f32, fp],
     "uir_frfn_gate_fwd": [C.POINTER(FrfnGateArgs), fp],
     "uir_frfn_gate_bwd": [C.POINTER(FrfnGateArgs), fp],
     "uir_layernorm_fwd": [fp, i32, fp, fp, fp, i32, fp, i64, i32, f32, fp],

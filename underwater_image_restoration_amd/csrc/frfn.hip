@@ -100,6 +100,20 @@ __global__ __launch_bounds__(256) void frfn_gate_bwd_kernel(const UirFrfnGateArg
   if (a.db_slab) frfn_col_partials(acc, cols4, a.db_slab);
 }
 
+// dz = dy * (y > 0 ? 1 : slope): backward of an in-place LeakyReLU given its OUTPUT (InputProjection, block.py:50)
+__global__ __launch_bounds__(256) void leaky_bwd_kernel(const float* __restrict__ y, int ldy, const float* __restrict__ dy, int lddy,
+                                                        float* __restrict__ dz, int lddz, long M, int cols4, float slope) {
+  const long total = M * cols4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / cols4;
+    const int c = (int)(e - m * cols4) * 4;
+    const float4 v = *reinterpret_cast<const float4*>(y + m * ldy + c);
+    const float4 d = *reinterpret_cast<const float4*>(dy + m * lddy + c);
+    *reinterpret_cast<float4*>(dz + m * lddz + c) =
+        make_float4(v.x > 0.f ? d.x : d.x * slope, v.y > 0.f ? d.y : d.y * slope, v.z > 0.f ? d.z : d.z * slope, v.w > 0.f ? d.w : d.w * slope);
+  }
+}
+
 inline unsigned grid_for(long total, int cap = 8192) {
   long g = (total + 255) / 256;
   return (unsigned)(g > cap ? cap : (g < 1 ? 1 : g));
@@ -152,5 +166,14 @@ extern "C" int uir_frfn_gate_bwd(const UirFrfnGateArgs* p, void* stream) {
   if (int rc = frfn_gate_check(a, true)) return rc;
   const unsigned g = a.db_slab ? (unsigned)a.db_blocks : grid_for(a.M * (a.hid / 4));
   hipLaunchKernelGGL(frfn_gate_bwd_kernel, dim3(g), dim3(256), 0, static_cast<hipStream_t>(stream), a);
+  return uir_launch_status();
+}
+
+extern "C" int uir_leaky_bwd(const float* y, int ldy, const float* dy, int lddy, float* dz, int lddz, long M, int cols, float slope,
+                             void* stream) {
+  UIR_REQUIRE(y && dy && dz && M > 0 && cols > 0 && (cols & 3) == 0 && ldy >= cols && lddy >= cols && lddz >= cols);
+  UIR_REQUIRE(((ldy | lddy | lddz) & 3) == 0 && uir_aligned16(y) && uir_aligned16(dy) && uir_aligned16(dz));
+  hipLaunchKernelGGL(leaky_bwd_kernel, dim3(grid_for(M * (cols / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), y, ldy, dy, lddy, dz,
+                     lddz, M, cols / 4, slope);
   return uir_launch_status();
 }

@@ -439,23 +439,23 @@ def record_decoder_block(rec: Recorder, pfx: str, xcat: torch.Tensor, dim: int, 
 
 
 class TokenPlan(Recorder):
-    """A launch plan over token rows [B*H*W, dim]: input buffer -> recorded forward -> output buffer, and the recorded backward.
-    Subclasses provide ``_record(x) -> (y, backward)``."""
+    """A launch plan: input buffer -> recorded forward -> output buffer, and the recorded backward.  By default input and output
+    are token rows [B*H*W, dim]; ``in_shape`` (e.g. an NCHW image) and the shape of what ``_record`` returns may differ
+    (down- / up-samplers, projections).  Subclasses provide ``_record(x_in) -> (y, backward)``."""
 
-    def __init__(self, fp: FlatParams, dim: int, B: int, H: int, W: int, want_backward: bool = True, out_dim: "int | None" = None):
+    def __init__(self, fp: FlatParams, dim: int, B: int, H: int, W: int, want_backward: bool = True, out_dim: "int | None" = None,
+                 in_shape: "tuple | None" = None):
         super().__init__(fp.device, fp, scratch_floats=8 * 1024 * 1024)
         self.dim, self.B, self.H, self.W = dim, B, H, W
-        self.out_dim = out_dim or dim
         self.want_backward = want_backward
-        M = B * H * W
-        self.x_in = self.alloc(M, dim)
+        self.x_in = self.alloc(*(in_shape or (B * H * W, dim)))
         self.cur = self.fwd
         self.y_out, bw = self._record(self.x_in)
-        assert self.y_out.shape == (M, self.out_dim)
+        self.out_dim = out_dim or self.y_out.shape[-1]
         self.mark("fwd.end")
         if want_backward:
             self.cur = self.bwd
-            self.dy_in = self.alloc(M, self.out_dim)
+            self.dy_in = self.alloc(*self.y_out.shape)
             self.dx_out = bw(self.dy_in)
             self.mark("bwd.end")
         self.cur = self.fwd
@@ -464,12 +464,12 @@ class TokenPlan(Recorder):
         raise NotImplementedError
 
     def forward(self, x_rows: torch.Tensor) -> torch.Tensor:
-        self.x_in.copy_(x_rows)
+        self.x_in.copy_(x_rows.reshape(self.x_in.shape))
         self.run(self.fwd)
         return self.y_out
 
     def backward(self, dy_rows: torch.Tensor) -> torch.Tensor:
-        self.dy_in.copy_(dy_rows)
+        self.dy_in.copy_(dy_rows.reshape(self.dy_in.shape))
         self.run(self.bwd)
         return self.dx_out
 
@@ -479,6 +479,107 @@ class TokenPlan(Recorder):
 
     def alg_bytes(self) -> int:
         return sum(m[2] for m in self.meta[id(self.fwd)]) + sum(m[2] for m in self.meta[id(self.bwd)])
+
+
+def record_conv3x3(rec: Recorder, name: str, x: torch.Tensor, Wt, bias, Cin: int, Cout: int, dims, *, Kp=None, Np=None,
+                   k_grp=(0, 0), n_grp=(0, 0), act=L.ACT_NONE, slope=0.01, need_dx=True):
+    """Dense 3x3 convolution, pad 1, optional bias / LeakyReLU, on HWC rows (native weight [Cout][Cin][3][3]).
+    Returns (y, backward(dy, dW, db) -> dx)."""
+    M = x.shape[0]
+    Kp, Np = Kp or Cin, Np or Cout
+    y = rec.alloc(M, Np)
+    rec.gemm(name, x, Wt, y, N=Np, K=Kp, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=dims[1:], k_grp=k_grp, n_grp=n_grp, bias=bias, act=act,
+             slope=slope)
+
+    def backward(dy, dW, db):
+        if act == L.ACT_LEAKY:                       # y = leaky(z): dz from the stored output
+            dz = rec.alloc(M, Np)
+            rec._hold(y, dy, dz)
+            rec._op(name + ".leaky_bwd", lib.uir_leaky_bwd, _ptr(y), _ld(y), _ptr(dy), _ld(dy), _ptr(dz), _ld(dz), M, Np, slope,
+                    nbytes=12 * M * Np)
+            dy = dz
+        with rec.bulk():
+            rec.gram(name + ".dW", dy, x, dW, N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:], n_grp=n_grp, k_grp=k_grp)
+            if db is not None:
+                rec.colsum(name + ".db", dy, 0, Cout, db)
+        if not need_dx:
+            return None
+        dx = rec.alloc(M, Kp)
+        rec.gemm(name + ".dX", dy, Wt, dx, N=Kp, K=Np, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=dims[1:], n_grp=k_grp, k_grp=n_grp)
+        return dx
+    return y, backward
+
+
+def record_downsample(rec: Recorder, pfx: str, x: torch.Tensor, C_: int, dims):
+    """Downsample.forward (block.py:113-122): conv3x3 C -> C/2 (no bias) + PixelUnshuffle(2): [B*H*W, C] -> [B*H*W/4, 2C]."""
+    B, H, W = dims
+    t, conv_bw = record_conv3x3(rec, pfx + "body.0", x, rec.P(pfx + "body.0.weight"), None, C_, C_ // 2, dims)
+    y = rec.alloc(B * (H // 2) * (W // 2), 2 * C_)
+    rec._op(pfx + "unshuffle", lib.uir_pixel_unshuffle, _ptr(t), _ld(t), 0, _ptr(y), _ld(y), B, H // 2, W // 2, C_ // 2, nbytes=8 * t.numel())
+
+    def backward(dy):
+        dt = rec.alloc(B * H * W, C_ // 2)
+        rec._op(pfx + "unshuffle.bwd", lib.uir_pixel_shuffle, _ptr(dy), _ld(dy), _ptr(dt), _ld(dt), 0, B, H // 2, W // 2, C_ // 2,
+                nbytes=8 * dt.numel())
+        return conv_bw(dt, rec.Gr(pfx + "body.0.weight"), None)
+    return y, backward
+
+
+def record_upsample(rec: Recorder, pfx: str, x: torch.Tensor, C_: int, dims):
+    """Upsample.forward (block.py:144-153): conv3x3 C -> 2C (no bias) + PixelShuffle(2): [B*H*W, C] -> [4*B*H*W, C/2]."""
+    B, H, W = dims
+    t, conv_bw = record_conv3x3(rec, pfx + "body.0", x, rec.P(pfx + "body.0.weight"), None, C_, 2 * C_, dims)
+    y = rec.alloc(4 * B * H * W, C_ // 2)
+    rec._op(pfx + "shuffle", lib.uir_pixel_shuffle, _ptr(t), _ld(t), _ptr(y), _ld(y), 0, B, H, W, C_ // 2, nbytes=8 * t.numel())
+
+    def backward(dy):
+        dt = rec.alloc(B * H * W, 2 * C_)
+        rec._op(pfx + "shuffle.bwd", lib.uir_pixel_unshuffle, _ptr(dy), _ld(dy), 0, _ptr(dt), _ld(dt), B, H, W, C_ // 2, nbytes=8 * dt.numel())
+        return conv_bw(dt, rec.Gr(pfx + "body.0.weight"), None)
+    return y, backward
+
+
+def record_input_projection(rec: Recorder, pfx: str, img_nchw: torch.Tensor, C_: int, dims):
+    """InputProjection.forward (block.py:58-63, norm_layer None): three 3x3 convolutions with bias (3 -> 8 -> 32 -> C), LeakyReLU
+    (nn.LeakyReLU default slope 0.01) after the last, NCHW image -> tokens.  backward(dy) returns None (the image needs no gradient)."""
+    B, H, W = dims
+    M = B * H * W
+    x4 = rec.alloc(M, 4)
+    rec._hold(img_nchw)
+    rec._op(pfx + "to_hwc", lib.uir_nchw3_to_hwc4, _ptr(img_nchw), _ptr(x4), B, H, W, nbytes=28 * M)
+    P, Gr = (lambda n: rec.P(pfx + n)), (lambda n: rec.Gr(pfx + n))
+    a, a_bw = record_conv3x3(rec, pfx + "proj.0", x4, P("proj.0.weight"), P("proj.0.bias"), 3, 8, dims, Kp=4, k_grp=(3, 4), need_dx=False)
+    b, b_bw = record_conv3x3(rec, pfx + "proj.1", a, P("proj.1.weight"), P("proj.1.bias"), 8, 32, dims)
+    c, c_bw = record_conv3x3(rec, pfx + "proj.2", b, P("proj.2.weight"), P("proj.2.bias"), 32, C_, dims, act=L.ACT_LEAKY, slope=0.01)
+
+    def backward(dy):
+        db_ = c_bw(dy, Gr("proj.2.weight"), Gr("proj.2.bias"))
+        da_ = b_bw(db_, Gr("proj.1.weight"), Gr("proj.1.bias"))
+        a_bw(da_, Gr("proj.0.weight"), Gr("proj.0.bias"))
+        return None
+    return c, backward
+
+
+def record_output_projection(rec: Recorder, pfx: str, x: torch.Tensor, C_: int, dims, residual_nchw=None):
+    """OutputProjection.forward (block.py:84-91, no norm / act): three 3x3 convolutions with bias (C -> 32 -> 8 -> 3) on the token
+    image -> NCHW [B, 3, H, W]."""
+    B, H, W = dims
+    M = B * H * W
+    P, Gr = (lambda n: rec.P(pfx + n)), (lambda n: rec.Gr(pfx + n))
+    a, a_bw = record_conv3x3(rec, pfx + "proj.0", x, P("proj.0.weight"), P("proj.0.bias"), C_, 32, dims)
+    b, b_bw = record_conv3x3(rec, pfx + "proj.1", a, P("proj.1.weight"), P("proj.1.bias"), 32, 8, dims)
+    c, c_bw = record_conv3x3(rec, pfx + "proj.2", b, P("proj.2.weight"), P("proj.2.bias"), 8, 3, dims, Np=4, n_grp=(3, 4))
+    out = rec.alloc(B, 3, H, W)
+    rec._op(pfx + "to_nchw", lib.uir_hwc4_to_nchw3, _ptr(c), _ptr(out), B, H, W, nbytes=28 * M)
+
+    def backward(dout_nchw):
+        dc = rec.alloc(M, 4)
+        rec._hold(dout_nchw)
+        rec._op(pfx + "to_hwc.bwd", lib.uir_nchw3_to_hwc4, _ptr(dout_nchw), _ptr(dc), B, H, W, nbytes=28 * M)
+        db_ = c_bw(dc, Gr("proj.2.weight"), Gr("proj.2.bias"))
+        da_ = b_bw(db_, Gr("proj.1.weight"), Gr("proj.1.bias"))
+        return a_bw(da_, Gr("proj.0.weight"), Gr("proj.0.bias"))
+    return out, backward
 
 
 class FrfnPlan(TokenPlan):
@@ -511,15 +612,14 @@ class FdfpPlan(TokenPlan):
 
 
 class _TokenFunction(torch.autograd.Function):
-    """One autograd node for a whole token-plan module: forward and backward are launch lists."""
+    """One autograd node for a whole plan-backed module: forward and backward are launch lists."""
 
     @staticmethod
     def forward(ctx, x, module, *params):
-        B, Ltok, C_ = x.shape
         plan = module._plan_for(x)
-        y = plan.forward(x.reshape(B * Ltok, C_)).clone().view(B, Ltok, plan.out_dim)
+        y = plan.forward(x).clone().view(module._out_shape(x, plan))
         module._serial += 1
-        ctx.module, ctx.plan, ctx.serial, ctx.shape = module, plan, module._serial, (B, Ltok, C_)
+        ctx.module, ctx.plan, ctx.serial, ctx.shape = module, plan, module._serial, tuple(x.shape)
         return y
 
     @staticmethod
@@ -528,8 +628,8 @@ class _TokenFunction(torch.autograd.Function):
         if ctx.serial != m._serial:
             raise RuntimeError(f"{type(m).__name__}(HIP): a later forward overwrote the saved activations; call backward before "
                                "the next forward")
-        B, Ltok, C_ = ctx.shape
-        dx = ctx.plan.backward(dy.contiguous().view(B * Ltok, ctx.plan.out_dim)).clone().view(B, Ltok, C_)
+        dx = ctx.plan.backward(dy.contiguous())
+        dx = None if dx is None else dx.clone().view(ctx.shape)
         fp = m._flat
         return (dx, None) + tuple(None if n in m._dead else fp.gview(n).clone() for n in m._names)
 
@@ -549,6 +649,16 @@ class TokenModule(nn.Module):
     def _make_plan(self, fp, B, H, W, want_backward) -> TokenPlan:
         raise NotImplementedError
 
+    def _out_shape(self, x, plan):
+        """Shape of the module's output for input x: tokens (B, L_out, C_out) from the plan's output rows."""
+        B = x.shape[0]
+        return (B, plan.y_out.shape[0] // B, plan.y_out.shape[1])
+
+    def _grid_of(self, x):
+        """(B, H, W) of the token grid of input x (B, L, C), L = H*H."""
+        hh = int(math.sqrt(x.shape[1]))
+        return x.shape[0], hh, hh
+
     def _ensure_flat(self, device) -> FlatParams:
         named = list(self.named_parameters())
         ok = self._flat is not None and self._flat.device == torch.device(device) and \
@@ -566,14 +676,12 @@ class TokenModule(nn.Module):
 
     def _plan_for(self, x: torch.Tensor, want_backward: bool = True) -> TokenPlan:
         fp = self._ensure_flat(x.device)
-        B, Ltok, _ = x.shape
-        hh = int(math.sqrt(Ltok))
-        key = (B, hh, hh)
+        key = self._grid_of(x)
         plan = self._plans.get(key)
         if plan is None or (want_backward and not plan.want_backward):
             while len(self._plans) >= 2:
                 self._plans.pop(next(iter(self._plans)))
-            plan = self._make_plan(fp, B, hh, hh, want_backward)
+            plan = self._make_plan(fp, *key, want_backward)
             self._plans[key] = plan
         return plan
 
@@ -589,10 +697,9 @@ class TokenModule(nn.Module):
         self._ensure_flat(x.device)
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return _TokenFunction.apply(x, self, *self.parameters())
-        B, Ltok, C_ = x.shape
         plan = self._plan_for(x, want_backward=False)
         self._serial += 1
-        return plan.forward(x.reshape(B * Ltok, C_)).clone().view(B, Ltok, plan.out_dim)
+        return plan.forward(x).clone().view(self._out_shape(x, plan))
 
 
 class FRFN(TokenModule):
@@ -756,3 +863,106 @@ class MDASSA(TokenModule):
         y = super().forward(x)
         hh = int(math.sqrt(x.shape[1]))
         return y.view(x.shape[0], hh, hh, self.dim)
+
+
+class _SimplePlan(TokenPlan):
+    """TokenPlan whose recording is a function of (rec, x) given at construction."""
+
+    def __init__(self, fp, dim, B, H, W, want_backward, fn, in_shape=None):
+        self._fn = fn
+        super().__init__(fp, dim, B, H, W, want_backward, in_shape=in_shape)
+
+    def _record(self, x):
+        return self._fn(self, x)
+
+
+class Downsample(TokenModule):
+    """Drop-in for ``src.model.block.Downsample`` (block.py:107-122): (B, L, C) -> (B, L/4, 2C)."""
+
+    def __init__(self, channels, out_channels):
+        super().__init__()
+        self.body = nn.Sequential(nn.Conv2d(channels, channels // 2, kernel_size=3, padding=1, bias=False), nn.PixelUnshuffle(2))
+        self.dim = channels
+        self._init_plumbing()
+
+    def _make_plan(self, fp, B, H, W, want_backward):
+        return _SimplePlan(fp, self.dim, B, H, W, want_backward, lambda rec, x: record_downsample(rec, "", x, self.dim, (B, H, W)))
+
+
+class Upsample(TokenModule):
+    """Drop-in for ``src.model.block.Upsample`` (block.py:138-153): (B, L, C) -> (B, 4L, C/2)."""
+
+    def __init__(self, channels, out_channels):
+        super().__init__()
+        self.body = nn.Sequential(nn.Conv2d(channels, channels * 2, kernel_size=3, padding=1, bias=False), nn.PixelShuffle(2))
+        self.dim = channels
+        self._init_plumbing()
+
+    def _make_plan(self, fp, B, H, W, want_backward):
+        return _SimplePlan(fp, self.dim, B, H, W, want_backward, lambda rec, x: record_upsample(rec, "", x, self.dim, (B, H, W)))
+
+
+class InputProjection(TokenModule):
+    """Drop-in for ``src.model.block.InputProjection`` (block.py:42-63) as MyBigFRFNModel builds it (3 -> 8 -> 32 -> C, kernel 3,
+    LeakyReLU, no norm): ``forward(x: (B, 3, H, W)) -> (B, H*W, C)``."""
+
+    def __init__(self, in_channels=3, out_channels=64, kernel_size=3, stride=1, norm_layer=None, act_layer=nn.LeakyReLU):
+        super().__init__()
+        if (in_channels, kernel_size, stride, norm_layer) != (3, 3, 1, None) or act_layer is not nn.LeakyReLU or out_channels % 4:
+            raise NotImplementedError("the HIP InputProjection is built for 3 input channels, kernel 3, stride 1, LeakyReLU, no norm")
+        self.proj = nn.Sequential(nn.Conv2d(in_channels, 8, kernel_size, stride, kernel_size // 2),
+                                  nn.Conv2d(8, 32, kernel_size, stride, kernel_size // 2),
+                                  nn.Conv2d(32, out_channels, kernel_size, stride, kernel_size // 2), act_layer(inplace=True))
+        self.norm = None
+        self.in_channel, self.out_channel = in_channels, out_channels
+        self.dim = out_channels
+        self._init_plumbing()
+
+    def _grid_of(self, x):
+        return x.shape[0], x.shape[2], x.shape[3]
+
+    def _out_shape(self, x, plan):
+        return (x.shape[0], x.shape[2] * x.shape[3], self.out_channel)
+
+    def _make_plan(self, fp, B, H, W, want_backward):
+        return _SimplePlan(fp, self.out_channel, B, H, W, want_backward,
+                           lambda rec, x: record_input_projection(rec, "", x, self.out_channel, (B, H, W)), in_shape=(B, 3, H, W))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError(f"expected (B, 3, H, W), got {tuple(x.shape)}")
+        if x.device.type != "cuda":
+            raise RuntimeError("InputProjection(HIP) runs on an AMD GPU ('cuda' device in PyTorch-ROCm); there is no CPU fallback")
+        x = x.contiguous().float()
+        self._ensure_flat(x.device)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            return _TokenFunction.apply(x, self, *self.parameters())
+        plan = self._plan_for(x, want_backward=False)
+        self._serial += 1
+        return plan.forward(x).clone().view(self._out_shape(x, plan))
+
+
+class OutputProjection(TokenModule):
+    """``src.model.block.OutputProjection`` (block.py:65-91; C -> 32 -> 8 -> 3, kernel 3, no norm / act) on the TOKEN image:
+    ``forward(x: (B, L, C)) -> (B, 3, H, W)``.  The reference's forward takes NCHW and is handed tokens by its own nets (the crash
+    SURVEY.md fact 2 records); this takes the tokens, i.e. includes the reshape model.py:435-437 shows."""
+
+    def __init__(self, in_channels=64, out_channel=3, kernel_size=3, stride=1, norm_layer=None, act_layer=None):
+        super().__init__()
+        if (out_channel, kernel_size, stride, norm_layer, act_layer) != (3, 3, 1, None, None) or in_channels % 4:
+            raise NotImplementedError("the HIP OutputProjection is built for 3 output channels, kernel 3, stride 1, no norm / act")
+        self.proj = nn.Sequential(nn.Conv2d(in_channels, 32, kernel_size, stride, kernel_size // 2),
+                                  nn.Conv2d(32, 8, kernel_size, stride, kernel_size // 2),
+                                  nn.Conv2d(8, out_channel, kernel_size, stride, kernel_size // 2))
+        self.act = None
+        self.norm = None
+        self.in_channel, self.out_channel = in_channels, out_channel
+        self.dim = in_channels
+        self._init_plumbing()
+
+    def _out_shape(self, x, plan):
+        hh = int(math.sqrt(x.shape[1]))
+        return (x.shape[0], 3, hh, hh)
+
+    def _make_plan(self, fp, B, H, W, want_backward):
+        return _SimplePlan(fp, self.dim, B, H, W, want_backward, lambda rec, x: record_output_projection(rec, "", x, self.dim, (B, H, W)))
