@@ -503,6 +503,10 @@ int uir_layernorm_fwd(const float* X, int ldx, const float* gamma, const float* 
                       float eps, void* stream);
 int uir_cmul_table(float* re, float* im, const float* tab_re, const float* tab_im, long rows, long P, int C, void* stream);
 int uir_transpose_rows(const float* src, float* dst, int B, int N1, int N2, int N3, int C, float scale, void* stream);
+/* dst[m][:] (+)= scale[m / rows_per_sample] * src[m][:] - DropPath (timm drop_path: one Bernoulli(keep) / keep factor per sample;
+ * EncoderBlock, model.py:27,54,91); scale is a device float[M / rows_per_sample]. */
+int uir_scale_rows(const float* src, int lds, float* dst, int ldd, const float* scale, long rows_per_sample, long M, int C, int accumulate,
+                   void* stream);
 /* Last stage of a length-N = 2 N2 complex DFT (sign +) along an axis of rows [O][N][I][C] whose first stage transformed the two
  * interleaved sub-sequences n = 2 n2 + n1 (uir_dft_axis2 over n2 with inner extent 2 I): Y rows [o][k2][n1][i], twiddle table
  * exp(2 pi i k2 / N) [N2];  X[o][k1 N2 + k2][i] = scale (Y[k2][0] + (-1)^k1 tw[k2] Y[k2][1]), natural order; x_im NULL = real part

@@ -190,3 +190,47 @@ def test_hip_encoder_block_dim_256_vs_oracle():
     worst = max(((n, _rel(p.grad, g64[n])) for n, p in m.named_parameters() if p.grad is not None), key=lambda t: t[1])
     print(f"EncoderBlock(256): y {_rel(y, y64):.2e} dx {_rel(xg.grad, dx64):.2e} worst {worst}")
     assert _rel(y, y64) < 1e-4 and _rel(xg.grad, dx64) < 2e-4 and worst[1] < 1e-3
+
+
+@gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_hip_encoder_block_drop_path():
+    """Stochastic depth (timm's drop_path, model.py:27,54,91): in training mode each branch of every sample is kept with probability
+    1 - p and scaled by 1 / (1 - p); eval mode is the identity.  The factors the plan used are read back and fed to the oracle:
+    output, input gradient and parameter gradients must match; the draws follow torch's generator (same seed -> same factors)."""
+    import torch.nn.functional as F
+    from underwater_image_restoration_amd.model.model import EncoderBlock
+    dim, B, S2, p = 32, 8, 16, 0.5
+    m = EncoderBlock(dim, (S2, S2), 4, token_mlp="frfn", freq_mlp="frfn", drop_path=p)
+    P = E.closed_form_params(dim, 4 * dim)
+    m.load_state_dict(P)
+    m = m.cuda()
+    x, probe = R.closed_form_input(B, S2 * S2, dim, 121), R.closed_form_input(B, S2 * S2, dim, 122)
+    m.eval()
+    with torch.no_grad():
+        y_eval = m(x.cuda())
+    y_ref, _, _ = E.out_and_grads(x.double(), {k: v.double() for k, v in P.items()}, probe.double())
+    assert _rel(y_eval, y_ref) < 2e-5                                  # eval: DropPath is the identity
+    m.train()
+    torch.manual_seed(7)
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    (y * probe.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    plan = m._plan_for(xg)
+    s = plan.dp_scale.cpu().double()                                   # [2][B]: row 0 = drop_path2 (frequency), row 1 = drop_path
+    assert set(s.unique().tolist()) <= {0.0, 1.0 / (1 - p)} and 0 < int((s == 0).sum()) < 2 * B
+    torch.manual_seed(7)                                               # the reference's draw order: drop_path2, then drop_path
+    want = torch.stack([torch.empty(B, device="cuda").bernoulli_(1 - p).div_(1 - p) for _ in range(2)]).cpu().double()
+    assert torch.equal(s, want)
+    leaves = {n: v.double().requires_grad_(True) for n, v in P.items()}
+    xd = x.double().requires_grad_(True)
+    sub = lambda pfx: {k[len(pfx):]: v for k, v in leaves.items() if k.startswith(pfx)}      # noqa: E731
+    x1 = R.frfn(F.layer_norm(xd, (dim,), leaves["norm1.weight"], leaves["norm1.bias"], 1e-5), sub("mlp."))
+    f = torch.fft.ifftn(R.frfn(torch.fft.fftn(x1, dim=(-2, -1)).real, sub("freq_mlp.")), dim=(-2, -1)).real
+    y64 = xd + s[0].view(B, 1, 1) * f + s[1].view(B, 1, 1) * x1
+    (y64 * probe.double()).sum().backward()
+    assert _rel(y, y64) < 2e-5 and _rel(xg.grad, xd.grad) < 5e-5
+    for n, prm in m.named_parameters():
+        if prm.grad is not None:
+            assert _rel(prm.grad, leaves[n].grad) < 3e-4, n

@@ -227,6 +227,7 @@ SIGNATURES = {
     "uir_layernorm_fwd": [fp, i32, fp, fp, fp, i32, fp, i64, i32, f32, fp],
     "uir_cmul_table": [fp, fp, fp, fp, i64, i64, i32, fp],
     "uir_transpose_rows": [fp, fp, i32, i32, i32, i32, i32, f32, fp],
+    "uir_scale_rows": [fp, i32, fp, i32, fp, i64, i64, i32, i32, fp],
     "uir_radix2_combine": [fp, fp, fp, fp, fp, fp, i64, i32, i64, i32, f32, fp],
     "uir_winattn_fwd": [C.POINTER(WinAttnArgs), fp],
     "uir_winattn_bwd": [C.POINTER(WinAttnArgs), fp],

@@ -158,6 +158,25 @@ __global__ __launch_bounds__(256) void radix2_combine_kernel(const float* __rest
   }
 }
 
+// dst[m][:] (+)= scale[m / rows_per_sample] * src[m][:]: stochastic depth (DropPath) - one factor per sample
+__global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd,
+                                                         const float* __restrict__ scale, long rows_per_sample, long M, int C4,
+                                                         int accumulate) {
+  const long total = M * C4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / C4;
+    const int c = (int)(e - m * C4) * 4;
+    const float f = scale[m / rows_per_sample];
+    float4 v = *reinterpret_cast<const float4*>(src + m * lds + c);
+    v.x *= f; v.y *= f; v.z *= f; v.w *= f;
+    if (accumulate) {
+      const float4 o = *reinterpret_cast<const float4*>(dst + m * ldd + c);
+      v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    *reinterpret_cast<float4*>(dst + m * ldd + c) = v;
+  }
+}
+
 inline unsigned grid_for(long total) {
   long g = (total + 255) / 256;
   return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -209,5 +228,14 @@ extern "C" int uir_radix2_combine(const float* y_re, const float* y_im, float* x
   const long IC4 = I * (C / 4);
   hipLaunchKernelGGL(radix2_combine_kernel, dim3(grid_for(O * N2 * IC4)), dim3(256), 0, static_cast<hipStream_t>(stream), y_re, y_im, x_re,
                      x_im, tab_re, tab_im, O, N2, IC4, scale);
+  return uir_launch_status();
+}
+
+extern "C" int uir_scale_rows(const float* src, int lds, float* dst, int ldd, const float* scale, long rows_per_sample, long M, int C,
+                              int accumulate, void* stream) {
+  UIR_REQUIRE(src && dst && scale && rows_per_sample > 0 && M > 0 && M % rows_per_sample == 0 && C > 0 && (C & 3) == 0);
+  UIR_REQUIRE(lds >= C && ldd >= C && ((lds | ldd) & 3) == 0 && uir_aligned16(src) && uir_aligned16(dst));
+  hipLaunchKernelGGL(scale_rows_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, dst, ldd,
+                     scale, rows_per_sample, M, C / 4, accumulate);
   return uir_launch_status();
 }

@@ -617,6 +617,7 @@ class _TokenFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, module, *params):
         plan = module._plan_for(x)
+        module._before_forward(plan)
         y = plan.forward(x).clone().view(module._out_shape(x, plan))
         module._serial += 1
         ctx.module, ctx.plan, ctx.serial, ctx.shape = module, plan, module._serial, tuple(x.shape)
@@ -648,6 +649,9 @@ class TokenModule(nn.Module):
 
     def _make_plan(self, fp, B, H, W, want_backward) -> TokenPlan:
         raise NotImplementedError
+
+    def _before_forward(self, plan) -> None:
+        """Hook: per-call device state of the plan (e.g. the stochastic-depth factors) is set here, before the launch list runs."""
 
     def _out_shape(self, x, plan):
         """Shape of the module's output for input x: tokens (B, L_out, C_out) from the plan's output rows."""
@@ -698,6 +702,7 @@ class TokenModule(nn.Module):
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return _TokenFunction.apply(x, self, *self.parameters())
         plan = self._plan_for(x, want_backward=False)
+        self._before_forward(plan)
         self._serial += 1
         return plan.forward(x).clone().view(self._out_shape(x, plan))
 

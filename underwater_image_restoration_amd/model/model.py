@@ -13,8 +13,8 @@ T / (L*C): one operator, also its own backward pass.  T runs as two uir_gemm (C 
 (L = H*W = N1*N2: uir_dft_axis over n1, uir_cmul_table twiddles, uir_dft_axis over n2, uir_transpose_rows); the two FRFNs
 are ``block.record_frfn``; LayerNorm is uir_layernorm_fwd / uir_layernorm_bwd.  No CPU / eager fallback.
 
-``token_mlp`` / ``freq_mlp`` may each be "frfn" or "leff" (the reference's default).  Not built yet (raise
-NotImplementedError): the Wavelet mode, ``drop_path > 0`` (stochastic depth of the
+``token_mlp`` / ``freq_mlp`` may each be "frfn" or "leff" (the reference's default); ``drop_path > 0`` applies timm's
+stochastic depth (per-sample factors, training mode only).  Not built (raise NotImplementedError): the Wavelet mode, ``drop_path > 0`` (stochastic depth of the
 deeper encoder levels), DecoderBlock / MDASSA / FDFP - SURVEY.md 8(f)-2, next.
 """
 from __future__ import annotations
@@ -130,15 +130,23 @@ class EncoderPlan(TokenPlan):
         x1, bw1 = _MLP_RECORDERS[self.token_mlp](self, "mlp.", xn, C_, self.hidden, dims)
         f1 = record_token_fft(self, "fftn", x1, dims, C_, 1.0)
         f2, bw2 = _MLP_RECORDERS[self.freq_mlp](self, "freq_mlp.", f1, C_, self.hidden, dims)
-        y = record_token_fft(self, "ifftn", f2, dims, C_, 1.0 / (Ltok * C_))
-        self.copy_cols("out+=x", x, 0, y, 0, C_, accumulate=1)          # shortcut + freq_x + x  (model.py:91)
-        self.copy_cols("out+=x1", x1, 0, y, 0, C_, accumulate=1)
+        f3 = record_token_fft(self, "ifftn", f2, dims, C_, 1.0 / (Ltok * C_))
+        # x = shortcut + drop_path2(freq_x) + drop_path(x)  (model.py:91): per-sample factors (1 in eval mode / for drop_path 0)
+        self.dp_scale = self.alloc(2, self.B)          # row 0: drop_path2 (frequency branch), row 1: drop_path (token branch)
+        self.dp_scale.fill_(1.0)
+        s2, s1 = self.dp_scale[0], self.dp_scale[1]
+        y = self.alloc(M, C_)
+        self.copy_cols("out=x", x, 0, y, 0, C_)
+        self._op("out+=dp2*freq", lib.uir_scale_rows, _ptr(f3), C_, _ptr(y), C_, _ptr(s2), Ltok, M, C_, 1, nbytes=12 * M * C_)
+        self._op("out+=dp*x1", lib.uir_scale_rows, _ptr(x1), C_, _ptr(y), C_, _ptr(s1), Ltok, M, C_, 1, nbytes=12 * M * C_)
 
         def backward(dy):
-            g2 = record_token_fft(self, "ifftn.bwd", dy, dims, C_, 1.0 / (Ltok * C_))     # T is symmetric: its own adjoint
+            dyf = self.alloc(M, C_)
+            self._op("dfreq=dp2*dy", lib.uir_scale_rows, _ptr(dy), C_, _ptr(dyf), C_, _ptr(s2), Ltok, M, C_, 0, nbytes=8 * M * C_)
+            g2 = record_token_fft(self, "ifftn.bwd", dyf, dims, C_, 1.0 / (Ltok * C_))    # T is symmetric: its own adjoint
             df1 = bw2(g2)
             dx1 = record_token_fft(self, "fftn.bwd", df1, dims, C_, 1.0)
-            self.copy_cols("dx1+=dy", dy, 0, dx1, 0, C_, accumulate=1)
+            self._op("dx1+=dp*dy", lib.uir_scale_rows, _ptr(dy), C_, _ptr(dx1), C_, _ptr(s1), Ltok, M, C_, 1, nbytes=12 * M * C_)
             dxn = bw1(dx1)
             dx = self.alloc(M, C_)
             self.ln_bwd("norm1.bwd", dxn, x, stats, g1, dy, dx, self.Gr("norm1.weight"), self.Gr("norm1.bias"), C_=C_)
@@ -158,9 +166,10 @@ class EncoderBlock(TokenModule):
             raise ValueError(f"Unknown token_mlp type: {token_mlp}")                     # the reference's errors (model.py:38,48)
         if freq_mlp not in ("leff", "frfn"):
             raise ValueError(f"Unknown freq_mlp type: {freq_mlp}")
-        if use_dwt != "Fourier" or drop_path > 0.0 or norm_layer is not nn.LayerNorm or act_layer is not nn.GELU:
-            raise NotImplementedError("the HIP EncoderBlock is built for use_dwt='Fourier', drop_path=0, LayerNorm, GELU "
-                                      "(encoder_0 / encoder_0_1 of MyBigFRFNModel, model.py:481-489)")
+        if use_dwt != "Fourier" or norm_layer is not nn.LayerNorm or act_layer is not nn.GELU:
+            raise NotImplementedError("the HIP EncoderBlock is built for use_dwt='Fourier', LayerNorm, GELU (MyBigFRFNModel, model.py:481-524)")
+        if not 0.0 <= drop_path < 1.0:
+            raise ValueError("drop_path must be in [0, 1)")
         if dim not in (32, 64, 128, 256, 512):
             raise NotImplementedError("dim in {32, 64, 128, 256, 512} (the LayerNorm kernels' channel counts)")
         self.dim = dim
@@ -168,7 +177,8 @@ class EncoderBlock(TokenModule):
         self.num_heads = num_heads
         self.mlp_ratio = mlp_ratio
         self.token_mlp = token_mlp
-        self.drop_path = nn.Identity()
+        self.drop_prob = float(drop_path)
+        self.drop_path = nn.Identity()                   # the stochastic-depth factors are applied inside the launch plan
         self.norm1 = norm_layer(dim)
         self.use_dwt = use_dwt
         mlp_hidden_dim = int(dim * mlp_ratio)
@@ -183,6 +193,17 @@ class EncoderBlock(TokenModule):
 
     def _make_plan(self, fp, B, H, W, want_backward):
         return EncoderPlan(fp, self.dim, self.hidden_dim, B, H, W, want_backward, self.token_mlp, self.freq_mlp_kind)
+
+    def _before_forward(self, plan) -> None:
+        """timm's drop_path (the published function the reference imports, model.py:7,27): in training mode with p > 0 each of
+        the two branches gets an independent per-sample factor Bernoulli(1 - p) / (1 - p); drawn in the reference's order
+        (``shortcut + drop_path2(freq_x) + drop_path(x)``: drop_path2 first) from torch's device generator."""
+        if self.training and self.drop_prob > 0.0:
+            keep = 1.0 - self.drop_prob
+            for r in (0, 1):
+                plan.dp_scale[r].copy_(torch.empty(plan.B, device=plan.dp_scale.device).bernoulli_(keep).div_(keep))
+        else:
+            plan.dp_scale.fill_(1.0)
 
 
 class DecoderPlan(TokenPlan):
