@@ -160,3 +160,27 @@ def output_projection(x: torch.Tensor, P: Params, pfx: str = "") -> torch.Tensor
     for i in range(3):
         v = F.conv2d(v, P[f"{pfx}proj.{i}.weight"], P[f"{pfx}proj.{i}.bias"], padding=1)
     return v
+
+
+def frfn_net(x: torch.Tensor, P: Params) -> torch.Tensor:
+    """MyBigFRFNModel.forward (src/model/model.py:596-643) in eval mode (DropPath = identity), with the token image handed to
+    output_proj reshaped as model.py:435-437 shows (the shipped forward crashes there) and WITHOUT the bottleneck
+    print (:628).  x: (B, 3, S, S)."""
+    from . import encoder_ref as E
+
+    def enc(t, pfx):
+        return E.encoder_block(t, _sub(P, pfx))
+
+    def dec(t, e, pfx):
+        return decoder_block(t, e, _sub(P, pfx), 4)
+    y = input_projection(x, P, "input_proj.")
+    conv0 = enc(enc(y, "encoder_0."), "encoder_0_1.")
+    conv1 = enc(enc(downsample(conv0, P, "downsample_0."), "encoder_1."), "encoder_1_1.")
+    conv2 = enc(enc(downsample(conv1, P, "downsample_1."), "encoder_2."), "encoder_2_1.")
+    conv3 = enc(enc(downsample(conv2, P, "downsample_2."), "encoder_3."), "encoder_3_1.")
+    bott = dec(downsample(conv3, P, "downsample_3."), None, "bottleneck.")
+    dec3 = dec(dec(upsample(bott, P, "upsample_3."), conv3, "decoder_3."), None, "decoder_3_1.")
+    dec2 = dec(dec(upsample(dec3, P, "upsample_2."), conv2, "decoder_2."), None, "decoder_2_1.")
+    dec1 = dec(dec(upsample(dec2, P, "upsample_1."), conv1, "decoder_1."), None, "decoder_1_1.")
+    dec0 = dec(dec(upsample(dec1, P, "upsample_0."), conv0, "decoder_0."), None, "decoder_0_1.")
+    return output_projection(dec0, P, "output_proj.") + x

@@ -1,0 +1,75 @@
+"""--arch NewBigFRFNModel (reference src/model/model.py:465-643) end to end.
+CPU: the factory builds it with the reference's 632 state_dict tensors, shapes and default-initialisation values under a seed
+(tests/golden/frfnnet_manifest.npz <- make_net_manifest.py).  GPU: forward + backward of the whole network against the fp64 oracle
+(oracle/decoder_ref.frfn_net: the block oracles, each pinned to the reference's classes, composed as MyBigFRFNModel.forward does)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import decoder_ref as D, frfn_ref as R
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "frfnnet_manifest.npz")
+
+
+def test_factory_builds_the_references_network():
+    from underwater_image_restoration_amd.Models import init_model, get_names
+    g = np.load(GOLDEN)
+    assert get_names() == ["SpectralTransformer", "NewModel", "NewBigModel", "NewBigFRFNModel", "AST"]
+    torch.manual_seed(1234)
+    m = init_model("NewBigFRFNModel", use_dwt="Fourier")
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["names"]) and len(sd) == 632
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 35949007
+    for (k, v), s in zip(sd.items(), g["sums"]):                       # same registration order and initialisers: same RNG stream
+        assert abs(float(v.double().sum()) - s) <= 1e-9 * max(1.0, abs(s)), k
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 100, 100))
+    # stochastic depth as the reference assigns it: linspace(0, 0.1, 4) to encoder_k, enc_dpr[0] = 0 to every encoder_k_1
+    assert [round(m.get_submodule(f"encoder_{k}").drop_prob, 4) for k in range(4)] == [0.0, 0.0333, 0.0667, 0.1]
+    assert all(m.get_submodule(f"encoder_{k}_1").drop_prob == 0.0 for k in range(4))
+
+
+gpu = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+@gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_hip_network_forward_backward_vs_oracle():
+    """128 x 128 input (bottleneck = one 8 x 8 window), B = 1, eval mode (DropPath off), closed-form weights: output and the gradient of
+    every used parameter vs the fp64 oracle; the parameters the reference never uses keep grad None."""
+    from underwater_image_restoration_amd.Models import init_model
+    m = init_model("NewBigFRFNModel")
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.is_floating_point() and ".dwt." not in k and ".idwt." not in k}
+    P = D.closed_form_params(shapes, "frfnnet")
+    m.load_state_dict(P, strict=False)
+    m = m.cuda().eval()
+    S2 = 128
+    x = R.closed_form_input(1, 3, S2 * S2, 131).reshape(1, 3, S2, S2)
+    probe = R.closed_form_input(1, 3, S2 * S2, 132).reshape(1, 3, S2, S2)
+    torch.set_num_threads(8)
+    y64, _, g64 = D.grads(lambda t, Pp: D.frfn_net(t, Pp), [x.double()], {k: v.double() for k, v in P.items()}, probe.double())
+    y = m(x.cuda())
+    assert y.shape == (1, 3, S2, S2)
+    (y * probe.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    e_y = _rel(y, y64)
+    worst, n_checked, n_dead = ("", 0.0), 0, 0
+    for n, p in m.named_parameters():
+        if n not in g64:
+            assert p.grad is None, n
+            n_dead += 1
+            continue
+        e = _rel(p.grad, g64[n])
+        n_checked += 1
+        worst = max(worst, (n, e), key=lambda t: t[1])
+    print(f"NewBigFRFNModel 128x128: out {e_y:.2e}; {n_checked} parameter gradients, worst {worst}; {n_dead} unused parameters")
+    assert e_y < 1e-4 and worst[1] < 2e-3
+    assert n_dead == 8 * 2 + 9 * 8          # norm2 of the 8 encoder blocks; norm_q / norm_kv / two unused projections in the 9 MDASSAs

@@ -2,15 +2,18 @@
 ``get_names``.  Only ``SpectralTransformer`` is built here (the MI355X hot path); the other
 reference architectures are outside this build's scope and raise with a clear message."""
 from .SpectralTransformer import SpectralTransformer
+from ..model.model import MyBigFRFNModel as NewBigFRFNModel
 
 __model_factory = {
     "SpectralTransformer": SpectralTransformer,
+    "NewBigFRFNModel": NewBigFRFNModel,
 }
-_REFERENCE_ONLY = ("NewModel", "NewBigModel", "NewBigFRFNModel", "AST")
+_REFERENCE_ONLY = ("NewModel", "NewBigModel", "AST")
+_ORDER = ("SpectralTransformer", "NewModel", "NewBigModel", "NewBigFRFNModel", "AST")       # src/Models/__init__.py:10-16
 
 
 def get_names():
-    return list(__model_factory.keys()) + list(_REFERENCE_ONLY)
+    return list(_ORDER)
 
 
 def init_model(name, *args, **kwargs):

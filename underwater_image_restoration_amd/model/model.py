@@ -3,7 +3,7 @@
 (``norm1.*``, ``mlp.*``, ``norm2.*``, ``freq_mlp.*``), ``forward(x: (B, L, C), mask=None) -> (B, L, C)``.
 
 Built for the configuration MyBigFRFNModel uses for its first level (model.py:481-489): ``token_mlp = freq_mlp = "frfn"``
-(or "leff", the class default), ``use_dwt = "Fourier"``, ``drop_path = 0``.  In that mode the reference computes
+(or "leff", the class default), ``use_dwt = "Fourier"``.  In that mode the reference computes
 
     x1 = mlp(norm1(x));  f = Re fftn(x1, dims (L, C));  f = freq_mlp(f);  f = Re ifftn(f, dims (L, C));  out = x + f + x1
 
@@ -14,7 +14,7 @@ T / (L*C): one operator, also its own backward pass.  T runs as two uir_gemm (C 
 are ``block.record_frfn``; LayerNorm is uir_layernorm_fwd / uir_layernorm_bwd.  No CPU / eager fallback.
 
 ``token_mlp`` / ``freq_mlp`` may each be "frfn" or "leff" (the reference's default); ``drop_path > 0`` applies timm's
-stochastic depth (per-sample factors, training mode only).  Not built (raise NotImplementedError): the Wavelet mode, ``drop_path > 0`` (stochastic depth of the
+stochastic depth (per-sample factors, training mode only).  Not built (raise NotImplementedError): the Wavelet mode (the
 deeper encoder levels), DecoderBlock / MDASSA / FDFP - SURVEY.md 8(f)-2, next.
 """
 from __future__ import annotations
@@ -27,7 +27,9 @@ import torch.nn as nn
 
 from .. import _lib as L
 from ..engine import FlatParams, _ptr
-from .block import FRFN, LeFF, MDASSA, MDASSA_DEAD, TokenModule, TokenPlan, record_decoder_block, record_frfn, record_leff
+from .block import (FRFN, LeFF, MDASSA, MDASSA_DEAD, Downsample, InputProjection, OutputProjection, TokenModule, TokenPlan, Upsample,
+                    record_decoder_block, record_frfn, record_leff)
+from .. import ops
 
 lib = L.lib
 _TABLES: dict = {}
@@ -258,3 +260,91 @@ class DecoderBlock(TokenModule):
             return super().forward(x)
         finally:
             self.dim = d
+
+
+class _ResidualImage(torch.autograd.Function):
+    """out + x for two NCHW images (MyBigFRFNModel.forward: ``out = out + x``, model.py:640) through uir_copy_cols; x is the input
+    image and gets no gradient."""
+
+    @staticmethod
+    def forward(ctx, out, x):
+        y = out.clone()
+        n = y.numel()
+        if n % 4:
+            raise ValueError("image element count must be a multiple of 4")
+        ops.flat_accumulate(x.contiguous().view(-1), y.view(-1), n, accumulate=True)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class MyBigFRFNModel(nn.Module):
+    """``--arch NewBigFRFNModel`` (src/model/model.py:465-643): a 5-level U-Net of EncoderBlocks (FRFN + (L, C)-Fourier branch) and
+    DecoderBlocks (MDASSA window attention + FRFN) over token images.  Same constructor, child names and registration order
+    (hence ``state_dict`` keys) as the reference.  Every child is a launch-plan module of this package; tensors between them are
+    device tensors handed over through autograd (one node per child).  Differences, both documented in DESIGN.md section 14:
+    ``output_proj`` receives the token image (the reference hands its NCHW-only OutputProjection the tokens and crashes there,
+    SURVEY.md fact 2; the reshape of model.py:435-437 is what is meant), and the per-forward ``print`` of the bottleneck shape
+    (:628) is not emitted."""
+
+    def __init__(self, img_size=512, dd_in=3, embed_dim=32, dropout_rate=0., drop_path_rate=0.1, use_dwt="Fourier"):
+        super().__init__()
+        if dd_in != 3 or dropout_rate != 0. or use_dwt != "Fourier":
+            raise NotImplementedError("the HIP MyBigFRFNModel is built for dd_in=3, dropout_rate=0, use_dwt='Fourier' (the defaults)")
+        self.img_size, self.embed_dim, self.num_enc_layers = img_size, embed_dim, 4
+        E_, r = embed_dim, img_size
+        self.input_proj = InputProjection(in_channels=dd_in, out_channels=E_)
+        self.pos_drop = nn.Dropout(p=dropout_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, self.num_enc_layers)]
+
+        def enc(dim, res, dp):
+            return EncoderBlock(dim=dim, input_resolution=(res, res), num_heads=4, mlp_ratio=4, token_mlp="frfn", drop_path=dp,
+                                norm_layer=nn.LayerNorm, act_layer=nn.GELU, drop=dropout_rate, freq_mlp="frfn", use_dwt=use_dwt)
+
+        def dec(dim, res, enc_out, ratio):
+            return DecoderBlock(dim=dim, input_resolution=(res, res), num_heads=4, win_size=8, shift_size=0, mlp_ratio=4,
+                                token_mlp="frfn", drop_path=0.0, norm_layer=nn.LayerNorm, act_layer=nn.GELU, drop=dropout_rate,
+                                token_projection="linear", enc_out=enc_out, freq_attn_win_ratio=ratio, use_dwt=use_dwt)
+        # registration order == reference (model.py:474-583); the *_1 encoders all take enc_dpr[0] there
+        self.encoder_0, self.encoder_0_1 = enc(E_, r, dpr[0]), enc(E_, r, dpr[0])
+        self.downsample_0 = Downsample(E_, E_ * 2)
+        self.encoder_1, self.encoder_1_1 = enc(E_ * 2, r // 2, dpr[1]), enc(E_ * 2, r // 2, dpr[0])
+        self.downsample_1 = Downsample(E_ * 2, E_ * 4)
+        self.encoder_2, self.encoder_2_1 = enc(E_ * 4, r // 4, dpr[2]), enc(E_ * 4, r // 4, dpr[0])
+        self.downsample_2 = Downsample(E_ * 4, E_ * 8)
+        self.encoder_3, self.encoder_3_1 = enc(E_ * 8, r // 8, dpr[3]), enc(E_ * 8, r // 8, dpr[0])
+        self.downsample_3 = Downsample(E_ * 8, E_ * 16)
+        self.bottleneck = dec(E_ * 16, r // 16, False, 2)
+        self.upsample_3 = Upsample(E_ * 16, E_ * 8)
+        self.decoder_3, self.decoder_3_1 = dec(E_ * 8, r // 8, True, 2), dec(E_ * 8, r // 8, False, 2)
+        self.upsample_2 = Upsample(E_ * 8, E_ * 4)
+        self.decoder_2, self.decoder_2_1 = dec(E_ * 4, r // 4, True, 4), dec(E_ * 4, r // 4, False, 2)
+        self.upsample_1 = Upsample(E_ * 4, E_ * 2)
+        self.decoder_1, self.decoder_1_1 = dec(E_ * 2, r // 2, True, 8), dec(E_ * 2, r // 2, False, 2)
+        self.upsample_0 = Upsample(E_ * 2, E_)
+        self.decoder_0, self.decoder_0_1 = dec(E_, r, True, 16), dec(E_, r, False, 2)
+        self.output_proj = OutputProjection(in_channels=E_, out_channel=dd_in, kernel_size=3, stride=1, norm_layer=None, act_layer=None)
+
+    def forward(self, x, mask=None):
+        if mask is not None:
+            raise NotImplementedError("mask=None (the trainer never passes one, src/ModelTrainer.py:79)")
+        if x.dim() != 4 or x.shape[1] != 3 or x.shape[2] != x.shape[3] or x.shape[2] % 128:
+            raise ValueError(f"expected (B, 3, S, S) with S a multiple of 128 (four 2x down-samplings to at least one 8 x 8 window), got {tuple(x.shape)}")
+        y = self.input_proj(x)
+        conv0 = self.encoder_0_1(self.encoder_0(y))
+        conv1 = self.encoder_1_1(self.encoder_1(self.downsample_0(conv0)))
+        conv2 = self.encoder_2_1(self.encoder_2(self.downsample_1(conv1)))
+        conv3 = self.encoder_3_1(self.encoder_3(self.downsample_2(conv2)))
+        bottleneck = self.bottleneck(self.downsample_3(conv3))
+        dec3 = self.decoder_3_1(self.decoder_3(self.upsample_3(bottleneck), enc_out=conv3))
+        dec2 = self.decoder_2_1(self.decoder_2(self.upsample_2(dec3), enc_out=conv2))
+        dec1 = self.decoder_1_1(self.decoder_1(self.upsample_1(dec2), enc_out=conv1))
+        dec0 = self.decoder_0_1(self.decoder_0(self.upsample_0(dec1), enc_out=conv0))
+        out = self.output_proj(dec0)
+        return _ResidualImage.apply(out, x.contiguous().float())
+
+    def plan_modules(self):
+        """The launch-plan children, in registration order (each owns one flat parameter / gradient buffer)."""
+        return [m for m in self.children() if isinstance(m, TokenModule)]
