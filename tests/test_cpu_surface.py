@@ -323,7 +323,7 @@ def test_trainer_calls_set_epoch(monkeypatch):
             raise AssertionError("no validation batches")
     monkeypatch.setattr(MT, "resolve_device", lambda d: torch.device("cpu"))
     monkeypatch.setattr(MT, "get_dataloaders", lambda *a, **k: (Wrapped(), []))
-    monkeypatch.setattr(MT, "TrainStep", Step)
+    monkeypatch.setattr(MT, "make_train_step", lambda *a, **k: Step())
     monkeypatch.setattr(MT.Models, "init_model", lambda **k: torch.nn.Linear(1, 1))
     monkeypatch.setattr(MT.ModelTrainer, "SaveModel", lambda self, *a: 0.0)
     args = types.SimpleNamespace(train_batch_size=2, lossf="L1", lr=3e-4, arch="SpectralTransformer", use_dwt="Fourier", optim="adam")

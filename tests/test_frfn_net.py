@@ -73,3 +73,44 @@ def test_hip_network_forward_backward_vs_oracle():
     print(f"NewBigFRFNModel 128x128: out {e_y:.2e}; {n_checked} parameter gradients, worst {worst}; {n_dead} unused parameters")
     assert e_y < 1e-4 and worst[1] < 2e-3
     assert n_dead == 8 * 2 + 9 * 8          # norm2 of the 8 encoder blocks; norm_q / norm_kv / two unused projections in the 9 MDASSAs
+
+
+@gpu
+@pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+def test_hip_network_train_steps_vs_oracle():
+    """Two full train steps of --arch NewBigFRFNModel through the generic fused step (trainer.ModuleTrainStep: autograd over the 27
+    launch-plan modules, HIP Charbonnier loss, ONE global-norm clip + Adam over the 27 flat buffers) vs the oracle: torch autograd on the
+    fp32 oracle network + clip_grad_norm_ + torch.optim.Adam.  eval-mode network (DropPath off) so both sides are deterministic."""
+    from underwater_image_restoration_amd.Models import init_model
+    from underwater_image_restoration_amd.trainer import make_train_step, ModuleTrainStep
+    m = init_model("NewBigFRFNModel")
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.is_floating_point() and ".dwt." not in k and ".idwt." not in k}
+    P = D.closed_form_params(shapes, "frfnnet")
+    m.load_state_dict(P, strict=False)
+    m = m.cuda().eval()
+    step = make_train_step(m, "charbonnier", 3e-4)
+    assert isinstance(step, ModuleTrainStep) and len(step.flats) == 27
+    S2 = 128
+    raw = R.closed_form_input(1, 3, S2 * S2, 141).reshape(1, 3, S2, S2)
+    ref = R.closed_form_input(1, 3, S2 * S2, 142).reshape(1, 3, S2, S2)
+    torch.set_num_threads(8)
+    leaves = {k: torch.nn.Parameter(v.clone()) for k, v in P.items()}
+    opt = torch.optim.Adam(list(leaves.values()), lr=3e-4)
+    for k in range(2):
+        loss, norm = step(raw.cuda(), ref.cuda())
+        opt.zero_grad()
+        out = D.frfn_net(raw, leaves)
+        want = torch.sqrt((out - ref) ** 2 + 1e-6).mean()                      # CharbonnierLoss (losses.py:190-192)
+        want.backward()
+        wnorm = torch.nn.utils.clip_grad_norm_([p for p in leaves.values() if p.grad is not None], 1.0)
+        opt.step()
+        print(f"step {k}: loss {float(loss):.7f} (oracle {float(want):.7f}) norm {float(norm):.6f} (oracle {float(wnorm):.6f})")
+        assert abs(float(loss) - float(want)) <= 1e-4 * float(want) and abs(float(norm) - float(wnorm)) <= 2e-3 * float(wnorm)
+    torch.cuda.synchronize()
+    worst = max(float((p.detach().cpu() - leaves[n].detach()).abs().max()) for n, p in m.named_parameters())
+    print("max |param - oracle param| after two Adam steps:", worst)
+    assert worst < 2e-4                                   # Adam's sign-like first steps on near-zero gradient entries (lr 3e-4)
+    vl, vp = step.evaluate(raw.cuda(), ref.cuda())
+    assert np.isfinite(float(vl)) and np.isfinite(float(vp))
+    sd = step.opt.state_dict()
+    assert len(sd["param_groups"][0]["params"]) == len(list(m.parameters())) and len(sd["state"]) == len(list(m.parameters()))

@@ -24,6 +24,58 @@ MFMA_F32_PEAK = 157.3e12
 HBM_PEAK = 8.0e12
 
 
+def bench_net(args):
+    """BASELINE configs[3] on one GPU: --arch NewBigFRFNModel, 256 x 256, bs 8, Charbonnier loss, full train step (forward, loss,
+    backward, clip 1.0, Adam) through trainer.ModuleTrainStep.  value = images/s; roofline: the plans' algorithmic bytes / flops."""
+    import contextlib
+    from underwater_image_restoration_amd.Models import init_model
+    from underwater_image_restoration_amd.trainer import make_train_step
+    B, S = args.batch, args.size
+    torch.manual_seed(1234)
+    with contextlib.redirect_stdout(sys.stderr):
+        model = init_model("NewBigFRFNModel").cuda()
+    model.train()
+    step = make_train_step(model, "charbonnier", 3e-4)
+    g = torch.Generator().manual_seed(1000)
+    raw = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).cuda()
+    ref = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).cuda()
+    for _ in range(args.warmup):
+        loss, norm = step(raw, ref)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, norm = step(raw, ref)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    plans = [p for m in model.plan_modules() for p in m._plans.values()]
+    nbytes, flops, launches = sum(p.alg_bytes() for p in plans), sum(p.flops() for p in plans), sum(len(p.fwd) + len(p.bwd) for p in plans)
+    line = {"metric": "train images/sec, NewBigFRFNModel 256x256 bs=8/GPU, Charbonnier (BASELINE configs[3], one GPU)",
+            "value": B / (ms * 1e-3), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"NewBigFRFNModel {S}x{S} bs={B}, charbonnier, clip 1.0 + Adam 3e-4, DropPath as the reference sets it",
+                       "params": sum(p.numel() for p in model.parameters()), "launches_per_step": launches,
+                       "final_loss": float(loss), "grad_norm": float(norm),
+                       "plan_memory_GB": sum(p.bytes for p in plans) / 1e9},
+            "roofline": {"bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": nbytes / (ms * 1e-3) / HBM_PEAK, "traffic": None, "plan_algorithmic_bytes": nbytes,
+                         "plan_flops": flops, "mfma_frac_fp32": flops / (ms * 1e-3) / MFMA_F32_PEAK,
+                         "note": "bytes / flops as the launch plans count them (every launch's operands once); the network is a chain of "
+                                 "separate HBM-bound launches this round"}}
+    if not args.no_cpu:
+        from oracle import decoder_ref as D
+        cores = min(16, len(os.sched_getaffinity(0)))
+        torch.set_num_threads(cores)
+        model.eval()
+        P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+        xb, pb = raw[:1].cpu(), ref[:1].cpu()
+        t0 = time.perf_counter()
+        D.grads(lambda t, Pp: D.frfn_net(t, Pp), [xb], P, pb)
+        dt = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port",
+                                "sample": f"1 forward+backward of one {S}x{S} image through oracle/decoder_ref.frfn_net (torch CPU fp32, {cores} threads)"}
+    print(json.dumps(line))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dim", type=int, default=32)
@@ -32,10 +84,12 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--what", default="frfn", choices=("frfn", "encoder", "decoder"),
+    ap.add_argument("--what", default="frfn", choices=("frfn", "encoder", "decoder", "net"),
                     help="frfn: one FRFN (block.py:249-282); encoder: one EncoderBlock = LN + 2 FRFN + 2 (L,C) transforms (model.py:16-93); "
                          "decoder: one DecoderBlock(dim, enc_out=True) = 2 LN + MDASSA (2 window attentions + FDFP) + FRFN(2 dim) + proj (model.py:96-160)")
     args = ap.parse_args()
+    if args.what == "net":
+        return bench_net(args)
     dim, hid, B, S = args.dim, 4 * args.dim, args.batch, args.size
     torch.manual_seed(0)
     enc, dec = args.what == "encoder", args.what == "decoder"

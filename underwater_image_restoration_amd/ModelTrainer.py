@@ -30,7 +30,7 @@ from . import Models
 from . import parallel
 from .DataManipulation.DataLoader import get_dataloaders
 from .Losses.losses import LossFunction  # noqa: F401  (re-exported surface)
-from .trainer import TrainStep
+from .trainer import TrainStep, make_train_step  # noqa: F401
 
 REFERENCE_IMAGE_SIZE = 1024      # transforms.Resize((1024, 1024)) hard-coded at src/DataManipulation/DataLoader.py:14
 ADAMW_WEIGHT_DECAY = 0.01        # torch.optim.AdamW default; the reference passes only lr (src/ModelTrainer.py:201)
@@ -99,7 +99,7 @@ class ModelTrainer:
                                                     device_resize=cfg["device_resize"], device=dev)
         print("Initializing model...")
         model = Models.init_model(name=arch, use_dwt=cfg["use_dwt"]).to(dev)
-        step = TrainStep(model, cfg["lossf"], lr=learning_rate, weight_decay=cfg["weight_decay"])
+        step = make_train_step(model, cfg["lossf"], learning_rate, cfg["weight_decay"])
         step.check_memory(cfg["batch_size"], image_size, image_size)
         t0 = time.time()
         directory = f"{args.lossf}-{args.lr}-{args.arch}-{t0}-{getattr(args, 'use_dwt', 'Fourier')}//"

@@ -632,6 +632,8 @@ class _TokenFunction(torch.autograd.Function):
         dx = ctx.plan.backward(dy.contiguous())
         dx = None if dx is None else dx.clone().view(ctx.shape)
         fp = m._flat
+        if m._flat_grads_only:       # a fused optimizer reads the module's flat gradient buffer directly (trainer.ModuleTrainStep)
+            return (dx, None) + (None,) * len(m._names)
         return (dx, None) + tuple(None if n in m._dead else fp.gview(n).clone() for n in m._names)
 
 
@@ -640,6 +642,7 @@ class TokenModule(nn.Module):
     the reference's ``forward(x: (B, L, C))`` contract with L = H*H."""
 
     _dead: frozenset = frozenset()        # parameters the reference never uses (their .grad stays None, as there)
+    _flat_grads_only = False              # True: backward leaves the gradients in the flat buffer only (no per-parameter .grad)
 
     def _init_plumbing(self):
         self._flat: "FlatParams | None" = None

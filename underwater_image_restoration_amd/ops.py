@@ -201,3 +201,58 @@ def axpy_scalar(dst: torch.Tensor, src: torch.Tensor, w: float, first: bool) -> 
 def flat_accumulate_add(src: torch.Tensor, dst: torch.Tensor, n: int) -> None:
     """dst[:n] += src[:n] (flat fp32 buffers, n a multiple of 4)."""
     flat_accumulate(src, dst, n, accumulate=True)
+
+
+class MultiFlatClipAdam:
+    """clip_grad_norm_(max_norm) + Adam / AdamW over SEVERAL flat parameter buffers (one per launch-plan module of a composed
+    network: NewBigFRFNModel has 27) with ONE global gradient norm - the same step tail as FusedClipAdam
+    (src/ModelTrainer.py:87-88,197-204): per buffer a sum-of-squares pass into one slab, one reduction, per buffer the fused
+    clip + Adam kernel with that shared sum.  Per-step scalars by value."""
+
+    def __init__(self, flats, lr: float = 3e-4, betas=(0.9, 0.999), eps: float = 1e-8, max_norm: float = 1.0, weight_decay: float = 0.0):
+        self.flats = list(flats)
+        self.lr, self.initial_lr, self.betas, self.eps, self.max_norm, self.weight_decay = lr, lr, betas, eps, max_norm, weight_decay
+        dev = self.flats[0].device
+        self.m = [torch.zeros(f.total, dtype=torch.float32, device=dev) for f in self.flats]
+        self.v = [torch.zeros(f.total, dtype=torch.float32, device=dev) for f in self.flats]
+        self.slab = torch.empty(len(self.flats) * _SUMSQ_BLOCKS, dtype=torch.float32, device=dev)
+        self.sumsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.norm = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.t = 0
+        self._args = [L.AdamArgs() for _ in self.flats]
+
+    def step(self, lr: "float | None" = None, grad_scale: float = 1.0) -> torch.Tensor:
+        if lr is not None:
+            self.lr = lr
+        self.t += 1
+        bc1, bc2 = 1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t
+        st = _stream()
+        for i, fp in enumerate(self.flats):
+            L.check(lib.uir_sumsq_partials(fp.grad.data_ptr(), fp.total, self.slab.data_ptr() + 4 * i * _SUMSQ_BLOCKS, _SUMSQ_BLOCKS, st),
+                    "uir_sumsq_partials")
+        L.check(lib.uir_reduce_slab(self.slab.data_ptr(), len(self.flats) * _SUMSQ_BLOCKS, 1, self.sumsq.data_ptr(), 1, 0, 1.0, st),
+                "uir_reduce_slab")
+        for a, fp, m, v in zip(self._args, self.flats, self.m, self.v):
+            a.p, a.g, a.m, a.v = fp.flat.data_ptr(), fp.grad.data_ptr(), m.data_ptr(), v.data_ptr()
+            a.sumsq, a.norm_out, a.n, a.hyper = self.sumsq.data_ptr(), self.norm.data_ptr(), fp.total, None
+            a.beta1, a.beta2, a.eps, a.max_norm, a.weight_decay = self.betas[0], self.betas[1], self.eps, self.max_norm, self.weight_decay
+            a.lr, a.bc1, a.bc2, a.gscale = self.lr, bc1, bc2, grad_scale
+            L.check(lib.uir_clip_adam_step(C.byref(a), st), "uir_clip_adam_step")
+        return self.norm
+
+    def state_dict(self):
+        """torch.optim.Adam layout over the concatenation of the modules' parameters in buffer order (= model.parameters() order
+        when the buffers are given in registration order); parameters without a gradient so far have no entry."""
+        state, params, i = {}, [], 0
+        for fp, m, v in zip(self.flats, self.m, self.v):
+            for name in fp.shapes:
+                o, n = fp.slots[name]
+                if self.t > 0:
+                    state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": m[o:o + n].view(fp.shapes[name]).clone(),
+                                "exp_avg_sq": v[o:o + n].view(fp.shapes[name]).clone()}
+                params.append(i)
+                i += 1
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.weight_decay, "amsgrad": False,
+                 "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+                 "decoupled_weight_decay": self.weight_decay > 0, "initial_lr": self.initial_lr, "params": params}
+        return {"state": state, "param_groups": [group]}

@@ -282,3 +282,66 @@ class TrainStep:
             if plan_fits_addressing(mb, H, W) and plan_bytes_estimate(mb, H, W, False) <= 0.95 * have:
                 return mb
         raise RuntimeError(f"SpectralTransformer(HIP): one {H}x{W} image does not fit in HBM for evaluation")
+
+
+class ModuleTrainStep:
+    """The train step (src/ModelTrainer.py:78-90) for a network COMPOSED of launch-plan modules (``--arch NewBigFRFNModel``: 27 of
+    them, each one autograd node): forward through autograd, loss and its gradient by the HIP loss kernels, ``backward`` runs every
+    module's backward launch list and leaves the gradients in the modules' flat buffers, (all-reduce per buffer under data
+    parallelism,) one global-norm clip + Adam over all buffers (ops.MultiFlatClipAdam).  No host synchronisation inside."""
+
+    def __init__(self, model, loss_name: str = "L1", lr: float = 3e-4, max_norm: float = 1.0, process_group=None, weight_decay: float = 0.0):
+        if loss_name not in L.LOSS_KINDS:
+            raise ValueError(f"Unsupported loss: {loss_name}")
+        self.model, self.kind, self.pg = model, L.LOSS_KINDS[loss_name], process_group
+        dev = next(model.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("the MI355X path needs the GPU ('cuda' device in PyTorch-ROCm); there is no CPU fallback")
+        self.mods = model.plan_modules()
+        owned = sum(len(list(m.parameters())) for m in self.mods)
+        if owned != len(list(model.parameters())):
+            raise RuntimeError("every parameter of the network must belong to a launch-plan module")
+        for m in self.mods:
+            m._ensure_flat(dev)
+            m._flat_grads_only = True
+        self.flats = [m._flat for m in self.mods]
+        self.world = parallel.world_size(process_group)
+        if self.world > 1:
+            for fp in self.flats:
+                parallel.broadcast_flat_params(fp.flat, process_group)
+        self.opt = ops.MultiFlatClipAdam(self.flats, lr=lr, max_norm=max_norm, weight_decay=weight_decay)
+        self._one = torch.ones(1, dtype=torch.float32, device=dev)
+
+    def check_memory(self, B: int, H: int, W: int) -> int:
+        return B
+
+    def __call__(self, raw: torch.Tensor, ref: torch.Tensor, lr: "float | None" = None):
+        for m in self.mods:                       # a module whose parameters moved (e.g. .to()) re-flattens: keep the optimizer's view
+            if m._flat is not self.flats[self.mods.index(m)]:
+                raise RuntimeError("the network's parameters were re-allocated after the train step was built")
+        out = self.model(raw)
+        res = ops.loss_sums(out.detach(), ref, self.kind)
+        dout = ops.loss_grad(out.detach(), ref, self._one, self.kind)
+        out.backward(dout)
+        scale = 1.0
+        for fp in self.flats:
+            scale = parallel.allreduce_flat_grads(fp.grad, fp.total, self.pg)
+        norm = self.opt.step(lr=lr, grad_scale=scale)
+        return res[0], norm[0]
+
+    @torch.no_grad()
+    def evaluate(self, raw: torch.Tensor, ref: torch.Tensor, with_ssim: bool = False):
+        out = self.model(raw)
+        res = ops.loss_sums(out, ref, self.kind)
+        if with_ssim:
+            return res[0], res[1], ops.ssim(ref, out, data_range=1.0)
+        return res[0], res[1]
+
+
+def make_train_step(model, loss_name: str, lr: float, weight_decay: float = 0.0):
+    """TrainStep for the single-plan SpectralTransformer, ModuleTrainStep for a network of launch-plan modules."""
+    if hasattr(model, "flat_params"):
+        return TrainStep(model, loss_name, lr=lr, weight_decay=weight_decay)
+    if hasattr(model, "plan_modules"):
+        return ModuleTrainStep(model, loss_name, lr=lr, weight_decay=weight_decay)
+    raise TypeError(f"{type(model).__name__} is not a launch-plan network of this package")
