@@ -355,6 +355,11 @@ int uir_gather_even(const float* src, int lds, int scol, float* dst, int ldd, in
  * dst [B,2H,2W,C] (channel c*4 + dy*2 + dx -> pixel (2h+dy, 2w+dx)); unshuffle is the inverse. */
 int uir_pixel_shuffle(const float* src, int lds, float* dst, int ldd, int dcol, int B, int H, int Wd, int C, void* stream);
 int uir_pixel_unshuffle(const float* src, int lds, int scol, float* dst, int ldd, int B, int H, int Wd, int C, void* stream);
+/* dst[i] = sum_{g < group} src[idx[i * group + g]], entries with idx < 0 count as 0 (i < n; idx is device int32).  Weight
+ * re-layouts of the AST samplers (src/Models/AST.py:408-443): the 4 x 4 stride-2 kernel of Downsample laid out as a 3 x 3
+ * kernel over the 2 x 2-unshuffled image (and its gradient gathered back), the per-channel bias of the ConvTranspose2d of
+ * Upsample repeated over the 2 x 2 output phases (and its gradient summed over them). */
+int uir_gather_sum(const float* src, const int* idx, float* dst, long n, int group, void* stream);
 /* dst[m][dcol + c] = src[m][scol + c] (+ dst if accumulate), c < C: torch.cat joins (:209,264-267) */
 int uir_copy_cols(const float* src, int lds, int scol, float* dst, int ldd, int dcol, long M, int C, int accumulate, void* stream);
 /* slab[block][c] = sum over that block's rows of src[m][col + c]: bias gradients of the 1x1
@@ -535,7 +540,10 @@ typedef struct UirWinAttnArgs {
   int ldq, ldk, ldv, ldo, lddq, lddk, lddv;
   int B, H, W, C, heads, ws;
   float scale;             /* qk_scale or head_dim^-0.5 (:291) */
-  int _pad;
+  int shift;               /* 0: plain windows.  s in (0, ws): the shifted windows of AST's TransformerBlock (src/Models/AST.py:568-616):
+                              window token (ty, tx) of window (wy, wx) is image pixel ((wy ws + ty + s) mod H, (wx ws + tx + s) mod W)
+                              (torch.roll by -s, window_partition, window_reverse, roll by +s - no data moves), and the additive
+                              -100 mask between tokens of different shift regions (:568-589) is applied to the scores */
 } UirWinAttnArgs;
 int uir_winattn_fwd(const UirWinAttnArgs* args, void* stream);
 int uir_winattn_bwd(const UirWinAttnArgs* args, void* stream);

@@ -1,0 +1,240 @@
+"""--arch AST (reference src/Models/AST.py) on the HIP path.
+CPU: the factory builds the reference's 274 state_dict tensors with the same default-initialisation values under a seed
+(tests/golden/ast_manifest.npz <- make_ast_vectors.py).  GPU: every building block and the whole network against outputs and
+gradients recorded from the reference's own classes (tests/golden/ast_ref.npz); training-mode stochastic depth and a larger
+token image against the fp64 oracle (oracle/ast_ref.py, itself pinned to the same fixtures by tests/test_ast_oracle.py)."""
+import ast
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ast_ref as O
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = np.load(os.path.join(HERE, "golden", "ast_ref.npz"))
+MAN = np.load(os.path.join(HERE, "golden", "ast_manifest.npz"))
+S = 16
+gpu = pytest.mark.gpu
+needs_gpu = pytest.mark.skipif(not torch.cuda.is_available(), reason="needs a GPU")
+
+
+def _rel(a, b):
+    a, b = torch.as_tensor(a).detach().double().cpu(), torch.as_tensor(b).detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def _params(tag, salt, dtype=torch.float32):
+    shapes = {n: ast.literal_eval(s) for n, s in zip(G[tag + ".param_names"], G[tag + ".param_shapes"])}
+    return O.closed_form_params(shapes, salt, dtype)
+
+
+def test_factory_builds_the_references_ast():
+    from underwater_image_restoration_amd.Models import init_model
+    torch.manual_seed(1234)
+    m = init_model("AST", use_dwt="Fourier")                    # the reference drops use_dwt for this arch (__init__.py:25-29)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(MAN["keys"]) and len(sd) == 274
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(MAN["shapes"])
+    assert sum(p.numel() for p in m.parameters()) == int(MAN["n_params"]) == 19919507
+    for (k, v), s, a in zip(sd.items(), MAN["sums"], MAN["abs_sums"]):      # same registration order and initialisers: same RNG stream
+        assert abs(float(v.double().sum()) - s) <= 1e-9 * max(1.0, abs(s)), k
+        assert abs(float(v.double().abs().sum()) - a) <= 1e-9 * max(1.0, a), k
+    blocks = [b for l in O.LAYERS for b in m.get_submodule(l).blocks]
+    assert np.allclose([b.drop_prob for b in blocks], MAN["drop_probs"], atol=1e-7)
+    assert [b.shift_size for b in blocks] == [0, 4] * 9 and [b.att for b in blocks] == [False] * 8 + [True] * 10
+    assert len(m.plan_modules()) == 28 and sum(len(list(t.parameters())) for t in m.plan_modules()) == len(list(m.parameters()))
+    with pytest.raises(ValueError):
+        m(torch.zeros(1, 3, 100, 100))
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(1, 3, 128, 128), mask=torch.zeros(1, 1, 128, 128))
+
+
+def _module(tag):
+    import importlib
+    A = importlib.import_module("underwater_image_restoration_amd.Models.AST")
+    blk = lambda dim, heads, shift, att: A.TransformerBlock(dim=dim, input_resolution=(S, S), num_heads=heads, win_size=8, shift_size=shift,
+                                                            drop_path=0.05, token_mlp="leff", att=att, sparseAtt=att)
+    return {"blk_att_s0": lambda: blk(64, 2, 0, True), "blk_att_s4": lambda: blk(64, 2, 4, True), "blk_noatt": lambda: blk(32, 1, 0, False),
+            "down_32": lambda: A.Downsample(32, 64), "up_64": lambda: A.Upsample(64, 32),
+            "inproj": lambda: A.InputProj(in_channel=3, out_channel=32), "outproj": lambda: A.OutputProj(in_channel=64, out_channel=3)}[tag]()
+
+
+CASES = {"blk_att_s0": ("astblk0", (2, S * S, 64, 171), (2, S * S, 64, 172)), "blk_att_s4": ("astblk4", (2, S * S, 64, 171), (2, S * S, 64, 172)),
+         "blk_noatt": ("astblkn", (2, S * S, 32, 173), (2, S * S, 32, 174)), "down_32": ("astdown", (2, S * S, 32, 173), (2, (S // 2) ** 2, 64, 175)),
+         "up_64": ("astup", (2, S * S, 64, 171), (2, 4 * S * S, 32, 176)), "inproj": ("astin", (2, 3, S * S, 177), (2, S * S, 32, 174)),
+         "outproj": ("astout", (2, S * S, 64, 171), (2, 3, S * S, 178))}
+
+
+def test_block_surfaces_are_the_references():
+    for tag in CASES:
+        assert list(_module(tag).state_dict().keys()) == list(G[tag + ".keys"]), tag
+
+
+@gpu
+@needs_gpu
+@pytest.mark.parametrize("tag", list(CASES))
+def test_hip_block_matches_reference(tag):
+    """Output, input gradient and every parameter gradient of the reference's own class (eval mode: DropPath inactive)."""
+    salt, xin, pin = CASES[tag]
+    m = _module(tag)
+    m.load_state_dict(_params(tag, salt), strict=False)
+    m = m.cuda().eval()
+    x = O.closed_form_input(*xin)
+    if tag == "inproj":
+        x = x.reshape(2, 3, S, S)
+    x = x.cuda().requires_grad_(tag != "inproj")
+    want_y = G[tag + ".y"]
+    y = m(x)
+    assert tuple(y.shape) == want_y.shape
+    (y * O.closed_form_input(*pin).cuda().reshape(y.shape)).sum().backward()
+    torch.cuda.synchronize()
+    e_y = _rel(y, want_y)
+    e_dx = _rel(x.grad, G[tag + ".dx0"]) if tag != "inproj" else 0.0
+    worst = max(((n, _rel(p.grad, G[f"{tag}.grad.{n}"])) for n, p in m.named_parameters()), key=lambda t: t[1])
+    print(f"{tag}: y {e_y:.2e} dx {e_dx:.2e} worst param grad {worst}")
+    assert e_y < 5e-5 and e_dx < 1e-4 and worst[1] < 5e-4
+
+
+@gpu
+@needs_gpu
+def test_hip_shifted_block_larger_and_stochastic_depth_vs_oracle():
+    """TransformerBlock(128, heads 4, shift 4) on 40 x 40 tokens (25 windows: every shift region), B = 3, TRAINING mode with
+    drop_path 0.5: the factors the plan drew are handed to the fp64 oracle; bitwise run-to-run for fixed factors."""
+    import importlib
+    A = importlib.import_module("underwater_image_restoration_amd.Models.AST")
+    dim, B, S2 = 128, 3, 40
+    m = A.TransformerBlock(dim=dim, input_resolution=(S2, S2), num_heads=4, shift_size=4, drop_path=0.5, att=True, sparseAtt=True)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.is_floating_point()}
+    P = O.closed_form_params(shapes, "astblk128")
+    m.load_state_dict(P, strict=False)
+    m = m.cuda().train()
+    x, probe = O.closed_form_input(B, S2 * S2, dim, 181), O.closed_form_input(B, S2 * S2, dim, 182)
+    torch.manual_seed(11)
+    xg = x.cuda().requires_grad_(True)
+    y = m(xg)
+    (y * probe.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    plan = next(iter(m._plans.values()))
+    dp = plan.dp_scale.cpu().double()
+    assert set(np.unique(dp.numpy())) <= {0.0, 2.0}
+    fn = lambda t, Pp: O.transformer_block(t, Pp, "", 4, 4, True, dp=(dp[0], dp[1]))
+    y64, dx64, g64 = O.grads(fn, [x.double()], {k: v.double() for k, v in P.items()}, probe.double())
+    worst = max(((n, _rel(p.grad, g64[n])) for n, p in m.named_parameters()), key=lambda t: t[1])
+    print("shifted 40x40 block, training:", _rel(y, y64), _rel(xg.grad, dx64[0]), worst, "factors", dp.tolist())
+    assert _rel(y, y64) < 5e-5 and _rel(xg.grad, dx64[0]) < 1e-4 and worst[1] < 5e-4
+    m.eval()
+    outs = []
+    for _ in range(2):
+        xe = x.cuda().requires_grad_(True)
+        ye = m(xe)
+        (ye * probe.cuda()).sum().backward()
+        outs.append((ye.detach().clone(), xe.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+@gpu
+@needs_gpu
+def test_hip_network_matches_reference():
+    """1 x 3 x 128 x 128 through the whole network, closed-form weights, eval mode: output, every gradient norm and thirteen full
+    gradients recorded from the reference's AST."""
+    from underwater_image_restoration_amd.Models import init_model
+    tag, N = "net128", 128
+    m = init_model("AST")
+    m.load_state_dict(_params(tag, "astnet"), strict=False)
+    m = m.cuda().eval()
+    x = O.closed_form_input(1, 3, N * N, 179).reshape(1, 3, N, N).cuda()
+    probe = O.closed_form_input(1, 3, N * N, 180).reshape(1, 3, N, N).cuda()
+    y = m(x)
+    (y * probe).sum().backward()
+    torch.cuda.synchronize()
+    e_y = _rel(y, G[tag + ".y"])
+    norms = dict(zip([str(n) for n in G[tag + ".grad_names"]], G[tag + ".grad_norms"]))
+    worst_n = ("", 0.0)
+    for n, p in m.named_parameters():
+        assert p.grad is not None, n
+        e = abs(float(p.grad.double().norm()) - norms[n]) / max(norms[n], 1e-12)
+        worst_n = max(worst_n, (n, e), key=lambda t: t[1])
+    worst_g = ("", 0.0)
+    pd = dict(m.named_parameters())
+    for k in G.files:
+        if k.startswith(tag + ".grad.") and k not in (tag + ".grad_names", tag + ".grad_norms"):
+            worst_g = max(worst_g, (k, _rel(pd[k[len(tag) + 6:]].grad, G[k])), key=lambda t: t[1])
+    print(f"AST 128x128: y {e_y:.2e}, worst gradient norm {worst_n}, worst full gradient {worst_g}")
+    assert e_y < 5e-5 and worst_n[1] < 5e-4 and worst_g[1] < 1e-3
+
+
+@gpu
+@needs_gpu
+def test_hip_network_train_steps_vs_torch_adam():
+    """Two train steps (Charbonnier, clip 1.0, Adam 3e-4) of trainer.ModuleTrainStep on --arch AST in eval-mode arithmetic
+    (drop_path_rate 0) vs torch autograd + clip_grad_norm_ + torch.optim.Adam on the fp64 oracle."""
+    from underwater_image_restoration_amd.Models import init_model
+    from underwater_image_restoration_amd.trainer import make_train_step
+    N = 128
+    m = init_model("AST", drop_path_rate=0.0)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.is_floating_point()}
+    P = O.closed_form_params(shapes, "asttrain")
+    m.load_state_dict(P, strict=False)
+    m = m.cuda().train()
+    raw = O.closed_form_input(1, 3, N * N, 191).reshape(1, 3, N, N)
+    ref = O.closed_form_input(1, 3, N * N, 192).reshape(1, 3, N, N)
+    step = make_train_step(m, "charbonnier", 3e-4)
+    leaves = {k: v.double().clone().requires_grad_(True) for k, v in P.items()}
+    opt = torch.optim.Adam(list(leaves.values()), lr=3e-4)
+    for it in range(2):
+        loss, norm = step(raw.cuda(), ref.cuda())
+        opt.zero_grad()
+        out = O.ast_net(raw.double(), leaves)
+        l64 = torch.sqrt((out - ref.double()) ** 2 + 1e-6).mean()
+        l64.backward()
+        n64 = torch.nn.utils.clip_grad_norm_(list(leaves.values()), 1.0)
+        opt.step()
+        print(f"step {it}: loss {float(loss):.8f} / {float(l64):.8f}  norm {float(norm):.6f} / {float(n64):.6f}")
+        assert abs(float(loss) - float(l64)) < 2e-5 * abs(float(l64)) and abs(float(norm) - float(n64)) < 5e-4 * float(n64)
+    worst = max(((n, float((p.detach().cpu().double() - leaves[n].detach()).abs().max())) for n, p in m.named_parameters()), key=lambda t: t[1])
+    print("worst parameter difference after two steps", worst)
+    assert worst[1] < 2e-4
+
+
+@gpu
+@needs_gpu
+def test_model_trainer_drives_ast(tmp_path, capsys):
+    """BASELINE configs[4]'s driver path (fp32, Charbonnier) on a tiny PNG dataset: ModelTrainer(dirs).train(args, "AST", ...) in
+    training mode (stochastic depth on), validation, a checkpoint with the reference's keys and 274 tensor names that reloads
+    bit-identically."""
+    import types
+    from PIL import Image
+    from underwater_image_restoration_amd.ModelTrainer import ModelTrainer
+    from underwater_image_restoration_amd.Models import init_model
+    rng = np.random.RandomState(0)
+    dirs = {}
+    for d in ("a", "b", "ta", "tb"):
+        p = tmp_path / d
+        p.mkdir()
+        dirs[d] = str(p)
+        for i in range(2 if d in ("a", "b") else 1):
+            Image.fromarray(rng.randint(0, 255, (128, 128, 3), dtype=np.uint8)).save(p / f"{i}_img_.png")
+    args = types.SimpleNamespace(train_batch_size=1, lossf="charbonnier", lr=3e-4, arch="AST", use_dwt="Fourier", optim="adam",
+                                 image_size=128, loader_workers=0)
+    cwd = os.getcwd()
+    os.chdir(tmp_path)
+    try:
+        torch.manual_seed(3)
+        model = ModelTrainer(dirs["a"], dirs["b"], dirs["ta"], dirs["tb"]).train(args, "AST", 1, 3e-4, "cuda")
+    finally:
+        os.chdir(cwd)
+    out = capsys.readouterr().out
+    assert "Batch 2/2, Loss:" in out and "Validation PSNR:" in out and "Training completed!" in out
+    ckpts = [os.path.join(r, f) for r, _, fs in os.walk(tmp_path) for f in fs if f.endswith(".pth")]
+    ck = torch.load(sorted(ckpts)[-1], weights_only=True)
+    assert set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss"}
+    assert list(ck["model_state_dict"].keys()) == list(MAN["keys"])
+    fresh = init_model("AST")
+    fresh.load_state_dict(ck["model_state_dict"])
+    fresh = fresh.cuda().eval()
+    model.eval()
+    x = O.closed_form_input(1, 3, 128 * 128, 151).reshape(1, 3, 128, 128).cuda()
+    with torch.no_grad():
+        assert torch.equal(fresh(x), model(x))

@@ -1,14 +1,16 @@
 """Model factory with the reference's surface (src/Models/__init__.py:10-30): ``init_model``,
-``get_names``.  Only ``SpectralTransformer`` is built here (the MI355X hot path); the other
-reference architectures are outside this build's scope and raise with a clear message."""
+``get_names``.  ``SpectralTransformer`` (the MI355X hot path), ``NewBigFRFNModel`` and ``AST`` are built
+here; ``NewModel`` / ``NewBigModel`` crash as shipped in the reference and raise with a clear message."""
 from .SpectralTransformer import SpectralTransformer
 from ..model.model import MyBigFRFNModel as NewBigFRFNModel
+from .AST import AST
 
 __model_factory = {
     "SpectralTransformer": SpectralTransformer,
     "NewBigFRFNModel": NewBigFRFNModel,
+    "AST": AST,
 }
-_REFERENCE_ONLY = ("NewModel", "NewBigModel", "AST")
+_REFERENCE_ONLY = ("NewModel", "NewBigModel")
 _ORDER = ("SpectralTransformer", "NewModel", "NewBigModel", "NewBigFRFNModel", "AST")       # src/Models/__init__.py:10-16
 
 

@@ -158,7 +158,7 @@ class WinAttnArgs(C.Structure):
                 ("dtable_slab", fp), ("dw_slab", fp),
                 ("ldq", C.c_int), ("ldk", C.c_int), ("ldv", C.c_int), ("ldo", C.c_int), ("lddq", C.c_int), ("lddk", C.c_int),
                 ("lddv", C.c_int), ("B", C.c_int), ("H", C.c_int), ("W", C.c_int), ("C", C.c_int), ("heads", C.c_int),
-                ("ws", C.c_int), ("scale", C.c_float), ("_pad", C.c_int)]
+                ("ws", C.c_int), ("scale", C.c_float), ("shift", C.c_int)]
 
 
 class UiqmArgs(C.Structure):
@@ -203,6 +203,7 @@ SIGNATURES = {
     "uir_gather_even": [fp, i32, i32, fp, i32, i32, i32, i32, i32, fp],
     "uir_pixel_shuffle": [fp, i32, fp, i32, i32, i32, i32, i32, i32, fp],
     "uir_pixel_unshuffle": [fp, i32, i32, fp, i32, i32, i32, i32, i32, fp],
+    "uir_gather_sum": [fp, fp, fp, i64, i32, fp],
     "uir_copy_cols": [fp, i32, i32, fp, i32, i32, i64, i32, i32, fp],
     "uir_colsum_partials": [fp, i32, i32, i64, i32, fp, i32, fp],
     "uir_nchw3_to_hwc4": [fp, fp, i32, i32, i32, fp],

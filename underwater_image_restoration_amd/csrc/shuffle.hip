@@ -128,8 +128,25 @@ __global__ void hwc4_to_nchw3_kernel(const float* __restrict__ src, float* __res
   }
 }
 
+// dst[i] = sum_{g < group} src[idx[i * group + g]] (entries with idx < 0 contribute 0): weight re-layouts of the AST samplers
+__global__ void gather_sum_kernel(const float* __restrict__ src, const int* __restrict__ idx, float* __restrict__ dst, long n, int group) {
+  GRID_STRIDE(i, n) {
+    float acc = 0.f;
+    for (int g = 0; g < group; ++g) {
+      const int j = idx[i * group + g];
+      acc += j >= 0 ? src[j] : 0.f;
+    }
+    dst[i] = acc;
+  }
+}
+
 }  // namespace
 
+extern "C" int uir_gather_sum(const float* src, const int* idx, float* dst, long n, int group, void* stream) {
+  UIR_REQUIRE(src && idx && dst && n > 0 && group > 0);
+  hipLaunchKernelGGL(gather_sum_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), src, idx, dst, n, group);
+  return uir_launch_status();
+}
 extern "C" int uir_scatter_even(const float* src, int lds, const float* fill, float* dst, int ldd, int dcol,
                                 int B, int H, int Wd, int C, void* stream) {
   UIR_REQUIRE(src && dst && B > 0 && H > 0 && Wd > 0 && C > 0 && lds >= C && ldd >= dcol + C);

@@ -1,6 +1,7 @@
 // Window attention core of WindowAttention_Sparse (reference src/model/block.py:284-370), forward and
-// backward, for the 8 x 8 non-shifted windows every DecoderBlock / MDASSA of NewBigFRFNModel uses (model.py:517-...: win_size 8,
-// shift_size 0, mask None):
+// backward, for the 8 x 8 windows every DecoderBlock / MDASSA of NewBigFRFNModel uses (model.py:517-...: win_size 8,
+// shift_size 0, mask None) and, with args.shift = 4, the shifted windows + region mask of AST's TransformerBlock
+// (src/Models/AST.py:144-219,568-616: same attention arithmetic, scores + mask before softmax and relu):
 //   attn = (q * scale) k^T + relative_position_bias            [heads, 64, 64] per window          (:340-352)
 //   attn = softmax(attn) * w1 + relu(attn)^2 * w2,  (w1, w2) = softmax(self.w)                      (:361-367)
 //   out  = attn v, heads concatenated along the channels                                             (:370)
@@ -21,7 +22,21 @@ __device__ __forceinline__ long token_row(const UirWinAttnArgs& a, int win, int 
   const int wpr = a.W / WS, wpi = (a.H / WS) * wpr;
   const int b = win / wpi, r = win - b * wpi;
   const int wy = r / wpr, wx = r - wy * wpr;
-  return ((long)b * a.H + wy * WS + (t >> 3)) * a.W + wx * WS + (t & 7);
+  int y = wy * WS + (t >> 3) + a.shift, x = wx * WS + (t & 7) + a.shift;     // shifted windows: the cyclic roll is an address
+  y -= y >= a.H ? a.H : 0;
+  x -= x >= a.W ? a.W : 0;
+  return ((long)b * a.H + y) * a.W + x;
+}
+
+// Shift-region id of window token t (AST.py:571-582: three row bands x three column bands of the ROLLED image, cut at
+// n - ws and n - shift); tokens of different regions get the additive -100 (:586-588).  shift = 0: one region.
+__device__ __forceinline__ int shift_region(const UirWinAttnArgs& a, int win, int t) {
+  const int wpr = a.W / WS, wpi = (a.H / WS) * wpr;
+  const int r = win % wpi;
+  const int y = (r / wpr) * WS + (t >> 3), x = (r % wpr) * WS + (t & 7);
+  const int ry = y < a.H - WS ? 0 : (y < a.H - a.shift ? 1 : 2);
+  const int rx = x < a.W - WS ? 0 : (x < a.W - a.shift ? 1 : 2);
+  return ry * 3 + rx;
 }
 
 // One channel chunk (CH <= 32 floats of head h, starting at column c0) of the 64 window tokens -> LDS rows, unpadded and 16-byte
@@ -78,8 +93,14 @@ __device__ __forceinline__ void score_row(const UirWinAttnArgs& a, int win, int 
   for (int j = 0; j < NT; ++j) {
     const int idx = (yi - (j >> 3) + WS - 1) * RP + (xi - (j & 7) + WS - 1);
     s[j] = fmaf(s[j], a.scale, a.table[idx * a.heads + h]);
-    mx = fmaxf(mx, s[j]);
   }
+  if (a.shift > 0) {                 // wave-uniform branch; the 64 region ids of the window travel by shuffle
+    const int mine = shift_region(a, win, i);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) s[j] += (__shfl(mine, j) != mine) ? -100.0f : 0.0f;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) mx = fmaxf(mx, s[j]);
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
@@ -244,7 +265,7 @@ __global__ void winattn_wgrad_kernel(const float* __restrict__ w, const float* _
 
 int check(const UirWinAttnArgs& a, bool bwd) {
   UIR_REQUIRE(a.Q && a.K && a.V && a.table && a.w && a.B > 0 && a.heads > 0 && a.C > 0 && a.C % a.heads == 0);
-  UIR_REQUIRE(a.ws == WS && a.H % WS == 0 && a.W % WS == 0);
+  UIR_REQUIRE(a.ws == WS && a.H % WS == 0 && a.W % WS == 0 && a.shift >= 0 && a.shift < WS);
   const int hd = a.C / a.heads;
   UIR_REQUIRE(hd == 8 || hd == 16 || hd == 32 || hd == 64 || hd == 128);
   UIR_REQUIRE(a.ldq >= a.C && a.ldk >= a.C && a.ldv >= a.C && ((a.ldq | a.ldk | a.ldv) & 3) == 0);

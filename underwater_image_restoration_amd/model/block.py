@@ -269,8 +269,9 @@ def record_fdfp(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     return y, backward
 
 
-def _winattn_args(q, k, v, table, w, dims, C_, heads):
+def _winattn_args(q, k, v, table, w, dims, C_, heads, shift=0):
     a = L.WinAttnArgs()
+    a.shift = shift
     a.Q, a.K, a.V, a.table, a.w = _ptr(q), _ptr(k), _ptr(v), _ptr(table), _ptr(w)
     a.ldq, a.ldk, a.ldv = _ld(q), _ld(k), _ld(v)
     a.B, a.H, a.W = dims
@@ -279,8 +280,11 @@ def _winattn_args(q, k, v, table, w, dims, C_, heads):
     return a
 
 
-def record_window_attention(rec: Recorder, pfx: str, xq: torch.Tensor, xkv: "torch.Tensor | None", dims, C_: int, heads: int):
-    """Record WindowAttention_Sparse.forward (block.py:336-373) applied to every 8 x 8 window of a token image, mask None.
+def record_window_attention(rec: Recorder, pfx: str, xq: torch.Tensor, xkv: "torch.Tensor | None", dims, C_: int, heads: int,
+                            qname: str = "to_qkv.to_q", kvname: "str | None" = None, shift: int = 0):
+    """Record WindowAttention_Sparse.forward (block.py:336-373) applied to every 8 x 8 window of a token image, mask None;
+    with ``shift`` > 0 the cyclically shifted windows and their region mask of AST's TransformerBlock (src/Models/AST.py:568-616;
+    its LinearProjection names its Linears ``qkv.to_q`` / ``qkv.to_kv``: ``qname`` / ``kvname``).
     xq rows [M, C]; xkv None: keys / values from xq through ``to_qkv.to_kv_from_q`` (:169-174); xkv rows [M, 2C]: through
     ``to_qkv.to_kv`` (:176-187, the frequency cross attention of MDASSA).  Returns (y rows [M, C], backward) where
     backward(dy) -> (d xq, d xkv or None)."""
@@ -288,8 +292,8 @@ def record_window_attention(rec: Recorder, pfx: str, xq: torch.Tensor, xkv: "tor
     M, nwin = B * H * W, B * (H // 8) * (W // 8)
     P, Gr = (lambda n: rec.P(pfx + n)), (lambda n: rec.Gr(pfx + n))
     table, wmix = P("relative_position_bias_table"), P("w")
-    Wq, bq = P("to_qkv.to_q.weight"), P("to_qkv.to_q.bias")
-    kvn = "to_qkv.to_kv" if xkv is not None else "to_qkv.to_kv_from_q"
+    Wq, bq = P(qname + ".weight"), P(qname + ".bias")
+    kvn = kvname or ("to_qkv.to_kv" if xkv is not None else "to_qkv.to_kv_from_q")
     Wkv, bkv = P(kvn + ".weight"), P(kvn + ".bias")
     Wp, bp = P("proj.weight"), P("proj.bias")
     src = xkv if xkv is not None else xq
@@ -299,7 +303,7 @@ def record_window_attention(rec: Recorder, pfx: str, xq: torch.Tensor, xkv: "tor
     rec.gemm(n + "to_q", xq, Wq, q, N=C_, K=C_, w_sn=C_, w_sk=1, bias=bq)
     rec.gemm(n + kvn.split(".")[-1], src, Wkv, kv, N=2 * C_, K=Kin, w_sn=Kin, w_sk=1, bias=bkv)
     k_, v_ = kv[:, :C_], kv[:, C_:]
-    fa = _winattn_args(q, k_, v_, table, wmix, dims, C_, heads)
+    fa = _winattn_args(q, k_, v_, table, wmix, dims, C_, heads, shift)
     fa.O, fa.ldo = _ptr(o), _ld(o)
     rec._hold(q, kv, o, table, wmix)
     rec.keep.append(fa)
@@ -314,7 +318,7 @@ def record_window_attention(rec: Recorder, pfx: str, xq: torch.Tensor, xkv: "tor
             _colsum_wide(rec, n + "proj.db", dy, C_, Gr("proj.bias"))
         rec.gemm(n + "proj.dX", dy, Wp, do, N=C_, K=C_, w_sn=1, w_sk=C_)
         tslab, wslab, wsum = rec.alloc(nwin, 225 * heads), rec.alloc(nwin * heads, 2), rec.alloc(2)
-        ba = _winattn_args(q, k_, v_, table, wmix, dims, C_, heads)
+        ba = _winattn_args(q, k_, v_, table, wmix, dims, C_, heads, shift)
         ba.dO, ba.ldo = _ptr(do), _ld(do)
         ba.dQ, ba.dK, ba.dV = _ptr(dq), _ptr(dkv[:, :C_]), _ptr(dkv[:, C_:])
         ba.lddq, ba.lddk, ba.lddv = _ld(dq), _ld(dkv), _ld(dkv)
@@ -334,8 +338,8 @@ def record_window_attention(rec: Recorder, pfx: str, xq: torch.Tensor, xkv: "tor
             else:
                 rec._reduce(n + "dw.sum", _ptr(wslab), rows, 2, _ptr(wsum), 2, immediate=True)
             rec._op(n + "dw", lib.uir_winattn_wgrad, _ptr(wmix), _ptr(wsum), _ptr(Gr("w")))
-            rec.gram(n + "to_q.dW", dq, xq, Gr("to_qkv.to_q.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
-            _colsum_wide(rec, n + "to_q.db", dq, C_, Gr("to_qkv.to_q.bias"))
+            rec.gram(n + "to_q.dW", dq, xq, Gr(qname + ".weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
+            _colsum_wide(rec, n + "to_q.db", dq, C_, Gr(qname + ".bias"))
             rec.gram(n + "kv.dW", dkv, src, Gr(kvn + ".weight"), N=2 * C_, K=Kin, o_sn=Kin, o_sk=1)
             _colsum_wide(rec, n + "kv.db", dkv, 2 * C_, Gr(kvn + ".bias"))
         rec.gemm(n + "to_q.dX", dq, Wq, dxq, N=C_, K=C_, w_sn=1, w_sk=C_)
@@ -501,7 +505,10 @@ def record_conv3x3(rec: Recorder, name: str, x: torch.Tensor, Wt, bias, Cin: int
         with rec.bulk():
             rec.gram(name + ".dW", dy, x, dW, N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:], n_grp=n_grp, k_grp=k_grp)
             if db is not None:
-                rec.colsum(name + ".db", dy, 0, Cout, db)
+                if Cout <= 256:
+                    rec.colsum(name + ".db", dy, 0, Cout, db)
+                else:
+                    _colsum_wide(rec, name + ".db", dy, Cout, db)
         if not need_dx:
             return None
         dx = rec.alloc(M, Kp)
