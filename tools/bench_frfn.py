@@ -26,14 +26,20 @@ HBM_PEAK = 8.0e12
 
 def bench_net(args):
     """BASELINE configs[3] on one GPU: --arch NewBigFRFNModel, 256 x 256, bs 8, Charbonnier loss, full train step (forward, loss,
-    backward, clip 1.0, Adam) through trainer.ModuleTrainStep.  value = images/s; roofline: the plans' algorithmic bytes / flops."""
+    backward, clip 1.0, Adam) through trainer.ModuleTrainStep.  value = images/s; roofline: the plans' algorithmic bytes / flops.
+    --what ast: BASELINE configs[4]'s network on one GPU: --arch AST, 512 x 512, bs 4, fp32 (the reference has no AMP path:
+    no autocast / GradScaler anywhere in src/), Charbonnier (fflMix needs a VGG16 download and two un-vendored packages)."""
     import contextlib
     from underwater_image_restoration_amd.Models import init_model
     from underwater_image_restoration_amd.trainer import make_train_step
+    arch = "AST" if args.what == "ast" else "NewBigFRFNModel"
+    cfg = "configs[4], fp32" if arch == "AST" else "configs[3]"
+    if arch == "AST" and (args.batch, args.size) == (8, 256):
+        args.batch, args.size = 4, 512
     B, S = args.batch, args.size
     torch.manual_seed(1234)
     with contextlib.redirect_stdout(sys.stderr):
-        model = init_model("NewBigFRFNModel").cuda()
+        model = init_model(arch).cuda()
     model.train()
     step = make_train_step(model, "charbonnier", 3e-4)
     g = torch.Generator().manual_seed(1000)
@@ -49,10 +55,10 @@ def bench_net(args):
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     plans = [p for m in model.plan_modules() for p in m._plans.values()]
     nbytes, flops, launches = sum(p.alg_bytes() for p in plans), sum(p.flops() for p in plans), sum(len(p.fwd) + len(p.bwd) for p in plans)
-    line = {"metric": "train images/sec, NewBigFRFNModel 256x256 bs=8/GPU, Charbonnier (BASELINE configs[3], one GPU)",
+    line = {"metric": f"train images/sec, {arch} {S}x{S} bs={B}/GPU, Charbonnier (BASELINE {cfg}, one GPU)",
             "value": B / (ms * 1e-3), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"NewBigFRFNModel {S}x{S} bs={B}, charbonnier, clip 1.0 + Adam 3e-4, DropPath as the reference sets it",
+            "config": {"workload": f"{arch} {S}x{S} bs={B}, charbonnier, clip 1.0 + Adam 3e-4, DropPath as the reference sets it",
                        "params": sum(p.numel() for p in model.parameters()), "launches_per_step": launches,
                        "final_loss": float(loss), "grad_norm": float(norm),
                        "plan_memory_GB": sum(p.bytes for p in plans) / 1e9},
@@ -62,17 +68,18 @@ def bench_net(args):
                          "note": "bytes / flops as the launch plans count them (every launch's operands once); the network is a chain of "
                                  "separate HBM-bound launches this round"}}
     if not args.no_cpu:
-        from oracle import decoder_ref as D
+        from oracle import decoder_ref as D, ast_ref as OA
+        net_fn = OA.ast_net if arch == "AST" else D.frfn_net
         cores = min(16, len(os.sched_getaffinity(0)))
         torch.set_num_threads(cores)
         model.eval()
         P = {k: v.detach().cpu() for k, v in model.state_dict().items()}
         xb, pb = raw[:1].cpu(), ref[:1].cpu()
         t0 = time.perf_counter()
-        D.grads(lambda t, Pp: D.frfn_net(t, Pp), [xb], P, pb)
+        D.grads(lambda t, Pp: net_fn(t, Pp), [xb], P, pb)
         dt = time.perf_counter() - t0
         line["cpu_baseline"] = {"value": 1.0 / dt, "unit": "images/s", "cores": cores, "kind": "port",
-                                "sample": f"1 forward+backward of one {S}x{S} image through oracle/decoder_ref.frfn_net (torch CPU fp32, {cores} threads)"}
+                                "sample": f"1 forward+backward of one {S}x{S} image through oracle/{net_fn.__module__.split('.')[-1]}.{net_fn.__name__} (torch CPU fp32, {cores} threads)"}
     print(json.dumps(line))
 
 
@@ -84,11 +91,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
-    ap.add_argument("--what", default="frfn", choices=("frfn", "encoder", "decoder", "net"),
+    ap.add_argument("--what", default="frfn", choices=("frfn", "encoder", "decoder", "net", "ast"),
                     help="frfn: one FRFN (block.py:249-282); encoder: one EncoderBlock = LN + 2 FRFN + 2 (L,C) transforms (model.py:16-93); "
                          "decoder: one DecoderBlock(dim, enc_out=True) = 2 LN + MDASSA (2 window attentions + FDFP) + FRFN(2 dim) + proj (model.py:96-160)")
     args = ap.parse_args()
-    if args.what == "net":
+    if args.what in ("net", "ast"):
         return bench_net(args)
     dim, hid, B, S = args.dim, 4 * args.dim, args.batch, args.size
     torch.manual_seed(0)
@@ -147,7 +154,8 @@ def main():
         line["roofline"]["note"] = ("algorithmic flops count the (L,C) transforms as FFTs (5 N log2 N); the plan executes the length-L "
                                     "transform as two dense 256-point MFMA contractions: executed_flops is what the launches do")
     if not args.no_cpu and dec:
-        from oracle import decoder_ref as D
+        from oracle import decoder_ref as D, ast_ref as OA
+        net_fn = OA.ast_net if arch == "AST" else D.frfn_net
         cores = min(16, len(os.sched_getaffinity(0)))
         torch.set_num_threads(cores)
         P = {n: v.detach().cpu() for n, v in m.state_dict().items()}

@@ -16,7 +16,7 @@ OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libuir_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-SOURCES = ["gemm", "gram", "dwconv", "gdfn", "layernorm", "attn", "spectral", "shuffle", "resize", "colsum", "loss", "ssim", "uiqm", "frfn", "tokenfft", "winattn", "optim", "abi_layout"]
+SOURCES = ["gemm", "tiled", "gram", "dwconv", "gdfn", "layernorm", "attn", "spectral", "shuffle", "resize", "colsum", "loss", "ssim", "uiqm", "frfn", "tokenfft", "winattn", "optim", "abi_layout"]
 
 
 def source_sha() -> str:

@@ -778,6 +778,24 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ntap = a.ntap > 0 ? a.ntap : a.taps;
   {
+    // Wide plain Linear layers (NewBigFRFNModel / AST: K, N up to 2048) on the LDS-tiled kernel of csrc/tiled.hip.  The panel
+    // kernel below keeps ALL K of one column group in LDS (fine for the SpectralTransformer's K <= 340), its un-staged fallback
+    // ran the K >= 1024 layers at 22-29 TFLOP/s.  UIR_TILED_MINK (default 256): smallest K sent there; 0 disables.
+    static const int mink = getenv("UIR_TILED_MINK") ? atoi(getenv("UIR_TILED_MINK")) : 256;
+    const bool w_kc = a.w_sk == 1 && (a.w_sn & 3) == 0, w_nc = a.w_sn == 1 && (a.w_sk & 3) == 0 && (a.N & 3) == 0;
+    if (mink > 0 && a.K >= mink && a.N >= 128 && a.M >= 256 && a.taps == 1 && a.batches == 1 && a.pro == UIR_PRO_NONE &&
+        a.epi == UIR_EPI_PLAIN && (a.act == UIR_ACT_NONE || a.act == UIR_ACT_GELU) && a.n_grp_pad <= 0 && a.k_grp_pad <= 0 &&
+        (a.K & 3) == 0 && (w_kc || w_nc) && uir_aligned16(a.W)) {
+      UirTiledArgs t{};
+      t.A = a.X; t.sa_i = a.ldx; t.sa_k = 1;
+      t.B = a.W; t.sb_j = a.w_sn; t.sb_k = a.w_sk;
+      t.D = a.Y; t.sd_i = a.ldy; t.sd_j = 1; t.d_split = 0;
+      t.MM = a.M; t.NN = a.N; t.KK = a.K; t.k_per_split = a.K;
+      t.bias = a.bias; t.R = a.R; t.ldr = a.ldr; t.pre_out = a.pre_out; t.ldpre = a.ldpre; t.act = a.act;
+      return uir_tiled_gemm(t, st);
+    }
+  }
+  {
     const int K8 = (a.K + 7) & ~7;
     // A 3x3 convolution whose nine-tap panel of even ONE 32-column tile does not fit the LDS path (K > 80: ups_1.Sups,
     // ups_{1,2}.Sups input gradients, 9.7 GFLOP each) runs as launches over tap groups of <= 50 KB that accumulate into Y;

@@ -471,6 +471,21 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
   UIR_REQUIRE((long)a.M * a.lda < (1L << 30) && (long)a.M * a.ldb < (1L << 30));   // 32-bit element offsets per batch
   const bool extras = a.sq_a_off >= 0 || a.sq_b_off >= 0 || a.cs_a_off >= 0;
   UIR_REQUIRE(!extras || a.pro_b == UIR_GRAM_PRO_NONE);
+  {
+    // Wide weight gradients (Linear layers of NewBigFRFNModel / AST, N and K >= UIR_TILED_GRAM_MIN, default 128): 128 x 128
+    // output tiles on the LDS-tiled kernel of csrc/tiled.hip, one k split per chunk - same partial-slab contract.
+    static const int minw = getenv("UIR_TILED_GRAM_MIN") ? atoi(getenv("UIR_TILED_GRAM_MIN")) : 128;
+    if (minw > 0 && a.N >= minw && a.K >= minw && a.taps == 1 && a.batches == 1 && a.pro_b == UIR_GRAM_PRO_NONE && !extras &&
+        a.n_grp_pad <= 0 && a.k_grp_pad <= 0 && ((a.N | a.K | a.lda | a.ldb | a.rows_per_chunk | a.M) & 3) == 0 &&
+        uir_aligned16(a.A) && uir_aligned16(a.B)) {
+      UirTiledArgs t{};
+      t.A = a.A; t.sa_i = 1; t.sa_k = a.lda;
+      t.B = a.B; t.sb_j = 1; t.sb_k = a.ldb;
+      t.D = a.slab; t.sd_i = a.o_sn; t.sd_j = a.o_sk; t.d_split = a.slab_stride;
+      t.MM = a.N; t.NN = a.K; t.KK = a.M; t.k_per_split = a.rows_per_chunk;
+      return uir_tiled_gemm(t, st);
+    }
+  }
   const int tn_tiles = (a.N + 31) / 32, tk_tiles = (a.K + 31) / 32;
   static const bool cols9 = !(getenv("UIR_GRAM_COLS9") && atoi(getenv("UIR_GRAM_COLS9")) == 0);   // A/B aid
   if (cols9 && a.taps == 9 && 9 * a.N <= 160 && tk_tiles == 1 && !extras && a.pro_b == UIR_GRAM_PRO_NONE) {

@@ -71,3 +71,22 @@ __device__ __forceinline__ float uir_wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+
+// Internal (not part of the C ABI): the LDS-tiled wide contraction of csrc/tiled.hip, reached through uir_gemm / uir_gram.
+//   D[split][i * sd_i + j * sd_j] = epilogue( sum_{k in split} A[i * sa_i + k * sa_k] * B[j * sb_j + k * sb_k] )
+// Each operand has sa_k == 1 (k-contiguous) or sa_i == 1 (index-contiguous); 16-byte aligned, strides multiples of 4.
+struct UirTiledArgs {
+  const float* A;
+  const float* B;
+  float* D;
+  long sa_i, sa_k, sb_j, sb_k, sd_i, sd_j;
+  long d_split;            // floats between the partial outputs of consecutive k splits
+  int MM, NN, KK;
+  int k_per_split;         // multiple of 4; ceil(KK / k_per_split) splits
+  const float* bias;       // [NN] or null
+  const float* R;          // residual [MM][ldr] or null
+  float* pre_out;          // pre-activation copy [MM][ldpre] or null
+  long ldr, ldpre;
+  int act;                 // UIR_ACT_NONE / UIR_ACT_GELU
+};
+int uir_tiled_gemm(const UirTiledArgs& t, hipStream_t st);
