@@ -8,6 +8,10 @@ run() { n=$1; shift
 }
 run tcc1 FETCH_SIZE GRBM_GUI_ACTIVE
 run tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-run ta TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_TA_BUSY
+# the four TA counters in ONE pass exceed what rocprofv3 can program (round 1: 'error code 38: Request exceeds the capabilities of the
+# hardware'): one derived TA sum per pass
+run ta1 TA_TA_BUSY_sum
+run ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum
+run ta3 TA_DATA_STALLED_BY_TC_CYCLES_sum
 run tcc3 TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_WRITE_sum
 run tcp TCP_PENDING_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_sum TCP_TCR_TCP_STALL_CYCLES_sum

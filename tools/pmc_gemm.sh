@@ -13,4 +13,6 @@ run sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM
 run sq3 SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_BRANCH SQ_IFETCH
 run tcc1 FETCH_SIZE GRBM_GUI_ACTIVE
 run tcc2 WRITE_SIZE TCC_HIT_sum TCC_MISS_sum
-run ta TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum GRBM_TA_BUSY
+run ta1 TA_TA_BUSY_sum
+run ta2 TA_ADDR_STALLED_BY_TC_CYCLES_sum
+run ta3 TA_DATA_STALLED_BY_TC_CYCLES_sum
