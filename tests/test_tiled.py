@@ -71,3 +71,37 @@ def test_wide_weight_gradient(M, N, K):
     again = out.clone()
     r.run(r.fwd)
     assert torch.equal(out, again)              # fixed summation order: bitwise run-to-run
+
+
+def test_split_bf16_mode_is_f32_accurate():
+    """UIR_TILED_SPLIT=1 (opt-in): the same contractions on the bf16 matrix pipe with every f32 operand split into three bf16 pieces
+    and six products per pair (csrc/tiled.hip): against fp64 the error must stay at the f32 kernel's level (<= 3e-6 of the largest
+    output here; measured 0.6-1.9e-6 for both).  The variable is read once per process: run in a child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from underwater_image_restoration_amd.engine import Recorder\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "M, K, N = 4096, 1024, 512\n"
+        "x = (torch.rand(M, K, generator=g, dtype=torch.float64) * 2 - 1) * torch.exp2(torch.randint(-6, 7, (M, 1), generator=g).double())\n"
+        "w = (torch.rand(N, K, generator=g, dtype=torch.float64) * 2 - 1) * K ** -0.5\n"
+        "dy = torch.rand(M, N, generator=g, dtype=torch.float64) * 2 - 1\n"
+        "r = Recorder('cuda', scratch_floats=16 << 20)\n"
+        "X, W, DY = x.float().cuda(), w.float().cuda(), dy.float().cuda()\n"
+        "Y, DX, DW = r.alloc(M, N), r.alloc(M, K), r.alloc(N, K)\n"
+        "r.gemm('f', X, W, Y, N=N, K=K, w_sn=K, w_sk=1)\n"
+        "r.gemm('dx', DY, W, DX, N=K, K=N, w_sn=1, w_sk=K)\n"
+        "r.gram('dw', DY, X, DW, N=N, K=K, o_sn=K, o_sk=1, own_slab=True)\n"
+        "r.run(r.fwd); torch.cuda.synchronize()\n"
+        "xd, wd, dyd = X.double().cpu(), W.double().cpu(), DY.double().cpu()\n"
+        "for got, ref in ((Y, xd @ wd.T), (DX, dyd @ wd), (DW, dyd.T @ xd)):\n"
+        "    e = float((got.double().cpu() - ref).abs().max() / ref.abs().max())\n"
+        "    print('ERR %%.3e' %% e)\n"
+        "    assert e < 3e-6, e\n" % root)
+    env = dict(os.environ, UIR_TILED_SPLIT="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ERR") == 3

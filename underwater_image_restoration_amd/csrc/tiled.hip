@@ -13,6 +13,7 @@
 // 16 LDS reads per wave and chunk.  Split-k over blockIdx.y writes partial slabs (deterministic; summed by uir_reduce_slab).
 #include "uir_common.h"
 #include "../../include/uir_kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -154,6 +155,192 @@ __global__ __launch_bounds__(256, 2) void uir_tiled_kernel(const UirTiledArgs t)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------
+// The same contraction on the BF16 matrix pipe with SPLIT f32 operands (opt-in: UIR_TILED_SPLIT=1).  On gfx950 the f32 MFMA runs at
+// 1/16 of the bf16 MFMA rate (64 vs 1024 FLOP/clk/SIMD).  An f32 value is the exact sum of three bf16 pieces (8 significant bits each:
+// hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits of x - hi - mid; the subtractions are exact), a bf16 x bf16 product
+// is exact in f32, so   a b = sum over the six piece pairs (h,h) (h,m) (m,h) (h,l) (l,h) (m,m)  up to 3 * 2^-24 |a b| (the dropped m l, l m,
+// l l terms) - the rounding level of an f32 multiply.  Six v_mfma_f32_32x32x16_bf16 (6 * 32 cycles for k = 16) replace eight
+// v_mfma_f32_32x32x2_f32 (8 * 64 cycles); accumulation stays in f32.  The split is done ONCE per element, when the chunk is staged:
+// LDS holds three bf16 planes per operand, [row][k] with 80-byte rows (conflict-free ds_read_b128 of a lane's 8 consecutive k).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SROW = 40;                   // bf16 per LDS row (32 + 8 pad)
+constexpr int SPLANE = TM * SROW;          // bf16 per plane
+constexpr int SSTAGE = 3 * SPLANE;         // bf16 per operand per stage
+
+__device__ int g_split_fake = 0;      // timing experiment only (UIR_TILED_SPLIT=2): skip the split arithmetic, results are WRONG
+__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __float_as_uint(x) & 0xffff0000u;
+  if (g_split_fake) { m = h; l = h; return; }
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xffff0000u;
+  const float r2 = r1 - __uint_as_float(m);
+  l = __float_as_uint(r2) & 0xffff0000u;
+}
+__device__ __forceinline__ uint32_t pack2(uint32_t lo_elem, uint32_t hi_elem) { return (hi_elem & 0xffff0000u) | (lo_elem >> 16); }
+
+// four consecutive k of one row -> 8 bytes in each of the three planes
+__device__ __forceinline__ void store_row4(unsigned short* s, int row, int k, const float (&x)[4]) {
+  uint32_t h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split3(x[e], h[e], m[e], l[e]);
+  unsigned short* d = s + row * SROW + k;
+  *reinterpret_cast<uint2*>(d) = make_uint2(pack2(h[0], h[1]), pack2(h[2], h[3]));
+  *reinterpret_cast<uint2*>(d + SPLANE) = make_uint2(pack2(m[0], m[1]), pack2(m[2], m[3]));
+  *reinterpret_cast<uint2*>(d + 2 * SPLANE) = make_uint2(pack2(l[0], l[1]), pack2(l[2], l[3]));
+}
+
+// global -> registers -> split -> LDS for one operand chunk of 128 x 32.
+// KC (k-contiguous): 4 float4 per thread, each 4 consecutive k of one row.  IC (index-contiguous): one 4 (k) x 4 (index) block per
+// thread = 4 float4 along the index at 4 consecutive k, transposed in registers.
+template <bool KC>
+struct SplitLoader {
+  const float* p[4];
+  int kk[4], row0;
+  __device__ __forceinline__ void init(const float* base, long s_idx, int idx0, int n_idx, int tid) {
+    if (KC) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q;
+        int r = idx0 + (e >> 3);
+        r = r < n_idx ? r : n_idx - 1;
+        kk[q] = 4 * (e & 7);
+        p[q] = base + (long)r * s_idx;
+      }
+    } else {
+      int i = idx0 + 4 * (tid & 31);
+      row0 = 4 * (tid & 31);
+      i = i + 4 <= n_idx ? i : n_idx - 4;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { kk[q] = 4 * (tid >> 5) + q; p[q] = base + i; }
+    }
+  }
+  __device__ __forceinline__ void load(float4 (&v)[4], int k0, int ke, long s_k) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + kk[q];
+      const int kc = k < ke ? k : ke - 4;
+      const float4 t = *reinterpret_cast<const float4*>(KC ? p[q] + kc : p[q] + (long)kc * s_k);
+      v[q] = k < ke ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(unsigned short* s, const float4 (&v)[4], int tid) const {
+    if (KC) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = tid + 256 * q;
+        const float x[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+        store_row4(s, e >> 3, 4 * (e & 7), x);
+      }
+    } else {
+      const int k = 4 * (tid >> 5);
+      const float r0[4] = {v[0].x, v[1].x, v[2].x, v[3].x}, r1[4] = {v[0].y, v[1].y, v[2].y, v[3].y};
+      const float r2[4] = {v[0].z, v[1].z, v[2].z, v[3].z}, r3[4] = {v[0].w, v[1].w, v[2].w, v[3].w};
+      store_row4(s, row0, k, r0);
+      store_row4(s, row0 + 1, k, r1);
+      store_row4(s, row0 + 2, k, r2);
+      store_row4(s, row0 + 3, k, r3);
+    }
+  }
+};
+
+__device__ __forceinline__ bf16x8 sfrag(const unsigned short* s, int row, int ks, int h2) {
+  return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(s + row * SROW + 16 * ks + 8 * h2));
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void uir_tiled_split_kernel(const UirTiledArgs t) {
+  extern __shared__ float smem[];
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);       // [SSTAGE]: one stage (3 planes x 2 operands = 60 KB, 2 WGs / CU);
+  unsigned short* Bs = As + SSTAGE;                                   // the next chunk waits in registers, the other workgroup of the CU
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;   // covers the two barriers per chunk
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_j = (t.NN + TN - 1) / TN;
+  const int i0 = (blockIdx.x / tiles_j) * TM, j0 = (blockIdx.x % tiles_j) * TN;
+  const int split = blockIdx.y;
+  const int ks = split * t.k_per_split;
+  const int ke = ks + t.k_per_split < t.KK ? ks + t.k_per_split : t.KK;
+
+  SplitLoader<AKC> la;
+  SplitLoader<BKC> lb;
+  la.init(t.A, t.sa_i, i0, t.MM, tid);
+  lb.init(t.B, t.sb_j, j0, t.NN, tid);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 va[4], vb[4];
+  la.load(va, ks, ke, t.sa_k);
+  lb.load(vb, ks, ke, t.sb_k);
+  la.store(As, va, tid);
+  lb.store(Bs, vb, tid);
+  __syncthreads();
+  for (int k0 = ks; k0 < ke; k0 += TK) {
+    const bool more = k0 + TK < ke;
+    if (more) {
+      la.load(va, k0 + TK, ke, t.sa_k);
+      lb.load(vb, k0 + TK, ke, t.sb_k);
+    }
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          fa[x][pl] = sfrag(As + pl * SPLANE, 64 * wr + 32 * x + li, kq, h2);
+          fb[x][pl] = sfrag(Bs + pl * SPLANE, 64 * wc + 32 * x + li, kq, h2);
+        }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          f32x16 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], c, 0, 0, 0);     // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], c, 0, 0, 0);
+          acc[a][b] = c;
+        }
+    }
+    __syncthreads();                 // every wave has read this chunk
+    if (more) {
+      la.store(As, va, tid);
+      lb.store(Bs, vb, tid);
+    }
+    __syncthreads();
+  }
+
+  float* D = t.D + (long)split * t.d_split;
+  const bool gelu = t.act == UIR_ACT_GELU;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = j0 + 64 * wc + 32 * b + li;
+      const float bj = (t.bias && col < t.NN) ? t.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 64 * wr + 32 * a + uir_mfma_row(r, h2);
+        if (row < t.MM && col < t.NN) {
+          float v = acc[a][b][r] + bj;
+          if (t.pre_out) t.pre_out[(long)row * t.ldpre + col] = v;
+          if (gelu) v = uir_gelu(v);
+          if (t.R) v += t.R[(long)row * t.ldr + col];
+          D[(long)row * t.sd_i + (long)col * t.sd_j] = v;
+        }
+      }
+    }
+}
+
 }  // namespace
 
 int uir_tiled_gemm(const UirTiledArgs& t, hipStream_t st) {
@@ -169,6 +356,21 @@ int uir_tiled_gemm(const UirTiledArgs& t, hipStream_t st) {
   const dim3 grid(((t.MM + TM - 1) / TM) * ((t.NN + TN - 1) / TN), nsplit);
   const size_t lds = (size_t)4 * STAGE * sizeof(float);
   static_assert(STAGE >= TK * IP, "stage size");
+  // opt-in: split-bf16 operands on the bf16 matrix pipe (see uir_tiled_split_kernel); needs whole 4-row blocks of the
+  // index-contiguous operands, which the checks above already guarantee
+  static const int split = getenv("UIR_TILED_SPLIT") ? atoi(getenv("UIR_TILED_SPLIT")) : 0;
+  if (split) {
+    static bool told = false;
+    if (!told) { const int f = split == 2; hipMemcpyToSymbol(HIP_SYMBOL(g_split_fake), &f, sizeof(int)); told = true; }
+    const size_t lds2 = (size_t)2 * SSTAGE * sizeof(unsigned short);
+#define UIR_TS(AK, BK) hipLaunchKernelGGL((uir_tiled_split_kernel<AK, BK>), grid, dim3(256), lds2, st, t)
+    if (akc && bkc) UIR_TS(true, true);
+    else if (akc) UIR_TS(true, false);
+    else if (bkc) UIR_TS(false, true);
+    else UIR_TS(false, false);
+#undef UIR_TS
+    return uir_launch_status();
+  }
 #define UIR_TL(AK, BK) hipLaunchKernelGGL((uir_tiled_kernel<AK, BK>), grid, dim3(256), lds, st, t)
   if (akc && bkc) UIR_TL(true, true);
   else if (akc) UIR_TL(true, false);
