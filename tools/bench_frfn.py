@@ -154,8 +154,7 @@ def main():
         line["roofline"]["note"] = ("algorithmic flops count the (L,C) transforms as FFTs (5 N log2 N); the plan executes the length-L "
                                     "transform as two dense 256-point MFMA contractions: executed_flops is what the launches do")
     if not args.no_cpu and dec:
-        from oracle import decoder_ref as D, ast_ref as OA
-        net_fn = OA.ast_net if arch == "AST" else D.frfn_net
+        from oracle import decoder_ref as D
         cores = min(16, len(os.sched_getaffinity(0)))
         torch.set_num_threads(cores)
         P = {n: v.detach().cpu() for n, v in m.state_dict().items()}
