@@ -792,6 +792,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
       t.D = a.Y; t.sd_i = a.ldy; t.sd_j = 1; t.d_split = 0;
       t.MM = a.M; t.NN = a.N; t.KK = a.K; t.k_per_split = a.K;
       t.bias = a.bias; t.R = a.R; t.ldr = a.ldr; t.pre_out = a.pre_out; t.ldpre = a.ldpre; t.act = a.act;
+      t.allow_split = a.K >= 512 || a.N >= 256;
       return uir_tiled_gemm(t, st);
     }
   }

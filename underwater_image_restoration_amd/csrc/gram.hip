@@ -483,6 +483,7 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
       t.B = a.B; t.sb_j = 1; t.sb_k = a.ldb;
       t.D = a.slab; t.sd_i = a.o_sn; t.sd_j = a.o_sk; t.d_split = a.slab_stride;
       t.MM = a.N; t.NN = a.K; t.KK = a.M; t.k_per_split = a.rows_per_chunk;
+      t.allow_split = a.N >= 256 || a.K >= 256;
       return uir_tiled_gemm(t, st);
     }
   }

@@ -88,5 +88,6 @@ struct UirTiledArgs {
   float* pre_out;          // pre-activation copy [MM][ldpre] or null
   long ldr, ldpre;
   int act;                 // UIR_ACT_NONE / UIR_ACT_GELU
+  int allow_split;         // caller's mark for the split-bf16 variant (wide layers only), see uir_tiled_gemm
 };
 int uir_tiled_gemm(const UirTiledArgs& t, hipStream_t st);
