@@ -585,7 +585,8 @@ class Recorder:
             groups = ((tn + 1) // 2) * ((tk + 1) // 2)
         if taps == 9 and tn == 1 and tk == 1 and not extras and pro_b == 0:
             nch, rpc = self._chunks(M, 1, batches)          # all 9 taps handled inside one workgroup
-        elif taps == 1 and batches == 1 and pro_b == 0 and not extras and min(N, K) >= 128 and not (n_grp[1] or k_grp[1]):
+        elif (taps == 1 and batches == 1 and pro_b == 0 and not extras and min(N, K) >= 128 and not (n_grp[1] or k_grp[1])
+              and shared_slab is None and fused_out is None):
             # wide weight gradient on csrc/tiled.hip (128 x 128 output tiles, one k split per chunk): enough chunks for ~3 workgroups
             # per CU, at least 512 token rows each
             t128 = ((N + 127) // 128) * ((K + 127) // 128)
