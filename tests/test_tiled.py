@@ -105,3 +105,25 @@ def test_split_bf16_mode_is_f32_accurate():
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ERR") == 3
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 10, 6, 512, 72), (1, 16, 16, 512, 200), (5, 60, 56, 256, 128)])
+def test_wide_conv3x3_forward_and_input_gradient(B, H, W, Cin, Cout):
+    """3 x 3 convolutions with >= 128 input channels (the sampler convolutions) as ONE launch of the tiled kernel: native weight
+    layout [Cout][Cin][3][3] read at its own strides, neighbour rows zero outside the image, pixel counts that are no multiple of
+    the 128-row tile, bias + residual; the input gradient through the same entry with mirrored taps."""
+    x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=2) * (9 * Cin) ** -0.5
+    bias, res = rnd(Cout, seed=4), rnd(B * H * W, Cout, seed=5)
+    y = F.conv2d(x, w, bias, padding=1)
+    dy = rnd(*y.shape, seed=3)
+    (dx,) = torch.autograd.grad((y * dy).sum(), x)
+    hwc = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+    r = Recorder(DEV, scratch_floats=1 << 20)
+    Wd = dev(w)
+    Y, dX = r.alloc(B * H * W, Cout), r.alloc(B * H * W, Cin)
+    r.gemm("c", dev(hwc(x.detach())), Wd, Y, N=Cout, K=Cin, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=(H, W), bias=dev(bias), R=dev(res))
+    r.gemm("c.dx", dev(hwc(dy)), Wd, dX, N=Cin, K=Cout, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=(H, W))
+    r.run(r.fwd)
+    assert rel(Y, hwc(y.detach()) + res) < 2e-5
+    assert rel(dX, hwc(dx)) < 2e-5

@@ -795,6 +795,22 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
       t.allow_split = a.K >= 512 || a.N >= 256;
       return uir_tiled_gemm(t, st);
     }
+    // 3 x 3 convolutions with many input channels (sampler convolutions of AST / NewBigFRFNModel, the SpectralTransformer's UpSample1):
+    // one launch on the LDS-tiled kernel instead of tap-group launches / the un-staged fallback.  UIR_TILED_CONV_MINK (default 256; 0 off);
+    // the SpectralTransformer's own 3 x 3 convolutions (K <= 256 on <= 16 384 pixels, side lane) stay on the tap-group path they were
+    // tuned and measured on
+    static const int cmink = getenv("UIR_TILED_CONV_MINK") ? atoi(getenv("UIR_TILED_CONV_MINK")) : 256;
+    if (cmink > 0 && a.taps == 9 && a.ntap <= 0 && a.K >= cmink && (a.K >= 512 || a.M > 16384) && a.N >= 64 && a.batches == 1 && a.pro == UIR_PRO_NONE &&
+        a.epi == UIR_EPI_PLAIN && a.act == UIR_ACT_NONE && a.n_grp_pad <= 0 && a.k_grp_pad <= 0 && (a.K & 3) == 0) {
+      UirTiledArgs t{};
+      t.A = a.X; t.sa_i = a.ldx; t.sa_k = 1;
+      t.B = a.W; t.sb_j = a.w_sn; t.sb_k = a.w_sk; t.sb_t = a.w_st;
+      t.D = a.Y; t.sd_i = a.ldy; t.sd_j = 1;
+      t.MM = a.M; t.NN = a.N; t.KK = a.K; t.k_per_split = a.K;
+      t.bias = a.bias; t.R = a.R; t.ldr = a.ldr; t.act = a.act;
+      t.H = a.H; t.Wd = a.Wd; t.flip = a.flip;
+      return uir_tiled_conv3x3(t, st);
+    }
   }
   {
     const int K8 = (a.K + 7) & ~7;

@@ -157,6 +157,163 @@ __global__ __launch_bounds__(256, 2) void uir_tiled_kernel(const UirTiledArgs t)
 
 
 // ------------------------------------------------------------------------------------------------------------------------
+// Dense 3 x 3 convolution with MANY input channels on the same tiles (Conv2d of the samplers: AST.py:408-424 after the re-layout of
+// Models/AST.py, src/model/block.py:107-153; the SpectralTransformer's UpSample1, SpectralTransformer.py:191-198):
+//     Y[m][n] = sum_tap sum_k X[nbr(m, tap)][k] * W[n * sb_j + k * sb_k + wt(tap) * sb_t]        (uir_gemm's taps = 9 contract)
+// A chunks are rows of the neighbour pixel (zero outside the image), B chunks are read with scalar loads at the weight's own strides
+// (native [N][K][3][3]: k stride 9 - L2-resident, 16 loads per thread and chunk) into the k-contiguous LDS layout.  The k loop runs
+// over 9 taps x K / 32 chunks.  uir_gemm kept a whole nine-tap panel in LDS (K <= 80), split the taps over 3-9 launches (K <= 380)
+// or fell back to an un-staged kernel (22-29 TFLOP/s) beyond.
+struct ConvLoaderA {
+  const float* p[4];
+  int kk[4], ph[4], pw[4];
+  __device__ __forceinline__ void init(const UirTiledArgs& t, int i0, int tid) {
+    const int HW = t.H * t.Wd;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      int r = i0 + (e >> 3);
+      r = r < t.MM ? r : t.MM - 1;
+      const int hw = r % HW;
+      ph[q] = hw / t.Wd;
+      pw[q] = hw - ph[q] * t.Wd;
+      kk[q] = 4 * (e & 7);
+      p[q] = t.A + (long)r * t.sa_i;
+    }
+  }
+  __device__ __forceinline__ void load(float4 (&v)[4], const UirTiledArgs& t, int tap, int k0) const {
+    const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+    const long shift = ((long)dy * t.Wd + dx) * t.sa_i;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + kk[q];
+      const int hh = ph[q] + dy, ww = pw[q] + dx;
+      const bool ok = k < t.KK && hh >= 0 && hh < t.H && ww >= 0 && ww < t.Wd;
+      const float4 x = *reinterpret_cast<const float4*>(p[q] + (ok ? shift + k : 0));     // clamped address, value selected below
+      v[q] = ok ? x : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __device__ __forceinline__ void store(float* s, const float4 (&v)[4], int tid) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid + 256 * q;
+      *reinterpret_cast<float4*>(s + (e >> 3) * KP + 4 * (e & 7)) = v[q];
+    }
+  }
+};
+
+struct ConvLoaderB {                          // element (j, k) of the chunk: j = (tid >> 5) + 8 q, k = tid & 31
+  const float* p0;
+  long jstep;
+  int jbase, k;
+  __device__ __forceinline__ void init(const UirTiledArgs& t, int j0, int tid) {
+    jbase = j0 + (tid >> 5);
+    k = tid & 31;
+    p0 = t.B;
+    jstep = t.sb_j;
+  }
+  __device__ __forceinline__ void load(float (&v)[16], const UirTiledArgs& t, int wt, int k0) const {
+    const int kg = k0 + k;
+    const bool kok = kg < t.KK;
+    const long koff = (long)(kok ? kg : 0) * t.sb_k + (long)wt * t.sb_t;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int j = jbase + 8 * q;
+      const bool ok = kok && j < t.NN;
+      const float x = p0[(long)(j < t.NN ? j : t.NN - 1) * jstep + koff];
+      v[q] = ok ? x : 0.f;
+    }
+  }
+  __device__ __forceinline__ void store(float* s, const float (&v)[16], int tid) const {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) s[((tid >> 5) + 8 * q) * KP + (tid & 31)] = v[q];
+  }
+};
+
+__global__ __launch_bounds__(256, 2) void uir_tiled_conv_kernel(const UirTiledArgs t) {
+  extern __shared__ float smem[];
+  float* As = smem;                       // [2][STAGE]
+  float* Bs = smem + 2 * STAGE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_j = (t.NN + TN - 1) / TN;
+  const int i0 = (blockIdx.x / tiles_j) * TM, j0 = (blockIdx.x % tiles_j) * TN;
+  const int kchunks = (t.KK + TK - 1) / TK, nchunks = 9 * kchunks;
+
+  ConvLoaderA la;
+  ConvLoaderB lb;
+  la.init(t, i0, tid);
+  lb.init(t, j0, tid);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  float4 va[4];
+  float vb[16];
+  la.load(va, t, 0, 0);
+  lb.load(vb, t, t.flip ? 8 : 0, 0);
+  la.store(As, va, tid);
+  lb.store(Bs, vb, tid);
+  __syncthreads();
+  int stage = 0, tap = 0, kc = 0;           // the chunk being computed
+  for (int c = 0; c < nchunks; ++c) {
+    int ntap = tap, nkc = kc + 1;            // the next chunk
+    if (nkc == kchunks) { nkc = 0; ++ntap; }
+    const bool more = c + 1 < nchunks;
+    if (more) {
+      la.load(va, t, ntap, nkc * TK);
+      lb.load(vb, t, t.flip ? 8 - ntap : ntap, nkc * TK);
+    }
+    const float* as = As + stage * STAGE;
+    const float* bs = Bs + stage * STAGE;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const float4 a0 = frag<true>(as, 64 * wr + li, jj, h2), a1 = frag<true>(as, 64 * wr + 32 + li, jj, h2);
+      const float4 b0 = frag<true>(bs, 64 * wc + li, jj, h2), b1 = frag<true>(bs, 64 * wc + 32 + li, jj, h2);
+      const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+      const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b) acc[a][b] = uir_mfma(av[a][e], bv[b][e], acc[a][b]);
+    }
+    if (more) {
+      la.store(As + (stage ^ 1) * STAGE, va, tid);
+      lb.store(Bs + (stage ^ 1) * STAGE, vb, tid);
+    }
+    __syncthreads();
+    stage ^= 1;
+    tap = ntap;
+    kc = nkc;
+  }
+
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int col = j0 + 64 * wc + 32 * b + li;
+      const float bj = (t.bias && col < t.NN) ? t.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = i0 + 64 * wr + 32 * a + uir_mfma_row(r, h2);
+        if (row < t.MM && col < t.NN) {
+          float v = acc[a][b][r] + bj;
+          if (t.R) v += t.R[(long)row * t.ldr + col];
+          t.D[(long)row * t.sd_i + (long)col * t.sd_j] = v;
+        }
+      }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------------
 // The same contraction on the BF16 matrix pipe with SPLIT f32 operands (opt-in: UIR_TILED_SPLIT=1).  On gfx950 the f32 MFMA runs at
 // 1/16 of the bf16 MFMA rate (64 vs 1024 FLOP/clk/SIMD).  An f32 value is the exact sum of three bf16 pieces (8 significant bits each:
 // hi = top 16 bits of x, mid = top 16 bits of x - hi, lo = top 16 bits of x - hi - mid; the subtractions are exact), a bf16 x bf16 product
@@ -349,6 +506,14 @@ __global__ __launch_bounds__(256, 3) void uir_tiled_split_kernel(const UirTiledA
 }
 
 }  // namespace
+
+int uir_tiled_conv3x3(const UirTiledArgs& t, hipStream_t st) {
+  UIR_REQUIRE(t.A && t.B && t.D && t.MM > 0 && t.NN > 0 && t.KK > 0 && (t.KK & 3) == 0 && t.sa_k == 1 && (t.sa_i & 3) == 0);
+  UIR_REQUIRE(t.H > 0 && t.Wd > 0 && t.MM % (t.H * t.Wd) == 0 && uir_aligned16(t.A) && t.act == UIR_ACT_NONE && !t.pre_out);
+  const dim3 grid(((t.MM + TM - 1) / TM) * ((t.NN + TN - 1) / TN));
+  hipLaunchKernelGGL(uir_tiled_conv_kernel, grid, dim3(256), (size_t)4 * STAGE * sizeof(float), st, t);
+  return uir_launch_status();
+}
 
 int uir_tiled_gemm(const UirTiledArgs& t, hipStream_t st) {
   UIR_REQUIRE(t.A && t.B && t.D && t.MM > 0 && t.NN > 0 && t.KK > 0 && t.k_per_split > 0 && (t.k_per_split & 3) == 0 && (t.KK & 3) == 0);

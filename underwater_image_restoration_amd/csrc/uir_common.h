@@ -89,5 +89,9 @@ struct UirTiledArgs {
   long ldr, ldpre;
   int act;                 // UIR_ACT_NONE / UIR_ACT_GELU
   int allow_split;         // caller's mark for the split-bf16 variant (wide layers only), see uir_tiled_gemm
+  int H, Wd, flip;         // uir_tiled_conv3x3: image size of the pixel rows, weight taps mirrored (input gradient)
+  long sb_t;               // uir_tiled_conv3x3: tap stride of the weight
 };
 int uir_tiled_gemm(const UirTiledArgs& t, hipStream_t st);
+// 3 x 3 convolution (uir_gemm's taps = 9 contract) with K >= 128 input channels: A k-contiguous pixel rows, any weight strides
+int uir_tiled_conv3x3(const UirTiledArgs& t, hipStream_t st);
