@@ -27,7 +27,7 @@ def dev(t):
     return t.float().to(DEV).contiguous()
 
 
-@pytest.mark.parametrize("M,K,N", [(4096, 2048, 512), (1000, 1024, 256), (260, 256, 72), (16384, 512, 2048)])
+@pytest.mark.parametrize("M,K,N", [(4096, 2048, 512), (1000, 1024, 256), (260, 256, 72), (16384, 512, 2048), (5000, 256, 64), (777, 512, 64)])
 def test_wide_linear_forward_bias_gelu_preout(M, K, N):
     """linear1 of a LeFF: Y = GELU(X W^T + b), pre-activation stored too (weights [N][K], k-contiguous operands)."""
     x, w, b = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5, rnd(N, seed=3)
@@ -39,7 +39,7 @@ def test_wide_linear_forward_bias_gelu_preout(M, K, N):
     assert rel(pre, want) < 2e-5 and rel(Y, F.gelu(want)) < 2e-5
 
 
-@pytest.mark.parametrize("M,K,N", [(4096, 2048, 512), (520, 1024, 256), (2048, 512, 100)])
+@pytest.mark.parametrize("M,K,N", [(4096, 2048, 512), (520, 1024, 256), (2048, 512, 100), (3000, 256, 64)])
 def test_wide_linear_input_gradient_and_residual(M, K, N):
     """dX = dY W (weights [K][N] read in place: the operand is contiguous along the OUTPUT index), + residual accumulate."""
     dy, w, res = rnd(M, K, seed=4), rnd(K, N, seed=5) * K ** -0.5, rnd(M, N, seed=6)
@@ -55,7 +55,8 @@ def test_wide_linear_input_gradient_and_residual(M, K, N):
         assert rel(dX, dy @ w) < 2e-5
 
 
-@pytest.mark.parametrize("M,N,K", [(4096, 512, 2048), (16384, 2048, 512), (65536, 128, 128), (3000, 256, 136), (1048576, 128, 256)])
+@pytest.mark.parametrize("M,N,K", [(4096, 512, 2048), (16384, 2048, 512), (65536, 128, 128), (3000, 256, 136), (1048576, 128, 256),
+                                   (262144, 256, 64), (50000, 64, 256), (4100, 192, 64), (2048, 64, 128)])   # the last four: 128 x 64 tiles
 def test_wide_weight_gradient(M, N, K):
     """dW[n][k] = sum_m dY[m][n] X[m][k] over the token rows, partial slabs per chunk + uir_reduce_slab; also the transposed
     output layout of the ConvTranspose2d weight."""

@@ -475,14 +475,25 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
     // Wide weight gradients (Linear layers of NewBigFRFNModel / AST, N and K >= UIR_TILED_GRAM_MIN, default 128): 128 x 128
     // output tiles on the LDS-tiled kernel of csrc/tiled.hip, one k split per chunk - same partial-slab contract.
     static const int minw = getenv("UIR_TILED_GRAM_MIN") ? atoi(getenv("UIR_TILED_GRAM_MIN")) : 128;
-    if (minw > 0 && a.N >= minw && a.K >= minw && a.taps == 1 && a.batches == 1 && a.pro_b == UIR_GRAM_PRO_NONE && !extras &&
+    const bool wide = a.N >= minw && a.K >= minw;
+    const bool narrow_k = a.N >= minw && a.K == 64, narrow_n = a.N == 64 && a.K >= minw;   // 128 x 64 tiles (the 64 side as second operand)
+    if (minw > 0 && (wide || narrow_k || narrow_n) && a.taps == 1 && a.batches == 1 && a.pro_b == UIR_GRAM_PRO_NONE && !extras &&
         a.n_grp_pad <= 0 && a.k_grp_pad <= 0 && ((a.N | a.K | a.lda | a.ldb | a.rows_per_chunk | a.M) & 3) == 0 &&
         uir_aligned16(a.A) && uir_aligned16(a.B)) {
       UirTiledArgs t{};
-      t.A = a.A; t.sa_i = 1; t.sa_k = a.lda;
-      t.B = a.B; t.sb_j = 1; t.sb_k = a.ldb;
-      t.D = a.slab; t.sd_i = a.o_sn; t.sd_j = a.o_sk; t.d_split = a.slab_stride;
-      t.MM = a.N; t.NN = a.K; t.KK = a.M; t.k_per_split = a.rows_per_chunk;
+      if (!narrow_n) {
+        t.A = a.A; t.sa_i = 1; t.sa_k = a.lda;
+        t.B = a.B; t.sb_j = 1; t.sb_k = a.ldb;
+        t.sd_i = a.o_sn; t.sd_j = a.o_sk;
+        t.MM = a.N; t.NN = a.K;
+      } else {                       // out[n][k] with only 64 rows n: the roles of the operands swap, the output strides with them
+        t.A = a.B; t.sa_i = 1; t.sa_k = a.ldb;
+        t.B = a.A; t.sb_j = 1; t.sb_k = a.lda;
+        t.sd_i = a.o_sk; t.sd_j = a.o_sn;
+        t.MM = a.K; t.NN = a.N;
+      }
+      t.D = a.slab; t.d_split = a.slab_stride;
+      t.KK = a.M; t.k_per_split = a.rows_per_chunk;
       t.allow_split = a.N >= 256 || a.K >= 256;
       return uir_tiled_gemm(t, st);
     }

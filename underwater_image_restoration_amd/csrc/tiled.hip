@@ -22,14 +22,15 @@ constexpr int KP = TK + 4;        // k-contiguous layout [128][36]: 16-byte rows
 constexpr int IP = TM + 4;        // index-contiguous layout [32][132]
 constexpr int STAGE = TM * KP;    // floats per operand per stage (>= 32 * IP)
 
-// global -> registers: the operand's 128 x 32 chunk as 4 float4 per thread
-template <bool KC>
+// global -> registers: the operand's ROWS x 32 chunk as ROWS / 32 float4 per thread (ROWS = 128, or 64 for a narrow B operand)
+template <bool KC, int ROWS>
 struct Loader {
-  const float* p[4];
-  int kk[4];                                        // k offset of each float4 inside the chunk (KC: its first k; IC: its k)
+  static constexpr int NQ = ROWS / 32, IQ = ROWS / 4;
+  const float* p[NQ];
+  int kk[NQ];                                       // k offset of each float4 inside the chunk (KC: its first k; IC: its k)
   __device__ __forceinline__ void init(const float* base, long s_idx, long s_k, int idx0, int n_idx, int tid) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int e = tid + 256 * q;
       if (KC) {
         int r = idx0 + (e >> 3);
@@ -37,67 +38,70 @@ struct Loader {
         kk[q] = 4 * (e & 7);
         p[q] = base + (long)r * s_idx;            // + k at load time
       } else {
-        int i = idx0 + 4 * (e & 31);
+        int i = idx0 + 4 * (e % IQ);
         i = i + 4 <= n_idx ? i : n_idx - 4;
-        kk[q] = e >> 5;
+        kk[q] = e / IQ;
         p[q] = base + i;
       }
     }
   }
-  __device__ __forceinline__ void load(float4 (&v)[4], int k0, int ke, long s_k) const {
+  __device__ __forceinline__ void load(float4 (&v)[NQ], int k0, int ke, long s_k) const {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int k = k0 + kk[q];
       const int kc = k < ke ? k : ke - 4;           // address stays inside the operand; the value is zeroed below
       const float4 t = *reinterpret_cast<const float4*>(KC ? p[q] + kc : p[q] + (long)kc * s_k);
       v[q] = k < ke ? t : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   }
-  __device__ __forceinline__ void store(float* s, const float4 (&v)[4], int tid) const {
+  __device__ __forceinline__ void store(float* s, const float4 (&v)[NQ], int tid) const {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
       const int e = tid + 256 * q;
-      float* d = KC ? s + (e >> 3) * KP + 4 * (e & 7) : s + (e >> 5) * IP + 4 * (e & 31);
+      float* d = KC ? s + (e >> 3) * KP + 4 * (e & 7) : s + (e / IQ) * (ROWS + 4) + 4 * (e % IQ);
       *reinterpret_cast<float4*>(d) = v[q];
     }
   }
 };
 
 // one operand fragment of a 32-row tile for k sub-block jj: the four k values 8 jj + 4 h2 + e of this lane's row
-template <bool KC>
+template <bool KC, int ROWS = TM>
 __device__ __forceinline__ float4 frag(const float* s, int row, int jj, int h2) {
   if (KC) return *reinterpret_cast<const float4*>(s + row * KP + 8 * jj + 4 * h2);
-  const float* c = s + (8 * jj + 4 * h2) * IP + row;
-  return make_float4(c[0], c[IP], c[2 * IP], c[3 * IP]);
+  const float* c = s + (8 * jj + 4 * h2) * (ROWS + 4) + row;
+  return make_float4(c[0], c[ROWS + 4], c[2 * (ROWS + 4)], c[3 * (ROWS + 4)]);
 }
 
-template <bool AKC, bool BKC>
+// TNW = 128: four waves as 2 x 2, each 64 x 64.  TNW = 64 (narrow second operand: K = 64 weight gradients, 64-channel outputs): each
+// wave 64 x 32.
+template <bool AKC, bool BKC, int TNW>
 __global__ __launch_bounds__(256, 2) void uir_tiled_kernel(const UirTiledArgs t) {
+  constexpr int CT = TNW / 64;             // 32-column tiles per wave
   extern __shared__ float smem[];
   float* As = smem;                       // [2][STAGE]
   float* Bs = smem + 2 * STAGE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
-  const int tiles_j = (t.NN + TN - 1) / TN;
-  const int i0 = (blockIdx.x / tiles_j) * TM, j0 = (blockIdx.x % tiles_j) * TN;
+  const int tiles_j = (t.NN + TNW - 1) / TNW;
+  const int i0 = (blockIdx.x / tiles_j) * TM, j0 = (blockIdx.x % tiles_j) * TNW;
   const int split = blockIdx.y;
   const int ks = split * t.k_per_split;
   const int ke = ks + t.k_per_split < t.KK ? ks + t.k_per_split : t.KK;
 
-  Loader<AKC> la;
-  Loader<BKC> lb;
+  Loader<AKC, TM> la;
+  Loader<BKC, TNW> lb;
   la.init(t.A, t.sa_i, t.sa_k, i0, t.MM, tid);
   lb.init(t.B, t.sb_j, t.sb_k, j0, t.NN, tid);
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][CT];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b)
+    for (int b = 0; b < CT; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float4 va[4], vb[4];
+  float4 va[4], vb[TNW / 32];
   la.load(va, ks, ke, t.sa_k);
   lb.load(vb, ks, ke, t.sb_k);
   la.store(As, va, tid);
@@ -115,15 +119,19 @@ __global__ __launch_bounds__(256, 2) void uir_tiled_kernel(const UirTiledArgs t)
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const float4 a0 = frag<AKC>(as, 64 * wr + li, jj, h2), a1 = frag<AKC>(as, 64 * wr + 32 + li, jj, h2);
-      const float4 b0 = frag<BKC>(bs, 64 * wc + li, jj, h2), b1 = frag<BKC>(bs, 64 * wc + 32 + li, jj, h2);
-      const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
-      const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+      float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+      float bv[CT][4];
+#pragma unroll
+      for (int b = 0; b < CT; ++b) {
+        const float4 bb = frag<BKC, TNW>(bs, 32 * CT * wc + 32 * b + li, jj, h2);
+        bv[b][0] = bb.x; bv[b][1] = bb.y; bv[b][2] = bb.z; bv[b][3] = bb.w;
+      }
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-          for (int b = 0; b < 2; ++b) acc[a][b] = uir_mfma(av[a][e], bv[b][e], acc[a][b]);
+          for (int b = 0; b < CT; ++b) acc[a][b] = uir_mfma(av[a][e], bv[b][e], acc[a][b]);
     }
     if (more) {
       la.store(As + (stage ^ 1) * STAGE, va, tid);
@@ -138,8 +146,8 @@ __global__ __launch_bounds__(256, 2) void uir_tiled_kernel(const UirTiledArgs t)
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int col = j0 + 64 * wc + 32 * b + li;
+    for (int b = 0; b < CT; ++b) {
+      const int col = j0 + 32 * CT * wc + 32 * b + li;
       const float bj = (t.bias && col < t.NN) ? t.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -546,7 +554,18 @@ int uir_tiled_gemm(const UirTiledArgs& t, hipStream_t st) {
 #undef UIR_TS
     return uir_launch_status();
   }
-#define UIR_TL(AK, BK) hipLaunchKernelGGL((uir_tiled_kernel<AK, BK>), grid, dim3(256), lds, st, t)
+  // narrow second operand (<= 64 columns, or 65 .. 127 where half of a 128-wide tile would be empty... only <= 64 here): 128 x 64 tiles
+  if (t.NN <= 64) {
+    const dim3 grid64(((t.MM + TM - 1) / TM) * ((t.NN + 63) / 64), nsplit);
+#define UIR_TL64(AK, BK) hipLaunchKernelGGL((uir_tiled_kernel<AK, BK, 64>), grid64, dim3(256), lds, st, t)
+    if (akc && bkc) UIR_TL64(true, true);
+    else if (akc) UIR_TL64(true, false);
+    else if (bkc) UIR_TL64(false, true);
+    else UIR_TL64(false, false);
+#undef UIR_TL64
+    return uir_launch_status();
+  }
+#define UIR_TL(AK, BK) hipLaunchKernelGGL((uir_tiled_kernel<AK, BK, 128>), grid, dim3(256), lds, st, t)
   if (akc && bkc) UIR_TL(true, true);
   else if (akc) UIR_TL(true, false);
   else if (bkc) UIR_TL(false, true);
