@@ -238,3 +238,65 @@ def test_model_trainer_drives_ast(tmp_path, capsys):
     x = O.closed_form_input(1, 3, 128 * 128, 151).reshape(1, 3, 128, 128).cuda()
     with torch.no_grad():
         assert torch.equal(fresh(x), model(x))
+
+
+def _dp_ast_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.cuda.set_device(0)                         # both ranks share the one GPU of this box: gloo moves the bucket
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from underwater_image_restoration_amd.Models import init_model
+    from underwater_image_restoration_amd.trainer import make_train_step
+    m = init_model("AST", drop_path_rate=0.0)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.is_floating_point()}
+    P = O.closed_form_params(shapes, "astdp")
+    if rank == 1:
+        P = {k: v + 0.125 for k, v in P.items()}      # rank 1 starts elsewhere: the step must broadcast rank 0's weights
+    m.load_state_dict(P, strict=False)
+    m = m.cuda().train()
+    step = make_train_step(m, "charbonnier", 3e-4)
+    N = 128
+    raw = O.closed_form_input(2, 3, N * N, 201).reshape(2, 3, N, N)[rank:rank + 1].cuda()
+    ref = O.closed_form_input(2, 3, N * N, 202).reshape(2, 3, N, N)[rank:rank + 1].cuda()
+    losses = []
+    for _ in range(2):
+        loss, norm = step(raw, ref)
+        losses.append((float(loss), float(norm)))
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
+    torch.save({"flat": flat, "losses": losses, "bucket": int(step.bucket.numel())}, f"{out}.{rank}")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@gpu
+@needs_gpu
+def test_ast_data_parallel_two_ranks(tmp_path):
+    """BASELINE configs[4]'s parallelism with the product's own step: 2 processes x 1 image (HIP forward / backward, ONE all-reduce of
+    the network's gradient bucket, fused clip + Adam with gscale = 1/2) == 1 process x 2 images for the mean-type Charbonnier loss;
+    replicas end bit-identical; rank 1's different initial weights are overwritten by the broadcast.  (gloo carries the bucket: two
+    ranks cannot share one GPU under RCCL.)"""
+    import torch.multiprocessing as mp
+    from underwater_image_restoration_amd.Models import init_model
+    from underwater_image_restoration_amd.trainer import make_train_step
+    out = str(tmp_path / "dpast")
+    port = 32500 + (os.getpid() % 2000)
+    mp.spawn(_dp_ast_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + ".0"), torch.load(out + ".1")
+    assert torch.equal(r0["flat"], r1["flat"]) and r0["bucket"] >= 19919507
+    m = init_model("AST", drop_path_rate=0.0)
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.is_floating_point()}
+    m.load_state_dict(O.closed_form_params(shapes, "astdp"), strict=False)
+    m = m.cuda().train()
+    step = make_train_step(m, "charbonnier", 3e-4)
+    N = 128
+    raw = O.closed_form_input(2, 3, N * N, 201).reshape(2, 3, N, N).cuda()
+    ref = O.closed_form_input(2, 3, N * N, 202).reshape(2, 3, N, N).cuda()
+    for k in range(2):
+        loss, norm = step(raw, ref)
+        assert abs(float(loss) - 0.5 * (r0["losses"][k][0] + r1["losses"][k][0])) <= 2e-5 * float(loss)
+        assert abs(float(norm) - r0["losses"][k][1]) <= 2e-4 * float(norm)
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
+    d = float((flat - r0["flat"]).abs().max())
+    assert d <= 2e-4, d

@@ -287,8 +287,8 @@ class TrainStep:
 class ModuleTrainStep:
     """The train step (src/ModelTrainer.py:78-90) for a network COMPOSED of launch-plan modules (``--arch NewBigFRFNModel``: 27 of
     them, each one autograd node): forward through autograd, loss and its gradient by the HIP loss kernels, ``backward`` runs every
-    module's backward launch list and leaves the gradients in the modules' flat buffers, (all-reduce per buffer under data
-    parallelism,) one global-norm clip + Adam over all buffers (ops.MultiFlatClipAdam).  No host synchronisation inside."""
+    module's backward launch list and leaves the gradients in the modules' flat buffers - views of ONE bucket -, (one all-reduce of
+    that bucket under data parallelism,) one global-norm clip + Adam over all buffers (ops.MultiFlatClipAdam).  No host synchronisation inside."""
 
     def __init__(self, model, loss_name: str = "L1", lr: float = 3e-4, max_norm: float = 1.0, process_group=None, weight_decay: float = 0.0):
         if loss_name not in L.LOSS_KINDS:
@@ -305,6 +305,15 @@ class ModuleTrainStep:
             m._ensure_flat(dev)
             m._flat_grads_only = True
         self.flats = [m._flat for m in self.mods]
+        # ONE gradient bucket for the whole network: every module's flat gradient buffer becomes a view of it, so data parallelism
+        # is one all-reduce per step (AST: 28 modules, 80 MB) instead of one per module.  Plans record raw gradient
+        # pointers when they are built: none may exist yet with the old buffers.
+        self.bucket = torch.zeros(sum(fp.total for fp in self.flats), dtype=torch.float32, device=dev)
+        off = 0
+        for m, fp in zip(self.mods, self.flats):
+            fp.grad = self.bucket[off:off + fp.total]
+            m._plans.clear()
+            off += fp.total
         self.world = parallel.world_size(process_group)
         if self.world > 1:
             for fp in self.flats:
@@ -323,9 +332,7 @@ class ModuleTrainStep:
         res = ops.loss_sums(out.detach(), ref, self.kind)
         dout = ops.loss_grad(out.detach(), ref, self._one, self.kind)
         out.backward(dout)
-        scale = 1.0
-        for fp in self.flats:
-            scale = parallel.allreduce_flat_grads(fp.grad, fp.total, self.pg)
+        scale = parallel.allreduce_flat_grads(self.bucket, self.bucket.numel(), self.pg)
         norm = self.opt.step(lr=lr, grad_scale=scale)
         return res[0], norm[0]
 
