@@ -6,7 +6,7 @@
 //
 //     D[i][j] (+ epilogue) = sum_k A(i, k) * B(j, k)          128 x 128 output tile per workgroup, k in chunks of 32
 //
-// with either operand "k-contiguous" (activation rows [M][K], weights [N][K]) or "index-contiguous" (the token contraction of a
+// (128 x 64 when the second operand has <= 64 rows) with either operand "k-contiguous" (activation rows [M][K], weights [N][K]) or "index-contiguous" (the token contraction of a
 // weight gradient: A(n, m) = dY[m][n]; transposed weights W[k][n] of an input gradient).  Both operand chunks are staged through
 // LDS with 16-byte global loads in the operand's own contiguous direction (next chunk in flight during the MFMAs, two LDS stages,
 // one barrier per chunk); 4 waves as 2 x 2, each 64 x 64 = four v_mfma_f32_32x32x2_f32 accumulators: 64 MFMAs (4096 cycles) per
@@ -544,7 +544,11 @@ int uir_tiled_gemm(const UirTiledArgs& t, hipStream_t st) {
   static const int mode = getenv("UIR_TILED_SPLIT") ? atoi(getenv("UIR_TILED_SPLIT")) : 0;
   if (mode == 1 || mode == 2 || (mode == 3 && t.allow_split)) {
     static bool told = false;
-    if (!told && mode == 2) { const int f = 1; hipMemcpyToSymbol(HIP_SYMBOL(g_split_fake), &f, sizeof(int)); told = true; }
+    if (!told && mode == 2) {      // timing experiment only; the copy is synchronous and happens once per process
+      const int f = 1;
+      if (hipMemcpyToSymbol(HIP_SYMBOL(g_split_fake), &f, sizeof(int)) != hipSuccess) return UIR_ELAUNCH;
+      told = true;
+    }
     const size_t lds2 = (size_t)2 * SSTAGE * sizeof(unsigned short);
 #define UIR_TS(AK, BK) hipLaunchKernelGGL((uir_tiled_split_kernel<AK, BK>), grid, dim3(256), lds2, st, t)
     if (akc && bkc) UIR_TS(true, true);
