@@ -3,7 +3,7 @@ VALU-bound) give different results when a tiled contraction runs beside it on an
     UIR_TILED_SPLIT=1 python tools/probe_split_interference.py dw          # split-bf16 weight-gradient contraction: ~185 of 200 runs differ
     UIR_TILED_SPLIT=1 python tools/probe_split_interference.py fwd | dx    # split-bf16 forward / input-gradient: 0 of 200
     python tools/probe_split_interference.py dw                            # f32-MFMA contraction (the default): 0 of 200
-    ... dw colsum | gram | dwfwd                                           # other victims: 0 of 200
+    ... dw colsum | gram | dwfwd | dwbwd                                   # other victims: 0 of 200
 In every differing run exactly one FMA (one pixel x one tap x one float4 component) of one 16-lane slice of one workgroup is missing."""
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -24,6 +24,11 @@ elif victim == "colsum":
 elif victim == "gram":
     dW = r1.alloc(64, 64)
     r1.gram("gr", dY, X, dW, N=64, K=64, o_sn=64, o_sk=1)
+elif victim == "dwbwd":          # the fused depthwise backward (input gradient + weight-gradient partials, ~240 VGPRs)
+    dW = r1.alloc(C, 9)
+    Wt, dXo = rnd(C, 9), r1.alloc(M, C)
+    os.environ["UIR_FUSED_DW_MINROWS"] = "1"
+    r1.dwconv_bwd("dwb", dY, X, Wt, dXo, dW, C_=C, creal=C, dims=(B, H, W))
 elif victim == "dwfwd":
     dW = r1.alloc(M, C)
     Wt = rnd(C, 9)
