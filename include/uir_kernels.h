@@ -373,7 +373,8 @@ int uir_im2col3x3_c3(const float* src, float* dst, int B, int H, int Wd, void* s
 int uir_hwc4_to_nchw3(const float* src, float* dst, int B, int H, int Wd, void* stream);
 
 /* ---------------------------------------------------------------- uir_loss */
-enum { UIR_LOSS_L1 = 0, UIR_LOSS_L2 = 1, UIR_LOSS_CHARBONNIER = 2, UIR_LOSS_LUMINANCE = 3, UIR_LOSS_L1_COLOR = 4 };
+enum { UIR_LOSS_L1 = 0, UIR_LOSS_L2 = 1, UIR_LOSS_CHARBONNIER = 2, UIR_LOSS_LUMINANCE = 3, UIR_LOSS_L1_COLOR = 4,
+       UIR_LOSS_LUM_CHARBONNIER = 5 /* "LuminanceCharbonnier" = LuminanceLoss + CharbonnierLoss, losses.py:118-123 */ };
 /* Partial sums over NCHW [B,3,H,W] pred/truth: slab[block][8] =
  * (sum|d|, sum d^2, sum sqrt(d^2+1e-6), sum lum^2, sum (clamp01(p)-clamp01(t))^2, 0,0,0).
  * Replaces nn.L1Loss / MSELoss / CharbonnierLoss / ColorLoss / LuminanceLoss
@@ -512,6 +513,11 @@ int uir_transpose_rows(const float* src, float* dst, int B, int N1, int N2, int 
  * EncoderBlock, model.py:27,54,91); scale is a device float[M / rows_per_sample]. */
 int uir_scale_rows(const float* src, int lds, float* dst, int ldd, const float* scale, long rows_per_sample, long M, int C, int accumulate,
                    void* stream);
+/* dst[m][:] = a[m][:] + scale[m / rows_per_sample] * b[m][:] (scale NULL: a + b): a residual join in one pass - `x + drop_path(f(x))`
+ * of AST's TransformerBlock (src/Models/AST.py:617,620), the shortcut sums of MDASSA / DecoderBlock (src/model/block.py:465,514,
+ * src/model/model.py:152,156).  FMA per element: (a + s b) rounded once. */
+int uir_add_scaled_rows(const float* a, int lda, const float* b, int ldb, float* dst, int ldd, const float* scale, long rows_per_sample,
+                        long M, int C, void* stream);
 /* Last stage of a length-N = 2 N2 complex DFT (sign +) along an axis of rows [O][N][I][C] whose first stage transformed the two
  * interleaved sub-sequences n = 2 n2 + n1 (uir_dft_axis2 over n2 with inner extent 2 I): Y rows [o][k2][n1][i], twiddle table
  * exp(2 pi i k2 / N) [N2];  X[o][k1 N2 + k2][i] = scale (Y[k2][0] + (-1)^k1 tw[k2] Y[k2][1]), natural order; x_im NULL = real part

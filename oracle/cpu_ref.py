@@ -341,6 +341,8 @@ def loss_by_name(name: str, p: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
         return loss_charbonnier(p, t)
     if name == "Luminance":
         return loss_luminance(p, t)
+    if name == "LuminanceCharbonnier":                 # src/Losses/losses.py:118-123
+        return loss_luminance(p, t) + loss_charbonnier(p, t)
     if name == "L1withColor":
         return (0.5 * loss_color(p, t) + 0.25 * loss_l1_mean(p, t) + 0.25 * loss_luminance(p, t)) / bc
     raise ValueError(f"Unsupported loss: {name}")

@@ -128,6 +128,7 @@ def test_plan_memory_estimate_and_loss_names():
     gib = 2 ** 30
     assert E.plan_bytes_estimate(16, 1024, 1024) > 288 * gib > E.plan_bytes_estimate(4, 1024, 1024)
     assert L.LOSS_KINDS["L1ColorLum"] == L.LOSS_KINDS["L1withColor"]            # same formula, losses.py:59-66 / :67-75
+    assert L.LOSS_KINDS["LuminanceCharbonnier"] == 5                              # losses.py:118-123
 
 
 def test_factory_and_loss_surface():

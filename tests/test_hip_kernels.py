@@ -682,7 +682,7 @@ def test_shuffle_family():
 
 
 # ------------------------------------------------------------ loss and optim
-@pytest.mark.parametrize("name", ["L1", "L2", "charbonnier", "Luminance", "L1withColor"])
+@pytest.mark.parametrize("name", ["L1", "L2", "charbonnier", "Luminance", "L1withColor", "LuminanceCharbonnier"])
 def test_losses_and_psnr(name):
     from oracle import cpu_ref as O
     p = rnd(3, 3, 20, 24, seed=1).requires_grad_(True)

@@ -82,6 +82,8 @@ def test_full_model_matches_reference(golden_dir):
     assert abs(float(O.loss_charbonnier(out, ref)) - float(g["loss_charbonnier"])) < 1e-6
     assert abs(float(O.loss_color(out, ref)) - float(g["loss_color"])) < 1e-6
     assert abs(float(O.loss_luminance(out, ref)) - float(g["loss_luminance"])) < 1e-6
+    # "LuminanceCharbonnier" (src/Losses/losses.py:118-123) = the sum of the two recorded reference values
+    assert abs(float(O.loss_by_name("LuminanceCharbonnier", out, ref)) - float(g["loss_luminance"]) - float(g["loss_charbonnier"])) < 2e-6
     assert abs(float(O.psnr(ref, out)) - float(g["psnr"])) < 1e-4
     # the reference leaves exactly these .grad = None
     assert sorted(g["grad_none"]) == sorted(n for n in P if O.is_dead_param(n))

@@ -22,7 +22,7 @@ from .. import _lib as L
 from .. import ops
 
 _REFERENCE_OTHER = ("perceptual", "gradient", "ms_ssim", "ffl", "mix", "fflMixTV", "bigMix", "fflCharbonnier", "fflMix",
-                    "LuminanceCharbonnier", "AdaptiveLuminanceCharbonnier", "AdaptiveLuminanceFFL", "LuminanceFFL",
+                    "AdaptiveLuminanceCharbonnier", "AdaptiveLuminanceFFL", "LuminanceFFL",
                     "ssimFFLCharbonnier")
 
 

@@ -13,7 +13,7 @@ values - with every forward / backward a launch list over the C ABI (include/uir
       (:144-219)                    scores + bias (+ shift mask), softmax * w1  uir_winattn_fwd / _bwd (args.shift: the cyclic roll
                                     + relu^2 * w2, . v                          of :598-616 is an address, the mask of :568-589 a
                                                                                 comparison of region ids)
-    TransformerBlock (:498-623)     norm1 -> attention -> + ; norm2 -> LeFF -> +, timm DropPath per branch (uir_scale_rows)
+    TransformerBlock (:498-623)     norm1 -> attention -> + ; norm2 -> LeFF -> +, timm DropPath per branch (uir_add_scaled_rows)
     BasicASTLayer (:629-677), AST (:680-921)
 
 One launch plan per TransformerBlock / sampler / projection (``plan_modules``); tensors travel between them through autograd.
@@ -31,8 +31,8 @@ import torch.nn as nn
 
 from .. import _lib as L
 from ..engine import _ld, _ptr
-from ..model.block import (LeFF, TokenModule, TokenPlan, _SimplePlan, _colsum_wide, record_conv3x3, record_layernorm, record_leff,
-                           record_window_attention)
+from ..model.block import (LeFF, TokenModule, TokenPlan, _SimplePlan, _add_rows, _colsum_wide, record_conv3x3, record_layernorm,
+                           record_leff, record_window_attention)
 from ..model.model import _ResidualImage
 
 lib = L.lib
@@ -130,14 +130,10 @@ def record_ast_block(rec, x: torch.Tensor, dim: int, heads: int, shift: int, att
     if att:
         xn, n1_bw = record_layernorm(rec, "norm1.", x, C_)
         a, a_bw = record_window_attention(rec, "attn.", xn, None, dims, C_, heads, qname="qkv.to_q", kvname="qkv.to_kv", shift=shift)
-        y = rec.alloc(M, C_)
-        rec.copy_cols("res1=x", x, 0, y, 0, C_)
-        scaled("res1+=dp*attn", a, y, s_att, 1)
+        y = _add_rows(rec, "res1=x+dp*attn", x, a, C_, scale=s_att, rows_per_sample=Ltok)
     x2, n2_bw = record_layernorm(rec, "norm2.", y, C_)
     m, m_bw = record_leff(rec, "mlp.", x2, C_, 4 * C_, dims)
-    out = rec.alloc(M, C_)
-    rec.copy_cols("res2=y", y, 0, out, 0, C_)
-    scaled("res2+=dp*mlp", m, out, s_mlp, 1)
+    out = _add_rows(rec, "res2=y+dp*mlp", y, m, C_, scale=s_mlp, rows_per_sample=Ltok)
 
     def backward(dout):
         dm = rec.alloc(M, C_)

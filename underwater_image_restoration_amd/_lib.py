@@ -18,7 +18,7 @@ PRO_NONE, PRO_LN, PRO_GATE = 0, 1, 2
 EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW, EPI_LN_BWD = 0, 1, 2, 3, 4
 ACT_NONE, ACT_LEAKY, ACT_GELU = 0, 1, 2
 # L1ColorLum has the same formula as L1withColor in the reference (src/Losses/losses.py:59-66 vs :67-75)
-LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4}
+LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4, "LuminanceCharbonnier": 5}
 
 
 class GemmArgs(C.Structure):
@@ -229,6 +229,7 @@ SIGNATURES = {
     "uir_cmul_table": [fp, fp, fp, fp, i64, i64, i32, fp],
     "uir_transpose_rows": [fp, fp, i32, i32, i32, i32, i32, f32, fp],
     "uir_scale_rows": [fp, i32, fp, i32, fp, i64, i64, i32, i32, fp],
+    "uir_add_scaled_rows": [fp, i32, fp, i32, fp, i32, fp, i64, i64, i32, fp],
     "uir_radix2_combine": [fp, fp, fp, fp, fp, fp, i64, i32, i64, i32, f32, fp],
     "uir_winattn_fwd": [C.POINTER(WinAttnArgs), fp],
     "uir_winattn_bwd": [C.POINTER(WinAttnArgs), fp],

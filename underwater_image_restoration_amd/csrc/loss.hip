@@ -58,7 +58,8 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __re
     case UIR_LOSS_L2: loss = l2 / bc; break;
     case UIR_LOSS_CHARBONNIER: loss = ch; break;
     case UIR_LOSS_LUMINANCE: loss = lum; break;
-    default: loss = (0.5f * l2 + 0.25f * l1 + 0.25f * lum) / bc; break;
+    case UIR_LOSS_LUM_CHARBONNIER: loss = lum + ch; break;          // losses.py:118-123
+    default: loss = (0.5f * l2 + 0.25f * l1 + 0.25f * lum) / bc; break;   // UIR_LOSS_L1_COLOR
   }
   out[0] = loss;
   out[1] = 20.f * log10f(1.f / sqrtf(sums[4] / n));
@@ -88,6 +89,7 @@ __global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __r
         case UIR_LOSS_L2: g = 2.f * d[c] / (nn * bc); break;
         case UIR_LOSS_CHARBONNIER: g = d[c] / sqrtf(d[c] * d[c] + CHARB_EPS2) / nn; break;
         case UIR_LOSS_LUMINANCE: g = 2.f * lum * yc / npix; break;
+        case UIR_LOSS_LUM_CHARBONNIER: g = 2.f * lum * yc / npix + d[c] / sqrtf(d[c] * d[c] + CHARB_EPS2) / nn; break;
         default: g = (0.5f * 2.f * d[c] / nn + 0.25f * sg / nn + 0.25f * 2.f * lum * yc / npix) / bc; break;
       }
       dpred[b * 3 * HW + c * HW + p] = g * gs;
@@ -103,12 +105,12 @@ extern "C" int uir_loss_partials(const float* pred, const float* truth, float* s
   return uir_launch_status();
 }
 extern "C" int uir_loss_finalize(const float* sums, float* out, int kind, int B, int HW, void* stream) {
-  UIR_REQUIRE(sums && out && kind >= 0 && kind <= UIR_LOSS_L1_COLOR && B > 0 && HW > 0);
+  UIR_REQUIRE(sums && out && kind >= 0 && kind <= UIR_LOSS_LUM_CHARBONNIER && B > 0 && HW > 0);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), sums, out, kind, B, (long)HW);
   return uir_launch_status();
 }
 extern "C" int uir_loss_bwd(const float* pred, const float* truth, const float* gscale, float* dpred, int kind, int B, int HW, void* stream) {
-  UIR_REQUIRE(pred && truth && gscale && dpred && kind >= 0 && kind <= UIR_LOSS_L1_COLOR && B > 0 && HW > 0);
+  UIR_REQUIRE(pred && truth && gscale && dpred && kind >= 0 && kind <= UIR_LOSS_LUM_CHARBONNIER && B > 0 && HW > 0);
   const long n = (long)B * HW;
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;

@@ -177,6 +177,21 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(const float* __restrict
   }
 }
 
+// dst[m][:] = a[m][:] + scale[m / rows_per_sample] * b[m][:]   (scale == nullptr: plain sum) - a residual join in ONE pass
+__global__ __launch_bounds__(256) void add_scaled_rows_kernel(const float* __restrict__ a, int lda, const float* __restrict__ b, int ldb,
+                                                              float* __restrict__ dst, int ldd, const float* __restrict__ scale,
+                                                              long rows_per_sample, long M, int C4) {
+  const long total = M * C4;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const long m = e / C4;
+    const int c = (int)(e - m * C4) * 4;
+    const float f = scale ? scale[m / rows_per_sample] : 1.0f;
+    const float4 x = *reinterpret_cast<const float4*>(a + m * lda + c);
+    const float4 y = *reinterpret_cast<const float4*>(b + m * ldb + c);
+    *reinterpret_cast<float4*>(dst + m * ldd + c) = make_float4(fmaf(f, y.x, x.x), fmaf(f, y.y, x.y), fmaf(f, y.z, x.z), fmaf(f, y.w, x.w));
+  }
+}
+
 inline unsigned grid_for(long total) {
   long g = (total + 255) / 256;
   return (unsigned)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
@@ -228,6 +243,15 @@ extern "C" int uir_radix2_combine(const float* y_re, const float* y_im, float* x
   const long IC4 = I * (C / 4);
   hipLaunchKernelGGL(radix2_combine_kernel, dim3(grid_for(O * N2 * IC4)), dim3(256), 0, static_cast<hipStream_t>(stream), y_re, y_im, x_re,
                      x_im, tab_re, tab_im, O, N2, IC4, scale);
+  return uir_launch_status();
+}
+
+extern "C" int uir_add_scaled_rows(const float* a, int lda, const float* b, int ldb, float* dst, int ldd, const float* scale,
+                                   long rows_per_sample, long M, int C, void* stream) {
+  UIR_REQUIRE(a && b && dst && rows_per_sample > 0 && M > 0 && M % rows_per_sample == 0 && C > 0 && (C & 3) == 0);
+  UIR_REQUIRE(lda >= C && ldb >= C && ldd >= C && ((lda | ldb | ldd) & 3) == 0 && uir_aligned16(a) && uir_aligned16(b) && uir_aligned16(dst));
+  hipLaunchKernelGGL(add_scaled_rows_kernel, dim3(grid_for(M * (C / 4))), dim3(256), 0, static_cast<hipStream_t>(stream), a, lda, b, ldb,
+                     dst, ldd, scale, rows_per_sample, M, C / 4);
   return uir_launch_status();
 }
 

@@ -369,10 +369,14 @@ def record_layernorm(rec: Recorder, pfx: str, x: torch.Tensor, C_: int):
     return y, backward
 
 
-def _add_rows(rec: Recorder, name: str, a: torch.Tensor, b: torch.Tensor, C_: int) -> torch.Tensor:
-    out = rec.alloc(a.shape[0], C_)
-    rec.copy_cols(name + ".copy", a, 0, out, 0, C_)
-    rec.copy_cols(name + ".add", b, 0, out, 0, C_, accumulate=1)
+def _add_rows(rec: Recorder, name: str, a: torch.Tensor, b: torch.Tensor, C_: int, scale: "torch.Tensor | None" = None,
+              rows_per_sample: "int | None" = None) -> torch.Tensor:
+    """out = a + b (or a + scale[sample] * b) in one pass (uir_add_scaled_rows)."""
+    M = a.shape[0]
+    out = rec.alloc(M, C_)
+    rec._hold(a, b, out, scale)
+    rec._op(name, lib.uir_add_scaled_rows, _ptr(a), _ld(a), _ptr(b), _ld(b), _ptr(out), _ld(out), _ptr(scale), rows_per_sample or M, M, C_,
+            nbytes=12 * M * C_)
     return out
 
 

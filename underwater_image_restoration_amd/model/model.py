@@ -27,7 +27,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from ..engine import FlatParams, _ptr
-from .block import (FRFN, LeFF, MDASSA, MDASSA_DEAD, Downsample, InputProjection, OutputProjection, TokenModule, TokenPlan, Upsample,
+from .block import (FRFN, LeFF, MDASSA, MDASSA_DEAD, _add_rows, Downsample, InputProjection, OutputProjection, TokenModule, TokenPlan, Upsample,
                     record_decoder_block, record_frfn, record_leff)
 from .. import ops
 
@@ -137,10 +137,8 @@ class EncoderPlan(TokenPlan):
         self.dp_scale = self.alloc(2, self.B)          # row 0: drop_path2 (frequency branch), row 1: drop_path (token branch)
         self.dp_scale.fill_(1.0)
         s2, s1 = self.dp_scale[0], self.dp_scale[1]
-        y = self.alloc(M, C_)
-        self.copy_cols("out=x", x, 0, y, 0, C_)
-        self._op("out+=dp2*freq", lib.uir_scale_rows, _ptr(f3), C_, _ptr(y), C_, _ptr(s2), Ltok, M, C_, 1, nbytes=12 * M * C_)
-        self._op("out+=dp*x1", lib.uir_scale_rows, _ptr(x1), C_, _ptr(y), C_, _ptr(s1), Ltok, M, C_, 1, nbytes=12 * M * C_)
+        y0 = _add_rows(self, "out=x+dp2*freq", x, f3, C_, scale=s2, rows_per_sample=Ltok)
+        y = _add_rows(self, "out+=dp*x1", y0, x1, C_, scale=s1, rows_per_sample=Ltok)
 
         def backward(dy):
             dyf = self.alloc(M, C_)
