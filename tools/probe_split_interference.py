@@ -1,6 +1,8 @@
-"""Reproducer of the interference recorded in DESIGN.md section 17: does a victim kernel (default: uir_dwconv_wgrad, 248 VGPRs, 36 KB LDS,
-VALU-bound) give different results when a tiled contraction runs beside it on another stream?
-    UIR_TILED_SPLIT=1 python tools/probe_split_interference.py dw          # split-bf16 weight-gradient contraction: ~185 of 200 runs differ
+"""Reproducer of the interference recorded in DESIGN.md section 17: does a victim kernel (default: uir_dwconv_wgrad - set UIR_DW_WGRAD_OLD=1 for
+its first version, the one that is disturbed: 248 VGPRs, 36 KB LDS, VALU-bound, ~100 v_mov per row) give different results when a tiled
+contraction runs beside it on another stream?
+    UIR_DW_WGRAD_OLD=1 UIR_TILED_SPLIT=1 python tools/probe_split_interference.py dw     # split-bf16 weight-gradient contraction: ~185 of 200 differ
+    UIR_TILED_SPLIT=1 python tools/probe_split_interference.py dw          # the current uir_dwconv_wgrad beside it: 0 of 200
     UIR_TILED_SPLIT=1 python tools/probe_split_interference.py fwd | dx    # split-bf16 forward / input-gradient: 0 of 200
     python tools/probe_split_interference.py dw                            # f32-MFMA contraction (the default): 0 of 200
     ... dw colsum | gram | dwfwd | dwbwd                                   # other victims: 0 of 200

@@ -7,6 +7,7 @@
 // the input-gradient) and then held in registers for the whole strip.
 #include "uir_common.h"
 #include "../../include/uir_kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -178,21 +179,25 @@ __device__ __forceinline__ void load_row_t(float4 (&v)[RR + 2], const float* bas
   }
 }
 
-template <int RR>
+// DX = false: the weight-gradient half alone (uir_dwconv_wgrad at the deep levels, where it runs on the weight-gradient lane beside a
+// separate input-gradient launch): same walk, no weights, no dX.
+template <int RR, bool DX>
 __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBwdArgs a, const int HS) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [9][C] weights, then [ny][c4n][36] reduction
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [9][C] weights (DX only), then [ny][c4n][36] reduction
   const int c4n = a.C >> 2;
   const int c4 = threadIdx.x, py = threadIdx.y, ny = blockDim.y;
   const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
   float* wl = sm;
-  float* red = sm + 9 * a.C;
-  for (int c = tid; c < a.C; c += nthr) {
-    const int cr = uir_colmap(c, a.grp_real, a.grp_pad);
-    const float* wp = a.Wt + (long)max(cr, 0) * 9;
+  float* red = DX ? sm + 9 * a.C : sm;
+  if (DX) {
+    for (int c = tid; c < a.C; c += nthr) {
+      const int cr = uir_colmap(c, a.grp_real, a.grp_pad);
+      const float* wp = a.Wt + (long)max(cr, 0) * 9;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) wl[t * a.C + c] = cr >= 0 ? wp[t] : 0.f;
+      for (int t = 0; t < 9; ++t) wl[t * a.C + c] = cr >= 0 ? wp[t] : 0.f;
+    }
+    __syncthreads();
   }
-  __syncthreads();
   const int runs = (a.Wd + RR - 1) / RR;
   const int strips = (a.H + HS - 1) / HS;
   const long items = (long)a.B * strips * runs;
@@ -227,24 +232,31 @@ __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBw
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
           // tap (dy, dx): dY row h-dy = {gp (dy=-1), gc (dy=0), gm (dy=+1)}, column index j+1-dx
-          const float4 wm = *reinterpret_cast<const float4*>(&wl[(0 * 3 + dx + 1) * a.C + c4 * 4]);   // dy = -1
-          const float4 w0v = *reinterpret_cast<const float4*>(&wl[(1 * 3 + dx + 1) * a.C + c4 * 4]);  // dy =  0
-          const float4 wp = *reinterpret_cast<const float4*>(&wl[(2 * 3 + dx + 1) * a.C + c4 * 4]);   // dy = +1
+          float4 wm = make_float4(0.f, 0.f, 0.f, 0.f), w0v = wm, wp = wm;
+          if (DX) {
+            wm = *reinterpret_cast<const float4*>(&wl[(0 * 3 + dx + 1) * a.C + c4 * 4]);    // dy = -1
+            w0v = *reinterpret_cast<const float4*>(&wl[(1 * 3 + dx + 1) * a.C + c4 * 4]);   // dy =  0
+            wp = *reinterpret_cast<const float4*>(&wl[(2 * 3 + dx + 1) * a.C + c4 * 4]);    // dy = +1
+          }
 #pragma unroll
           for (int j = 0; j < RR; ++j) {
             const int jj = j + 1 - dx;
-            o[j] = f4_fma(gp[jj], wm, o[j]);
-            o[j] = f4_fma(gc[jj], w0v, o[j]);
-            o[j] = f4_fma(gm[jj], wp, o[j]);
+            if (DX) {
+              o[j] = f4_fma(gp[jj], wm, o[j]);
+              o[j] = f4_fma(gc[jj], w0v, o[j]);
+              o[j] = f4_fma(gm[jj], wp, o[j]);
+            }
             acc[0 * 3 + dx + 1] = f4_fma(x[j], gp[jj], acc[0 * 3 + dx + 1]);
             acc[1 * 3 + dx + 1] = f4_fma(x[j], gc[jj], acc[1 * 3 + dx + 1]);
             acc[2 * 3 + dx + 1] = f4_fma(x[j], gm[jj], acc[2 * 3 + dx + 1]);
           }
         }
-        float* op = a.dX + ((long)(b * a.H + h) * a.Wd) * a.ldo + c4 * 4;
+        if (DX) {
+          float* op = a.dX + ((long)(b * a.H + h) * a.Wd) * a.ldo + c4 * 4;
 #pragma unroll
-        for (int j = 0; j < RR; ++j)
-          if (w0 + j < a.Wd) *reinterpret_cast<float4*>(op + (long)(w0 + j) * a.ldo) = o[j];
+          for (int j = 0; j < RR; ++j)
+            if (w0 + j < a.Wd) *reinterpret_cast<float4*>(op + (long)(w0 + j) * a.ldo) = o[j];
+        }
       };
 #pragma unroll 1
       for (int h = h0; h < hend; h += 3) {
@@ -305,6 +317,19 @@ extern "C" int uir_dwconv_wgrad(const UirDwWgradArgs* p, void* stream) {
   UIR_REQUIRE(c4n <= 256);
   const int ny = 256 / c4n;
   const size_t lds = (size_t)ny * c4n * 36 * sizeof(float);
+  // default: the rotating-window walk of the fused backward without its dX half (no register-copy chains); UIR_DW_WGRAD_OLD=1 keeps
+  // the first version (a window of X shifted by ~100 v_mov per row)
+  static const bool old_kernel = getenv("UIR_DW_WGRAD_OLD") && atoi(getenv("UIR_DW_WGRAD_OLD")) != 0;
+  if (!old_kernel) {
+    UirDwBwdArgs b{};
+    b.dY = a.dY; b.X = a.X; b.slab = a.slab;
+    b.ldy = a.ldy; b.ldx = a.ldx;
+    b.B = a.B; b.H = a.H; b.Wd = a.Wd; b.C = a.C;
+    b.grp_real = a.grp_real; b.grp_pad = a.grp_pad; b.creal = a.creal; b.nblocks = a.nblocks;
+    hipLaunchKernelGGL((uir_dwconv_bwd_fused_kernel<2, false>), dim3(a.nblocks), dim3(c4n, ny), lds, static_cast<hipStream_t>(stream), b,
+                       uir_dw_strip(a.B, a.H, a.Wd, a.C));
+    return uir_launch_status();
+  }
   hipLaunchKernelGGL(uir_dwconv_wgrad_kernel, dim3(a.nblocks), dim3(c4n, ny), lds, static_cast<hipStream_t>(stream), a,
                      uir_dw_strip(a.B, a.H, a.Wd, a.C));
   return uir_launch_status();
@@ -321,7 +346,7 @@ extern "C" int uir_dwconv_bwd_fused(const UirDwBwdArgs* p, void* stream) {
   const int ny = 256 / c4n;
   const size_t lds = ((size_t)9 * a.C + (size_t)ny * c4n * 36) * sizeof(float);
   UIR_REQUIRE(lds <= 96 * 1024);
-  hipLaunchKernelGGL(uir_dwconv_bwd_fused_kernel<2>, dim3(a.nblocks), dim3(c4n, ny), lds, static_cast<hipStream_t>(stream), a,
+  hipLaunchKernelGGL((uir_dwconv_bwd_fused_kernel<2, true>), dim3(a.nblocks), dim3(c4n, ny), lds, static_cast<hipStream_t>(stream), a,
                      uir_dw_strip(a.B, a.H, a.Wd, a.C));
   return uir_launch_status();
 }
