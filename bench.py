@@ -91,7 +91,6 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--loss", default="L1withColor")
     ap.add_argument("--micro-batch", type=int, default=0, help="experiment: run the batch as micro-batches of this size (gradient accumulation)")
-    ap.add_argument("--lanes", type=int, default=0, help="sample lanes of the train step (0: TrainStep's default / UIR_LANES)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-breakdown", action="store_true")
     ap.add_argument("--breakdown-file", default="")
@@ -121,7 +120,7 @@ def main():
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # the factory prints "modelCreated" like the reference: keep stdout = ONE JSON line
         model = init_model("SpectralTransformer").to(dev)
-    step = TrainStep(model, args.loss, lr=3e-4, micro_batch=args.micro_batch or None, lanes=args.lanes or None)
+    step = TrainStep(model, args.loss, lr=3e-4, micro_batch=args.micro_batch or None)
     g = torch.Generator(device="cpu").manual_seed(1000 + rank)
     B, S = args.batch, args.size
     raw = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(dev)

@@ -291,6 +291,8 @@ def _load() -> C.CDLL:
 
 
 lib = _load()
+from . import knobs as _knobs  # noqa: E402
+_knobs.report()                # prints the non-default knobs of this process, once
 
 
 class UirError(RuntimeError):

@@ -781,7 +781,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // Wide plain Linear layers (NewBigFRFNModel / AST: K, N up to 2048) on the LDS-tiled kernel of csrc/tiled.hip.  The panel
     // kernel below keeps ALL K of one column group in LDS (fine for the SpectralTransformer's K <= 340), its un-staged fallback
     // ran the K >= 1024 layers at 22-29 TFLOP/s.  UIR_TILED_MINK (default 256): smallest K sent there; 0 disables.
-    static const int mink = getenv("UIR_TILED_MINK") ? atoi(getenv("UIR_TILED_MINK")) : 256;
+    constexpr int mink = 256;
     const bool w_kc = a.w_sk == 1 && (a.w_sn & 3) == 0, w_nc = a.w_sn == 1 && (a.w_sk & 3) == 0 && (a.N & 3) == 0;
     if (mink > 0 && a.K >= mink && a.N >= 128 && a.M >= 256 && a.taps == 1 && a.batches == 1 && a.pro == UIR_PRO_NONE &&
         a.epi == UIR_EPI_PLAIN && (a.act == UIR_ACT_NONE || a.act == UIR_ACT_GELU) && a.n_grp_pad <= 0 && a.k_grp_pad <= 0 &&
@@ -799,7 +799,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // one launch on the LDS-tiled kernel instead of tap-group launches / the un-staged fallback.  UIR_TILED_CONV_MINK (default 256; 0 off);
     // the SpectralTransformer's own 3 x 3 convolutions (K <= 256 on <= 16 384 pixels, side lane) stay on the tap-group path they were
     // tuned and measured on
-    static const int cmink = getenv("UIR_TILED_CONV_MINK") ? atoi(getenv("UIR_TILED_CONV_MINK")) : 256;
+    constexpr int cmink = 256;
     if (cmink > 0 && a.taps == 9 && a.ntap <= 0 && a.K >= cmink && (a.K >= 512 || a.M > 16384) && a.N >= 64 && a.batches == 1 && a.pro == UIR_PRO_NONE &&
         a.epi == UIR_EPI_PLAIN && a.act == UIR_ACT_NONE && a.n_grp_pad <= 0 && a.k_grp_pad <= 0 && (a.K & 3) == 0) {
       UirTiledArgs t{};
@@ -818,8 +818,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // ups_{1,2}.Sups input gradients, 9.7 GFLOP each) runs as launches over tap groups of <= 50 KB that accumulate into Y;
     // the un-staged fallback below reads weights per MFMA step and reaches 22-29 TFLOP/s there.  (K = 64 keeps its single
     // 74 KB launch: 178 us against 219 us split.)
-    static const bool split_ok = !(getenv("UIR_TAP_SPLIT") && atoi(getenv("UIR_TAP_SPLIT")) == 0);
-    if (split_ok && a.taps == 9 && a.ntap <= 0 && (size_t)32 * (K8 * 9 + 4) * 4 > 96 * 1024 && (size_t)32 * (K8 + 4) * 4 <= 48 * 1024 &&
+    if (a.taps == 9 && a.ntap <= 0 && (size_t)32 * (K8 * 9 + 4) * 4 > 96 * 1024 && (size_t)32 * (K8 + 4) * 4 <= 48 * 1024 &&
         a.pro == UIR_PRO_NONE && a.epi == UIR_EPI_PLAIN && a.act == UIR_ACT_NONE) {
       int g = 1;
       while (g < 3 && (size_t)32 * (K8 * (g + 1) + 4) * 4 <= 50 * 1024) ++g;
@@ -842,7 +841,6 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // small problems (deep U-Net levels): favour many narrow column groups over A re-use - the
     // row panel is L2-resident there and parallelism is what is missing
     if ((long)((a.M + 127) / 128) * groups1 * a.batches < 1024) nt1 = 1;
-    if (const char* e = getenv("UIR_NT")) { const int v = atoi(e); if (v >= 1 && v <= 3) nt1 = v < tiles ? v : tiles; }  // tuning aid
     if (a.epi == UIR_EPI_LN_BWD) nt1 = tiles;          // the row reductions need every channel in one workgroup
     while (nt1 > 1 && (size_t)nt1 * 32 * Kp * 4 > 60 * 1024) { --nt1; }
     groups1 = (tiles + nt1 - 1) / nt1;
@@ -854,12 +852,12 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     const bool combo_ok = (a.pro == UIR_PRO_NONE) || (a.epi == UIR_EPI_PLAIN && !(a.pro == UIR_PRO_LN && a.R));
     if (lds <= 100 * 1024 && combo_ok) {
       const int rtiles = (a.M + 127) / 128;
-      static const int gx_total = getenv("UIR_GEMM_GX") ? atoi(getenv("UIR_GEMM_GX")) : 768;   // = the resident workgroups at 3 per CU (1536: +0.15 ms/step)
+      constexpr int gx_total = 768;   // = the resident workgroups at 3 per CU (1536: +0.15 ms/step)
       int gx = gx_total / (groups1 * a.batches);
       if (gx < 1) gx = 1;
       // the variants with fused reductions run 2 workgroups per CU (launch bounds): 512 resident workgroups take all
       // the tiles, and every workgroup writes one slab row for uir_reduce_slab - no point in more rows than that
-      static const int slab_rows = getenv("UIR_GEMM_ROWS") ? atoi(getenv("UIR_GEMM_ROWS")) : UIR_GEMM_SLAB_ROWS;   // tuning aid (<= engine's slab)
+      constexpr int slab_rows = UIR_GEMM_SLAB_ROWS;
       if ((a.epi == UIR_EPI_GATE_BWD_DW || a.epi == UIR_EPI_LN_BWD) && gx > slab_rows) gx = slab_rows;
       if (gx > rtiles) gx = rtiles;
       dim3 grid1(gx, groups1, a.batches);

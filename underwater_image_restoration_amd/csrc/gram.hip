@@ -474,7 +474,7 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
   {
     // Wide weight gradients (Linear layers of NewBigFRFNModel / AST, N and K >= UIR_TILED_GRAM_MIN, default 128): 128 x 128
     // output tiles on the LDS-tiled kernel of csrc/tiled.hip, one k split per chunk - same partial-slab contract.
-    static const int minw = getenv("UIR_TILED_GRAM_MIN") ? atoi(getenv("UIR_TILED_GRAM_MIN")) : 128;
+    constexpr int minw = 128;
     const bool wide = a.N >= minw && a.K >= minw;
     const bool narrow_k = a.N >= minw && a.K == 64, narrow_n = a.N == 64 && a.K >= minw;   // 128 x 64 tiles (the 64 side as second operand)
     if (minw > 0 && (wide || narrow_k || narrow_n) && a.taps == 1 && a.batches == 1 && a.pro_b == UIR_GRAM_PRO_NONE && !extras &&
@@ -499,7 +499,7 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
     }
   }
   const int tn_tiles = (a.N + 31) / 32, tk_tiles = (a.K + 31) / 32;
-  static const bool cols9 = !(getenv("UIR_GRAM_COLS9") && atoi(getenv("UIR_GRAM_COLS9")) == 0);   // A/B aid
+  constexpr bool cols9 = true;
   if (cols9 && a.taps == 9 && 9 * a.N <= 160 && tk_tiles == 1 && !extras && a.pro_b == UIR_GRAM_PRO_NONE) {
     dim3 grid(a.nchunks, 1, a.batches);
     const int nt = (9 * a.N + 31) / 32;

@@ -37,16 +37,9 @@ CHANNELS = (16, 32, 64, 128)
 NUM_REFINEMENT = 4
 EXPANSION = 2.66
 LN_EPS = 1e-5
-_SKIP_SIDE = os.environ.get("UIR_SKIP_SIDE", "0") == "1"
-_SKIP_RED = os.environ.get("UIR_SKIP_RED", "0") == "1"
-_SKIP_OPS = [k for k in os.environ.get("UIR_SKIP_OPS", "").split(",") if k]
-# channel counts whose GDFN forward runs as the tile-fused kernel (csrc/gdfn.hip); "" = three separate kernels
-_GDFN_FUSED = set(filter(None, os.environ.get("UIR_GDFN_FUSED", "16,32,64,128").split(",")))
-_ATTNV_FUSED = set(filter(None, os.environ.get("UIR_ATTNV_FUSED", "32,64").split(",")))   # C=16 / 128: half-empty tiles / one WG per CU, unfused is as fast
-_QKV_FUSED = set(filter(None, os.environ.get("UIR_QKV_FUSED", "16,32,64,128").split(",")))
-# opt-in: after the gate-backward epilogue fix the three HBM-bound kernels (869 us at C=32, 256x256) beat the fused,
-# latency-bound kernel (959 us, SIMDs 47 % busy); full step 51.9 vs 52.7 ms (profiles/r01/d_ab_notes.md)
-_GDFN_BWD_FUSED = set(filter(None, os.environ.get("UIR_GDFN_BWD_FUSED", "").split(",")))
+# Which tile-fused kernels each level uses is fixed here (measured choices, profiles/r01/d_ab_notes.md), not read from the
+# environment: the only environment variables the product reads are listed in knobs.py.
+_ATTNV_FUSED = (32, 64)        # MDTA tail as uir_attnv_fwd; C = 16 / 128: half-empty tiles / one workgroup per CU, three kernels are as fast
 SCRATCH_FLOATS = 96 * 1024 * 1024  # 384 MB of slab scratch shared by every reduction
 
 
@@ -148,10 +141,9 @@ def twiddles(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     return _TWIDDLE_CACHE[key]
 
 
-_NO_SIDE_STREAM = os.environ.get("UIR_NO_SIDE_STREAM", "0") == "1"
-_RED_BATCH = os.environ.get("UIR_RED_BATCH", "1") == "1"       # one batched slab-reduction launch per stage on the bulk lane
-_GRAM_WGS = int(os.environ.get("UIR_GRAM_WGS", 1024))           # workgroups (= partial rows x column groups) per Gram launch; tuning aid
-GEMM_SLAB_ROWS = int(os.environ.get("UIR_GEMM_ROWS", 512))      # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
+_GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per Gram launch
+GEMM_SLAB_ROWS = 512           # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
+FUSED_DW_MINROWS = 16 * 128 * 128   # depthwise backward as ONE pass (dX + dW) from this many pixels on; below, two kernels on two lanes
 _DFT2_CACHE: dict = {}
 
 
@@ -257,7 +249,7 @@ class Recorder:
     # are collected and issued as ONE uir_reduce_slab_batch launch per network stage (flushed at every stage mark): ~380
     # launches of 7-30 us per step become ~75.  Bit-identical to the per-tensor launches (same summation order).
     def _batching(self) -> bool:
-        return _RED_BATCH and self.lane == 4
+        return self.lane == 4
 
     def _reduce(self, name: str, src: int, rows: int, stride: int, dst: int, n: int, immediate: bool = False):
         if self._batching() and not immediate:
@@ -369,8 +361,6 @@ class Recorder:
         main = torch.cuda.current_stream()
         st0 = C.c_void_p(main.cuda_stream)
         lanes = self.lanes[id(ops)]
-        if _NO_SIDE_STREAM:          # experiment: side-lane work in list order on the main stream (weight-gradient lane kept)
-            lanes = [0 if l == 1 else (3 if l == 2 else l) for l in lanes]
         if serial or (1 not in lanes and 4 not in lanes):
             for fn, args, name in ops:
                 if fn is None:
@@ -382,18 +372,11 @@ class Recorder:
         if self._side_stream is None:
             # lowest priority: the side lane fills bandwidth the critical dX chain leaves idle
             lo = max(torch.cuda.Stream.priority_range()) if hasattr(torch.cuda.Stream, "priority_range") else 0
-            self._side_stream = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("UIR_SIDE_PRIO", lo)))
+            self._side_stream = torch.cuda.Stream(device=self.dev, priority=lo)
         side = self._side_stream
         st1 = C.c_void_p(side.cuda_stream)
         if self._bulk_stream is None:
-            ncu = int(os.environ.get("UIR_BULK_CUS", "0"))
-            if ncu > 0:      # weight-gradient lane confined to `ncu` compute units (uir_stream_create_cu_masked)
-                h = C.c_void_p()
-                L.check(lib.uir_stream_create_cu_masked(ncu, C.byref(h)), "uir_stream_create_cu_masked")
-                self._bulk_stream = torch.cuda.ExternalStream(h.value, device=self.dev)
-                self._bulk_handle = h          # lives as long as the plan
-            else:
-                self._bulk_stream = torch.cuda.Stream(device=self.dev)
+            self._bulk_stream = torch.cuda.Stream(device=self.dev)
         bulk = self._bulk_stream
         st4 = C.c_void_p(bulk.cuda_stream)
         nev = 0
@@ -416,12 +399,6 @@ class Recorder:
                 main.wait_event(ev)
                 continue
             if lane == 4:
-                if _SKIP_SIDE:      # timing experiment only (UIR_SKIP_SIDE=1): results are wrong
-                    continue
-                if _SKIP_RED and fn is lib.uir_reduce_slab:   # timing experiment only (UIR_SKIP_RED=1): results are wrong
-                    continue
-                if _SKIP_OPS and any(k in name for k in _SKIP_OPS):   # timing experiment only (UIR_SKIP_OPS=a,b): wrong results
-                    continue
                 if bulk_dirty:
                     if nev == len(self._events):
                         self._events.append(torch.cuda.Event())
@@ -772,12 +749,12 @@ class Recorder:
         self._op(name, lib.uir_dwconv_wgrad, C.byref(a), nbytes=8 * rows * C_, flops=18 * rows * C_)
         self._reduce(name + ".red", _ptr(slab), a.nblocks, creal * 9, _ptr(out), creal * 9)
 
-    def dwconv_bwd(self, name, dY, X, Wt, dX, dW, *, C_, creal, dims, grp=(0, 0)):
+    def dwconv_bwd(self, name, dY, X, Wt, dX, dW, *, C_, creal, dims, grp=(0, 0), min_rows=None):
         """Fused input-gradient + weight-gradient of a depthwise 3x3 (dY read once)."""
         # fused only where bytes bind (full and half resolution); at the deep levels the chain is latency-bound and the
         # split keeps the weight-gradient half off it
         rows_total = dims[0] * dims[1] * dims[2]
-        if os.environ.get("UIR_FUSED_DW", "1") != "1" or rows_total < int(os.environ.get("UIR_FUSED_DW_MINROWS", 16 * 128 * 128)):
+        if rows_total < (FUSED_DW_MINROWS if min_rows is None else min_rows):
             # two kernels (input-gradient on the chain, weight-gradient on the bulk lane): dY is read twice.  The fused
             # kernel (2-pixel runs, window rotating by register name, ~240 VGPRs, 2 waves/SIMD) reads it once:
             # A/B on one MI355X 51.3 vs 51.9 ms/step (profiles/r01/d_ab_notes.md); the first fused version
@@ -798,7 +775,7 @@ class Recorder:
             hs //= 2
         items = dims[0] * ((dims[1] + hs - 1) // hs) * ((dims[2] + 3) // 4)
         ny = 256 // (C_ // 4)
-        a.nblocks = max(1, min(int(os.environ.get("UIR_DW_NBLOCKS", "512")), items // max(1, ny)))
+        a.nblocks = max(1, min(512, items // max(1, ny)))
         # private partial-slab buffer: the kernel runs on the chain, its (tiny) reduction on the bulk lane, so the
         # shared chain scratch may be overwritten in between
         slab = self.alloc(a.nblocks * creal * 9)
@@ -849,7 +826,7 @@ class Recorder:
         self._hold(in_re, in_im, out_re, out_im)
         elems = O * N * I * C_
         planes = (1 if in_im is None else 2) + (1 if out_im is None else 2)
-        if N in (32, 64, 128) and os.environ.get("UIR_DFT2", "1") == "1":
+        if N in (32, 64, 128):
             a = L.Dft2Args()
             a.in_re, a.in_im, a.out_re, a.out_im = _ptr(in_re), _ptr(in_im), _ptr(out_re), _ptr(out_im)
             ta, tb = dft2_tables(N, sign, self.dev)
@@ -929,53 +906,29 @@ class Plan(Recorder):
 
         n = pfx
         # ---- MDTA (live path of :93-100,107,110,113) ----
-        if str(C_) in _QKV_FUSED:
-            self.qkv_fwd(n + ".qkv+conv", x, (g1, b1), Wqkv, Wdw, qkv_pre, qkv, C_=C_, dims=dims, stats=stats1)
-        else:
-            self.gemm(n + ".qkv", x, Wqkv, qkv_pre, N=3 * C_, K=C_, w_sn=C_, w_sk=1, pro=L.PRO_LN, ln=(g1, b1), stats=stats1)
-            self.dwconv(n + ".qkv_conv", qkv_pre, Wdw, qkv, C_=3 * C_, dims=dims)
+        self.qkv_fwd(n + ".qkv+conv", x, (g1, b1), Wqkv, Wdw, qkv_pre, qkv, C_=C_, dims=dims, stats=stats1)
         # P = W_kv[vf] @ W_o depends on weights only: side lane, joined right before its first use
         with self.side():
             self.gemm(n + ".P", Wkvf, Wo, Pm, N=C_, K=C_, w_sn=1, w_sk=C_)
-        # the per-sample Gram partials (and, in the backward, the dWA | dWB partials) are summed inside the attention kernels:
-        # two ~7 us reduction launches less on the chain per block, but 16-128 workgroups walking 64 partial rows take longer than that
-        inred = os.environ.get("UIR_ATTN_INRED", "0") == "1"     # opt-in: measured 43.33 vs 42.9 ms/step
         fa = L.AttnFwdArgs()
-        if inred:
-            tn_ = (C_ + 31) // 32
-            nch_g, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B)
-            gstride = B * C_ * C_ + 2 * B * C_
-            gslab = self.alloc(nch_g * gstride)
-            got = self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
-                            out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, shared_slab=(gslab, 0, gstride))
-            assert got == nch_g
-            fa.slab, fa.nch, fa.slab_stride = _ptr(gslab), nch_g, gstride
-            fa.sq_q_off, fa.sq_k_off = B * C_ * C_, B * C_ * C_ + B * C_
-        else:
-            self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
-                      out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, fused_out=gbuf)
+        self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
+                  out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, fused_out=gbuf)
         self.join(n + ".P.join")
         fa.G, fa.sq_q, fa.sq_k, fa.temperature, fa.P, fa.Wof = _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp), _ptr(Pm), _ptr(Wof)
         fa.attn, fa.WA, fa.WB = _ptr(attn), _ptr(WA), _ptr(WB)
         fa.B, fa.C, fa.heads = B, C_, heads
         self.keep.append(fa)
         self._op(n + ".attn_fwd", lib.uir_attn_fwd, C.byref(fa))
-        if str(C_) in _ATTNV_FUSED:
+        if C_ in _ATTNV_FUSED:
             self.attnv_fwd(n + ".WA+kv_conv+WB", v_, WA, WB, Wkvdw_f, x, u, vf, x1, C_=C_, dims=dims)
         else:
             self.gemm(n + ".WA", v_, WA, u, N=C_, K=C_, w_sn=C_, w_sk=1, w_bs=C_ * C_, batches=B)
             self.dwconv(n + ".kv_conv", u, Wkvdw_f, vf, C_=C_, dims=dims)
             self.gemm(n + ".WB", vf, WB, x1, N=C_, K=C_, w_sn=C_, w_sk=1, w_bs=C_ * C_, batches=B, R=x)
         # ---- GDFN (:127-130) ----
-        if str(C_) in _GDFN_FUSED:
-            # one pass over the pixels; t1/t2 written once for the backward kernels, never re-read in the forward
-            self.gdfn_fwd(n + ".gdfn", x1, (g2, b2), Win, Wffdw, Wout, y, C_=C_, h=h, hp=hp, dims=dims,
-                          T1=gpre, T2=g, stats=stats2)
-        else:
-            self.gemm(n + ".ffn_in", x1, Win, gpre, N=2 * hp, K=C_, w_sn=C_, w_sk=1, n_grp=(h, hp), pro=L.PRO_LN, ln=(g2, b2),
-                      stats=stats2)
-            self.dwconv(n + ".ffn_conv", gpre, Wffdw, g, C_=2 * hp, dims=dims, grp=(h, hp))
-            self.gemm(n + ".ffn_out", g, Wout, y, N=C_, K=h, w_sn=h, w_sk=1, pro=L.PRO_GATE, gate_off=hp, R=x1)
+        # one pass over the pixels; t1/t2 written once for the backward kernels, never re-read in the forward
+        self.gdfn_fwd(n + ".gdfn", x1, (g2, b2), Win, Wffdw, Wout, y, C_=C_, h=h, hp=hp, dims=dims,
+                      T1=gpre, T2=g, stats=stats2)
 
         def backward(dy: torch.Tensor) -> torch.Tensor:
             dg, dgpre = self.alloc(M, ldg)[:, :2 * hp], self.alloc(M, ldg)[:, :2 * hp]
@@ -990,93 +943,62 @@ class Plan(Recorder):
             dx = self.alloc(M, C_)
             # GDFN
             # LayerNorm backward as the epilogue of the GEMM that produces its output gradient (one 32-column tile)
-            fuse_ln = C_ <= 32 and M % 128 == 0 and os.environ.get("UIR_LNBWD_FUSED", "1") == "1"
-            fuse_dwout = (str(C_) not in _GDFN_BWD_FUSED and C_ <= 32 and hp <= 96 and M % 128 == 0 and
-                          os.environ.get("UIR_DWOUT_FUSED", "1") == "1")
+            fuse_ln = C_ <= 32 and M % 128 == 0
+            fuse_dwout = C_ <= 32 and hp <= 96 and M % 128 == 0
             if not fuse_dwout:
                 with self.bulk():
                     self.gram(n + ".dWout", dy, g, Gr(f"{pfx}.ffn.project_out.weight"), N=C_, K=h, o_sn=h, o_sk=1,
                               pro_b=L.PRO_GATE, gate_off=hp)
-            if str(C_) in _GDFN_BWD_FUSED:
-                # dY -> dt2 -> dt1 -> dt in one pass; dt2 / dt1 are written once for the weight-gradient lane
-                self.gdfn_bwd(n + ".gdfn_bwd", dy, g, Wout, Wffdw, Win, dg, dgpre, dt, C_=C_, h=h, hp=hp, dims=dims)
+            if fuse_dwout:
+                # project_out weight gradient inside the gate-backward GEMM (its accumulator layout is the
+                # B-operand layout of the pixel contraction): the bulk lane keeps only the tiny slab reduction.
+                # Rows beyond the launch's gridDim.x are never written: the slab is zero-filled once, here.
+                dws = torch.zeros(GEMM_SLAB_ROWS, C_ * h, device=self.dev, dtype=torch.float32)
+                self.gemm(n + ".dgate+dWout", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp),
+                          epi=L.EPI_GATE_BWD_DW, G=g, g_off=hp, dw_slab=dws)
                 with self.bulk():
-                    self.dwconv_wgrad(n + ".dgpre+dWffdw.dW", dg, gpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
-                                      dims=dims, grp=(h, hp))
-                    self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
-                              n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
+                    self._reduce(n + ".dWout.red", _ptr(dws), GEMM_SLAB_ROWS, C_ * h,
+                             _ptr(Gr(f"{pfx}.ffn.project_out.weight")), C_ * h)
             else:
-                if fuse_dwout:
-                    # project_out weight gradient inside the gate-backward GEMM (its accumulator layout is the
-                    # B-operand layout of the pixel contraction): the bulk lane keeps only the tiny slab reduction.
-                    # Rows beyond the launch's gridDim.x are never written: the slab is zero-filled once, here.
-                    dws = torch.zeros(GEMM_SLAB_ROWS, C_ * h, device=self.dev, dtype=torch.float32)
-                    self.gemm(n + ".dgate+dWout", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp),
-                              epi=L.EPI_GATE_BWD_DW, G=g, g_off=hp, dw_slab=dws)
-                    with self.bulk():
-                        self._reduce(n + ".dWout.red", _ptr(dws), GEMM_SLAB_ROWS, C_ * h,
-                                 _ptr(Gr(f"{pfx}.ffn.project_out.weight")), C_ * h)
-                else:
-                    self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g,
-                              g_off=hp)
-                self.dwconv_bwd(n + ".dgpre+dWffdw", dg, gpre, Wffdw, dgpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
-                                dims=dims, grp=(h, hp))
-                def dwin():
-                    with self.bulk():
-                        self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
-                                  n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
-                late = os.environ.get("UIR_LATE_GRAMS", "1") == "1"
-                if not late:
-                    dwin()
-                if fuse_ln:
-                    self.gemm_ln_bwd(n + ".dt2+ln2_bwd", dgpre, Win, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"),
-                                     Gr(f"{pfx}.norm2.bias"), C_=C_, K=2 * hp, k_grp=(h, hp))
-                else:
-                    self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
-                if late:      # released after the GEMM that shares its dgpre operand (the persistent 2-WG/CU GEMM with the
-                    dwin()    # LayerNorm epilogue lost 60 % when this Gram started beside it: serial 267 us, overlapped 430 us)
-            if not (fuse_ln and str(C_) not in _GDFN_BWD_FUSED):
+                self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g,
+                          g_off=hp)
+            self.dwconv_bwd(n + ".dgpre+dWffdw", dg, gpre, Wffdw, dgpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
+                            dims=dims, grp=(h, hp))
+            if fuse_ln:
+                self.gemm_ln_bwd(n + ".dt2+ln2_bwd", dgpre, Win, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"),
+                                 Gr(f"{pfx}.norm2.bias"), C_=C_, K=2 * hp, k_grp=(h, hp))
+            else:
+                self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
+            # released after the GEMM that shares its dgpre operand (the persistent 2-WG/CU GEMM with the LayerNorm
+            # epilogue lost 60 % when this Gram started beside it: serial 267 us, overlapped 430 us)
+            with self.bulk():
+                self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
+                          n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
+            if not fuse_ln:
                 self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
             # MDTA
-            # the two per-sample weight-gradient Grams are needed only by uir_attn_bwd: side lane, joined right before it
-            side_grams = os.environ.get("UIR_SIDE_GRAMS", "0") == "1"   # opt-in: A/B neutral (46.1-46.2 vs 46.2-46.3 ms/step)
-            if side_grams:
-                with self.side():
-                    self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
-                              out_elems=B * C_ * C_, own_slab=True)
-            else:
-                # dWB | dWA partials side by side in one slab: a single reduction launch (before uir_attn_bwd) instead of two
-                nab = B * C_ * C_
-                tn_ = (C_ + 31) // 32
-                nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B)
-                slab_ab = self.alloc(nch_ab * 2 * nab)
-                assert dWA.data_ptr() == dWB.data_ptr() + 4 * nab
-                got = self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
-                                shared_slab=(slab_ab, 0, 2 * nab))
-                assert got == nch_ab
+            # dWB | dWA partials side by side in one slab: a single reduction launch (before uir_attn_bwd) instead of two
+            nab = B * C_ * C_
+            tn_ = (C_ + 31) // 32
+            nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B)
+            slab_ab = self.alloc(nch_ab * 2 * nab)
+            assert dWA.data_ptr() == dWB.data_ptr() + 4 * nab
+            got = self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
+                            shared_slab=(slab_ab, 0, 2 * nab))
+            assert got == nch_ab
             self.gemm(n + ".dvf", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
             self.dwconv_bwd(n + ".du+dWkvdw", dvf, u, Wkvdw_f, du, Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, creal=C_,
                             dims=dims)
-            if side_grams:
-                with self.side():
-                    self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
-                              out_elems=B * C_ * C_, own_slab=True)
-            else:
-                got = self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
-                                shared_slab=(slab_ab, nab, 2 * nab))
-                assert got == nch_ab
-                if not inred:
-                    self._reduce(n + ".dWAB.red", _ptr(slab_ab), nch_ab, 2 * nab, _ptr(dWB), 2 * nab)
+            got = self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
+                            shared_slab=(slab_ab, nab, 2 * nab))
+            assert got == nch_ab
+            self._reduce(n + ".dWAB.red", _ptr(slab_ab), nch_ab, 2 * nab, _ptr(dWB), 2 * nab)
             self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
-            if side_grams:
-                self.join(n + ".dWAB.join")
             ba = L.AttnBwdArgs()
             ba.dWA, ba.dWB, ba.G, ba.sq_q, ba.sq_k, ba.temperature = _ptr(dWA), _ptr(dWB), _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp)
             ba.attn, ba.P, ba.Wof = _ptr(attn), _ptr(Pm), _ptr(Wof)
             ba.Mqk, ba.dP, ba.dWof, ba.dT = _ptr(Mqk), _ptr(dPb), _ptr(dWofb), _ptr(dTb)
             ba.B, ba.C, ba.heads = B, C_, heads
-            if inred and not side_grams:
-                ba.slab, ba.nch, ba.slab_stride, ba.dWB_off, ba.dWA_off = _ptr(slab_ab), nch_ab, 2 * nab, 0, nab
             self.keep.append(ba)
             self._op(n + ".attn_bwd", lib.uir_attn_bwd, C.byref(ba))
             with self.bulk():
@@ -1090,21 +1012,15 @@ class Plan(Recorder):
                       w_bs=4 * C_ * C_, batches=B)
             self.dwconv_bwd(n + ".dqkv_pre+dWqkvdw", dqkv, qkv_pre, Wdw, dqkv_pre, Gr(f"{a}.qkv_conv.weight"), C_=3 * C_,
                             creal=3 * C_, dims=dims)
-            def dwqkv():
-                with self.bulk():
-                    self.gram(n + ".dWqkv", dqkv_pre, x, Gr(f"{a}.qkv.weight"), N=3 * C_, K=C_, o_sn=C_, o_sk=1,
-                              pro_b=L.PRO_LN, ln=(g1, b1), stats=stats1)
-            late_q = os.environ.get("UIR_LATE_GRAMS", "1") == "1"
-            if not late_q:
-                dwqkv()
             if fuse_ln:
                 self.gemm_ln_bwd(n + ".dt1+ln1_bwd", dqkv_pre, Wqkv, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"),
                                  Gr(f"{pfx}.norm1.bias"), C_=C_, K=3 * C_)
             else:
                 self.gemm(n + ".dt1", dqkv_pre, Wqkv, dt, N=C_, K=3 * C_, w_sn=1, w_sk=C_)
                 self.ln_bwd(n + ".ln1_bwd", dt, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_)
-            if late_q:
-                dwqkv()
+            with self.bulk():      # after the GEMM that shares its dqkv_pre operand (see dWin above)
+                self.gram(n + ".dWqkv", dqkv_pre, x, Gr(f"{a}.qkv.weight"), N=3 * C_, K=C_, o_sn=C_, o_sk=1,
+                          pro_b=L.PRO_LN, ln=(g1, b1), stats=stats1)
             return dx
 
         return y, backward
@@ -1262,23 +1178,17 @@ class Plan(Recorder):
         self.out_nchw = self.alloc(B, 3, H, W)
         self.dout_nchw = self.alloc(B, 3, H, W)
         self.cur = self.fwd
-        if os.environ.get("UIR_EMBED_IM2COL", "1") == "1":
-            # embed_conv_rgb (3 -> 16, 3x3) on 3x3 patches [M][28]: one K = 27 GEMM forward and one <1,1> Gram for its weight
-            # gradient (the last launch of the step) instead of nine 4-channel taps on 32x32 MFMA tiles
-            x27 = self.alloc(M0, 28)
-            Wemb = P("embed_conv_rgb.weight")
-            self._op("in.im2col", lib.uir_im2col3x3_c3, _ptr(self.in_nchw), _ptr(x27), B, H, W, nbytes=4 * M0 * 31)
-            self.mark("fwd.start")
-            f0 = self.alloc(M0, 16)
-            self.gemm("embed", x27, Wemb, f0, N=16, K=27, w_sn=27, w_sk=1)
+        # embed_conv_rgb (3 -> 16, 3x3) on 3x3 patches [M][28]: one K = 27 GEMM forward and one <1,1> Gram for its weight
+        # gradient (the last launch of the step) instead of nine 4-channel taps on 32x32 MFMA tiles
+        x27 = self.alloc(M0, 28)
+        Wemb = P("embed_conv_rgb.weight")
+        self._op("in.im2col", lib.uir_im2col3x3_c3, _ptr(self.in_nchw), _ptr(x27), B, H, W, nbytes=4 * M0 * 31)
+        self.mark("fwd.start")
+        f0 = self.alloc(M0, 16)
+        self.gemm("embed", x27, Wemb, f0, N=16, K=27, w_sn=27, w_sk=1)
 
-            def embed_bw(dy, need_dx=False, dw_on_chain=True):
-                self.gram("embed.dW", dy, x27, self.Gr("embed_conv_rgb.weight"), N=16, K=27, o_sn=27, o_sk=1)
-        else:
-            x4 = self.alloc(M0, 4)
-            self._op("in.to_hwc", lib.uir_nchw3_to_hwc4, _ptr(self.in_nchw), _ptr(x4), B, H, W)
-            self.mark("fwd.start")
-            f0, embed_bw = self._conv3("embed", x4, "embed_conv_rgb.weight", 3, 16, d0, k_grp=(3, 4), Kp=4)
+        def embed_bw(dy, need_dx=False, dw_on_chain=True):
+            self.gram("embed.dW", dy, x27, self.Gr("embed_conv_rgb.weight"), N=16, K=27, o_sn=27, o_sk=1)
         e1, enc1_bw = self._stack("encoders.0", f0, 2, 16, 1, d0)
         self.mark("fwd.enc0(L0,C16)")
         t1, down1_bw = self._down("down1", e1, 16, d0)
@@ -1373,28 +1283,7 @@ class Plan(Recorder):
         self.mark("bwd.enc0(L0,C16)")
         embed_bw(df0, need_dx=False, dw_on_chain=True)
         self.mark("bwd.embed")
-        self._defer_bulk(self.bwd, os.environ.get("UIR_DEFER_AT", "bwd.dec2(L0,C32)"))
         self.cur = self.fwd
-
-    def _defer_bulk(self, ops: list, marker: str) -> None:
-        """Move every bulk-lane (weight-gradient) launch recorded before `marker` to just after it, keeping
-        their order.  At full resolution the main chain is HBM-bound and concurrent weight-gradient work
-        only steals its bandwidth (measured: +10 ms/step); the deeper levels are latency-bound and leave
-        the bandwidth idle.  Legal because every plan buffer is written exactly once per step."""
-        if os.environ.get("UIR_DEFER", "0") != "1":      # opt-in: A/B measured +0.6 ms/step (contention moves to L1)
-            return
-        lanes, meta, variants = self.lanes[id(ops)], self.meta[id(ops)], self.variants[id(ops)]
-        names = [o[2] for o in ops]
-        if marker not in names:
-            return
-        cut = names.index(marker)
-        keep = [i for i in range(cut + 1) if lanes[i] != 4]
-        moved = [i for i in range(cut + 1) if lanes[i] == 4]
-        order = keep + moved + list(range(cut + 1, len(ops)))
-        ops[:] = [ops[i] for i in order]
-        lanes[:] = [lanes[i] for i in order]
-        meta[:] = [meta[i] for i in order]
-        variants[:] = [variants[i] for i in order]
 
     # ------------------------------------------------------------------- run
     def forward(self, x_nchw: torch.Tensor, serial: bool = False) -> torch.Tensor:

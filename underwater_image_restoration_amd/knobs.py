@@ -1,0 +1,49 @@
+"""The ONLY environment variables the product reads (tests/test_cpu_surface.py greps the package for any other).
+
+A clean environment reads none of them: every kernel / schedule choice of the train step is a constant in engine.py or in the
+library.  Each knob below is covered by a parity test with the knob ON; `report()` (called once by _lib at import) prints the
+ones that are set, so a stray variable cannot silently change what trains.
+"""
+from __future__ import annotations
+
+import os
+
+KNOBS = {
+    # name: (default, what it does, the test that holds results with it on)
+    "UIR_GRAPH": ("0", "1: the train step replays ONE captured hipGraph (forward + loss + backward + clip/Adam) instead of eager launch lists",
+                  "tests/test_hip_model.py::test_adam_scalars_survive_an_unsynchronised_host"),
+    "UIR_TILED_SPLIT": ("0", "read by libuir_hip.so: 1 = every wide contraction of csrc/tiled.hip on split-bf16 MFMA (3 bf16 planes, 6 products, "
+                        "f32-accurate); 3 = only the marked ones",
+                        "tests/test_tiled.py::test_split_bf16_mode_is_f32_accurate"),
+    "UIR_FORCE_ALLREDUCE": ("0", "1: run the gradient all-reduce even in a world of one process (exercises the RCCL call path on a 1-GPU box)",
+                            "tests/test_hip_model.py::test_rccl_allreduce_call_path_world1"),
+}
+# process plumbing, not knobs: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torch.distributed.run), HIPCC / UIR_LLVM_BIN (build.py)
+PLUMBING = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HIPCC", "UIR_LLVM_BIN")
+
+
+def get(name: str) -> str:
+    assert name in KNOBS, f"{name} is not a documented knob (knobs.py)"
+    return os.environ.get(name, KNOBS[name][0])
+
+
+def flag(name: str) -> bool:
+    return get(name) == "1"
+
+
+_reported = False
+
+
+def report() -> None:
+    """Print, once per process, every knob whose value differs from its default, and every other UIR_* variable (ignored)."""
+    global _reported
+    if _reported:
+        return
+    _reported = True
+    for k, (default, what, _test) in KNOBS.items():
+        v = os.environ.get(k)
+        if v is not None and v != default:
+            print(f"[uir] {k}={v} (default {default}): {what}", flush=True)
+    stray = sorted(k for k in os.environ if k.startswith("UIR_") and k not in KNOBS and k not in PLUMBING and k not in ("UIR_CPU_THREADS", "UIR_CPU_BATCH"))
+    if stray:
+        print(f"[uir] ignored environment variables (not knobs of this build): {', '.join(stray)}", flush=True)

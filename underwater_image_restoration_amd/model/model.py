@@ -71,14 +71,13 @@ def token_factors(H: int, W: int):
     """Stage lengths (N1, N2[, N3]) with product H*W.  Prefer factors the fast DFT kernel handles (65 536 = 64*32*32,
     4096 = 64*64); otherwise the two dense stages (H, W)."""
     Ltok = H * W
-    if os.environ.get("UIR_TOKEN_FFT_DENSE", "0") != "1":
-        for a in _FAST:
-            if Ltok % a == 0 and Ltok // a in _FAST:
-                return (a, Ltok // a)
-        for a in _FAST:
-            for b in _FAST:
-                if Ltok % (a * b) == 0 and Ltok // (a * b) in _FAST and a >= b >= Ltok // (a * b):
-                    return (a, b, Ltok // (a * b))
+    for a in _FAST:
+        if Ltok % a == 0 and Ltok // a in _FAST:
+            return (a, Ltok // a)
+    for a in _FAST:
+        for b in _FAST:
+            if Ltok % (a * b) == 0 and Ltok // (a * b) in _FAST and a >= b >= Ltok // (a * b):
+                return (a, b, Ltok // (a * b))
     return (H, W)
 
 

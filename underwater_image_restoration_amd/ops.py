@@ -198,11 +198,6 @@ def axpy_scalar(dst: torch.Tensor, src: torch.Tensor, w: float, first: bool) -> 
         dst.add_(src.reshape(1), alpha=w)
 
 
-def flat_accumulate_add(src: torch.Tensor, dst: torch.Tensor, n: int) -> None:
-    """dst[:n] += src[:n] (flat fp32 buffers, n a multiple of 4)."""
-    flat_accumulate(src, dst, n, accumulate=True)
-
-
 class MultiFlatClipAdam:
     """clip_grad_norm_(max_norm) + Adam / AdamW over SEVERAL flat parameter buffers (one per launch-plan module of a composed
     network: NewBigFRFNModel has 27) with ONE global gradient norm - the same step tail as FusedClipAdam

@@ -12,6 +12,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from . import knobs
+
 
 def world_size(group=None) -> int:
     return dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
@@ -37,7 +39,7 @@ def allreduce_flat_grads(flat_grad: torch.Tensor, n_live: int, group=None) -> fl
     optimizer must apply - the fused clip+Adam kernel folds it into its gradient read, so the
     bucket is touched exactly once by the collective and once by the optimizer."""
     w = world_size(group)
-    if w == 1 and not (os.environ.get("UIR_FORCE_ALLREDUCE") == "1" and dist.is_initialized()):
+    if w == 1 and not (knobs.flag("UIR_FORCE_ALLREDUCE") and dist.is_initialized()):
         return 1.0
     dist.all_reduce(flat_grad[:n_live], op=dist.ReduceOp.SUM, group=group)
     return 1.0 / w

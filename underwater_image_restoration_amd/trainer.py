@@ -5,19 +5,18 @@ flat gradient buffer is all-reduced once over RCCL/xGMI between backward and the
 """
 from __future__ import annotations
 
-import os
-
 import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import knobs
 from . import ops
 from . import parallel
 
 
 class TrainStep:
     def __init__(self, model, loss_name: str = "L1", lr: float = 3e-4, max_norm: float = 1.0, process_group=None,
-                 weight_decay: float = 0.0, micro_batch: "int | None" = None, lanes: "int | None" = None):
+                 weight_decay: float = 0.0, micro_batch: "int | None" = None):
         if loss_name not in L.LOSS_KINDS:
             raise ValueError(f"Unsupported loss: {loss_name}")
         self.model = model
@@ -29,39 +28,19 @@ class TrainStep:
                                "call torch.cuda.set_device(...) first (one process per GPU)")
         self.opt = ops.FusedClipAdam(self.flat, lr=lr, max_norm=max_norm, weight_decay=weight_decay)
         self.pg = process_group
-        # Sample lanes: the batch is split into `lanes` equal parts, each with its OWN plan and HIP stream, running concurrently.
-        # The deep U-Net levels are latency-bound (a few hundred workgroups per kernel) and the full-resolution stages are
-        # HBM-bound: with the lanes out of phase (the host enqueues lane 0's lists first) one lane's deep levels fill the idle
-        # CUs / bandwidth under the other lane's full-resolution kernels.  Exact (no cross-sample statistics).
-        self.lanes = int(lanes if lanes is not None else os.environ.get("UIR_LANES", "1"))
-        self._lane_state = {}
         self.micro_batch = micro_batch          # None: the largest divisor of the batch whose plan fits in HBM
         self._acc = None                        # flat gradient accumulator of micro-batched steps
         self.world = parallel.world_size(process_group)
         if self.world > 1:
             parallel.broadcast_flat_params(self.flat.flat, process_group)
         self._one = torch.ones(1, dtype=torch.float32, device=self.flat.device)
-        self._graph_on = os.environ.get("UIR_GRAPH", "0") == "1" and self.flat.device.type == "cuda"
+        self._graph_on = knobs.flag("UIR_GRAPH") and self.flat.device.type == "cuda"
         # opt-in (UIR_GRAPH=1): on ROCm 7.2 replaying the ~1400-node graph measured 62.2 ms/step vs 57.9 eager
         # a captured graph is stored ON its plan (plan._graph): it can never outlive the buffers it was recorded over
-        # optional (UIR_MAIN_HIPRIO=1): critical chain on a high-priority stream; measured neutral on MI355X
-        self._hp = None
-        if self.flat.device.type == "cuda" and os.environ.get("UIR_MAIN_HIPRIO", "0") == "1":
-            hi = min(torch.cuda.Stream.priority_range()) if hasattr(torch.cuda.Stream, "priority_range") else 0
-            self._hp = torch.cuda.Stream(device=self.flat.device, priority=hi)
 
     def __call__(self, raw: torch.Tensor, ref: torch.Tensor, lr: float | None = None):
         """One optimisation step on a device-resident batch.  Returns (loss, grad_norm) as
         device tensors (reading them is the only synchronisation, and it is the caller's)."""
-        if self._hp is not None:
-            cur = torch.cuda.current_stream()
-            self._hp.wait_stream(cur)
-            with torch.cuda.stream(self._hp):
-                res, norm = self._step(raw, ref, lr)
-            cur.wait_stream(self._hp)
-            res.record_stream(cur)      # allocated on the high-priority stream, consumed by the caller's stream
-            norm.record_stream(cur)
-            return res, norm
         return self._step(raw, ref, lr)
 
     # ---- memory: one plan keeps every activation of its batch (62 GB at 16 x 256 x 256); the reference's own default run
@@ -123,63 +102,7 @@ class TrainStep:
         norm = self.opt.step(lr=lr, grad_scale=scale, grad=self._acc)
         return self._loss_acc[0].clone(), norm[0]
 
-    def _lanes_for(self, shape):
-        """Per (shape) state of the concurrent sample lanes: per lane a FlatParams view (shared weights, own gradient
-        bucket), a Plan built on it, a stream."""
-        import copy
-        from .engine import Plan
-        key = tuple(shape)
-        st = self._lane_state.get(key)
-        if st is None:
-            B, _, H, W = shape
-            b = B // self.lanes
-            st = []
-            for i in range(self.lanes):
-                fp = self.flat if i == 0 else copy.copy(self.flat)
-                if i > 0:
-                    fp.grad = torch.zeros_like(self.flat.grad)       # weights (fp.flat) stay shared; gradients are per lane
-                st.append({"fp": fp, "plan": Plan(fp, b, H, W), "stream": torch.cuda.Stream(device=self.flat.device),
-                           "done": torch.cuda.Event()})
-            self._lane_state = {key: st}                              # one shape at a time (plans are large)
-            self._wdev = torch.zeros(1, dtype=torch.float32, device=self.flat.device)
-            self._loss_parts = torch.zeros(self.lanes, dtype=torch.float32, device=self.flat.device)
-        return st
-
-    def _step_lanes(self, raw, ref, lr):
-        B = raw.shape[0]
-        n = self.flat.n_live
-        st = self._lanes_for(raw.shape)
-        b = B // self.lanes
-        w = self._weights(b, B)
-        cur = torch.cuda.current_stream()
-        self._wdev.fill_(w)
-        start = torch.cuda.Event()
-        start.record(cur)
-        for i, lane in enumerate(st):
-            s_ = lane["stream"]
-            s_.wait_event(start)                       # the previous optimizer step and this step's inputs are visible
-            with torch.cuda.stream(s_):
-                r, f = raw[i * b:(i + 1) * b], ref[i * b:(i + 1) * b]
-                plan = lane["plan"]
-                ser = os.environ.get("UIR_LANE_SERIAL", "0") == "1"      # experiment: one stream per lane (no side / bulk streams)
-                out = plan.forward(r, serial=ser)
-                res = ops.loss_sums(out, f, self.kind)
-                dout = ops.loss_grad(out, f, self._wdev, self.kind)
-                plan.backward(dout, serial=ser)
-                self._loss_parts[i:i + 1].copy_(res[0:1])
-                lane["done"].record(s_)
-        for lane in st:
-            cur.wait_event(lane["done"])
-        self.model._fwd_serial += 1
-        for i, lane in enumerate(st[1:]):              # lane 0 writes the main bucket; the others are added to it
-            ops.flat_accumulate_add(lane["fp"].grad, self.flat.grad, n)
-        scale = parallel.allreduce_flat_grads(self.flat.grad, n, self.pg)
-        norm = self.opt.step(lr=lr, grad_scale=scale)
-        return (self._loss_parts.sum() * w), norm[0]
-
     def _step(self, raw, ref, lr):
-        if self.lanes > 1 and raw.shape[0] % self.lanes == 0 and self.flat.device.type == "cuda":
-            return self._step_lanes(raw, ref, lr)
         mb = self.micro_batch_for(raw.shape[0], raw.shape[2], raw.shape[3])
         if mb != raw.shape[0]:
             return self._step_micro(raw, ref, lr, mb)
