@@ -243,6 +243,36 @@ typedef struct UirGdfnBwdArgs {
 } UirGdfnBwdArgs;
 int uir_gdfn_bwd(const UirGdfnBwdArgs* args, void* stream);
 
+/* ------------------------------------------------------------- uir_dwln_bwd */
+/* Backward of  LayerNorm -> 1x1 conv (C -> CH, no bias) -> depthwise 3x3 (no bias)  in one pass over the pixels (csrc/dwln.hip):
+ *   dP = dw3x3^T(G) (kept on chip),  dX = dRes + LayerNorm'(dP . W1),  and the partial sums of all four parameter gradients.
+ * Replaces autograd's backward of norm2 -> ffn.project_in -> ffn.conv (SpectralTransformer.py:122-124,147; hp > 0: the GDFN
+ * column layout, x1 half at columns [0, h), x2 half at [hp, hp + h), weight rows [0, h) and [h, 2h)) and of
+ * norm1 -> attn.qkv -> attn.qkv_conv (:81-82,94,144; hp = 0: ch consecutive channels).
+ * slab[block][slab_stride] = dWdw (CHreal*9, Conv2d layout [CHreal][1][3][3]) | dW1 (CHreal*C, [CHreal][C]) | dgamma (C) | dbeta (C),
+ * CHreal = 2h or ch; uir_reduce_slab sums the nblocks rows.  Every workgroup writes its whole row. */
+typedef struct UirDwLnBwdArgs {
+  const float* G;      /* [B*H*W][ldg] gradient of the depthwise output, float4-aligned rows                 */
+  const float* XP;     /* [B*H*W][ldp] depthwise input saved by the forward (same column layout as G)         */
+  const float* Wdw;    /* [CHreal][9]                                                                       */
+  const float* W1;     /* [CHreal][C]                                                                       */
+  const float* X;      /* [B*H*W][ldx] LayerNorm input                                                      */
+  const float* stats;  /* [B*H*W][2] (mean, rstd) written by the forward                                    */
+  const float* gamma;  /* [C]                                                                               */
+  const float* beta;   /* [C]                                                                               */
+  const float* dRes;   /* [B*H*W][ldr] gradient arriving on the residual path                               */
+  float* dX;           /* [B*H*W][ldo]                                                                      */
+  float* slab;
+  long slab_stride;
+  int ldg, ldp, ldx, ldr, ldo;
+  int B, H, Wd;
+  int C;               /* 16 or 32                                                                          */
+  int h, hp;           /* GDFN layout (hp > 0, multiple of 16): (C, hp) in {(32, 96), (16, 48)}             */
+  int ch;              /* consecutive layout (hp == 0): (C, ch) in {(32, 96), (16, 48)}                     */
+  int nblocks;         /* persistent workgroups = slab rows                                                 */
+} UirDwLnBwdArgs;
+int uir_dwln_bwd(const UirDwLnBwdArgs* args, void* stream);
+
 /* ----------------------------------------------------------- uir_layernorm */
 /* Input-gradient of the channel LayerNorm (+ residual-path gradient) and per-block partials
  * of dgamma/dbeta: dX = dRes + LN'(dT).  slab[block][2*C] = (dgamma | dbeta).

@@ -723,3 +723,67 @@ def test_clip_adam_matches_oracle(gnorm_scale):
         assert abs(float(norm) - want) < 1e-5 * want
         for n in shapes:
             assert rel(fp.view(n), P[n]) < 1e-6
+
+
+# ------------------------------------------------------------------ uir_dwln_bwd (round 3)
+def _dwln_case(B, H, W, C, split, seed):
+    """fp64 autograd reference of LayerNorm -> 1x1 conv -> depthwise 3x3 and the kernel's operands in its column layouts."""
+    h = int(C * 2.66) if split else 0
+    hp = (h + 15) // 16 * 16 if split else 0
+    chreal = 2 * h if split else 3 * C
+    cols = 2 * hp if split else 3 * C
+    M = B * H * W
+    x = rnd(B, C, H, W, seed=seed).requires_grad_(True)
+    gam = (1 + 0.3 * rnd(C, seed=seed + 1)).requires_grad_(True)
+    bet = (0.2 * rnd(C, seed=seed + 2)).requires_grad_(True)
+    w1 = (rnd(chreal, C, seed=seed + 3) / math.sqrt(C)).requires_grad_(True)
+    wdw = (rnd(chreal, 1, 3, 3, seed=seed + 4) / 3).requires_grad_(True)
+    g_out = rnd(B, chreal, H, W, seed=seed + 5)
+    d_res = rnd(B, C, H, W, seed=seed + 6)
+    xr = x.permute(0, 2, 3, 1)
+    mean = xr.mean(-1, keepdim=True)
+    var = ((xr - mean) ** 2).mean(-1, keepdim=True)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    t = ((xr - mean) * rstd * gam + bet).permute(0, 3, 1, 2)
+    xp = F.conv2d(t, w1[:, :, None, None])
+    y = F.conv2d(xp, wdw, padding=1, groups=chreal)
+    (y * g_out).sum().backward()
+    stats = torch.cat([mean, rstd], -1).reshape(M, 2).detach()
+
+    def to_cols(t4):          # [B, chreal, H, W] -> rows in the kernel's column layout (pads exact zero)
+        rows = hwc(t4.detach())
+        if not split:
+            return rows
+        out = torch.zeros(M, 2 * hp, dtype=rows.dtype)
+        out[:, :h] = rows[:, :h]
+        out[:, hp:hp + h] = rows[:, h:]
+        return out
+    ref = dict(dx=hwc(x.grad + d_res), dwdw=wdw.grad.reshape(chreal, 9), dw1=w1.grad, dgam=gam.grad, dbet=bet.grad)
+    ops_ = dict(G=to_cols(g_out), XP=to_cols(xp), X=hwc(x.detach()), stats=stats, dRes=hwc(d_res), gam=gam.detach(), bet=bet.detach(),
+                w1=w1.detach(), wdw=wdw.detach().reshape(chreal, 9))
+    return ref, ops_, dict(h=h, hp=hp, ch=0 if split else 3 * C, chreal=chreal, cols=cols)
+
+
+@pytest.mark.parametrize("B,H,W,C,split", [(2, 16, 32, 32, True), (1, 24, 16, 32, False), (2, 8, 16, 16, True), (1, 16, 16, 16, False),
+                                           (1, 20, 24, 32, True), (3, 12, 40, 16, False), (1, 40, 72, 32, False)])
+def test_dwln_bwd_vs_autograd(B, H, W, C, split):
+    """The fused backward of norm -> 1x1 -> depthwise 3x3 (SpectralTransformer.py:81-82,94,144 / :122-124,147) against fp64
+    autograd: input gradient and all four parameter gradients; image sizes that are not multiples of the 8 x 16 tile included."""
+    ref, o, g = _dwln_case(B, H, W, C, split, seed=11)
+    r = rec()
+    M = B * H * W
+    dX = r.alloc(M, C)
+    dWdw, dW1, dgb = r.alloc(g["chreal"], 9), r.alloc(g["chreal"], C), r.alloc(2 * C)
+    r.dwln_bwd("dwln", dev(o["G"]), dev(o["XP"]), dev(o["wdw"]), dev(o["w1"]), dev(o["X"]), dev(o["stats"]), dev(o["gam"]), dev(o["bet"]),
+               dev(o["dRes"]), dX, dWdw, dW1, dgb[:C], dgb[C:], C_=C, dims=(B, H, W), h=g["h"], hp=g["hp"], ch=g["ch"], nblocks=5)
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    assert rel(dX, ref["dx"]) < TOL
+    assert rel(dWdw, ref["dwdw"]) < TOL
+    assert rel(dW1, ref["dw1"]) < TOL
+    assert rel(dgb[:C], ref["dgam"]) < TOL and rel(dgb[C:], ref["dbet"]) < TOL
+    # bitwise run-to-run (fixed summation order), also with another number of persistent workgroups for dX
+    first = [t.clone() for t in (dX, dWdw, dW1, dgb)]
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a_, b_) for a_, b_ in zip(first, (dX, dWdw, dW1, dgb)))

@@ -612,28 +612,6 @@ def test_adamw_and_optimizer_state_layout():
     assert all(torch.equal(sd2["state"][k]["exp_avg"], sd["state"][k]["exp_avg"]) for k in sd["state"])
 
 
-def test_concurrent_sample_lanes_equal_one_lane():
-    """TrainStep(lanes=2): two half-batches on their own plans / streams / gradient buckets (an opt-in schedule, DESIGN.md
-    section 15) must take the same step as one lane: loss, clip norm, gradient bucket (summation order differs: 2e-5)."""
-    raw, ref = O.closed_form_images(4, 64, 81).to(DEV), O.closed_form_images(4, 64, 82).to(DEV)
-    model, step = _fresh_step("L1withColor")
-    l0, n0 = step(raw, ref)
-    l0, n0 = l0.clone(), n0.clone()
-    torch.cuda.synchronize()
-    g0 = model.flat_params().grad[:model.flat_params().n_live].clone()
-    model2, step2 = _fresh_step("L1withColor", lanes=2)
-    l1, n1 = step2(raw, ref)
-    l1, n1 = l1.clone(), n1.clone()
-    torch.cuda.synchronize()
-    g1 = model2.flat_params().grad[:g0.numel()]
-    assert float((g1 - g0).abs().max()) <= 2e-5 * float(g0.abs().max())
-    assert abs(float(l1) - float(l0)) <= 2e-6 * abs(float(l0)) and abs(float(n1) - float(n0)) <= 2e-5 * abs(float(n0))
-    for _ in range(2):                                  # and stays consistent over further steps (stream hand-over both ways)
-        la, _ = step(raw, ref)
-        lb, _ = step2(raw, ref)
-    assert abs(float(la) - float(lb)) <= 1e-4 * abs(float(la))
-
-
 def test_reference_default_resolution_fits_through_micro_batches():
     """The reference's own default run resizes every image to 1024 x 1024 (DataLoader.py:14); a plan keeps ~63 GB of
     activations per such image, so a batch of 8 cannot be one plan on 288 GB.  TrainStep must pick a micro-batch by itself,

@@ -93,6 +93,14 @@ class GdfnBwdArgs(C.Structure):
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int), ("h", C.c_int), ("hp", C.c_int)]
 
 
+class DwLnBwdArgs(C.Structure):
+    _fields_ = [("G", fp), ("XP", fp), ("Wdw", fp), ("W1", fp), ("X", fp), ("stats", fp), ("gamma", fp), ("beta", fp),
+                ("dRes", fp), ("dX", fp), ("slab", fp), ("slab_stride", C.c_long),
+                ("ldg", C.c_int), ("ldp", C.c_int), ("ldx", C.c_int), ("ldr", C.c_int), ("ldo", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int), ("h", C.c_int), ("hp", C.c_int),
+                ("ch", C.c_int), ("nblocks", C.c_int)]
+
+
 class LnBwdArgs(C.Structure):
     _fields_ = [("dT", fp), ("X", fp), ("stats", fp), ("gamma", fp), ("dRes", fp), ("dX", fp), ("slab", fp),
                 ("ldt", C.c_int), ("ldx", C.c_int), ("ldr", C.c_int), ("ldo", C.c_int),
@@ -188,6 +196,7 @@ SIGNATURES = {
     "uir_gdfn_bwd": [C.POINTER(GdfnBwdArgs), fp],
     "uir_qkv_fwd": [C.POINTER(QkvFwdArgs), fp],
     "uir_attnv_fwd": [C.POINTER(AttnvFwdArgs), fp],
+    "uir_dwln_bwd": [C.POINTER(DwLnBwdArgs), fp],
     "uir_layernorm_bwd": [C.POINTER(LnBwdArgs), fp],
     "uir_attn_fwd": [C.POINTER(AttnFwdArgs), fp],
     "uir_attn_bwd": [C.POINTER(AttnBwdArgs), fp],
@@ -244,7 +253,7 @@ SIGNATURES = {
 # C struct name -> ctypes mirror (every argument struct of include/uir_kernels.h)
 STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirDwArgs": DwArgs, "UirDwWgradArgs": DwWgradArgs,
            "UirDwBwdArgs": DwBwdArgs, "UirGdfnFwdArgs": GdfnFwdArgs, "UirQkvFwdArgs": QkvFwdArgs,
-           "UirAttnvFwdArgs": AttnvFwdArgs, "UirGdfnBwdArgs": GdfnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
+           "UirAttnvFwdArgs": AttnvFwdArgs, "UirGdfnBwdArgs": GdfnBwdArgs, "UirDwLnBwdArgs": DwLnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
            "UirAttnFwdArgs": AttnFwdArgs, "UirAttnBwdArgs": AttnBwdArgs, "UirDftArgs": DftArgs, "UirDft2Args": Dft2Args,
            "UirAdamArgs": AdamArgs, "UirResizeImage": ResizeImage, "UirResizeArgs": ResizeArgs, "UirSsimArgs": SsimArgs,
            "UirUiqmArgs": UiqmArgs, "UirReduceDesc": ReduceDesc,

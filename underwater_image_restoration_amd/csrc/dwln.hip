@@ -1,0 +1,473 @@
+// uir_dwln_bwd: the backward of  LayerNorm -> 1x1 conv (C -> CH) -> depthwise 3x3  in ONE pass over the pixels:
+//
+//   dP  = dw3x3^T(G)                                  gradient of the depthwise INPUT - never leaves the chip
+//   dT  = dP . W1,   dX = dRes + LayerNorm'(dT)       the block's input gradient
+//   dWdw[c][t] = sum_q XP[q][c] G[q - off_t][c]       depthwise weight gradient
+//   dW1[c][n]  = sum_q dP[q][c] (xhat[q][n] gamma[n] + beta[n])     1x1 weight gradient
+//   dgamma[n]  = sum_q dT[q][n] xhat[q][n],  dbeta[n] = sum_q dT[q][n]
+//
+// It is used twice per TransformerBlock of SpectralTransformer.py:142-148: for norm2 -> ffn.project_in -> ffn.conv (:122-124,
+// "split" column layout of the GDFN tensors: x1 half at [0, h), x2 half at [hp, hp + h)) and for norm1 -> attn.qkv -> attn.qkv_conv
+// (:81-82,94; 3C consecutive columns).  It replaces three launches per use - uir_dwconv_bwd_fused (dP written to HBM), the
+// LayerNorm-epilogue uir_gemm (dP read) and the uir_gram of the 1x1 weight gradient (dP read again): 1088 -> ~560 floats per pixel
+// at C = 32 for the GDFN half, 608 -> ~320 for the qkv half.
+//
+// One persistent workgroup walks 8 x 16 pixel tiles.  Per tile the LayerNorm input is normalised into LDS (xhat); then the CH
+// channels are walked in chunks of 32 (16 + 16 in the split layout):
+//   (a) G chunk on tile + ring: global -> registers (one chunk ahead) -> LDS
+//   (b) transposed depthwise 3x3 from LDS with the rotating three-row register window of uir_gdfn_fwd (packed f32 over the
+//       channel pair); the SAME window elements times the centre XP value give the 9 depthwise weight-gradient terms;
+//       dP chunk -> LDS; the weight-gradient terms are summed over the wave's four strips by shuffles, over waves through LDS
+//   (c) dT += dP chunk . W1 chunk        v_mfma_f32_32x32x2_f32, one 32-pixel row tile per wave, accumulators live across chunks
+//   (d) dW1 chunk += dP^T . (LN output)  v_mfma_f32_16x16x4_f32: each wave owns one 16 x 16 granule of the chunk's 32 x C tile and
+//       contracts over the tile's pixels, so a wave keeps 4 accumulator registers per chunk across all its tiles
+// and the tile ends with the LayerNorm backward on the dT accumulators (channel on the lane: row means by xor-shuffles).
+// Partial sums leave as one slab row per workgroup (fixed summation order everywhere: bitwise run-to-run).
+#include "uir_common.h"
+#include "../../include/uir_kernels.h"
+
+namespace {
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+template <int C, int NCH, bool SPLIT>
+struct DwLn {
+  static constexpr int TH = 8, TW = 16, RW = TW + 2, RH = TH + 2;
+  static constexpr int NPX1 = RW * RH;                    // 180 tile + ring pixels
+  static constexpr int NI = TH * TW;                      // 128 interior pixels = 4 MFMA row tiles, one per wave
+  static constexpr int NLD = (NPX1 * 8 + 255) / 256;      // float4 loads per thread and G chunk (6)
+  static constexpr int S1 = 40, SG = 36, SX = 36;         // LDS row strides (floats): G chunk / dP chunk / xhat
+  static constexpr int GS1_ROWS = NLD * 32;               // 192 (rows >= NPX1 hold zeros)
+  static constexpr int NXL = (NI * (C / 4)) / 256;        // float4 loads per thread of the x tile (4 at C = 32, 2 at C = 16)
+  static constexpr int NG = 2 * (C / 16);                 // 16 x 16 granules of a chunk's dW1 tile (4 at C = 32, 2 at C = 16)
+  static constexpr int PARTS = 4 / NG;                    // waves sharing a granule split the pixels (C = 16: 2)
+  static constexpr int STEPS = NI / 4 / PARTS;            // 16x16x4 MFMA steps per wave and chunk
+  static constexpr int OFF_GS = GS1_ROWS * S1;
+  static constexpr int OFF_XH = OFF_GS + NI * SG;
+  static constexpr int OFF_RS = OFF_XH + NI * SX;
+  static constexpr int OFF_WR = OFF_RS + NI;
+  static constexpr int OFF_DWA = OFF_WR + 4 * 16 * 18;
+  static constexpr int LDS_FLOATS = OFF_DWA + NCH * 16 * 18;
+  static_assert(C == 16 || C == 32, "channel count");
+};
+
+// Per-thread coordinates are RE-DERIVED from an opaque copy of threadIdx.x at the top of every scope that uses them (tile, chunk,
+// epilogue).  Derived once at kernel scope, hipcc hoisted every address / index expression built from them out of both loops
+// (~150 loop-invariant VGPRs), spilled ~100 of them and reloaded some INSIDE the chunk loop - and a scratch reload is a VMEM
+// load: its s_waitcnt vmcnt(0) drains every prefetch in flight.  Recomputing ~60 integer ops per chunk is far cheaper.
+#define UIR_DWLN_COORDS                                                                                                   \
+  int t_ = threadIdx.x;                                                                                                   \
+  asm volatile("" : "+v"(t_));                                                                                            \
+  const int lane = t_ & 63, wave = __builtin_amdgcn_readfirstlane(t_ >> 6), li = lane & 31, h2 = lane >> 5;              \
+  const int cp = t_ & 15, sx = wave * 4 + ((((lane >> 4) & 1) << 1) | (lane >> 5));                                       \
+  const int l16 = lane & 15, j16 = lane >> 4;                                                                             \
+  const int gr_k = (T::NG == 4) ? (wave >> 1) : (wave & 1), gr_n = (T::NG == 4) ? (wave & 1) : 0;                         \
+  const int part = (T::NG == 4) ? 0 : (wave >> 1), n16 = 16 * gr_n + l16;                                                 \
+  (void)li; (void)h2; (void)cp; (void)sx; (void)l16; (void)j16; (void)gr_k; (void)part; (void)n16
+
+template <int C, int NCH, bool SPLIT>
+__global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdArgs a) {
+  using T = DwLn<C, NCH, SPLIT>;
+  extern __shared__ float smem[];
+  float* GS1 = smem;
+  float* Gs = smem + T::OFF_GS;
+  float* XH = smem + T::OFF_XH;
+  float* RS = smem + T::OFF_RS;
+  float* WR = smem + T::OFF_WR;
+  float* DWA = smem + T::OFF_DWA;
+  const int tiles_x = (a.Wd + T::TW - 1) / T::TW, tiles_y = (a.H + T::TH - 1) / T::TH;
+  const int ntiles = a.B * tiles_x * tiles_y;
+  const int h = a.h, hp = a.hp, ch = a.ch;
+  const int chcols = SPLIT ? 2 * hp : ch;                 // columns of G / XP that exist
+
+  // chunk geometry: two groups of 16 channels; column of the group in G / XP, real weight row, validity of channel i of the group
+  auto colA = [&](int ci) { return SPLIT ? 16 * ci : 32 * ci; };
+  auto colB = [&](int ci) { return SPLIT ? hp + 16 * ci : 32 * ci + 16; };
+  auto rowA = [&](int ci, int i) { return (SPLIT ? 16 * ci : 32 * ci) + i; };
+  auto rowB = [&](int ci, int i) { return SPLIT ? h + 16 * ci + i : 32 * ci + 16 + i; };
+  auto okA = [&](int ci, int i) { return SPLIT ? 16 * ci + i < h : 32 * ci + i < ch; };
+  auto okB = [&](int ci, int i) { return SPLIT ? 16 * ci + i < h : 32 * ci + 16 + i < ch; };
+  auto g_col = [&](int ci, int e) {                        // first column of float4 slot e & 7 of a G / XP chunk row
+    const int j = e & 7;
+    return j < 4 ? colA(ci) + 4 * j : colB(ci) + 4 * (j - 4);
+  };
+
+  float gam16, bet16, gam_n;
+  {
+    UIR_DWLN_COORDS;
+    gam16 = a.gamma[n16];
+    bet16 = a.beta[n16];
+    gam_n = li < C ? a.gamma[li] : 0.f;
+    for (int e = t_; e < NCH * 16 * 18; e += 256) DWA[e] = 0.f;
+  }
+  // dW1 granule accumulators, one per chunk, live across all tiles.  Named registers selected by a uniform branch: the chunk loop
+  // stays ROLLED (unrolled, hipcc hoisted every chunk's weight / address work and spilled 339 VGPRs).
+  static_assert(NCH <= 6, "accumulator set");
+  const f32x4v zero4 = f32x4v{0.f, 0.f, 0.f, 0.f};
+  f32x4v dw0 = zero4, dw1 = zero4, dw2 = zero4, dw3 = zero4, dw4 = zero4, dw5 = zero4;
+#define DW_GET(ci, v) do { if (ci == 0) v = dw0; else if (ci == 1) v = dw1; else if (ci == 2) v = dw2; else if (ci == 3) v = dw3; else if (ci == 4) v = dw4; else v = dw5; } while (0)
+#define DW_PUT(ci, v) do { if (ci == 0) dw0 = v; else if (ci == 1) dw1 = v; else if (ci == 2) dw2 = v; else if (ci == 3) dw3 = v; else if (ci == 4) dw4 = v; else dw5 = v; } while (0)
+  float dgam = 0.f, dbet = 0.f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    int bid = tile;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    const int b = bid / tiles_y;
+    const int y0 = ty * T::TH, x0 = tx * T::TW;
+    const unsigned img = (unsigned)b * (unsigned)(a.H * a.Wd);       // 32-bit row indices / offsets everywhere (checked by the launcher)
+    const int nrows = a.H - y0;                                      // rows of the tile inside the image (>= 1)
+    const unsigned xrstep = (unsigned)(a.Wd * a.ldp);
+
+    // ring-pixel row of G load slot e = t + 256 it: byte offset of the row in G, or ~0u outside the image / past the ring
+    auto g_off = [&](int e) -> unsigned {
+      const int p = e >> 3;
+      const int ry = p / T::RW, rx = p - ry * T::RW;
+      const int iy = y0 + ry - 1, ix = x0 + rx - 1;
+      const bool ok = p < T::NPX1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
+      return ok ? (img + (unsigned)(iy * a.Wd + ix)) * (unsigned)a.ldg * 4u : ~0u;
+    };
+    // Prefetches carry RAW values from clamped (always valid) addresses; the zeroing of out-of-image pixels / missing columns is a
+    // multiplication where the value is consumed.  (`ok ? load : 0` becomes a branch around the load plus an immediate
+    // s_waitcnt: no prefetch at all; and vmcnt retires in issue order, so whatever is needed first must be issued first.)
+    float4 gv[T::NLD];
+    unsigned goff[T::NLD];                                     // once per tile (6 registers across the chunk loop: ~280 VALU ops per chunk less)
+    auto load_g = [&](int ci, int t) {
+#pragma unroll
+      for (int it = 0; it < T::NLD; ++it) {
+        const int col = g_col(ci, t + 256 * it);
+        const unsigned off = (goff[it] != ~0u ? goff[it] : 0u) + (unsigned)(col + 4 <= chcols ? col : 0) * 4u;
+        gv[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.G) + off);
+      }
+    };
+    // centre XP values of the thread's walk: pixel (row y, column sx), channels cp of group A and group B
+    f32x2 xpv[T::TH];
+    auto load_xp = [&](int ci, int cp_, int sx_) {
+      const bool colok = x0 + sx_ < a.Wd;
+      const unsigned xrow0 = (img + (unsigned)(y0 * a.Wd + (colok ? x0 + sx_ : 0))) * (unsigned)a.ldp;
+      const int ca = colA(ci) + cp_, cb = colB(ci) + cp_;
+      const unsigned oa = xrow0 + (unsigned)(ca < chcols ? ca : 0), ob = xrow0 + (unsigned)(cb < chcols ? cb : 0);
+#pragma unroll
+      for (int y = 0; y < T::TH; ++y) {
+        const float* rowp = a.XP + (size_t)((unsigned)(y < nrows ? y : 0) * xrstep);   // uniform: scalar base + one offset VGPR
+        xpv[y] = f32x2{rowp[oa], rowp[ob]};
+      }
+    };
+    // depthwise taps of the thread's channel pair, window order (window position t meets tap 8 - t): raw rows, masked at use
+    f32x2 wf[9], wf_n[9];
+    auto load_wf = [&](int ci, int cp_) {
+      const unsigned pa = (unsigned)(okA(ci, cp_) ? rowA(ci, cp_) : 0) * 9u, pb = (unsigned)(okB(ci, cp_) ? rowB(ci, cp_) : 0) * 9u;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) wf_n[t] = f32x2{a.Wdw[pa + (8 - t)], a.Wdw[pb + (8 - t)]};
+    };
+    {
+      UIR_DWLN_COORDS;
+#pragma unroll
+      for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it);
+      load_wf(0, cp);
+      load_g(0, t_);
+      load_xp(0, cp, sx);
+
+      // ---- xhat of the tile's interior -> LDS (all waves are past the previous tile's reads of XH / RS after this barrier) ----
+      lds_barrier2();
+#pragma unroll
+      for (int it = 0; it < T::NXL; ++it) {
+        const int e = t_ + 256 * it, p = e / (C / 4), q = e - p * (C / 4);
+        const int py = p / T::TW, px = p - py * T::TW;
+        const int iy = y0 + py, ix = x0 + px;
+        const bool ok = iy < a.H && ix < a.Wd;
+        const unsigned m = ok ? img + (unsigned)(iy * a.Wd + ix) : img;
+        const float4 v = *reinterpret_cast<const float4*>(a.X + (m * (unsigned)a.ldx + 4u * q));
+        const float2 st = *reinterpret_cast<const float2*>(a.stats + m * 2u);
+        const float rs = ok ? st.y : 0.f;
+        *reinterpret_cast<float4*>(XH + p * T::SX + 4 * q) =
+            make_float4((v.x - st.x) * rs, (v.y - st.x) * rs, (v.z - st.x) * rs, (v.w - st.x) * rs);
+        if (q == 0) RS[p] = rs;
+      }
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+#pragma unroll 1
+    for (int ci = 0; ci < NCH; ++ci) {
+      UIR_DWLN_COORDS;
+      const bool colok = x0 + sx < a.Wd;
+      const int cn = ci + 1 < NCH ? ci + 1 : ci;            // last chunk: re-fetch (L2 hits) - the load count stays static
+      // ---- (a) this chunk's G (tile + ring) -> LDS ----
+#pragma unroll
+      for (int it = 0; it < T::NLD; ++it) {
+        const int e = t_ + 256 * it;
+        const float k = (goff[it] != ~0u && g_col(ci, e) + 4 <= chcols) ? 1.f : 0.f;
+        *reinterpret_cast<float4*>(GS1 + (e >> 3) * T::S1 + 4 * (e & 7)) = make_float4(gv[it].x * k, gv[it].y * k, gv[it].z * k, gv[it].w * k);
+      }
+      {
+        const f32x2 wm = f32x2{okA(ci, cp) ? 1.f : 0.f, okB(ci, cp) ? 1.f : 0.f};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wf[t] = wf_n[t] * wm;
+      }
+      lds_barrier2();
+      // issue order = need order (vmcnt retires in order): this chunk's 1x1 weights now (used after the walk); the next chunk's
+      // G, XP and depthwise taps after the walk, when its window / tap / accumulator registers are free - they land during (c), (d)
+      float w1v[16];                                        // (c) B operand: W1[row of k-slot 8 jj + 4 h2 + e][n = li], raw
+#pragma unroll
+      for (int s = 0; s < 16; ++s) {
+        const int kk = 8 * (s >> 2) + 4 * h2 + (s & 3);
+        const bool ok = li < C && (kk < 16 ? okA(ci, kk) : okB(ci, kk - 16));
+        const int row = kk < 16 ? rowA(ci, kk) : rowB(ci, kk - 16);
+        w1v[s] = a.W1[ok ? (unsigned)(row * C + li) : 0u];
+      }
+      const f32x2 xm = f32x2{colok && colA(ci) + cp < chcols ? 1.f : 0.f, colok && colB(ci) + cp < chcols ? 1.f : 0.f};
+
+      // ---- (b) transposed depthwise 3x3 + depthwise weight-gradient terms ----
+      f32x2 dwa[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) dwa[t] = f32x2{0.f, 0.f};
+      {
+        const float* rp = GS1 + sx * T::S1 + cp;
+        f32x2 rw[3][3];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            rw[rr][dx] = f32x2{rp[(rr * T::RW + dx) * T::S1], rp[(rr * T::RW + dx) * T::S1 + 16]};
+        rp += 3 * T::RW * T::S1;
+        float* gdst = Gs + sx * T::SG + cp;
+        auto step = [&](f32x2 (&p0)[3], f32x2 (&p1)[3], f32x2 (&p2)[3], const f32x2 xc, const float keep) {
+          f32x2 t = wf[0] * p0[0];
+          t = __builtin_elementwise_fma(wf[1], p0[1], t);
+          t = __builtin_elementwise_fma(wf[2], p0[2], t);
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) dwa[dx] = __builtin_elementwise_fma(xc, p0[dx], dwa[dx]);
+          // p0 is free now: fetch ring row y + 3 (the last fetches read past the ring: inside smem, never used)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx) p0[dx] = f32x2{rp[dx * T::S1], rp[dx * T::S1 + 16]};
+          rp += T::RW * T::S1;
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            t = __builtin_elementwise_fma(wf[3 + kx], p1[kx], t);
+            t = __builtin_elementwise_fma(wf[6 + kx], p2[kx], t);
+            dwa[3 + kx] = __builtin_elementwise_fma(xc, p1[kx], dwa[3 + kx]);
+            dwa[6 + kx] = __builtin_elementwise_fma(xc, p2[kx], dwa[6 + kx]);
+          }
+          gdst[0] = t.x * keep;                             // pixels outside the image contribute nothing to dW1 / dT
+          gdst[16] = t.y * keep;
+          gdst += T::TW * T::SG;
+        };
+        auto keep_of = [&](int y) { return (colok && y < nrows) ? 1.f : 0.f; };
+        step(rw[0], rw[1], rw[2], xpv[0] * (xm * keep_of(0)), keep_of(0));
+        step(rw[1], rw[2], rw[0], xpv[1] * (xm * keep_of(1)), keep_of(1));
+        step(rw[2], rw[0], rw[1], xpv[2] * (xm * keep_of(2)), keep_of(2));
+        step(rw[0], rw[1], rw[2], xpv[3] * (xm * keep_of(3)), keep_of(3));
+        step(rw[1], rw[2], rw[0], xpv[4] * (xm * keep_of(4)), keep_of(4));
+        step(rw[2], rw[0], rw[1], xpv[5] * (xm * keep_of(5)), keep_of(5));
+        step(rw[0], rw[1], rw[2], xpv[6] * (xm * keep_of(6)), keep_of(6));
+        step(rw[1], rw[2], rw[0], xpv[7] * (xm * keep_of(7)), keep_of(7));
+      }
+      load_g(cn, t_);
+      load_xp(cn, cp, sx);
+      load_wf(cn, cp);
+      // sum over the wave's four strips (lanes cp, cp + 16, cp + 32, cp + 48), then one row per wave in LDS
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        float vx = dwa[t].x, vy = dwa[t].y;
+        vx += __shfl_xor(vx, 16); vy += __shfl_xor(vy, 16);
+        vx += __shfl_xor(vx, 32); vy += __shfl_xor(vy, 32);
+        if (lane < 16) {
+          WR[(wave * 16 + cp) * 18 + t] = vx;
+          WR[(wave * 16 + cp) * 18 + 9 + t] = vy;
+        }
+      }
+      lds_barrier2();
+      for (int e = t_; e < 16 * 18; e += 256)
+        DWA[ci * 288 + e] += (WR[e] + WR[288 + e]) + (WR[576 + e] + WR[864 + e]);
+
+      // ---- (c) dT += dP chunk . W1 chunk (row tile = wave) ----
+      {
+        const float* gr = Gs + (wave * 32 + li) * T::SG + 4 * h2;
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const f32x4v v = *reinterpret_cast<const f32x4v*>(gr + 8 * jj);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kk = 8 * jj + 4 * h2 + e;
+            const float m = (li < C && (kk < 16 ? okA(ci, kk) : okB(ci, kk - 16))) ? 1.f : 0.f;
+            acc = uir_mfma(v[e], w1v[4 * jj + e] * m, acc);
+          }
+        }
+      }
+      // ---- (d) dW1 chunk granule += dP^T . (xhat gamma + beta) over this wave's pixels.  k-slot j of step s is pixel
+      //      8 (s >> 1) + 2 (s & 1) + (j >> 1) + 4 (j & 1): the two rows a 32-lane half reads sit 4 * 36 floats = 16 banks apart ----
+      {
+        const float* ga = Gs + 16 * gr_k + l16 + ((j16 >> 1) + 4 * (j16 & 1) + 8 * (part * (T::STEPS / 2))) * T::SG;
+        const float* xb = XH + n16 + ((j16 >> 1) + 4 * (j16 & 1) + 8 * (part * (T::STEPS / 2))) * T::SX;
+        f32x4v d;
+        DW_GET(ci, d);
+#pragma unroll 1
+        for (int s0 = 0; s0 < T::STEPS; s0 += 8) {           // 8 steps = 32 pixels per trip: bounded operand registers
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const int p = 8 * (s >> 1) + 2 * (s & 1);        // compile-time LDS offsets inside the trip
+            const float av = ga[p * T::SG];
+            const float bv = fmaf(xb[p * T::SX], gam16, bet16);
+            d = mfma16(av, bv, d);
+          }
+          ga += 32 * T::SG;
+          xb += 32 * T::SX;
+        }
+        DW_PUT(ci, d);
+      }
+    }
+
+    // ---- tile epilogue: LayerNorm backward on the dT accumulators (lane = channel, registers = pixels of row tile `wave`).
+    //      Register r is tile row 2 wave + (r >> 3), column (r & 3) + 8 ((r >> 2) & 1) + 4 h2 ----
+    {
+      UIR_DWLN_COORDS;
+      const int nn = li < C ? li : 0;
+      const float invc = 1.0f / (float)C;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        const int iy = y0 + 2 * wave + half;
+        const bool rowok = iy < a.H && li < C;
+        const unsigned mrow = img + (unsigned)((iy < a.H ? iy : a.H - 1) * a.Wd);
+        float xh[8], rs[8], rv[8];
+        unsigned mm[8];
+        bool ok[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int px = (q & 3) + 8 * (q >> 2) + 4 * h2;
+          const int p = (2 * wave + half) * T::TW + px;
+          const int ix = x0 + px;
+          ok[q] = rowok && ix < a.Wd;
+          mm[q] = mrow + (unsigned)(ix < a.Wd ? ix : a.Wd - 1);
+          rv[q] = a.dRes[mm[q] * (unsigned)a.ldr + nn];
+          xh[q] = XH[p * T::SX + nn];
+          rs[q] = RS[p];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float dt = acc[8 * half + q];
+          const float xq = li < C ? xh[q] : 0.f;
+          const float g = dt * gam_n;
+          float s1 = g, s2 = g * xq;
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+          }
+          const float dx = rs[q] * (g - s1 * invc - xq * (s2 * invc)) + rv[q];
+          if (ok[q]) a.dX[mm[q] * (unsigned)a.ldo + nn] = dx;
+          dgam = fmaf(dt, xq, dgam);
+          dbet += dt;
+        }
+        asm volatile("" ::: "memory");
+      }
+    }
+  }
+
+  // ---- slab row of this workgroup: dWdw (CHreal x 9) | dW1 (CHreal x C) | dgamma (C) | dbeta (C) ----
+  UIR_DWLN_COORDS;
+  const int chreal = SPLIT ? 2 * h : ch;
+  float* slab = a.slab + (long)blockIdx.x * a.slab_stride;
+  float* sw1 = slab + (long)chreal * 9;
+  lds_barrier2();                                            // every wave is past its last reads of GS1 / Gs / XH
+  if (T::PARTS == 2) {                                       // C = 16: the two pixel parts of a granule meet in LDS
+    if (part == 1) {
+#pragma unroll 1
+      for (int ci = 0; ci < NCH; ++ci) {
+        f32x4v d;
+        DW_GET(ci, d);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) GS1[((ci * 2 + gr_k) * 4 + r) * 64 + lane] = d[r];
+      }
+    }
+    lds_barrier2();
+  }
+  if (part == 0) {
+#pragma unroll 1
+    for (int ci = 0; ci < NCH; ++ci) {
+      f32x4v d;
+      DW_GET(ci, d);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = d[r];
+        if (T::PARTS == 2) v += GS1[((ci * 2 + gr_k) * 4 + r) * 64 + lane];
+        const int k = 16 * gr_k + 4 * j16 + r;               // chunk-local channel: row of the 16 x 16 result
+        const bool ok = n16 < C && (k < 16 ? okA(ci, k) : okB(ci, k - 16));
+        const long row = k < 16 ? rowA(ci, k) : rowB(ci, k - 16);
+        if (ok) sw1[row * C + n16] = v;
+      }
+    }
+  }
+#undef DW_GET
+#undef DW_PUT
+  for (int e = t_; e < NCH * 288; e += 256) {
+    const int ci = e / 288, rem = e - ci * 288, c = rem / 18, q = rem - c * 18;
+    const int grp = q / 9, t = q - grp * 9;
+    const bool ok = grp == 0 ? okA(ci, c) : okB(ci, c);
+    const long row = grp == 0 ? rowA(ci, c) : rowB(ci, c);
+    if (ok) slab[row * 9 + (8 - t)] = DWA[e];
+  }
+  {
+    const float g = dgam + __shfl_xor(dgam, 32), bsum = dbet + __shfl_xor(dbet, 32);
+    lds_barrier2();
+    if (h2 == 0) {
+      WR[(wave * 2 + 0) * 32 + li] = g;
+      WR[(wave * 2 + 1) * 32 + li] = bsum;
+    }
+    lds_barrier2();
+    float* sgb = sw1 + (long)chreal * C;
+    for (int e = t_; e < 2 * C; e += 256) {
+      const int which = e / C, n = e - which * C;
+      float s = 0.f;
+      for (int w = 0; w < 4; ++w) s += WR[(w * 2 + which) * 32 + n];
+      sgb[which * C + n] = s;
+    }
+  }
+}
+#undef UIR_DWLN_COORDS
+
+template <int C, int NCH, bool SPLIT>
+int dwln_launch(const UirDwLnBwdArgs& a, hipStream_t st) {
+  using T = DwLn<C, NCH, SPLIT>;
+  hipLaunchKernelGGL((uir_dwln_bwd_kernel<C, NCH, SPLIT>), dim3(a.nblocks), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
+  return uir_launch_status();
+}
+
+}  // namespace
+
+extern "C" int uir_dwln_bwd(const UirDwLnBwdArgs* p, void* stream) {
+  const UirDwLnBwdArgs& a = *p;
+  UIR_REQUIRE(a.G && a.XP && a.Wdw && a.W1 && a.X && a.stats && a.gamma && a.beta && a.dRes && a.dX && a.slab);
+  UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0 && a.nblocks > 0 && (a.C == 16 || a.C == 32));
+  UIR_REQUIRE((a.ldg & 3) == 0 && (a.ldx & 3) == 0 && uir_aligned16(a.G) && uir_aligned16(a.X) && (a.ldx >= a.C) && a.ldr >= a.C && a.ldo >= a.C);
+  UIR_REQUIRE((reinterpret_cast<uintptr_t>(a.stats) & 7u) == 0);
+  const bool split = a.hp > 0;
+  const int chreal = split ? 2 * a.h : a.ch;
+  if (split) UIR_REQUIRE(a.h > 0 && a.hp >= a.h && (a.hp & 15) == 0 && a.ldg >= 2 * a.hp && a.ldp >= 2 * a.hp);
+  else UIR_REQUIRE(a.ch > 0 && (a.ch & 15) == 0 && a.ldg >= a.ch && a.ldp >= a.ch);
+  UIR_REQUIRE(a.slab_stride >= (long)chreal * 9 + (long)chreal * a.C + 2 * a.C);
+  // 32-bit byte offsets into G
+  {
+    const long rows = (long)a.B * a.H * a.Wd;
+    const long ldmax = a.ldg > a.ldp ? a.ldg : a.ldp;
+    UIR_REQUIRE(rows * ldmax < (1L << 30) && rows * a.ldx < (1L << 30) && rows * a.ldr < (1L << 30) && rows * a.ldo < (1L << 30));
+  }
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nch = split ? a.hp / 16 : (a.ch + 31) / 32;
+#define UIR_DWLN(CV, NV, SV) return dwln_launch<CV, NV, SV>(a, st)
+  if (split) {
+    if (a.C == 32 && nch == 6) UIR_DWLN(32, 6, true);
+    if (a.C == 16 && nch == 3) UIR_DWLN(16, 3, true);
+  } else {
+    if (a.C == 32 && nch == 3) UIR_DWLN(32, 3, false);
+    if (a.C == 16 && nch == 2) UIR_DWLN(16, 2, false);
+  }
+#undef UIR_DWLN
+  return UIR_EINVAL;
+}

@@ -44,9 +44,9 @@ SCRATCH_FLOATS = 96 * 1024 * 1024  # 384 MB of slab scratch shared by every redu
 
 
 # Plan memory model: every activation / gradient buffer lives for the plan's lifetime and is linear in B*H*W
-# (measured by building plans of several shapes: 59.2-60.4 KB per pixel with the backward list, 28.8-29.2 KB forward only;
+# (measured by building plans of several shapes: 52.7-53.6 KB per pixel with the backward list, 28.8-29.2 KB forward only;
 # tests/test_cpu_surface.py holds the estimate to the real Plan.bytes), plus two slab scratch areas.
-PLAN_BYTES_PER_PIXEL_TRAIN = 60_500
+PLAN_BYTES_PER_PIXEL_TRAIN = 54_000
 PLAN_BYTES_PER_PIXEL_EVAL = 29_300
 
 
@@ -727,6 +727,41 @@ class Recorder:
                 self._reduce(name + ".dg", _ptr(slab), GEMM_SLAB_ROWS, 2 * C_, _ptr(dgamma), C_)
                 self._reduce(name + ".db", slab.data_ptr() + 4 * C_, GEMM_SLAB_ROWS, 2 * C_, _ptr(dbeta), C_)
 
+    def dwln_bwd(self, name, G, XP, Wdw, W1, X, stats, gamma, beta, dRes, dX, dWdw, dW1, dgamma, dbeta, *, C_, dims, h=0, hp=0, ch=0,
+                 nblocks=512):
+        """Backward of LayerNorm -> 1x1 conv -> depthwise 3x3 in one pass (csrc/dwln.hip): dX = dRes + LN'(dw^T(G) . W1) and the four
+        parameter gradients (per-workgroup slab rows, summed on the bulk lane).  hp > 0: GDFN column layout (x1 half at [0, h), x2
+        half at [hp, hp + h)); hp == 0: `ch` consecutive channels."""
+        self._hold(G, XP, Wdw, W1, X, stats, gamma, beta, dRes, dX, dWdw, dW1, dgamma, dbeta)
+        B, H, W = dims
+        chreal = 2 * h if hp else ch
+        a = L.DwLnBwdArgs()
+        a.G, a.XP, a.Wdw, a.W1, a.X, a.stats = _ptr(G), _ptr(XP), _ptr(Wdw), _ptr(W1), _ptr(X), _ptr(stats)
+        a.gamma, a.beta, a.dRes, a.dX = _ptr(gamma), _ptr(beta), _ptr(dRes), _ptr(dX)
+        a.ldg, a.ldp, a.ldx, a.ldr, a.ldo = _ld(G), _ld(XP), _ld(X), _ld(dRes), _ld(dX)
+        a.B, a.H, a.Wd, a.C, a.h, a.hp, a.ch = B, H, W, C_, h, hp, ch
+        tiles = B * ((H + 7) // 8) * ((W + 15) // 16)
+        a.nblocks = max(1, min(nblocks, tiles))
+        stride = chreal * 9 + chreal * C_ + 2 * C_
+        slab = self.alloc(a.nblocks, stride)          # private: the reductions run later, on the bulk lane
+        a.slab, a.slab_stride = _ptr(slab), stride
+        assert X.shape[0] == B * H * W and G.shape[0] == X.shape[0] and dWdw.numel() == chreal * 9 and dW1.numel() == chreal * C_
+        self.keep.append(a)
+        rows = B * H * W
+        cols = 2 * hp if hp else ch
+        self._op(name, lib.uir_dwln_bwd, C.byref(a), nbytes=4 * rows * (2 * cols + 3 * C_),
+                 flops=rows * (36 * cols + 4 * cols * C_), variant="uir_dwln_bwd_kernel<*>")
+        sp = slab.data_ptr()
+        with self.bulk():
+            self._reduce(name + ".dWdw", sp, a.nblocks, stride, _ptr(dWdw), chreal * 9)
+            self._reduce(name + ".dW1", sp + 4 * chreal * 9, a.nblocks, stride, _ptr(dW1), chreal * C_)
+            off = chreal * 9 + chreal * C_
+            if dbeta.data_ptr() == dgamma.data_ptr() + 4 * C_:
+                self._reduce(name + ".dgb", sp + 4 * off, a.nblocks, stride, _ptr(dgamma), 2 * C_)
+            else:
+                self._reduce(name + ".dg", sp + 4 * off, a.nblocks, stride, _ptr(dgamma), C_)
+                self._reduce(name + ".db", sp + 4 * (off + C_), a.nblocks, stride, _ptr(dbeta), C_)
+
     def dwconv_wgrad(self, name, dY, X, out, *, C_, creal, dims, grp=(0, 0)):
         self._hold(dY, X, out)
         a = L.DwWgradArgs()
@@ -931,19 +966,23 @@ class Plan(Recorder):
                       T1=gpre, T2=g, stats=stats2)
 
         def backward(dy: torch.Tensor) -> torch.Tensor:
-            dg, dgpre = self.alloc(M, ldg)[:, :2 * hp], self.alloc(M, ldg)[:, :2 * hp]
-            dt = self.alloc(M, C_)
+            # C <= 32 (full resolution and level 1, ~85 % of the step's bytes): depthwise-transpose -> 1x1-transpose -> LayerNorm
+            # backward with all four parameter gradients in ONE kernel (uir_dwln_bwd): the depthwise input gradient never reaches HBM
+            fuse_dwln = C_ <= 32
+            dg = self.alloc(M, ldg)[:, :2 * hp]
+            dgpre = None if fuse_dwln else self.alloc(M, ldg)[:, :2 * hp]
+            dt = None if fuse_dwln else self.alloc(M, C_)
             dx1 = self.alloc(M, C_)
             dWBA = self.alloc(2 * B * C_ * C_)                      # dWB | dWA adjacent: one reduction writes both
             dWB, dWA = dWBA[:B * C_ * C_].view(B, C_ * C_), dWBA[B * C_ * C_:].view(B, C_ * C_)
             dvf, du = self.alloc(M, C_), self.alloc(M, C_)
-            dqkv, dqkv_pre = self.alloc(M, 3 * C_), self.alloc(M, 3 * C_)
+            dqkv = self.alloc(M, 3 * C_)
+            dqkv_pre = None if fuse_dwln else self.alloc(M, 3 * C_)
             Mqk = self.alloc(B, 4 * C_ * C_)
             dPb, dWofb, dTb, dPsum = self.alloc(B, C_ * C_), self.alloc(B, C_ * C_), self.alloc(B, heads), self.alloc(C_, C_)
             dx = self.alloc(M, C_)
             # GDFN
             # LayerNorm backward as the epilogue of the GEMM that produces its output gradient (one 32-column tile)
-            fuse_ln = C_ <= 32 and M % 128 == 0
             fuse_dwout = C_ <= 32 and hp <= 96 and M % 128 == 0
             if not fuse_dwout:
                 with self.bulk():
@@ -962,19 +1001,18 @@ class Plan(Recorder):
             else:
                 self.gemm(n + ".dgate", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=g,
                           g_off=hp)
-            self.dwconv_bwd(n + ".dgpre+dWffdw", dg, gpre, Wffdw, dgpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
-                            dims=dims, grp=(h, hp))
-            if fuse_ln:
-                self.gemm_ln_bwd(n + ".dt2+ln2_bwd", dgpre, Win, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"),
-                                 Gr(f"{pfx}.norm2.bias"), C_=C_, K=2 * hp, k_grp=(h, hp))
+            if fuse_dwln:
+                self.dwln_bwd(n + ".ffn_dwln_bwd", dg, gpre, Wffdw, Win, x1, stats2, g2, b2, dy, dx1, Gr(f"{pfx}.ffn.conv.weight"),
+                              Gr(f"{pfx}.ffn.project_in.weight"), Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"),
+                              C_=C_, dims=dims, h=h, hp=hp)
             else:
+                self.dwconv_bwd(n + ".dgpre+dWffdw", dg, gpre, Wffdw, dgpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
+                                dims=dims, grp=(h, hp))
                 self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
-            # released after the GEMM that shares its dgpre operand (the persistent 2-WG/CU GEMM with the LayerNorm
-            # epilogue lost 60 % when this Gram started beside it: serial 267 us, overlapped 430 us)
-            with self.bulk():
-                self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
-                          n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
-            if not fuse_ln:
+                # released after the GEMM that shares its dgpre operand (a Gram starting beside a persistent 2-WG/CU GEMM cost it 60 %)
+                with self.bulk():
+                    self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
+                              n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
                 self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
             # MDTA
             # dWB | dWA partials side by side in one slab: a single reduction launch (before uir_attn_bwd) instead of two
@@ -1010,14 +1048,14 @@ class Plan(Recorder):
                 self.gram(n + ".dWo", Wkvf, dPsum, Gr(f"{a}.project_out.weight"), N=C_, K=C_, o_sn=C_, o_sk=1)
             self.gemm(n + ".dqk", qkv[:, :2 * C_], Mqk, dqkv[:, :2 * C_], N=2 * C_, K=2 * C_, w_sn=2 * C_, w_sk=1,
                       w_bs=4 * C_ * C_, batches=B)
+            if fuse_dwln:
+                self.dwln_bwd(n + ".qkv_dwln_bwd", dqkv, qkv_pre, Wdw, Wqkv, x, stats1, g1, b1, dx1, dx, Gr(f"{a}.qkv_conv.weight"),
+                              Gr(f"{a}.qkv.weight"), Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_, dims=dims, ch=3 * C_)
+                return dx
             self.dwconv_bwd(n + ".dqkv_pre+dWqkvdw", dqkv, qkv_pre, Wdw, dqkv_pre, Gr(f"{a}.qkv_conv.weight"), C_=3 * C_,
                             creal=3 * C_, dims=dims)
-            if fuse_ln:
-                self.gemm_ln_bwd(n + ".dt1+ln1_bwd", dqkv_pre, Wqkv, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"),
-                                 Gr(f"{pfx}.norm1.bias"), C_=C_, K=3 * C_)
-            else:
-                self.gemm(n + ".dt1", dqkv_pre, Wqkv, dt, N=C_, K=3 * C_, w_sn=1, w_sk=C_)
-                self.ln_bwd(n + ".ln1_bwd", dt, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_)
+            self.gemm(n + ".dt1", dqkv_pre, Wqkv, dt, N=C_, K=3 * C_, w_sn=1, w_sk=C_)
+            self.ln_bwd(n + ".ln1_bwd", dt, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_)
             with self.bulk():      # after the GEMM that shares its dqkv_pre operand (see dWin above)
                 self.gram(n + ".dWqkv", dqkv_pre, x, Gr(f"{a}.qkv.weight"), N=3 * C_, K=C_, o_sn=C_, o_sk=1,
                           pro_b=L.PRO_LN, ln=(g1, b1), stats=stats1)
