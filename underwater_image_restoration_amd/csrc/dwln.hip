@@ -31,7 +31,35 @@ namespace {
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ void lds_barrier2() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// uniform base pointer + 32-bit byte offset: hipcc emits the scalar-base form `global_load_dword v, v_off, s[base:base+1]` (one offset
+// VGPR, no 64-bit address arithmetic per load); `base[unsigned_index]` made it build a 64-bit VGPR address for every load.
+__device__ __forceinline__ float ldg_off(const float* base, unsigned byte_off) {
+  return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+}
 __device__ __forceinline__ f32x4v mfma16(float a, float b, f32x4v c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// Cross-lane sums without the LDS pipe (__shfl_xor lowers to ds_bpermute_b32: an address VGPR, an LDS instruction and its latency
+// per step).  Inside a 16-lane row: DPP butterfly (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror: every lane ends with
+// the row sum).  Across rows: gfx950's v_permlane16_swap / v_permlane32_swap - called with both operands = x they return
+// {x.r0, x.r0, x.r2, x.r2} | {x.r1, x.r1, x.r3, x.r3} resp. {x.lo32, x.lo32} | {x.hi32, x.hi32}; their sum is the lane-wise total.
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float x) {
+  return x + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float row_sum16(float x) {
+  x = dpp_add<0xB1>(x);
+  x = dpp_add<0x4E>(x);
+  x = dpp_add<0x141>(x);
+  return dpp_add<0x140>(x);
+}
+__device__ __forceinline__ float swap16_sum(float x) {        // lanes l and l ^ 16
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ float swap32_sum(float x) {        // lanes l and l ^ 32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <int C, int NCH, bool SPLIT>
 struct DwLn {
@@ -112,66 +140,80 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
 #define DW_PUT(ci, v) do { if (ci == 0) dw0 = v; else if (ci == 1) dw1 = v; else if (ci == 2) dw2 = v; else if (ci == 3) dw3 = v; else if (ci == 4) dw4 = v; else dw5 = v; } while (0)
   float dgam = 0.f, dbet = 0.f;
 
-  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    int bid = tile;
+  // tile coordinates: first row / column, first pixel row of the image, rows of the tile inside the image (>= 1)
+  struct Tc { int y0, x0; unsigned img; int nrows; };
+  auto coords = [&](int tile) {
+    int bid = tile < ntiles ? tile : ntiles - 1;             // past the end: a valid tile (its prefetch is never consumed)
     const int tx = bid % tiles_x;
     bid /= tiles_x;
     const int ty = bid % tiles_y;
     const int b = bid / tiles_y;
-    const int y0 = ty * T::TH, x0 = tx * T::TW;
-    const unsigned img = (unsigned)b * (unsigned)(a.H * a.Wd);       // 32-bit row indices / offsets everywhere (checked by the launcher)
-    const int nrows = a.H - y0;                                      // rows of the tile inside the image (>= 1)
-    const unsigned xrstep = (unsigned)(a.Wd * a.ldp);
+    Tc c;
+    c.y0 = ty * T::TH; c.x0 = tx * T::TW;
+    c.img = (unsigned)b * (unsigned)(a.H * a.Wd);            // 32-bit row indices / offsets everywhere (checked by the launcher)
+    c.nrows = a.H - c.y0;
+    return c;
+  };
+  const unsigned xrstep = (unsigned)(a.Wd * a.ldp);
+  // ring-pixel row of G load slot e = t + 256 it: byte offset of the row in G, or ~0u outside the image / past the ring
+  auto g_off = [&](int e, const Tc& c) -> unsigned {
+    const int p = e >> 3;
+    const int ry = p / T::RW, rx = p - ry * T::RW;
+    const int iy = c.y0 + ry - 1, ix = c.x0 + rx - 1;
+    const bool ok = p < T::NPX1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
+    return ok ? (c.img + (unsigned)(iy * a.Wd + ix)) * (unsigned)a.ldg * 4u : ~0u;
+  };
+  // Prefetches carry RAW values from clamped (always valid) addresses; the zeroing of out-of-image pixels / missing columns is a
+  // multiplication where the value is consumed.  (`ok ? load : 0` becomes a branch around the load plus an immediate
+  // s_waitcnt: no prefetch at all; and vmcnt retires in issue order, so whatever is needed first must be issued first.)
+  // gv / goff / xpv / wf_n always describe the NEXT (tile, chunk) unit: chunk ci + 1 of the tile, or chunk 0 of the workgroup's
+  // next tile - a tile starts with its first chunk already in flight.
+  float4 gv[T::NLD];
+  unsigned goff[T::NLD];                                     // per tile (6 registers across the chunk loop: ~280 VALU ops per chunk less)
+  auto load_g = [&](int ci, int t) {
+#pragma unroll
+    for (int it = 0; it < T::NLD; ++it) {
+      const int col = g_col(ci, t + 256 * it);
+      const unsigned off = (goff[it] != ~0u ? goff[it] : 0u) + (unsigned)(col + 4 <= chcols ? col : 0) * 4u;
+      gv[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.G) + off);
+    }
+  };
+  // centre XP values of the thread's walk: pixel (row y, column sx), channels cp of group A and group B
+  f32x2 xpv[T::TH];
+  auto load_xp = [&](int ci, int cp_, int sx_, const Tc& c) {
+    const bool colok = c.x0 + sx_ < a.Wd;
+    const unsigned xrow0 = (c.img + (unsigned)(c.y0 * a.Wd + (colok ? c.x0 + sx_ : 0))) * (unsigned)a.ldp;
+    const int ca = colA(ci) + cp_, cb = colB(ci) + cp_;
+    const unsigned oa = (xrow0 + (unsigned)(ca < chcols ? ca : 0)) * 4u, ob = (xrow0 + (unsigned)(cb < chcols ? cb : 0)) * 4u;
+#pragma unroll
+    for (int y = 0; y < T::TH; ++y) {
+      const float* rowp = a.XP + (size_t)((unsigned)(y < c.nrows ? y : 0) * xrstep);   // uniform: scalar base + one offset VGPR
+      xpv[y] = f32x2{ldg_off(rowp, oa), ldg_off(rowp, ob)};
+    }
+  };
+  // depthwise taps of the thread's channel pair, window order (window position t meets tap 8 - t): raw rows, masked at use
+  f32x2 wf[9], wf_n[9];
+  auto load_wf = [&](int ci, int cp_) {
+    const unsigned pa = (unsigned)(okA(ci, cp_) ? rowA(ci, cp_) : 0) * 36u, pb = (unsigned)(okB(ci, cp_) ? rowB(ci, cp_) : 0) * 36u;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wf_n[t] = f32x2{ldg_off(a.Wdw + (8 - t), pa), ldg_off(a.Wdw + (8 - t), pb)};
+  };
+  {
+    UIR_DWLN_COORDS;
+    const Tc c0 = coords(blockIdx.x);
+#pragma unroll
+    for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it, c0);
+    load_wf(0, cp);
+    load_g(0, t_);
+    load_xp(0, cp, sx, c0);
+  }
 
-    // ring-pixel row of G load slot e = t + 256 it: byte offset of the row in G, or ~0u outside the image / past the ring
-    auto g_off = [&](int e) -> unsigned {
-      const int p = e >> 3;
-      const int ry = p / T::RW, rx = p - ry * T::RW;
-      const int iy = y0 + ry - 1, ix = x0 + rx - 1;
-      const bool ok = p < T::NPX1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
-      return ok ? (img + (unsigned)(iy * a.Wd + ix)) * (unsigned)a.ldg * 4u : ~0u;
-    };
-    // Prefetches carry RAW values from clamped (always valid) addresses; the zeroing of out-of-image pixels / missing columns is a
-    // multiplication where the value is consumed.  (`ok ? load : 0` becomes a branch around the load plus an immediate
-    // s_waitcnt: no prefetch at all; and vmcnt retires in issue order, so whatever is needed first must be issued first.)
-    float4 gv[T::NLD];
-    unsigned goff[T::NLD];                                     // once per tile (6 registers across the chunk loop: ~280 VALU ops per chunk less)
-    auto load_g = [&](int ci, int t) {
-#pragma unroll
-      for (int it = 0; it < T::NLD; ++it) {
-        const int col = g_col(ci, t + 256 * it);
-        const unsigned off = (goff[it] != ~0u ? goff[it] : 0u) + (unsigned)(col + 4 <= chcols ? col : 0) * 4u;
-        gv[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.G) + off);
-      }
-    };
-    // centre XP values of the thread's walk: pixel (row y, column sx), channels cp of group A and group B
-    f32x2 xpv[T::TH];
-    auto load_xp = [&](int ci, int cp_, int sx_) {
-      const bool colok = x0 + sx_ < a.Wd;
-      const unsigned xrow0 = (img + (unsigned)(y0 * a.Wd + (colok ? x0 + sx_ : 0))) * (unsigned)a.ldp;
-      const int ca = colA(ci) + cp_, cb = colB(ci) + cp_;
-      const unsigned oa = xrow0 + (unsigned)(ca < chcols ? ca : 0), ob = xrow0 + (unsigned)(cb < chcols ? cb : 0);
-#pragma unroll
-      for (int y = 0; y < T::TH; ++y) {
-        const float* rowp = a.XP + (size_t)((unsigned)(y < nrows ? y : 0) * xrstep);   // uniform: scalar base + one offset VGPR
-        xpv[y] = f32x2{rowp[oa], rowp[ob]};
-      }
-    };
-    // depthwise taps of the thread's channel pair, window order (window position t meets tap 8 - t): raw rows, masked at use
-    f32x2 wf[9], wf_n[9];
-    auto load_wf = [&](int ci, int cp_) {
-      const unsigned pa = (unsigned)(okA(ci, cp_) ? rowA(ci, cp_) : 0) * 9u, pb = (unsigned)(okB(ci, cp_) ? rowB(ci, cp_) : 0) * 9u;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) wf_n[t] = f32x2{a.Wdw[pa + (8 - t)], a.Wdw[pb + (8 - t)]};
-    };
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const Tc tc = coords(tile), tn = coords(tile + gridDim.x);
+    const int y0 = tc.y0, x0 = tc.x0, nrows = tc.nrows;
+    const unsigned img = tc.img;
     {
       UIR_DWLN_COORDS;
-#pragma unroll
-      for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it);
-      load_wf(0, cp);
-      load_g(0, t_);
-      load_xp(0, cp, sx);
-
       // ---- xhat of the tile's interior -> LDS (all waves are past the previous tile's reads of XH / RS after this barrier) ----
       lds_barrier2();
 #pragma unroll
@@ -198,7 +240,8 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     for (int ci = 0; ci < NCH; ++ci) {
       UIR_DWLN_COORDS;
       const bool colok = x0 + sx < a.Wd;
-      const int cn = ci + 1 < NCH ? ci + 1 : ci;            // last chunk: re-fetch (L2 hits) - the load count stays static
+      const bool last = ci + 1 == NCH;
+      const int cn = last ? 0 : ci + 1;                      // next unit: chunk ci + 1 of this tile, or chunk 0 of the next tile
       // ---- (a) this chunk's G (tile + ring) -> LDS ----
 #pragma unroll
       for (int it = 0; it < T::NLD; ++it) {
@@ -220,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         const int kk = 8 * (s >> 2) + 4 * h2 + (s & 3);
         const bool ok = li < C && (kk < 16 ? okA(ci, kk) : okB(ci, kk - 16));
         const int row = kk < 16 ? rowA(ci, kk) : rowB(ci, kk - 16);
-        w1v[s] = a.W1[ok ? (unsigned)(row * C + li) : 0u];
+        w1v[s] = ldg_off(a.W1, ok ? (unsigned)(row * C + li) * 4u : 0u);
       }
       const f32x2 xm = f32x2{colok && colA(ci) + cp < chcols ? 1.f : 0.f, colok && colB(ci) + cp < chcols ? 1.f : 0.f};
 
@@ -269,15 +312,17 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         step(rw[0], rw[1], rw[2], xpv[6] * (xm * keep_of(6)), keep_of(6));
         step(rw[1], rw[2], rw[0], xpv[7] * (xm * keep_of(7)), keep_of(7));
       }
+      if (last) {                                            // (uniform branch, no loads inside: the load count per chunk stays static)
+#pragma unroll
+        for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it, tn);
+      }
       load_g(cn, t_);
-      load_xp(cn, cp, sx);
+      load_xp(cn, cp, sx, last ? tn : tc);
       load_wf(cn, cp);
       // sum over the wave's four strips (lanes cp, cp + 16, cp + 32, cp + 48), then one row per wave in LDS
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        float vx = dwa[t].x, vy = dwa[t].y;
-        vx += __shfl_xor(vx, 16); vy += __shfl_xor(vy, 16);
-        vx += __shfl_xor(vx, 32); vy += __shfl_xor(vy, 32);
+        const float vx = swap32_sum(swap16_sum(dwa[t].x)), vy = swap32_sum(swap16_sum(dwa[t].y));
         if (lane < 16) {
           WR[(wave * 16 + cp) * 18 + t] = vx;
           WR[(wave * 16 + cp) * 18 + 9 + t] = vy;
@@ -306,20 +351,29 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       {
         const float* ga = Gs + 16 * gr_k + l16 + ((j16 >> 1) + 4 * (j16 & 1) + 8 * (part * (T::STEPS / 2))) * T::SG;
         const float* xb = XH + n16 + ((j16 >> 1) + 4 * (j16 & 1) + 8 * (part * (T::STEPS / 2))) * T::SX;
-        f32x4v d;
+        f32x4v d, d1 = f32x4v{0.f, 0.f, 0.f, 0.f};             // two chains: a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles, not 32
         DW_GET(ci, d);
-#pragma unroll 1
-        for (int s0 = 0; s0 < T::STEPS; s0 += 8) {           // 8 steps = 32 pixels per trip: bounded operand registers
+        constexpr int NGR = T::STEPS / 8;                      // groups of 8 steps = 32 pixels; operands of group g + 1 are read
+        float av[2][8], bv[2][8];                              // from LDS before the MFMAs of group g are issued
+        auto fetch = [&](int g, float (&ao)[8], float (&bo)[8]) {
 #pragma unroll
           for (int s = 0; s < 8; ++s) {
-            const int p = 8 * (s >> 1) + 2 * (s & 1);        // compile-time LDS offsets inside the trip
-            const float av = ga[p * T::SG];
-            const float bv = fmaf(xb[p * T::SX], gam16, bet16);
-            d = mfma16(av, bv, d);
+            const int p = 32 * g + 8 * (s >> 1) + 2 * (s & 1);   // compile-time LDS offsets
+            ao[s] = ga[p * T::SG];
+            bo[s] = xb[p * T::SX];
           }
-          ga += 32 * T::SG;
-          xb += 32 * T::SX;
+        };
+        fetch(0, av[0], bv[0]);
+#pragma unroll
+        for (int g = 0; g < NGR; ++g) {
+          if (g + 1 < NGR) fetch(g + 1, av[(g + 1) & 1], bv[(g + 1) & 1]);
+#pragma unroll
+          for (int s = 0; s < 8; s += 2) {
+            d = mfma16(av[g & 1][s], fmaf(bv[g & 1][s], gam16, bet16), d);
+            d1 = mfma16(av[g & 1][s + 1], fmaf(bv[g & 1][s + 1], gam16, bet16), d1);
+          }
         }
+        d += d1;
         DW_PUT(ci, d);
       }
     }
@@ -354,12 +408,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
           const float dt = acc[8 * half + q];
           const float xq = li < C ? xh[q] : 0.f;
           const float g = dt * gam_n;
-          float s1 = g, s2 = g * xq;
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) {
-            s1 += __shfl_xor(s1, o);
-            s2 += __shfl_xor(s2, o);
-          }
+          const float s1 = swap16_sum(row_sum16(g)), s2 = swap16_sum(row_sum16(g * xq));   // over the 32 channel lanes of the half
           const float dx = rs[q] * (g - s1 * invc - xq * (s2 * invc)) + rv[q];
           if (ok[q]) a.dX[mm[q] * (unsigned)a.ldo + nn] = dx;
           dgam = fmaf(dt, xq, dgam);
