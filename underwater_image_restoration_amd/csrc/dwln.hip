@@ -379,42 +379,33 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     }
 
     // ---- tile epilogue: LayerNorm backward on the dT accumulators (lane = channel, registers = pixels of row tile `wave`).
-    //      Register r is tile row 2 wave + (r >> 3), column (r & 3) + 8 ((r >> 2) & 1) + 4 h2 ----
+    //      Register r is tile row 2 wave + (r >> 3), column (r & 3) + 8 ((r >> 2) & 1) + 4 h2.  All 16 residual-gradient loads
+    //      are issued first: their latency runs under the 32 row reductions, which do not need them ----
     {
       UIR_DWLN_COORDS;
       const int nn = li < C ? li : 0;
       const float invc = 1.0f / (float)C;
+      float rv[16];
+      unsigned mo[16];
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        const int iy = y0 + 2 * wave + half;
-        const bool rowok = iy < a.H && li < C;
-        const unsigned mrow = img + (unsigned)((iy < a.H ? iy : a.H - 1) * a.Wd);
-        float xh[8], rs[8], rv[8];
-        unsigned mm[8];
-        bool ok[8];
+      for (int r = 0; r < 16; ++r) {
+        const int iy = y0 + 2 * wave + (r >> 3), ix = x0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h2;
+        const unsigned m = img + (unsigned)((iy < a.H ? iy : a.H - 1) * a.Wd + (ix < a.Wd ? ix : a.Wd - 1));
+        mo[r] = (iy < a.H && ix < a.Wd && li < C) ? m : ~0u;
+        rv[r] = ldg_off(a.dRes, (m * (unsigned)a.ldr + nn) * 4u);
+      }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int px = (q & 3) + 8 * (q >> 2) + 4 * h2;
-          const int p = (2 * wave + half) * T::TW + px;
-          const int ix = x0 + px;
-          ok[q] = rowok && ix < a.Wd;
-          mm[q] = mrow + (unsigned)(ix < a.Wd ? ix : a.Wd - 1);
-          rv[q] = a.dRes[mm[q] * (unsigned)a.ldr + nn];
-          xh[q] = XH[p * T::SX + nn];
-          rs[q] = RS[p];
-        }
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const float dt = acc[8 * half + q];
-          const float xq = li < C ? xh[q] : 0.f;
-          const float g = dt * gam_n;
-          const float s1 = swap16_sum(row_sum16(g)), s2 = swap16_sum(row_sum16(g * xq));   // over the 32 channel lanes of the half
-          const float dx = rs[q] * (g - s1 * invc - xq * (s2 * invc)) + rv[q];
-          if (ok[q]) a.dX[mm[q] * (unsigned)a.ldo + nn] = dx;
-          dgam = fmaf(dt, xq, dgam);
-          dbet += dt;
-        }
-        asm volatile("" ::: "memory");
+      for (int r = 0; r < 16; ++r) {
+        const int p = (2 * wave + (r >> 3)) * T::TW + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h2;
+        const float xq = li < C ? XH[p * T::SX + nn] : 0.f;
+        const float rs = RS[p];
+        const float dt = acc[r];
+        const float g = dt * gam_n;
+        const float s1 = swap16_sum(row_sum16(g)), s2 = swap16_sum(row_sum16(g * xq));   // over the 32 channel lanes of the half
+        const float dx = rs * (g - s1 * invc - xq * (s2 * invc)) + rv[r];
+        if (mo[r] != ~0u) a.dX[mo[r] * (unsigned)a.ldo + nn] = dx;
+        dgam = fmaf(dt, xq, dgam);
+        dbet += dt;
       }
     }
   }

@@ -74,34 +74,37 @@ __device__ __forceinline__ float4 frag(const float* s, int row, int jj, int h2) 
 
 // TNW = 128: four waves as 2 x 2, each 64 x 64.  TNW = 64 (narrow second operand: K = 64 weight gradients, 64-channel outputs): each
 // wave 64 x 32.
-template <bool AKC, bool BKC, int TNW>
+// TMW = 64 (few row tiles: the deep U-Net levels of the SpectralTransformer, 16 384 rows): 64-row tiles, each wave 32 rows x TNW / 2
+// columns, so a 16 384 x 128 output is 256 workgroups instead of 128.
+template <bool AKC, bool BKC, int TNW, int TMW = TM>
 __global__ __launch_bounds__(256, 2) void uir_tiled_kernel(const UirTiledArgs t) {
   constexpr int CT = TNW / 64;             // 32-column tiles per wave
+  constexpr int RT = TMW / 64;             // 32-row tiles per wave
   extern __shared__ float smem[];
   float* As = smem;                       // [2][STAGE]
   float* Bs = smem + 2 * STAGE;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
   const int wr = wave >> 1, wc = wave & 1;
   const int tiles_j = (t.NN + TNW - 1) / TNW;
-  const int i0 = (blockIdx.x / tiles_j) * TM, j0 = (blockIdx.x % tiles_j) * TNW;
+  const int i0 = (blockIdx.x / tiles_j) * TMW, j0 = (blockIdx.x % tiles_j) * TNW;
   const int split = blockIdx.y;
   const int ks = split * t.k_per_split;
   const int ke = ks + t.k_per_split < t.KK ? ks + t.k_per_split : t.KK;
 
-  Loader<AKC, TM> la;
+  Loader<AKC, TMW> la;
   Loader<BKC, TNW> lb;
   la.init(t.A, t.sa_i, t.sa_k, i0, t.MM, tid);
   lb.init(t.B, t.sb_j, t.sb_k, j0, t.NN, tid);
 
-  f32x16 acc[2][CT];
+  f32x16 acc[RT][CT];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int b = 0; b < CT; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float4 va[4], vb[TNW / 32];
+  float4 va[TMW / 32], vb[TNW / 32];
   la.load(va, ks, ke, t.sa_k);
   lb.load(vb, ks, ke, t.sb_k);
   la.store(As, va, tid);
@@ -118,8 +121,12 @@ __global__ __launch_bounds__(256, 2) void uir_tiled_kernel(const UirTiledArgs t)
     const float* bs = Bs + stage * STAGE;
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-      const float4 a0 = frag<AKC>(as, 64 * wr + li, jj, h2), a1 = frag<AKC>(as, 64 * wr + 32 + li, jj, h2);
-      float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+      float av[RT][4];
+#pragma unroll
+      for (int a = 0; a < RT; ++a) {
+        const float4 aa = frag<AKC, TMW>(as, 32 * RT * wr + 32 * a + li, jj, h2);
+        av[a][0] = aa.x; av[a][1] = aa.y; av[a][2] = aa.z; av[a][3] = aa.w;
+      }
       float bv[CT][4];
 #pragma unroll
       for (int b = 0; b < CT; ++b) {
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void uir_tiled_kernel(const UirTiledArgs t)
 #pragma unroll
       for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < RT; ++a)
 #pragma unroll
           for (int b = 0; b < CT; ++b) acc[a][b] = uir_mfma(av[a][e], bv[b][e], acc[a][b]);
     }
@@ -144,14 +151,14 @@ __global__ __launch_bounds__(256, 2) void uir_tiled_kernel(const UirTiledArgs t)
   float* D = t.D + (long)split * t.d_split;
   const bool gelu = t.act == UIR_ACT_GELU;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int b = 0; b < CT; ++b) {
       const int col = j0 + 32 * CT * wc + 32 * b + li;
       const float bj = (t.bias && col < t.NN) ? t.bias[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int row = i0 + 64 * wr + 32 * a + uir_mfma_row(r, h2);
+        const int row = i0 + 32 * RT * wr + 32 * a + uir_mfma_row(r, h2);
         if (row < t.MM && col < t.NN) {
           float v = acc[a][b][r] + bj;
           if (t.pre_out) t.pre_out[(long)row * t.ldpre + col] = v;
@@ -559,6 +566,17 @@ int uir_tiled_gemm(const UirTiledArgs& t, hipStream_t st) {
     else if (bkc) UIR_TL64(false, true);
     else UIR_TL64(false, false);
 #undef UIR_TL64
+    return uir_launch_status();
+  }
+  // few row tiles (the deep levels of the SpectralTransformer: 16 384 rows x 128 columns = 128 tiles on 256 CUs): 64-row tiles
+  if ((long)grid.x * nsplit < 256 && t.MM > 64) {
+    const dim3 gridh(((t.MM + 63) / 64) * ((t.NN + TN - 1) / TN), nsplit);
+#define UIR_TLH(AK, BK) hipLaunchKernelGGL((uir_tiled_kernel<AK, BK, 128, 64>), gridh, dim3(256), lds, st, t)
+    if (akc && bkc) UIR_TLH(true, true);
+    else if (akc) UIR_TLH(true, false);
+    else if (bkc) UIR_TLH(false, true);
+    else UIR_TLH(false, false);
+#undef UIR_TLH
     return uir_launch_status();
   }
 #define UIR_TL(AK, BK) hipLaunchKernelGGL((uir_tiled_kernel<AK, BK, 128>), grid, dim3(256), lds, st, t)
