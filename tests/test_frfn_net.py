@@ -112,8 +112,15 @@ def test_hip_network_train_steps_vs_oracle():
     assert worst < 2e-4                                   # Adam's sign-like first steps on near-zero gradient entries (lr 3e-4)
     vl, vp = step.evaluate(raw.cuda(), ref.cuda())
     assert np.isfinite(float(vl)) and np.isfinite(float(vp))
+    # the optimizer state has torch's layout: one entry per parameter that received a gradient - the 88 tensors the reference
+    # never uses (encoder norm2, the unused MDASSA projections) have none, were not decayed, and the state round-trips
     sd = step.opt.state_dict()
-    assert len(sd["param_groups"][0]["params"]) == len(list(m.parameters())) and len(sd["state"]) == len(list(m.parameters()))
+    n_live = sum(1 for p in leaves.values() if p.grad is not None)
+    assert len(sd["param_groups"][0]["params"]) == len(list(m.parameters())) and len(sd["state"]) == n_live < len(list(m.parameters()))
+    torch.optim.Adam(list(leaves.values()), lr=3e-4).load_state_dict(sd)      # loads into the real thing
+    before = [mm.clone() for mm in step.opt.m]
+    step.opt.load_state_dict(sd)
+    assert step.opt.t == 2 and all(torch.equal(x_, y_) for x_, y_ in zip(before, step.opt.m))
 
 
 @gpu

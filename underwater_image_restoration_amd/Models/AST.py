@@ -404,6 +404,11 @@ class AST(nn.Module):
     """``--arch AST`` (AST.py:680-921) with the reference's defaults: embed_dim 32, nine BasicASTLayers of depth 2 (encoders LeFF
     only, bottleneck and decoders with sparse window attention, every second block shifted), stochastic depth 0 ... 0.1."""
 
+    # device memory the 28 launch plans keep per input pixel (measured, tests/test_ast.py holds it): ModuleTrainStep sizes micro-batches with it
+    # (tools/measure_module_plans.py: 3.2 / 12.1 / 21.9 GiB at 1 x 128^2 / 2 x 256^2 / 1 x 512^2 = 81 KB per pixel + 2.2 GiB of per-plan scratch)
+    PLAN_BYTES_PER_PIXEL_TRAIN, PLAN_BYTES_FIXED_TRAIN = 82_000, 2_600_000_000
+    PLAN_BYTES_PER_PIXEL_EVAL, PLAN_BYTES_FIXED_EVAL = 39_000, 2_200_000_000
+
     def __init__(self, img_size=256, in_chans=3, dd_in=3, embed_dim=32, depths=[2, 2, 2, 2, 2, 2, 2, 2, 2],
                  num_heads=[1, 2, 4, 8, 16, 16, 8, 4, 2], win_size=8, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0.,
                  attn_drop_rate=0., drop_path_rate=0.1, norm_layer=nn.LayerNorm, patch_norm=True, use_checkpoint=False,

@@ -96,8 +96,11 @@ class FlatParams:
     """All parameters in one flat fp32 buffer (live first, 16-byte aligned slots) plus a
     parallel gradient buffer.  `view(name)` / `gview(name)` are tensor views."""
 
-    def __init__(self, shapes: "Dict[str, Tuple[int, ...]]", device):
-        names = [n for n in shapes if not is_dead_param(n)] + [n for n in shapes if is_dead_param(n)]
+    def __init__(self, shapes: "Dict[str, Tuple[int, ...]]", device, dead: "frozenset | None" = None):
+        """dead: names of the parameters that never receive a gradient (default: the SpectralTransformer's, is_dead_param).
+        They sit AFTER the live ones: the optimizer works on [0, n_live) only, as torch's skips `p.grad is None`."""
+        isdead = is_dead_param if dead is None else (lambda n: n in dead)
+        names = [n for n in shapes if not isdead(n)] + [n for n in shapes if isdead(n)]
         self.shapes = dict(shapes)
         self.slots: Dict[str, Tuple[int, int]] = {}
         off = 0
@@ -106,13 +109,14 @@ class FlatParams:
             numel = int(np.prod(shapes[n]))
             self.slots[n] = (off, numel)
             off += pad4(numel)
-            if not is_dead_param(n):
+            if not isdead(n):
                 self.n_live = off
         self.total = off
         self.device = torch.device(device)
         self.flat = torch.zeros(self.total, dtype=torch.float32, device=device)
         self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
-        self.live_names = [n for n in names if not is_dead_param(n)]
+        self.live_names = [n for n in names if not isdead(n)]
+        self.dead_names = frozenset(n for n in names if isdead(n))
 
     def view(self, name: str) -> torch.Tensor:
         o, n = self.slots[name]

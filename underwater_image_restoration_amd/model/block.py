@@ -657,7 +657,7 @@ class TokenModule(nn.Module):
 
     def _init_plumbing(self):
         self._flat: "FlatParams | None" = None
-        self._plans: Dict[Tuple[int, int, int], TokenPlan] = {}
+        self._plans: Dict[Tuple[int, int, int, bool], TokenPlan] = {}
         self._names = [n for n, _ in self.named_parameters()]
         self._serial = 0
 
@@ -682,7 +682,7 @@ class TokenModule(nn.Module):
         ok = self._flat is not None and self._flat.device == torch.device(device) and \
             all(p.data_ptr() == self._flat.view(n).data_ptr() for n, p in named)
         if not ok:
-            fp = FlatParams({n: tuple(p.shape) for n, p in named}, device)
+            fp = FlatParams({n: tuple(p.shape) for n, p in named}, device, dead=frozenset(self._dead))
             with torch.no_grad():
                 for n, p in named:
                     v = fp.view(n)
@@ -694,12 +694,17 @@ class TokenModule(nn.Module):
 
     def _plan_for(self, x: torch.Tensor, want_backward: bool = True) -> TokenPlan:
         fp = self._ensure_flat(x.device)
-        key = self._grid_of(x)
+        grid = self._grid_of(x)
+        # (shape, want_backward) keys with room for four plans, like SpectralTransformer._plan_for: a real epoch sees the training
+        # batch, its tail, and the validation batch and its tail (forward-only plans) - none may evict the training plan
+        key = grid + (bool(want_backward),)
         plan = self._plans.get(key)
-        if plan is None or (want_backward and not plan.want_backward):
-            while len(self._plans) >= 2:
+        if plan is None and not want_backward:
+            plan = self._plans.get(grid + (True,))           # a training plan of this shape serves a forward as well
+        if plan is None:
+            while len(self._plans) >= 4:
                 self._plans.pop(next(iter(self._plans)))
-            plan = self._make_plan(fp, *key, want_backward)
+            plan = self._make_plan(fp, *grid, want_backward)
             self._plans[key] = plan
         return plan
 

@@ -223,13 +223,15 @@ class MultiFlatClipAdam:
         bc1, bc2 = 1.0 - self.betas[0] ** self.t, 1.0 - self.betas[1] ** self.t
         st = _stream()
         for i, fp in enumerate(self.flats):
-            L.check(lib.uir_sumsq_partials(fp.grad.data_ptr(), fp.total, self.slab.data_ptr() + 4 * i * _SUMSQ_BLOCKS, _SUMSQ_BLOCKS, st),
+            # live parameters only: torch.optim skips `p.grad is None` (no moments, no weight decay for the parameters the reference
+            # never uses - 88 tensors of NewBigFRFNModel); FlatParams keeps them behind n_live
+            L.check(lib.uir_sumsq_partials(fp.grad.data_ptr(), fp.n_live, self.slab.data_ptr() + 4 * i * _SUMSQ_BLOCKS, _SUMSQ_BLOCKS, st),
                     "uir_sumsq_partials")
         L.check(lib.uir_reduce_slab(self.slab.data_ptr(), len(self.flats) * _SUMSQ_BLOCKS, 1, self.sumsq.data_ptr(), 1, 0, 1.0, st),
                 "uir_reduce_slab")
         for a, fp, m, v in zip(self._args, self.flats, self.m, self.v):
             a.p, a.g, a.m, a.v = fp.flat.data_ptr(), fp.grad.data_ptr(), m.data_ptr(), v.data_ptr()
-            a.sumsq, a.norm_out, a.n, a.hyper = self.sumsq.data_ptr(), self.norm.data_ptr(), fp.total, None
+            a.sumsq, a.norm_out, a.n, a.hyper = self.sumsq.data_ptr(), self.norm.data_ptr(), fp.n_live, None
             a.beta1, a.beta2, a.eps, a.max_norm, a.weight_decay = self.betas[0], self.betas[1], self.eps, self.max_norm, self.weight_decay
             a.lr, a.bc1, a.bc2, a.gscale = self.lr, bc1, bc2, grad_scale
             L.check(lib.uir_clip_adam_step(C.byref(a), st), "uir_clip_adam_step")
@@ -237,12 +239,13 @@ class MultiFlatClipAdam:
 
     def state_dict(self):
         """torch.optim.Adam layout over the concatenation of the modules' parameters in buffer order (= model.parameters() order
-        when the buffers are given in registration order); parameters without a gradient so far have no entry."""
+        when the buffers are given in registration order); the parameters that never receive a gradient have no entry, as in
+        torch (state is created on the first gradient)."""
         state, params, i = {}, [], 0
         for fp, m, v in zip(self.flats, self.m, self.v):
             for name in fp.shapes:
                 o, n = fp.slots[name]
-                if self.t > 0:
+                if self.t > 0 and name not in fp.dead_names:
                     state[i] = {"step": torch.tensor(float(self.t)), "exp_avg": m[o:o + n].view(fp.shapes[name]).clone(),
                                 "exp_avg_sq": v[o:o + n].view(fp.shapes[name]).clone()}
                 params.append(i)
@@ -251,3 +254,32 @@ class MultiFlatClipAdam:
                  "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
                  "decoupled_weight_decay": self.weight_decay > 0, "initial_lr": self.initial_lr, "params": params}
         return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        """Resume from a torch.optim.Adam / AdamW-style state_dict over model.parameters() order (what SaveModel writes)."""
+        if "param_groups" not in sd:
+            raise ValueError("expected a torch.optim.Adam-style state_dict ({'state', 'param_groups'})")
+        g = sd["param_groups"][0]
+        self.lr = float(g["lr"])
+        self.initial_lr = float(g.get("initial_lr", self.initial_lr))
+        self.betas, self.eps = tuple(g.get("betas", self.betas)), float(g.get("eps", self.eps))
+        self.weight_decay = float(g.get("weight_decay", self.weight_decay))
+        index = []                                            # parameter index -> (buffer, name)
+        for k, fp in enumerate(self.flats):
+            index += [(k, name) for name in fp.shapes]
+        steps = set()
+        for m, v in zip(self.m, self.v):
+            m.zero_()
+            v.zero_()
+        for i, st in sd["state"].items():
+            k, name = index[int(i)]
+            fp = self.flats[k]
+            if name in fp.dead_names:
+                raise ValueError(f"optimizer state for '{name}', which never receives a gradient")
+            o, n = fp.slots[name]
+            self.m[k][o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.v[k][o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"per-parameter step counts differ ({sorted(steps)}): not a state this optimizer can resume")
+        self.t = steps.pop() if steps else 0

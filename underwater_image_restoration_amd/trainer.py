@@ -213,10 +213,14 @@ class ModuleTrainStep:
     module's backward launch list and leaves the gradients in the modules' flat buffers - views of ONE bucket -, (one all-reduce of
     that bucket under data parallelism,) one global-norm clip + Adam over all buffers (ops.MultiFlatClipAdam).  No host synchronisation inside."""
 
-    def __init__(self, model, loss_name: str = "L1", lr: float = 3e-4, max_norm: float = 1.0, process_group=None, weight_decay: float = 0.0):
+    def __init__(self, model, loss_name: str = "L1", lr: float = 3e-4, max_norm: float = 1.0, process_group=None, weight_decay: float = 0.0,
+                 micro_batch: "int | None" = None):
         if loss_name not in L.LOSS_KINDS:
             raise ValueError(f"Unsupported loss: {loss_name}")
         self.model, self.kind, self.pg = model, L.LOSS_KINDS[loss_name], process_group
+        self.micro_batch = micro_batch          # None: the largest divisor of the batch whose plans fit in HBM
+        self._acc = None
+        self._mb_cache = {}
         dev = next(model.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("the MI355X path needs the GPU ('cuda' device in PyTorch-ROCm); there is no CPU fallback")
@@ -244,28 +248,108 @@ class ModuleTrainStep:
         self.opt = ops.MultiFlatClipAdam(self.flats, lr=lr, max_norm=max_norm, weight_decay=weight_decay)
         self._one = torch.ones(1, dtype=torch.float32, device=dev)
 
+    # ---- memory: every module's plan keeps all its activations.  The per-pixel figure is a constant of the architecture
+    # (model.PLAN_BYTES_PER_PIXEL_TRAIN / _EVAL, held to the real plan bytes by tests/test_frfn_net.py / test_ast.py): AST needs
+    # ~21 GB per 512 x 512 image, ~84 GB per image at the reference's default 1024 x 1024 (DataLoader.py:14), so a batch that does
+    # not fit runs as micro-batches with gradient accumulation - exact in eval mode (no cross-sample statistics); in training mode
+    # the stochastic-depth factors are drawn per micro-batch (another, equally valid draw).
+    def plan_bytes(self) -> int:
+        return sum(p.bytes for m in self.mods for p in m._plans.values())
+
+    def plan_bytes_estimate(self, B: int, H: int, W: int, train: bool = True) -> int:
+        per = getattr(self.model, "PLAN_BYTES_PER_PIXEL_TRAIN" if train else "PLAN_BYTES_PER_PIXEL_EVAL", None)
+        if per is None:
+            raise RuntimeError(f"{type(self.model).__name__} does not declare its plan memory per pixel")
+        fixed = getattr(self.model, "PLAN_BYTES_FIXED_TRAIN" if train else "PLAN_BYTES_FIXED_EVAL", 0)
+        return int(per) * B * H * W + int(fixed)
+
+    def micro_batch_for(self, B: int, H: int, W: int, train: bool = True) -> int:
+        if self.micro_batch is not None:
+            mb = int(self.micro_batch)
+            if mb < 1 or B % mb:
+                raise ValueError(f"micro_batch={mb} must divide the batch size {B}")
+            return mb
+        key = (B, H, W, train)
+        if key in self._mb_cache:                 # decided once per shape (the plans exist from then on)
+            return self._mb_cache[key]
+        from .engine import device_bytes_available
+        dev = self.bucket.device
+        have = device_bytes_available(dev) + self.plan_bytes()
+        for mb in sorted((d for d in range(1, B + 1) if B % d == 0), reverse=True):
+            if self.plan_bytes_estimate(mb, H, W, train) <= 0.92 * have:
+                self._mb_cache[key] = mb
+                return mb
+        raise RuntimeError(f"{type(self.model).__name__}(HIP): even one {H}x{W} image needs ~{self.plan_bytes_estimate(1, H, W, train) / 2**30:.1f} GiB "
+                           f"of HBM for its launch plans ({have / 2**30:.1f} GiB available)")
+
     def check_memory(self, B: int, H: int, W: int) -> int:
-        return B
+        """Fail before the first batch, with the numbers, if the configuration cannot run; returns the micro-batch."""
+        mb = self.micro_batch_for(B, H, W)
+        if mb != B and parallel.rank() == 0:
+            print(f"[uir] batch {B} at {H}x{W} runs as {B // mb} micro-batches of {mb} (gradient accumulation; the launch plans keep "
+                  f"every activation of their micro-batch in HBM: ~{self.plan_bytes_estimate(mb, H, W) / 2**30:.0f} GiB)")
+        return mb
+
+    def _weights(self, mb: int, B: int) -> float:
+        f = mb / B                                # see TrainStep._weights (losses the reference also divides by the batch size)
+        return f * f if self.kind in (0, 1, 4) else f
 
     def __call__(self, raw: torch.Tensor, ref: torch.Tensor, lr: "float | None" = None):
         for m in self.mods:                       # a module whose parameters moved (e.g. .to()) re-flattens: keep the optimizer's view
             if m._flat is not self.flats[self.mods.index(m)]:
                 raise RuntimeError("the network's parameters were re-allocated after the train step was built")
-        out = self.model(raw)
-        res = ops.loss_sums(out.detach(), ref, self.kind)
-        dout = ops.loss_grad(out.detach(), ref, self._one, self.kind)
-        out.backward(dout)
+        B = raw.shape[0]
+        mb = self.micro_batch_for(B, raw.shape[2], raw.shape[3])
+        if mb == B:
+            out = self.model(raw)
+            res = ops.loss_sums(out.detach(), ref, self.kind)
+            dout = ops.loss_grad(out.detach(), ref, self._one, self.kind)
+            out.backward(dout)
+            loss = res[0]
+        else:
+            if self._acc is None:
+                self._acc = torch.zeros_like(self.bucket)
+                self._wdev = torch.zeros(1, dtype=torch.float32, device=self.bucket.device)
+                self._loss_acc = torch.zeros(1, dtype=torch.float32, device=self.bucket.device)
+            w = self._weights(mb, B)
+            self._wdev.fill_(w)
+            n = self.bucket.numel()
+            for i, o in enumerate(range(0, B, mb)):
+                out = self.model(raw[o:o + mb])
+                res = ops.loss_sums(out.detach(), ref[o:o + mb], self.kind)
+                dout = ops.loss_grad(out.detach(), ref[o:o + mb], self._wdev, self.kind)
+                out.backward(dout)
+                ops.flat_accumulate(self.bucket, self._acc, n, accumulate=i > 0)
+                ops.axpy_scalar(self._loss_acc, res[0], w, first=i == 0)
+            ops.flat_accumulate(self._acc, self.bucket, n, accumulate=False)
+            loss = self._loss_acc[0].clone()
         scale = parallel.allreduce_flat_grads(self.bucket, self.bucket.numel(), self.pg)
         norm = self.opt.step(lr=lr, grad_scale=scale)
-        return res[0], norm[0]
+        return loss, norm[0]
 
     @torch.no_grad()
     def evaluate(self, raw: torch.Tensor, ref: torch.Tensor, with_ssim: bool = False):
-        out = self.model(raw)
-        res = ops.loss_sums(out, ref, self.kind)
-        if with_ssim:
-            return res[0], res[1], ops.ssim(ref, out, data_range=1.0)
-        return res[0], res[1]
+        B = raw.shape[0]
+        mb = self.micro_batch_for(B, raw.shape[2], raw.shape[3], train=False)
+        if mb == B:
+            out = self.model(raw)
+            res = ops.loss_sums(out, ref, self.kind)
+            if with_ssim:
+                return res[0], res[1], ops.ssim(ref, out, data_range=1.0)
+            return res[0], res[1]
+        w = self._weights(mb, B)
+        loss = mse = ss = None
+        for o in range(0, B, mb):
+            out = self.model(raw[o:o + mb])
+            res = ops.loss_sums(out, ref[o:o + mb], self.kind)
+            l_i, m_i = res[0] * w, torch.pow(10.0, -res[1] / 10.0) * (mb / B)      # PSNR recombines through the mean squared error
+            loss = l_i if loss is None else loss + l_i
+            mse = m_i if mse is None else mse + m_i
+            if with_ssim:
+                s_i = ops.ssim(ref[o:o + mb], out, data_range=1.0) * (mb / B)
+                ss = s_i if ss is None else ss + s_i
+        psnr = -10.0 * torch.log10(mse)
+        return (loss, psnr, ss) if with_ssim else (loss, psnr)
 
 
 def make_train_step(model, loss_name: str, lr: float, weight_decay: float = 0.0):
