@@ -404,17 +404,29 @@ int uir_hwc4_to_nchw3(const float* src, float* dst, int B, int H, int Wd, void* 
 
 /* ---------------------------------------------------------------- uir_loss */
 enum { UIR_LOSS_L1 = 0, UIR_LOSS_L2 = 1, UIR_LOSS_CHARBONNIER = 2, UIR_LOSS_LUMINANCE = 3, UIR_LOSS_L1_COLOR = 4,
-       UIR_LOSS_LUM_CHARBONNIER = 5 /* "LuminanceCharbonnier" = LuminanceLoss + CharbonnierLoss, losses.py:118-123 */ };
+       UIR_LOSS_LUM_CHARBONNIER = 5, /* "LuminanceCharbonnier" = LuminanceLoss + CharbonnierLoss, losses.py:118-123 */
+       UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER = 6, /* "AdaptiveLuminanceCharbonnier", losses.py:130-140: 0.5 * softmax(-log(losses + 1e-6))
+                                               * weights (detached) over (Charbonnier, Luminance) */
+       UIR_LOSS_GRADIENT = 7 /* "gradient" = Gradient_Loss, losses.py:162-181: L1 between the valid 3x3 Laplacians of pred and truth */ };
 /* Partial sums over NCHW [B,3,H,W] pred/truth: slab[block][8] =
  * (sum|d|, sum d^2, sum sqrt(d^2+1e-6), sum lum^2, sum (clamp01(p)-clamp01(t))^2, 0,0,0).
  * Replaces nn.L1Loss / MSELoss / CharbonnierLoss / ColorLoss / LuminanceLoss
  * (src/Losses/losses.py:55-57,76-78,190-192,209-212; luminanceLoss.py:16-19) and the PSNR
  * reduction (src/ModelTrainer.py:17-21). */
 int uir_loss_partials(const float* pred, const float* truth, float* slab, int nblocks, int B, int HW, void* stream);
-/* sums[8] (reduced slab) -> out[0] = loss(kind), out[1] = PSNR */
+/* sums[8] (reduced slab) -> out[4]: out[0] = loss(kind), out[1] = PSNR, out[2..3] = the two detached weights of
+ * UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER (0 otherwise).  UIR_LOSS_GRADIENT reads sums[5] = its mean (uir_gradloss_partials + reduction). */
 int uir_loss_finalize(const float* sums, float* out, int kind, int B, int HW, void* stream);
-/* dpred = dL/dpred * gscale[0]  (gscale = upstream scalar gradient on device) */
-int uir_loss_bwd(const float* pred, const float* truth, const float* gscale, float* dpred, int kind, int B, int HW, void* stream);
+/* dpred = dL/dpred * gscale[0]  (gscale = upstream scalar gradient on device); aux = the out[4] of uir_loss_finalize of the same
+ * pair (read by UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER only, may be NULL otherwise).  UIR_LOSS_GRADIENT: uir_gradloss_bwd. */
+int uir_loss_bwd(const float* pred, const float* truth, const float* gscale, const float* aux, float* dpred, int kind, int B, int HW,
+                 void* stream);
+/* Gradient_Loss (src/Losses/losses.py:162-181): F.conv2d with the 3x3 Laplacian [[0,1,0],[1,-4,1],[0,1,0]] per channel, no padding
+ * (output (H-2) x (W-2)), nn.L1Loss between the two results = mean |lap(pred - truth)|.  slab[block] = partial sum of |lap(d)|
+ * (sum the nblocks entries and divide by B*3*(H-2)*(W-2)); H, W >= 3. */
+int uir_gradloss_partials(const float* pred, const float* truth, float* slab, int nblocks, int B, int H, int Wd, void* stream);
+/* dpred = gscale[0] / (B*3*(H-2)*(W-2)) * lap^T(sign(lap(pred - truth))) */
+int uir_gradloss_bwd(const float* pred, const float* truth, const float* gscale, float* dpred, int B, int H, int Wd, void* stream);
 
 /* --------------------------------------------------------------- uir_optim */
 /* slab[block] = partial sum of squares of g[0..n) */

@@ -269,6 +269,14 @@ def _val_worker(rank, world, port, out):
     from torch.utils.data.distributed import DistributedSampler
     batches = [(torch.full((2, 3, 4, 4), float(i + 1)), torch.zeros(2, 3, 4, 4)) for i in range(5)]
     got = ModelTrainer.validate(_FakeStep(), batches, torch.device("cpu"), world)
+    # get_dataloaders' validation loader under data parallelism: this rank's batches only (RankBatches), same means
+    from torch.utils.data import DataLoader
+    from underwater_image_restoration_amd.DataManipulation.DataLoader import RankBatches
+    raw9 = torch.stack([torch.full((3, 4, 4), float(i // 2 + 1)) for i in range(9)])        # 9 items, batches of 2: 5 batches
+    ds9 = TensorDataset(raw9, torch.zeros(9, 3, 4, 4))
+    rb = RankBatches(9, 2, rank, world)
+    assert [b[0] // 2 for b in rb] == list(range(5))[rank::world] and sum(len(b) for b in rb) == (5 if rank == 0 else 4)
+    got_sharded = ModelTrainer.validate(_FakeStep(), DataLoader(ds9, batch_sampler=rb), torch.device("cpu"), world)
     # the train sampler reshuffles per epoch only when set_epoch is called - which train() now does
     ds = TensorDataset(torch.arange(16))
     s = DistributedSampler(ds, shuffle=True, drop_last=True)
@@ -276,7 +284,7 @@ def _val_worker(rank, world, port, out):
     for epoch in range(2):
         s.set_epoch(epoch)
         orders.append(list(iter(s)))
-    torch.save({"val": got, "orders": orders}, f"{out}.{rank}")
+    torch.save({"val": got, "val_sharded": got_sharded, "orders": orders}, f"{out}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -291,6 +299,7 @@ def test_validation_means_are_all_reduced_over_ranks(tmp_path):
     want = sum(range(1, 6)) / 5.0
     for r in (r0, r1):
         assert abs(r["val"][0] - want) < 1e-12 and abs(r["val"][1] - 10 * want) < 1e-12 and abs(r["val"][2] - 0.1 * want) < 1e-12
+        assert abs(r["val_sharded"][0] - want) < 1e-12 and abs(r["val_sharded"][1] - 10 * want) < 1e-12
     assert r0["orders"][0] != r0["orders"][1]                         # a new shuffle each epoch
     assert not set(r0["orders"][0]) & set(r1["orders"][0])             # disjoint shards
 

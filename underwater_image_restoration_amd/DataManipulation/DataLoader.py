@@ -16,6 +16,22 @@ from torch.utils.data.distributed import DistributedSampler
 from .UIEBDataset import UIEBDataset
 
 
+class RankBatches:
+    """batch_sampler of the validation loader under data parallelism: the reference's consecutive test batches
+    (DataLoader.py:30: shuffle=False, batch i = items [i * bs, (i + 1) * bs)), of which this rank gets i = rank, rank + world, ...
+    Nothing is decoded or resized for the other ranks' batches; the per-batch means recombine exactly (ModelTrainer.validate)."""
+    rank_sharded = True
+
+    def __init__(self, n_items: int, batch_size: int, rank: int, world: int):
+        self.batches = [list(range(i, min(i + batch_size, n_items))) for i in range(0, n_items, batch_size)][rank::world]
+
+    def __iter__(self):
+        return iter(self.batches)
+
+    def __len__(self):
+        return len(self.batches)
+
+
 def get_dataloaders(raw_dir, ref_dir, test_raw_dir, test_ref_dir, batch_size=16, num_workers=4, image_size=1024,
                     shuffle=True, pin_memory=True, device_resize=False, device="cuda", persistent_workers=None):
     train_ds = UIEBDataset(raw_dir, ref_dir, image_size, decode_only=device_resize)
@@ -35,8 +51,13 @@ def get_dataloaders(raw_dir, ref_dir, test_raw_dir, test_ref_dir, batch_size=16,
         pin_memory = False                 # items are variable-size byte arrays; the resizer owns the pinned staging
     train_loader = DataLoader(train_ds, batch_size=batch_size, shuffle=(shuffle and sampler is None), sampler=sampler,
                               num_workers=num_workers, pin_memory=pin_memory, drop_last=sampler is not None, **extra)
-    test_loader = DataLoader(test_ds, batch_size=batch_size, shuffle=False, num_workers=num_workers, pin_memory=pin_memory,
-                             **extra)
+    if sampler is not None:            # data parallel: each rank loads only the validation batches it evaluates
+        test_loader = DataLoader(test_ds, batch_sampler=RankBatches(len(test_ds), batch_size, torch.distributed.get_rank(),
+                                                                    torch.distributed.get_world_size()),
+                                 num_workers=num_workers, pin_memory=pin_memory, **extra)
+    else:
+        test_loader = DataLoader(test_ds, batch_size=batch_size, shuffle=False, num_workers=num_workers, pin_memory=pin_memory,
+                                 **extra)
     if device_resize:
         train_loader = DevicePrefetchLoader(train_loader, image_size, device)
         test_loader = DevicePrefetchLoader(test_loader, image_size, device)

@@ -10,6 +10,9 @@ truth)`` (src/Losses/losses.py:30-160), for the loss names on the SpectralTransf
                 name, :49), so this is the evident intent, without the
                 four `print(loss.item())` host syncs.
   L1ColorLum    the same formula (:67-75; in the reference it raises the same AttributeError as L1withColor)
+  LuminanceCharbonnier          LuminanceLoss + CharbonnierLoss                                  (:118-123)
+  AdaptiveLuminanceCharbonnier  sum_i loss_i * 0.5 * softmax(-log(loss + 1e-6))_i, weights detached (:130-140)
+  gradient      nn.L1Loss between the valid 3x3 Laplacians of pred and truth (Gradient_Loss, :162-181)
 
 Forward and backward are HIP reductions (uir_loss_*).  Other reference loss names need
 third-party packages / pretrained VGG weights that are outside this build's scope.
@@ -21,23 +24,26 @@ import torch
 from .. import _lib as L
 from .. import ops
 
-_REFERENCE_OTHER = ("perceptual", "gradient", "ms_ssim", "ffl", "mix", "fflMixTV", "bigMix", "fflCharbonnier", "fflMix",
-                    "AdaptiveLuminanceCharbonnier", "AdaptiveLuminanceFFL", "LuminanceFFL",
-                    "ssimFFLCharbonnier")
+# names the reference defines on top of packages / weights that are not in the image: torchvision's pretrained VGG16 (a download,
+# losses.py:219-222: "perceptual" and every mix), pytorch_msssim.MS_SSIM and focal_frequency_loss.FocalFrequencyLoss (un-vendored,
+# unpinned pip packages, requirements.txt:14-15).  "fflMix" (:108-117) needs all three: its pinnable terms - Charbonnier and
+# Gradient_Loss - are the losses above; the other three terms cannot be held to the reference here.
+_REFERENCE_OTHER = ("perceptual", "ms_ssim", "ffl", "mix", "fflMixTV", "bigMix", "fflCharbonnier", "fflMix",
+                    "AdaptiveLuminanceFFL", "LuminanceFFL", "ssimFFLCharbonnier")
 
 
 class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, truth, kind):
         out = ops.loss_sums(pred, truth, kind)
-        ctx.save_for_backward(pred, truth)
+        ctx.save_for_backward(pred, truth, out)
         ctx.kind = kind
         return out[0]
 
     @staticmethod
     def backward(ctx, g):
-        pred, truth = ctx.saved_tensors
-        return ops.loss_grad(pred, truth, g, ctx.kind), None, None
+        pred, truth, out = ctx.saved_tensors
+        return ops.loss_grad(pred, truth, g, ctx.kind, aux=out), None, None
 
 
 class LossFunction:
@@ -50,7 +56,9 @@ class LossFunction:
         if name in L.LOSS_KINDS:
             return _LossFn.apply(predicted_data, truth_data.detach(), L.LOSS_KINDS[name])
         if name in _REFERENCE_OTHER:
-            raise NotImplementedError(f"loss '{name}' is outside the MI355X hot-path build (DESIGN.md, out of scope)")
+            raise NotImplementedError(f"loss '{name}' needs torchvision's pretrained VGG16 and / or the pytorch_msssim and "
+                                      f"focal_frequency_loss packages, none of which exist in this image (DESIGN.md section 16); "
+                                      f"its Charbonnier / Luminance / Gradient_Loss terms are available as 'charbonnier', 'Luminance', 'gradient'")
         raise ValueError(f"Unsupported loss: {self.loss_name}")
 
 

@@ -140,11 +140,14 @@ class ModelTrainer:
     @staticmethod
     def validate(step, test_loader, dev, world=1):
         """Per-batch loss / PSNR / SSIM means (src/ModelTrainer.py:134-158).  With several ranks each one evaluates the
-        batches ``rank, rank + world, ...`` and the sums are all-reduced (three scalars + a count)."""
+        batches ``rank, rank + world, ...`` and the sums are all-reduced (three scalars + a count).  get_dataloaders hands every
+        rank a loader of ITS batches only (RankBatches: nothing is decoded for the others); any other iterable is strided here."""
         rank = parallel.rank()
         acc = torch.zeros(4, dtype=torch.float64, device=dev)
+        inner = getattr(test_loader, "loader", test_loader)
+        sharded = getattr(getattr(inner, "batch_sampler", None), "rank_sharded", False)
         for i, (raw_imgs, ref_imgs) in enumerate(test_loader):
-            if world > 1 and i % world != rank:
+            if world > 1 and not sharded and i % world != rank:
                 continue
             vl, vp, vs = step.evaluate(raw_imgs.to(dev), ref_imgs.to(dev), with_ssim=True)   # :148-150
             acc += torch.stack([vl.double(), vp.double(), vs.double(), torch.ones((), dtype=torch.float64, device=dev)])

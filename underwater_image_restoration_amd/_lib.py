@@ -18,7 +18,9 @@ PRO_NONE, PRO_LN, PRO_GATE = 0, 1, 2
 EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW, EPI_LN_BWD = 0, 1, 2, 3, 4
 ACT_NONE, ACT_LEAKY, ACT_GELU = 0, 1, 2
 # L1ColorLum has the same formula as L1withColor in the reference (src/Losses/losses.py:59-66 vs :67-75)
-LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4, "LuminanceCharbonnier": 5}
+LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4, "LuminanceCharbonnier": 5,
+              "AdaptiveLuminanceCharbonnier": 6, "gradient": 7}
+LOSS_GRADIENT = 7
 
 
 class GemmArgs(C.Structure):
@@ -220,7 +222,9 @@ SIGNATURES = {
     "uir_hwc4_to_nchw3": [fp, fp, i32, i32, i32, fp],
     "uir_loss_partials": [fp, fp, fp, i32, i32, i32, fp],
     "uir_loss_finalize": [fp, fp, i32, i32, i32, fp],
-    "uir_loss_bwd": [fp, fp, fp, fp, i32, i32, i32, fp],
+    "uir_loss_bwd": [fp, fp, fp, fp, fp, i32, i32, i32, fp],
+    "uir_gradloss_partials": [fp, fp, fp, i32, i32, i32, i32, fp],
+    "uir_gradloss_bwd": [fp, fp, fp, fp, i32, i32, i32, fp],
     "uir_sumsq_partials": [fp, i64, fp, i32, fp],
     "uir_clip_adam_step": [C.POINTER(AdamArgs), fp],
     "uir_adam_set_hyper": [fp, f32, f32, f32, f32, fp],

@@ -26,17 +26,25 @@ def _req(t: torch.Tensor, what: str) -> torch.Tensor:
 
 
 def loss_sums(pred: torch.Tensor, truth: torch.Tensor, kind: int) -> torch.Tensor:
-    """-> device tensor [2] = (loss(kind), PSNR)."""
+    """-> device tensor [4] = (loss(kind), PSNR, and the two detached weights of AdaptiveLuminanceCharbonnier - pass it to
+    loss_grad as `aux`)."""
     pred, truth = _req(pred, "loss"), _req(truth, "loss")
     if pred.shape != truth.shape or pred.dim() != 4 or pred.shape[1] != 3:
         raise ValueError(f"loss expects matching [B,3,H,W] tensors, got {tuple(pred.shape)} / {tuple(truth.shape)}")
     B, _, H, W = pred.shape
     slab = torch.empty(_LOSS_BLOCKS * 8, dtype=torch.float32, device=pred.device)
     sums = torch.empty(8, dtype=torch.float32, device=pred.device)
-    out = torch.empty(2, dtype=torch.float32, device=pred.device)
+    out = torch.empty(4, dtype=torch.float32, device=pred.device)
     st = _stream()
     L.check(lib.uir_loss_partials(pred.data_ptr(), truth.data_ptr(), slab.data_ptr(), _LOSS_BLOCKS, B, H * W, st), "uir_loss_partials")
     L.check(lib.uir_reduce_slab(slab.data_ptr(), _LOSS_BLOCKS, 8, sums.data_ptr(), 8, 0, 1.0, st), "uir_reduce_slab")
+    if kind == L.LOSS_GRADIENT:          # Gradient_Loss: its own stencil pass; the mean lands in sums[5]
+        if H < 3 or W < 3:
+            raise ValueError("the gradient loss needs H, W >= 3 (valid 3x3 Laplacian)")
+        gslab = torch.empty(_LOSS_BLOCKS, dtype=torch.float32, device=pred.device)
+        L.check(lib.uir_gradloss_partials(pred.data_ptr(), truth.data_ptr(), gslab.data_ptr(), _LOSS_BLOCKS, B, H, W, st), "uir_gradloss_partials")
+        L.check(lib.uir_reduce_slab(gslab.data_ptr(), _LOSS_BLOCKS, 1, sums.data_ptr() + 20, 1, 0, 1.0 / (B * 3 * (H - 2) * (W - 2)), st),
+                "uir_reduce_slab")
     L.check(lib.uir_loss_finalize(sums.data_ptr(), out.data_ptr(), kind, B, H * W, st), "uir_loss_finalize")
     return out
 
@@ -68,12 +76,20 @@ def ssim(x: torch.Tensor, y: torch.Tensor, data_range: float = 1.0) -> torch.Ten
     return out[0]
 
 
-def loss_grad(pred: torch.Tensor, truth: torch.Tensor, gscale: torch.Tensor, kind: int) -> torch.Tensor:
+def loss_grad(pred: torch.Tensor, truth: torch.Tensor, gscale: torch.Tensor, kind: int, aux: "torch.Tensor | None" = None) -> torch.Tensor:
+    """dL/dpred * gscale.  aux = the tensor loss_sums returned for the same pair (needed by AdaptiveLuminanceCharbonnier: its weights
+    are functions of the two loss values, detached - src/Losses/losses.py:135-138)."""
     pred, truth = _req(pred, "loss"), _req(truth, "loss")
     B, _, H, W = pred.shape
     gs = _req(gscale.reshape(1), "loss")
     dpred = torch.empty_like(pred)
-    L.check(lib.uir_loss_bwd(pred.data_ptr(), truth.data_ptr(), gs.data_ptr(), dpred.data_ptr(), kind, B, H * W, _stream()), "uir_loss_bwd")
+    if kind == L.LOSS_GRADIENT:
+        L.check(lib.uir_gradloss_bwd(pred.data_ptr(), truth.data_ptr(), gs.data_ptr(), dpred.data_ptr(), B, H, W, _stream()), "uir_gradloss_bwd")
+        return dpred
+    if kind == L.LOSS_KINDS["AdaptiveLuminanceCharbonnier"] and aux is None:
+        aux = loss_sums(pred, truth, kind)
+    L.check(lib.uir_loss_bwd(pred.data_ptr(), truth.data_ptr(), gs.data_ptr(), aux.data_ptr() if aux is not None else None, dpred.data_ptr(),
+                             kind, B, H * W, _stream()), "uir_loss_bwd")
     return dpred
 
 

@@ -76,6 +76,9 @@ class TrainStep:
     def _weights(self, mb: int, B: int) -> float:
         """Weight of one micro-batch's loss in the full-batch loss: b/B for plain means; (b/B)^2 for the losses the
         reference also divides by the batch size (L1, L2, L1withColor / L1ColorLum: src/Losses/losses.py:57,65,74,78)."""
+        if self.kind == L.LOSS_KINDS["AdaptiveLuminanceCharbonnier"] and mb != B:
+            raise NotImplementedError("AdaptiveLuminanceCharbonnier weights its two terms by their values over the WHOLE batch "
+                                      "(losses.py:135-138): it cannot be accumulated over micro-batches")
         f = mb / B
         return f * f if self.kind in (0, 1, 4) else f
 
@@ -93,7 +96,7 @@ class TrainStep:
             plan = self.model._plan_for(r)
             out = plan.forward(r)
             res = ops.loss_sums(out, f, self.kind)
-            dout = ops.loss_grad(out, f, self._wdev, self.kind)
+            dout = ops.loss_grad(out, f, self._wdev, self.kind, aux=res)
             plan.backward(dout)
             self.model._fwd_serial += 1
             ops.flat_accumulate(self.flat.grad, self._acc, n, accumulate=i > 0)
@@ -122,7 +125,7 @@ class TrainStep:
                 return g["res"][0], self.opt.norm[0]
         out = plan.forward(raw)
         res = ops.loss_sums(out, ref, self.kind)
-        dout = ops.loss_grad(out, ref, self._one, self.kind)
+        dout = ops.loss_grad(out, ref, self._one, self.kind, aux=res)
         plan.backward(dout)
         self.model._fwd_serial += 1
         # single flat bucket of the live gradients (8.8 MB): one all-reduce over xGMI
@@ -142,7 +145,7 @@ class TrainStep:
             with torch.cuda.graph(graph):
                 plan.run(plan.fwd)
                 res = ops.loss_sums(plan.out_nchw, ref_s, self.kind)
-                dout = ops.loss_grad(plan.out_nchw, ref_s, self._one, self.kind)
+                dout = ops.loss_grad(plan.out_nchw, ref_s, self._one, self.kind, aux=res)
                 plan.backward(dout)
                 self.opt.launch()
             g = {"graph": graph, "ref": ref_s, "res": res}
@@ -291,6 +294,8 @@ class ModuleTrainStep:
         return mb
 
     def _weights(self, mb: int, B: int) -> float:
+        if self.kind == L.LOSS_KINDS["AdaptiveLuminanceCharbonnier"] and mb != B:
+            raise NotImplementedError("AdaptiveLuminanceCharbonnier cannot be accumulated over micro-batches (losses.py:135-138)")
         f = mb / B                                # see TrainStep._weights (losses the reference also divides by the batch size)
         return f * f if self.kind in (0, 1, 4) else f
 
@@ -303,7 +308,7 @@ class ModuleTrainStep:
         if mb == B:
             out = self.model(raw)
             res = ops.loss_sums(out.detach(), ref, self.kind)
-            dout = ops.loss_grad(out.detach(), ref, self._one, self.kind)
+            dout = ops.loss_grad(out.detach(), ref, self._one, self.kind, aux=res)
             out.backward(dout)
             loss = res[0]
         else:
@@ -317,7 +322,7 @@ class ModuleTrainStep:
             for i, o in enumerate(range(0, B, mb)):
                 out = self.model(raw[o:o + mb])
                 res = ops.loss_sums(out.detach(), ref[o:o + mb], self.kind)
-                dout = ops.loss_grad(out.detach(), ref[o:o + mb], self._wdev, self.kind)
+                dout = ops.loss_grad(out.detach(), ref[o:o + mb], self._wdev, self.kind, aux=res)
                 out.backward(dout)
                 ops.flat_accumulate(self.bucket, self._acc, n, accumulate=i > 0)
                 ops.axpy_scalar(self._loss_acc, res[0], w, first=i == 0)
