@@ -913,8 +913,9 @@ class Plan(Recorder):
         return self
 
     # ------------------------------------------------------------ sub-graphs
-    def _block(self, pfx: str, x: torch.Tensor, C_: int, heads: int, dims) -> Tuple[torch.Tensor, Callable]:
-        """TransformerBlock (SpectralTransformer.py:142-148) on HWC rows x [M, C]."""
+    def _block(self, pfx: str, x: torch.Tensor, C_: int, heads: int, dims, y_out: "torch.Tensor | None" = None) -> Tuple[torch.Tensor, Callable]:
+        """TransformerBlock (SpectralTransformer.py:142-148) on HWC rows x [M, C].  y_out: where the block's output goes (a column
+        slice of a decoder's concat buffer for the last block of an encoder level: the skip `torch.cat` of :264-267 costs no copy)."""
         B, H, W = dims
         M, HW = B * H * W, H * W
         h = hidden_of(C_)
@@ -940,7 +941,8 @@ class Plan(Recorder):
         attn, WA, WB = self.alloc(B * C_ * (C_ // heads)), self.alloc(B, C_ * C_), self.alloc(B, C_ * C_)
         u, vf, x1 = self.alloc(M, C_), self.alloc(M, C_), self.alloc(M, C_)
         gpre, g = self.alloc(M, ldg)[:, :2 * hp], self.alloc(M, ldg)[:, :2 * hp]
-        y = self.alloc(M, C_)
+        y = self.alloc(M, C_) if y_out is None else y_out
+        assert tuple(y.shape) == (M, C_)
         q_, k_, v_ = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
 
         n = pfx
@@ -1067,10 +1069,10 @@ class Plan(Recorder):
 
         return y, backward
 
-    def _stack(self, pfx, x, nb, C_, heads, dims):
+    def _stack(self, pfx, x, nb, C_, heads, dims, y_out=None):
         bws = []
         for j in range(nb):
-            x, bw = self._block(f"{pfx}.{j}", x, C_, heads, dims)
+            x, bw = self._block(f"{pfx}.{j}", x, C_, heads, dims, y_out=y_out if j == nb - 1 else None)
             bws.append(bw)
 
         def backward(dy):
@@ -1089,7 +1091,8 @@ class Plan(Recorder):
             y = self.alloc(M, Np)
         self.gemm(name, x, Wt, y, N=Np, K=Kp, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=dims[1:], k_grp=k_grp, n_grp=n_grp)
 
-        def backward(dy, need_dx=True, dw_on_chain=False):
+        def backward(dy, need_dx=True, dw_on_chain=False, R=None):
+            """R: a gradient to ADD to the input gradient (the skip path's share: no separate accumulate pass)."""
             def dw():
                 self.gram(name + ".dW", dy, x, self.Gr(Wname), N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:],
                           n_grp=n_grp, k_grp=k_grp)
@@ -1102,7 +1105,7 @@ class Plan(Recorder):
                 return None
             dx = self.alloc(M, Kp)
             self.gemm(name + ".dX", dy, Wt, dx, N=Kp, K=Np, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=dims[1:],
-                      n_grp=k_grp, k_grp=n_grp)
+                      n_grp=k_grp, k_grp=n_grp, R=R)
             return dx
         return y, backward
 
@@ -1113,10 +1116,10 @@ class Plan(Recorder):
         y = self.alloc(B * (H // 2) * (W // 2), 2 * C_)
         self._op(pfx + ".unshuffle", lib.uir_pixel_unshuffle, _ptr(t), _ld(t), 0, _ptr(y), _ld(y), B, H // 2, W // 2, C_ // 2)
 
-        def backward(dy):
+        def backward(dy, R=None):
             dt = self.alloc(B * H * W, C_ // 2)
             self._op(pfx + ".unshuffle_bwd", lib.uir_pixel_shuffle, _ptr(dy), _ld(dy), _ptr(dt), _ld(dt), 0, B, H // 2, W // 2, C_ // 2)
-            return conv_bw(dt)
+            return conv_bw(dt, R=R)
         return y, backward
 
     def _fuse(self, pfx, x, C_):
@@ -1231,37 +1234,35 @@ class Plan(Recorder):
 
         def embed_bw(dy, need_dx=False, dw_on_chain=True):
             self.gram("embed.dW", dy, x27, self.Gr("embed_conv_rgb.weight"), N=16, K=27, o_sn=27, o_sk=1)
-        e1, enc1_bw = self._stack("encoders.0", f0, 2, 16, 1, d0)
+        # the decoders' concat buffers (SpectralTransformer.py:264-267) exist from the start: each encoder level's last block writes its
+        # output straight into the skip half, and in the backward the skip half of the concat gradient is ADDED by the down-sampler's
+        # input-gradient GEMM (R operand) - the two copy passes and the accumulate pass per level of rounds 1-2 are gone
+        cat1, cat2, cat3 = self.alloc(M0, 32), self.alloc(M1, 64), self.alloc(M2, 128)
+        e1, enc1_bw = self._stack("encoders.0", f0, 2, 16, 1, d0, y_out=cat1[:, 16:])
         self.mark("fwd.enc0(L0,C16)")
         t1, down1_bw = self._down("down1", e1, 16, d0)
-        e2, enc2_bw = self._stack("encoders.1", t1, 3, 32, 2, d1)
+        e2, enc2_bw = self._stack("encoders.1", t1, 3, 32, 2, d1, y_out=cat2[:, 32:])
         self.mark("fwd.enc1(L1)")
         t2, down2_bw = self._down("down2", e2, 32, d1)
-        e3, enc3_bw = self._stack("encoders.2", t2, 3, 64, 4, d2)
+        e3, enc3_bw = self._stack("encoders.2", t2, 3, 64, 4, d2, y_out=cat3[:, 64:])
         self.mark("fwd.enc2(L2)")
         t3, down3_bw = self._down("down3", e3, 64, d2)
         e4, enc4_bw = self._stack("encoders.3", t3, 4, 128, 8, d3)
         self.mark("fwd.enc3(L3)")
         # decoder level 3: cat[ups_1(e4), e3] -> reduces1 (SpectralTransformer.py:263-264)
-        cat3 = self.alloc(M2, 128)
         ups1_bw = self._ups("ups_1", e4, 128, d3, cat3[:, :64])
-        self.copy_cols("cat3.skip", e3, 0, cat3, 64, 64)
         r3 = self.alloc(M2, 64)
         self.gemm("reduces1", cat3, P("reduces1.weight"), r3, N=64, K=128, w_sn=128, w_sk=1)
         self.mark("fwd.ups_1")
         dd3, dec3_bw = self._stack("decoders.0", r3, 3, 64, 4, d2)
         self.mark("fwd.dec0(L2)")
-        cat2 = self.alloc(M1, 64)
         ups2_bw = self._ups("ups_2", dd3, 64, d2, cat2[:, :32])
-        self.copy_cols("cat2.skip", e2, 0, cat2, 32, 32)
         r2 = self.alloc(M1, 32)
         self.gemm("reduces2", cat2, P("reduces2.weight"), r2, N=32, K=64, w_sn=64, w_sk=1)
         self.mark("fwd.ups_2")
         dd2, dec2_bw = self._stack("decoders.1", r2, 3, 32, 2, d1)
         self.mark("fwd.dec1(L1)")
-        cat1 = self.alloc(M0, 32)
         ups3_bw = self._ups("ups_3", dd2, 32, d1, cat1[:, :16])
-        self.copy_cols("cat1.skip", e1, 0, cat1, 16, 16)
         self.mark("fwd.ups_3")
         fd, dec1_bw = self._stack("decoders.2", cat1, 2, 32, 1, d0)
         self.mark("fwd.dec2(L0,C32)")
@@ -1285,8 +1286,6 @@ class Plan(Recorder):
         self.mark("bwd.refine(L0,C32)")
         dcat1 = dec1_bw(dfd)
         self.mark("bwd.dec2(L0,C32)")
-        de1 = self.alloc(M0, 16)
-        self.copy_cols("cat1.skip_bwd", dcat1, 16, de1, 0, 16)
         ddd2 = ups3_bw(dcat1[:, :16])
         self.mark("bwd.ups_3")
         dr2 = dec2_bw(ddd2)
@@ -1295,8 +1294,6 @@ class Plan(Recorder):
         with self.bulk():
             self.gram("reduces2.dW", dr2, cat2, self.Gr("reduces2.weight"), N=32, K=64, o_sn=64, o_sk=1)
         self.gemm("reduces2.dX", dr2, P("reduces2.weight"), dcat2, N=64, K=32, w_sn=1, w_sk=64)
-        de2 = self.alloc(M1, 32)
-        self.copy_cols("cat2.skip_bwd", dcat2, 32, de2, 0, 32)
         ddd3 = ups2_bw(dcat2[:, :32])
         self.mark("bwd.ups_2")
         dr3 = dec3_bw(ddd3)
@@ -1305,22 +1302,17 @@ class Plan(Recorder):
         with self.bulk():
             self.gram("reduces1.dW", dr3, cat3, self.Gr("reduces1.weight"), N=64, K=128, o_sn=128, o_sk=1)
         self.gemm("reduces1.dX", dr3, P("reduces1.weight"), dcat3, N=128, K=64, w_sn=1, w_sk=128)
-        de3 = self.alloc(M2, 64)
-        self.copy_cols("cat3.skip_bwd", dcat3, 64, de3, 0, 64)
         de4 = ups1_bw(dcat3[:, :64])
         self.mark("bwd.ups_1")
         dt3 = enc4_bw(de4)
         self.mark("bwd.enc3(L3)")
-        d_e3 = down3_bw(dt3)
-        self.copy_cols("e3.grad_sum", d_e3, 0, de3, 0, 64, accumulate=1)
+        de3 = down3_bw(dt3, R=dcat3[:, 64:])        # + the skip path's gradient
         dt2 = enc3_bw(de3)
         self.mark("bwd.enc2(L2)")
-        d_e2 = down2_bw(dt2)
-        self.copy_cols("e2.grad_sum", d_e2, 0, de2, 0, 32, accumulate=1)
+        de2 = down2_bw(dt2, R=dcat2[:, 32:])
         dt1 = enc2_bw(de2)
         self.mark("bwd.enc1(L1)")
-        d_e1 = down1_bw(dt1)
-        self.copy_cols("e1.grad_sum", d_e1, 0, de1, 0, 16, accumulate=1)
+        de1 = down1_bw(dt1, R=dcat1[:, 16:])
         df0 = enc1_bw(de1)
         self.mark("bwd.enc0(L0,C16)")
         embed_bw(df0, need_dx=False, dw_on_chain=True)
