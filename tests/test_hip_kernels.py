@@ -187,6 +187,37 @@ def test_gemm_conv3x3_fwd_and_input_grad(B, H, W, Cin, Cout):
     assert rel(chw(Yb, B, H, W), y + bias.view(1, -1, 1, 1) + chw(res, B, H, W)) < TOL
 
 
+@pytest.mark.parametrize("Cin,Cout", [(32, 8), (8, 3), (16, 8), (32, 16)])
+def test_gemm_conv3x3_small_channels(Cin, Cout):
+    """the direct small-channel kernel behind uir_gemm (conv3s.hip): outputl / output / down1 / down2 shapes and their input
+    gradients, ragged 16 x 16 tiles, residual, padded 3-of-4 channel groups"""
+    B, H, W = 2, 19, 35
+    x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = rnd(Cout, Cin, 3, 3, seed=2)
+    y = F.conv2d(x, w, padding=1)
+    dy = rnd(*y.shape, seed=3)
+    (dx,) = torch.autograd.grad((y * dy).sum(), x)
+    Np = (Cout + 3) // 4 * 4
+    r = rec()
+    Wd = dev(w)
+    res = rnd(B * H * W, Np, seed=5)
+    Y, Yr, dX = r.alloc(B * H * W, Np), r.alloc(B * H * W, Np), r.alloc(B * H * W, Cin)
+    Y.fill_(7.0)
+    grp = dict(n_grp=(Cout, Np)) if Np != Cout else {}
+    r.gemm("c", dev(hwc(x.detach())), Wd, Y, N=Np, K=Cin, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=(H, W), **grp)
+    r.gemm("c.r", dev(hwc(x.detach())), Wd, Yr, N=Np, K=Cin, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=(H, W), R=dev(res), **grp)
+    dyp = torch.zeros(B * H * W, Np, dtype=torch.float64)
+    dyp[:, :Cout] = hwc(dy)
+    kgrp = dict(k_grp=(Cout, Np)) if Np != Cout else {}
+    r.gemm("c.dx", dev(dyp), Wd, dX, N=Cin, K=Np, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=(H, W), **kgrp)
+    r.run(r.fwd)
+    assert rel(chw(Y[:, :Cout], B, H, W), y) < TOL
+    assert rel(chw(Yr[:, :Cout], B, H, W), y + chw(res[:, :Cout], B, H, W)) < TOL
+    assert rel(chw(dX, B, H, W), dx) < TOL
+    if Np != Cout:
+        assert float(Y[:, Cout:].abs().max()) == 0
+
+
 def test_gemm_embed_and_output_padding():
     B, H, W = 2, 6, 5
     x = rnd(B, 3, H, W, seed=1)

@@ -19,6 +19,8 @@
 #include "../../include/uir_kernels.h"
 #include <cstdlib>
 
+int uir_conv3x3_small(const UirGemmArgs& a, void* stream);     // csrc/conv3s.hip; -1 = not its shape
+
 namespace {
 
 template <int NT>
@@ -801,6 +803,12 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   else UIR_REQUIRE(!a.pre_out);
   UIR_REQUIRE(a.ntap <= 0 || (a.taps == 9 && a.tap0 >= 0 && a.tap0 + a.ntap <= 9));
   UIR_REQUIRE(a.ntap > 0 || a.tap0 == 0);
+  {
+    // 3 x 3 convolutions with <= 32 channels on both sides (outputl / output / down1 / down2 and their input gradients): the direct
+    // VALU kernel of csrc/conv3s.hip (an MFMA tile is 3/4 ... 7/8 empty for 8 or 4 output channels)
+    const int rc = uir_conv3x3_small(a, stream);
+    if (rc >= 0) return rc;
+  }
   const int tiles = (a.N + 31) / 32;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int ntap = a.ntap > 0 ? a.ntap : a.taps;
