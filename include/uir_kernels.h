@@ -134,6 +134,13 @@ typedef struct UirDwArgs {
   int B, H, Wd, C;     /* C = padded channel count                                               */
   int grp_real, grp_pad; /* padded channel -> real weight row (exact-zero pads)                  */
   int flip;
+  /* LeFF / FRFN (src/model/block.py:234-247, src/Models/AST.py:294-326): Linear -> GELU -> depthwise 3x3 (+ bias) -> GELU.
+   * act_in = 1: X holds the PRE-activation of the first GELU, which is applied on load (the activated tensor is never stored);
+   * G != NULL: second output G = gelu(Y + bias[c]) written in the same pass (Y, the pre-activation, is kept for the backward). */
+  int act_in;
+  const float* bias;   /* [C], with G                                                            */
+  float* G;            /* [B*H*W][ldg] or NULL                                                   */
+  int ldg;
 } UirDwArgs;
 int uir_dwconv(const UirDwArgs* args, void* stream);
 
@@ -157,6 +164,11 @@ typedef struct UirDwBwdArgs {
   int grp_real, grp_pad;
   int creal;
   int nblocks;
+  /* act = 1: X holds the pre-activation p of a GELU in front of the convolution (LeFF / FRFN): the weight gradient uses gelu(p)
+   * and dX is the gradient with respect to p, i.e. conv^T(dY) * gelu'(p) - Linear1's GELU backward in the same pass; db_slab
+   * (optional, [nblocks][creal]) then receives the partial column sums of dX = the gradient of Linear1's bias. */
+  int act;
+  float* db_slab;
 } UirDwBwdArgs;
 int uir_dwconv_bwd_fused(const UirDwBwdArgs* args, void* stream);
 

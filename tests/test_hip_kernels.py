@@ -351,6 +351,32 @@ def test_dwconv_fwd_bwd(B, H, W, C):
     assert rel(dW.reshape(C, 1, 3, 3), dw) < TOL
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 9, 7, 32), (1, 16, 12, 128), (2, 5, 6, 8)])
+def test_dwconv_with_fused_gelus(B, H, W, C):
+    """LeFF's middle (src/model/block.py:240-244): gelu -> depthwise 3x3 + bias -> gelu with the activations inside the depthwise
+    kernels - forward: X is the pre-activation, second output G = gelu(Y + bias); backward: dX = conv^T(dY) * gelu'(pre), weight
+    gradient on gelu(pre), bias gradient of the producer = column sums of dX."""
+    pre = rnd(B, C, H, W, seed=1, scale=1.5).requires_grad_(True)
+    w = rnd(C, 1, 3, 3, seed=2).requires_grad_(True)
+    b = rnd(C, seed=4)
+    u = F.conv2d(F.gelu(pre), w, padding=1, groups=C)
+    g = F.gelu(u + b.view(1, -1, 1, 1))
+    du = rnd(*u.shape, seed=3)
+    dpre, dw = torch.autograd.grad((u * du).sum(), (pre, w))
+    r = rec()
+    Wt = dev(w.detach())
+    P, dU = dev(hwc(pre.detach())), dev(hwc(du))
+    U, G, dP, dW, dB = r.alloc(B * H * W, C), r.alloc(B * H * W, C), r.alloc(B * H * W, C), r.alloc(C, 9), r.alloc(C)
+    r.dwconv("f", P, Wt, U, C_=C, dims=(B, H, W), act_in=1, bias=dev(b), G=G)
+    r.dwconv_bwd("b", dU, P, Wt, dP, dW, C_=C, creal=C, dims=(B, H, W), act=1, dbias=dB)
+    r.run(r.fwd)
+    assert rel(chw(U, B, H, W), u) < TOL
+    assert rel(chw(G, B, H, W), g) < TOL
+    assert rel(chw(dP, B, H, W), dpre) < TOL
+    assert rel(dW.reshape(C, 1, 3, 3), dw) < TOL
+    assert rel(dB, dpre.sum((0, 2, 3))) < TOL
+
+
 def test_dwconv_padded_groups():
     B, H, W, h, hp = 2, 6, 5, 42, 44
     xr = rnd(B, 2 * h, H, W, seed=1)

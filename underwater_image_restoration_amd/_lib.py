@@ -53,7 +53,8 @@ class GramArgs(C.Structure):
 class DwArgs(C.Structure):
     _fields_ = [("X", fp), ("Wt", fp), ("Y", fp), ("ldx", C.c_int), ("ldy", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
-                ("grp_real", C.c_int), ("grp_pad", C.c_int), ("flip", C.c_int)]
+                ("grp_real", C.c_int), ("grp_pad", C.c_int), ("flip", C.c_int),
+                ("act_in", C.c_int), ("bias", fp), ("G", fp), ("ldg", C.c_int)]
 
 
 class DwWgradArgs(C.Structure):
@@ -66,7 +67,8 @@ class DwBwdArgs(C.Structure):
     _fields_ = [("dY", fp), ("X", fp), ("Wt", fp), ("dX", fp), ("slab", fp),
                 ("ldy", C.c_int), ("ldx", C.c_int), ("ldo", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
-                ("grp_real", C.c_int), ("grp_pad", C.c_int), ("creal", C.c_int), ("nblocks", C.c_int)]
+                ("grp_real", C.c_int), ("grp_pad", C.c_int), ("creal", C.c_int), ("nblocks", C.c_int),
+                ("act", C.c_int), ("db_slab", fp)]
 
 
 class GdfnFwdArgs(C.Structure):

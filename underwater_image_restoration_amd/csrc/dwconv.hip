@@ -40,6 +40,14 @@ __device__ __forceinline__ void load_row(float4 (&v)[R + 2], const float* base, 
 // rows: it keeps a rolling 3-row register window and loads each input row ONCE per strip (1.5
 // float4 loads per output instead of 4.5), so the rows above/below are not re-fetched by
 // workgroups on other XCDs (whose L2s are private).
+__device__ __forceinline__ float4 f4_gelu(float4 v) {
+  return make_float4(uir_gelu(v.x), uir_gelu(v.y), uir_gelu(v.z), uir_gelu(v.w));
+}
+
+// ACT (LeFF / FRFN): the input rows hold the pre-activation of the GELU in front of the convolution - applied per loaded value
+// (1.5 evaluations per output, ~15 VALU each: the pass stays HBM-bound) - and, if a.G is given, G = gelu(Y + bias) leaves in the same
+// pass: the two activated tensors of  Linear -> GELU -> dwconv -> GELU -> Linear  are never stored / read back.
+template <bool ACT>
 __global__ __launch_bounds__(256) void uir_dwconv_kernel(const UirDwArgs a, const int HS) {
   extern __shared__ __attribute__((aligned(16))) float wl[];  // [9][C]
   for (int c = threadIdx.x; c < a.C; c += blockDim.x) {     // one colmap (integer division) per channel, not per tap
@@ -72,8 +80,18 @@ __global__ __launch_bounds__(256) void uir_dwconv_kernel(const UirDwArgs a, cons
     float4 r0[R + 2], r1[R + 2], r2[R + 2];
     load_row(r0, xb, a.ldx, b, h0 - 1, w0, a.H, a.Wd);
     load_row(r1, xb, a.ldx, b, h0, w0, a.H, a.Wd);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (ACT) {                                             // gelu(0) = 0: the zero padding is the same before and after the activation
+#pragma unroll
+      for (int j = 0; j < R + 2; ++j) { r0[j] = f4_gelu(r0[j]); r1[j] = f4_gelu(r1[j]); }
+      if (a.G) bv = *reinterpret_cast<const float4*>(a.bias + c4 * 4);
+    }
     for (int h = h0; h < hend; ++h) {
       load_row(r2, xb, a.ldx, b, h + 1, w0, a.H, a.Wd);
+      if (ACT) {
+#pragma unroll
+        for (int j = 0; j < R + 2; ++j) r2[j] = f4_gelu(r2[j]);
+      }
       float* yp = a.Y + ((long)(b * a.H + h) * a.Wd) * a.ldy + c4 * 4;
 #pragma unroll
       for (int j = 0; j < R; ++j) {
@@ -84,7 +102,12 @@ __global__ __launch_bounds__(256) void uir_dwconv_kernel(const UirDwArgs a, cons
           acc = f4_fma(r1[j + dx], wv[3 + dx], acc);
           acc = f4_fma(r2[j + dx], wv[6 + dx], acc);
         }
-        if (w0 + j < a.Wd) *reinterpret_cast<float4*>(yp + (long)(w0 + j) * a.ldy) = acc;
+        if (w0 + j < a.Wd) {
+          *reinterpret_cast<float4*>(yp + (long)(w0 + j) * a.ldy) = acc;
+          if (ACT && a.G)
+            *reinterpret_cast<float4*>(a.G + ((long)(b * a.H + h) * a.Wd + w0 + j) * a.ldg + c4 * 4) =
+                f4_gelu(make_float4(acc.x + bv.x, acc.y + bv.y, acc.z + bv.z, acc.w + bv.w));
+        }
       }
 #pragma unroll
       for (int j = 0; j < R + 2; ++j) { r0[j] = r1[j]; r1[j] = r2[j]; }
@@ -117,9 +140,13 @@ __device__ __forceinline__ void load_row_t(float4 (&v)[RR + 2], const float* bas
 
 // DX = false: the weight-gradient half alone (uir_dwconv_wgrad at the deep levels, where it runs on the weight-gradient lane beside a
 // separate input-gradient launch): same walk, no weights, no dX.
-template <int RR, bool DX>
+// ACT (with DX): X is the pre-activation p of the GELU in front of the convolution: gelu(p) enters the weight gradient, dX leaves
+// multiplied by gelu'(p) (both from one uir_gelu_pair of the centre value that is loaded anyway) and its column sums (the bias
+// gradient of the Linear that produced p) join the partial slab - the separate GELU-backward pass (read p, read dX, write) is gone.
+template <int RR, bool DX, bool ACT = false>
 __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBwdArgs a, const int HS) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];   // [9][C] weights (DX only), then [ny][c4n][36] reduction
+  extern __shared__ __attribute__((aligned(16))) float sm[];   // [9][C] weights (DX only), then [ny][c4n][RS] reduction
+  constexpr int RS = ACT ? 40 : 36;
   const int c4n = a.C >> 2;
   const int c4 = threadIdx.x, py = threadIdx.y, ny = blockDim.y;
   const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
@@ -140,6 +167,7 @@ __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBw
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
   if (c4 < c4n) {
     const float* gb = a.dY + c4 * 4;
     for (long it = (long)blockIdx.x * ny + py; it < items; it += (long)gridDim.x * ny) {
@@ -162,6 +190,17 @@ __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBw
 #pragma unroll
         for (int j = 0; j < RR; ++j)
           if (w0 + j >= a.Wd) x[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 dact[RR];
+        if (ACT) {
+#pragma unroll
+          for (int j = 0; j < RR; ++j) {
+            const float4 p = x[j];
+            uir_gelu_pair(p.x, x[j].x, dact[j].x);
+            uir_gelu_pair(p.y, x[j].y, dact[j].y);
+            uir_gelu_pair(p.z, x[j].z, dact[j].z);
+            uir_gelu_pair(p.w, x[j].w, dact[j].w);
+          }
+        }
         float4 o[RR];
 #pragma unroll
         for (int j = 0; j < RR; ++j) o[j] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -191,7 +230,13 @@ __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBw
           float* op = a.dX + ((long)(b * a.H + h) * a.Wd) * a.ldo + c4 * 4;
 #pragma unroll
           for (int j = 0; j < RR; ++j)
-            if (w0 + j < a.Wd) *reinterpret_cast<float4*>(op + (long)(w0 + j) * a.ldo) = o[j];
+            if (w0 + j < a.Wd) {
+              if (ACT) {
+                o[j] = make_float4(o[j].x * dact[j].x, o[j].y * dact[j].y, o[j].z * dact[j].z, o[j].w * dact[j].w);
+                dbs = make_float4(dbs.x + o[j].x, dbs.y + o[j].y, dbs.z + o[j].z, dbs.w + o[j].w);
+              }
+              *reinterpret_cast<float4*>(op + (long)(w0 + j) * a.ldo) = o[j];
+            }
         }
       };
 #pragma unroll 1
@@ -201,19 +246,29 @@ __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBw
         if (h + 2 < hend) step(g2, g0, g1, h + 2);
       }
     }
-    float* rp = red + ((long)py * c4n + c4) * 36;
+    float* rp = red + ((long)py * c4n + c4) * RS;
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
       rp[0 * 9 + t] = acc[t].x; rp[1 * 9 + t] = acc[t].y; rp[2 * 9 + t] = acc[t].z; rp[3 * 9 + t] = acc[t].w;
     }
+    if (ACT) { rp[36] = dbs.x; rp[37] = dbs.y; rp[38] = dbs.z; rp[39] = dbs.w; }
   }
   __syncthreads();
+  if (ACT && a.db_slab) {
+    for (int c = tid; c < a.C; c += nthr) {
+      const int cr = uir_colmap(c, a.grp_real, a.grp_pad);
+      if (cr < 0) continue;
+      float sb = 0.f;
+      for (int y = 0; y < ny; ++y) sb += red[((long)y * c4n + (c >> 2)) * RS + 36 + (c & 3)];
+      a.db_slab[(long)blockIdx.x * a.creal + cr] = sb;
+    }
+  }
   for (int e = tid; e < a.C * 9; e += nthr) {
     const int c = e / 9, t = e - c * 9;
     const int cr = uir_colmap(c, a.grp_real, a.grp_pad);
     if (cr < 0) continue;
     float s = 0.f;
-    for (int y = 0; y < ny; ++y) s += red[((long)y * c4n + (c >> 2)) * 36 + (c & 3) * 9 + t];
+    for (int y = 0; y < ny; ++y) s += red[((long)y * c4n + (c >> 2)) * RS + (c & 3) * 9 + t];
     a.slab[(long)blockIdx.x * a.creal * 9 + (long)cr * 9 + t] = s;
   }
 }
@@ -239,7 +294,10 @@ extern "C" int uir_dwconv(const UirDwArgs* p, void* stream) {
   const long total = (long)a.B * ((a.H + HS - 1) / HS) * ((a.Wd + R - 1) / R) * (a.C >> 2);
   long blocks = (total + 255) / 256;
   if (blocks > 256 * 16) blocks = 256 * 16;
-  hipLaunchKernelGGL(uir_dwconv_kernel, dim3((unsigned)blocks), dim3(256), lds, static_cast<hipStream_t>(stream), a, HS);
+  UIR_REQUIRE(a.act_in == 0 || a.act_in == 1);
+  UIR_REQUIRE(!a.G || (a.act_in == 1 && a.bias && uir_aligned16(a.bias) && uir_aligned16(a.G) && a.ldg >= a.C && (a.ldg & 3) == 0));
+  if (a.act_in) hipLaunchKernelGGL(uir_dwconv_kernel<true>, dim3((unsigned)blocks), dim3(256), lds, static_cast<hipStream_t>(stream), a, HS);
+  else hipLaunchKernelGGL(uir_dwconv_kernel<false>, dim3((unsigned)blocks), dim3(256), lds, static_cast<hipStream_t>(stream), a, HS);
   return uir_launch_status();
 }
 
@@ -274,9 +332,14 @@ extern "C" int uir_dwconv_bwd_fused(const UirDwBwdArgs* p, void* stream) {
   const int c4n = a.C >> 2;
   UIR_REQUIRE(c4n <= 256);
   const int ny = 256 / c4n;
-  const size_t lds = ((size_t)9 * a.C + (size_t)ny * c4n * 36) * sizeof(float);
+  UIR_REQUIRE(a.act == 0 || a.act == 1);
+  const size_t lds = ((size_t)9 * a.C + (size_t)ny * c4n * (a.act ? 40 : 36)) * sizeof(float);
   UIR_REQUIRE(lds <= 96 * 1024);
-  hipLaunchKernelGGL((uir_dwconv_bwd_fused_kernel<2, true>), dim3(a.nblocks), dim3(c4n, ny), lds, static_cast<hipStream_t>(stream), a,
-                     uir_dw_strip(a.B, a.H, a.Wd, a.C));
+  if (a.act)
+    hipLaunchKernelGGL((uir_dwconv_bwd_fused_kernel<2, true, true>), dim3(a.nblocks), dim3(c4n, ny), lds,
+                       static_cast<hipStream_t>(stream), a, uir_dw_strip(a.B, a.H, a.Wd, a.C));
+  else
+    hipLaunchKernelGGL((uir_dwconv_bwd_fused_kernel<2, true>), dim3(a.nblocks), dim3(c4n, ny), lds, static_cast<hipStream_t>(stream), a,
+                       uir_dw_strip(a.B, a.H, a.Wd, a.C));
   return uir_launch_status();
 }

@@ -110,7 +110,7 @@ template <int HK>
 __device__ __forceinline__ void ld_run(const float* __restrict__ base, unsigned off, float (&v)[HK]) {
 #pragma unroll
   for (int c = 0; c < HK; c += 4) {
-    const float4 t = *reinterpret_cast<const float4*>(base + off + c);
+    const float4 t = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + (off + c) * 4u);   // s[base] + v_off
     v[c] = t.x; v[c + 1] = t.y; v[c + 2] = t.z; v[c + 3] = t.w;
   }
 }
@@ -130,7 +130,7 @@ __device__ __forceinline__ void score_pair(const float* __restrict__ A, int lda,
   for (int ck = 0; ck < nck; ++ck) {
     const int col = h * HD + ck * T::CK + g.half * T::HK;
     float a0[T::HK], a1[T::HK], b[T::HK];
-    ld_run<T::HK>(Bm, (unsigned)g.pix_tm[tb] * ldb + col, b);
+    ld_run<T::HK>(Bm, (unsigned)(tb ? g.pix_tm[1] : g.pix_tm[0]) * ldb + col, b);   // (a runtime index would put the array in scratch)
     ld_run<T::HK>(A, (unsigned)g.pix_tm[0] * lda + col, a0);
     ld_run<T::HK>(A, (unsigned)g.pix_tm[1] * lda + col, a1);
 #pragma unroll
@@ -181,9 +181,12 @@ __device__ __forceinline__ void store_rows(float* __restrict__ D, int ldd, const
   unsigned vo[4];
 #pragma unroll
   for (int e = 0; e < 4; ++e) vo[e] = ((unsigned)g.xcol[e] * ldd + col) * 4u;
+  int rp[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) rp[j] = tile ? g.rowp[4 + j] : g.rowp[j];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    char* rb = reinterpret_cast<char*>(D) + (size_t)((unsigned)g.rowp[tile * 4 + r / 4] * ldd) * 4u;
+    char* rb = reinterpret_cast<char*>(D) + (size_t)((unsigned)rp[r / 4] * ldd) * 4u;
     *reinterpret_cast<float*>(rb + vo[r % 4]) = out[r] * mul;
   }
 }
@@ -203,14 +206,15 @@ struct WaveLds {
   int regs[NT];
 };
 
-// Orientation 1 (S^T: register <-> key, lane <-> query of tile qt): scores -> softmax.  s0 / s1 hold the raw products on entry and
-// the biased (masked) scores on return; p0 / p1 the softmax.
-__device__ __forceinline__ void softmax_cols(const UirWinAttnArgs& a, const WinGeo& g, const WaveLds& L, int qt, f32x16& s0, f32x16& s1,
-                                             f32x16& p0, f32x16& p1, float& mx_out, float& inv_out) {
+// Orientation 1 (S^T: register <-> key, lane <-> query of tile qt): raw products -> biased (masked) scores in place; returns the
+// query's row maximum.  The softmax itself is never stored: exp(s - mx) is evaluated once for the row sums and once more where the
+// probability is consumed (32 more v_exp_f32 per tile against 32 more live registers: the backward drops from 199 to < 168 VGPRs,
+// i.e. from two to three waves per SIMD).
+__device__ __forceinline__ float bias_scores(const UirWinAttnArgs& a, const WinGeo& g, const WaveLds& L, int qt, f32x16& s0, f32x16& s1) {
   const int yi = qt * 4 + (g.l32 >> 3), xi = g.l32 & 7;
   const float* tb = L.tab + ((yi + 7) * RP + xi + 7 - g.half * 4);
   const int* rg = L.regs + g.half * 4;
-  const int mine = g.region_q[qt];
+  const int mine = qt ? g.region_q[1] : g.region_q[0];
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -230,20 +234,7 @@ __device__ __forceinline__ void softmax_cols(const UirWinAttnArgs& a, const WinG
   float mx = -__builtin_huge_valf();
 #pragma unroll
   for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-  mx = swap32_max(mx);
-  float sum = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    p0[r] = __expf(s0[r] - mx);
-    p1[r] = __expf(s1[r] - mx);
-    sum += p0[r] + p1[r];
-  }
-  sum = swap32_sum(sum);
-  const float inv = 1.0f / sum;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) { p0[r] *= inv; p1[r] *= inv; }
-  mx_out = mx;
-  inv_out = inv;
+  return swap32_max(mx);
 }
 
 template <int HD>
@@ -263,16 +254,19 @@ __global__ __launch_bounds__(256, 2) void winattn_fwd_kernel(const UirWinAttnArg
   lds_wait();
 #pragma unroll 1
   for (int qt = 0; qt < 2; ++qt) {
-    f32x16 s0, s1, p0, p1;
+    f32x16 s0, s1;
     score_pair<HD>(a.K, a.ldk, a.Q, a.ldq, qt, g, h, s0, s1);
     phase();
-    float mx, inv;
-    softmax_cols(a, g, L, qt, s0, s1, p0, p1, mx, inv);
+    const float mx = bias_scores(a, g, L, qt, s0, s1);
+    float sum = 0.f;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {                    // the mixed attention (:361-367)
+    for (int r = 0; r < 16; ++r) sum += __expf(s0[r] - mx) + __expf(s1[r] - mx);
+    const float inv = w1 / swap32_sum(sum);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {                    // the mixed attention (:361-367), in place
       const float r0 = fmaxf(s0[r], 0.f), r1 = fmaxf(s1[r], 0.f);
-      p0[r] = fmaf(w1, p0[r], w2 * r0 * r0);
-      p1[r] = fmaf(w1, p1[r], w2 * r1 * r1);
+      s0[r] = fmaf(inv, __expf(s0[r] - mx), w2 * r0 * r0);
+      s1[r] = fmaf(inv, __expf(s1[r] - mx), w2 * r1 * r1);
     }
     phase();
     int nct = T::NCT;
@@ -280,7 +274,7 @@ __global__ __launch_bounds__(256, 2) void winattn_fwd_kernel(const UirWinAttnArg
 #pragma unroll 1
     for (int ct = 0; ct < nct; ++ct) {
       f32x16 o;
-      acc_times<HD>(p0, p1, a.V, a.ldv, g, h, ct, o);
+      acc_times<HD>(s0, s1, a.V, a.ldv, g, h, ct, o);
       store_rows<HD>(a.O, a.ldo, g, h, ct, qt, o, 1.0f);
     }
   }
@@ -310,23 +304,25 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_kernel(const UirWinAttnArg
 #pragma unroll 1
   for (int qt = 0; qt < 2; ++qt) {
     // dP tiles first: while the score tiles accumulate only 32 + 32 accumulator registers and one chunk of operands are live
-    f32x16 s0, s1, p0, p1, d0, d1;
+    f32x16 s0, s1, d0, d1;
     score_pair<HD>(a.V, a.ldv, a.dO, a.ldo, qt, g, h, d0, d1);          // dP^T[key][query] = v_key . dO_query
     phase();
     score_pair<HD>(a.K, a.ldk, a.Q, a.ldq, qt, g, h, s0, s1);
     phase();
-    float mx, inv;
-    softmax_cols(a, g, L, qt, s0, s1, p0, p1, mx, inv);
-    float sp = 0.f;
+    const float mx = bias_scores(a, g, L, qt, s0, s1);
+    float sum = 0.f, sp = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
+      const float e0 = __expf(s0[r] - mx), e1 = __expf(s1[r] - mx);
       const float r0 = fmaxf(s0[r], 0.f), r1 = fmaxf(s1[r], 0.f);
-      sp = fmaf(d0[r], p0[r], sp);
-      sp = fmaf(d1[r], p1[r], sp);
+      sum += e0 + e1;
+      sp = fmaf(d0[r], e0, sp);
+      sp = fmaf(d1[r], e1, sp);
       dw2 = fmaf(d0[r], r0 * r0, dw2);
       dw2 = fmaf(d1[r], r1 * r1, dw2);
     }
-    sp = swap32_sum(sp);
+    const float inv = 1.0f / swap32_sum(sum);
+    sp = swap32_sum(sp) * inv;                                           // sum_j dP_ij p_ij
     dw1 += g.half == 0 ? sp : 0.f;                                       // once per query
     if (g.half == 0) {
       const int i = qt * 32 + g.l32;
@@ -334,11 +330,12 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_kernel(const UirWinAttnArg
       L.inv[i] = inv;
       L.sp[i] = sp;
     }
+    const float w1i = w1 * inv;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {                                        // softmax backward + relu^2 backward: d0 / d1 become dS^T
       const float r0 = fmaxf(s0[r], 0.f), r1 = fmaxf(s1[r], 0.f);
-      d0[r] = fmaf(w1 * p0[r], d0[r] - sp, w2 * d0[r] * 2.f * r0);
-      d1[r] = fmaf(w1 * p1[r], d1[r] - sp, w2 * d1[r] * 2.f * r1);
+      d0[r] = fmaf(w1i * __expf(s0[r] - mx), d0[r] - sp, w2 * d0[r] * 2.f * r0);
+      d1[r] = fmaf(w1i * __expf(s1[r] - mx), d1[r] - sp, w2 * d1[r] * 2.f * r1);
     }
     {  // relative-position-bias table: entry (yi - yj + 7) * 15 + (xi - xj + 7) collects dS over the pairs with that offset.  Inside one
        // instruction the 32 active lanes are 32 different queries against one key: distinct entries, no collision, fixed order.
@@ -390,7 +387,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_kernel(const UirWinAttnArg
     const float* tb = L.tab + ((7 - yj) * RP + 7 - xj + g.half * 4);
     const int* rg = L.regs + g.half * 4;
     const float *smx = L.mx + g.half * 4, *sinv = L.inv + g.half * 4, *ssp = L.sp + g.half * 4;
-    const int mine = g.region_q[kt];
+    const int mine = kt ? g.region_q[1] : g.region_q[0];
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt)
 #pragma unroll

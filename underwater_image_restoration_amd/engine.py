@@ -637,8 +637,9 @@ class Recorder:
                 t = extras[key]
                 self._reduce(name + ".red." + key, sp + 4 * off, nch, stride, _ptr(t), t.numel())
 
-    def dwconv(self, name, X, Wt, Y, *, C_, dims, grp=(0, 0), flip=0):
-        self._hold(X, Wt, Y)
+    def dwconv(self, name, X, Wt, Y, *, C_, dims, grp=(0, 0), flip=0, act_in=0, bias=None, G=None):
+        """act_in = 1: X is the pre-activation of a GELU applied on load; G (with bias): second output gelu(Y + bias)."""
+        self._hold(X, Wt, Y, bias, G)
         a = L.DwArgs()
         a.X, a.Wt, a.Y = _ptr(X), _ptr(Wt), _ptr(Y)
         a.ldx, a.ldy = _ld(X), _ld(Y)
@@ -646,10 +647,14 @@ class Recorder:
         a.C = C_
         a.grp_real, a.grp_pad = grp
         a.flip = flip
+        a.act_in = act_in
+        if G is not None:
+            assert act_in == 1 and bias is not None
+            a.bias, a.G, a.ldg = _ptr(bias), _ptr(G), _ld(G)
         assert C_ % 4 == 0 and a.ldx >= C_ and a.ldy >= C_ and X.shape[0] == dims[0] * dims[1] * dims[2]
         self.keep.append(a)
         rows = dims[0] * dims[1] * dims[2]
-        self._op(name, lib.uir_dwconv, C.byref(a), nbytes=8 * rows * C_, flops=18 * rows * C_)
+        self._op(name, lib.uir_dwconv, C.byref(a), nbytes=(8 + (4 if G is not None else 0)) * rows * C_, flops=18 * rows * C_)
 
     def gdfn_fwd(self, name, X, ln, Win, Wdw, Wout, Y, *, C_, h, hp, dims, T1=None, T2=None, stats=None, eps=1e-5):
         """Tile-fused GDFN forward (csrc/gdfn.hip): Y = X + W_out.(gelu(dw(W_in.LN(X))[:h]) * dw(...)[h:])."""
@@ -788,8 +793,11 @@ class Recorder:
         self._op(name, lib.uir_dwconv_wgrad, C.byref(a), nbytes=8 * rows * C_, flops=18 * rows * C_)
         self._reduce(name + ".red", _ptr(slab), a.nblocks, creal * 9, _ptr(out), creal * 9)
 
-    def dwconv_bwd(self, name, dY, X, Wt, dX, dW, *, C_, creal, dims, grp=(0, 0), min_rows=None):
-        """Fused input-gradient + weight-gradient of a depthwise 3x3 (dY read once)."""
+    def dwconv_bwd(self, name, dY, X, Wt, dX, dW, *, C_, creal, dims, grp=(0, 0), min_rows=None, act=0, dbias=None):
+        """Fused input-gradient + weight-gradient of a depthwise 3x3 (dY read once).  act = 1: X is the pre-activation p of a GELU
+        in front of the convolution: dW uses gelu(p), dX = conv^T(dY) * gelu'(p), dbias (optional) = column sums of dX."""
+        if act:
+            min_rows = 0              # the activation-fused form exists as one pass only
         # fused only where bytes bind (full and half resolution); at the deep levels the chain is latency-bound and the
         # split keeps the weight-gradient half off it
         rows_total = dims[0] * dims[1] * dims[2]
@@ -819,11 +827,18 @@ class Recorder:
         # shared chain scratch may be overwritten in between
         slab = self.alloc(a.nblocks * creal * 9)
         a.slab = _ptr(slab)
+        a.act = act
+        dbs = None
+        if act and dbias is not None:
+            dbs = self.alloc(a.nblocks * creal)
+            a.db_slab = _ptr(dbs)
         self.keep.append(a)
         rows = dims[0] * dims[1] * dims[2]
         self._op(name, lib.uir_dwconv_bwd_fused, C.byref(a), nbytes=12 * rows * C_, flops=36 * rows * C_)
         with self.bulk():
             self._reduce(name + ".red", _ptr(slab), a.nblocks, creal * 9, _ptr(dW), creal * 9)
+            if dbs is not None:
+                self._reduce(name + ".db", _ptr(dbs), a.nblocks, creal, _ptr(dbias), creal)
 
     def ln_bwd(self, name, dT, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_):
         self._hold(dT, X, stats, gamma, dRes, dX, dgamma, dbeta)

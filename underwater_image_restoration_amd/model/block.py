@@ -86,17 +86,18 @@ def _gate(rec, name, hid, U, bias, V, G=None, dG=None, dU=None, dV=None, dbias=N
 _DW_MAX = 1024       # channels per depthwise launch: the kernels keep the 9-tap weights of their channels in LDS (<= 64 KB)
 
 
-def _dwconv_wide(rec, name, X, Wt, Y, C_, dims):
+def _dwconv_wide(rec, name, X, Wt, Y, C_, dims, act_in=0, bias=None, G=None):
     for c0 in range(0, C_, _DW_MAX):
         n = min(_DW_MAX, C_ - c0)
-        rec.dwconv(f"{name}[{c0}]" if C_ > _DW_MAX else name, X[:, c0:c0 + n], Wt[c0:c0 + n], Y[:, c0:c0 + n], C_=n, dims=dims)
+        rec.dwconv(f"{name}[{c0}]" if C_ > _DW_MAX else name, X[:, c0:c0 + n], Wt[c0:c0 + n], Y[:, c0:c0 + n], C_=n, dims=dims,
+                   act_in=act_in, bias=None if bias is None else bias[c0:c0 + n], G=None if G is None else G[:, c0:c0 + n])
 
 
-def _dwconv_bwd_wide(rec, name, dY, X, Wt, dX, dW, C_, dims):
+def _dwconv_bwd_wide(rec, name, dY, X, Wt, dX, dW, C_, dims, act=0, dbias=None):
     for c0 in range(0, C_, _DW_MAX):
         n = min(_DW_MAX, C_ - c0)
         rec.dwconv_bwd(f"{name}[{c0}]" if C_ > _DW_MAX else name, dY[:, c0:c0 + n], X[:, c0:c0 + n], Wt[c0:c0 + n], dX[:, c0:c0 + n],
-                       dW[c0:c0 + n], C_=n, creal=n, dims=dims)
+                       dW[c0:c0 + n], C_=n, creal=n, dims=dims, act=act, dbias=None if dbias is None else dbias[c0:c0 + n])
 
 
 def _colsum_wide(rec, name, src, cols, out):
@@ -159,22 +160,25 @@ def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     W1, b1 = P("linear1.0.weight"), P("linear1.0.bias")
     Wdw, bdw = P("dwconv.0.weight"), P("dwconv.0.bias")
     W2, b2 = P("linear2.0.weight"), P("linear2.0.bias")
-    pre, t, u, g, y = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
+    # Three hidden-wide tensors are stored - pre (Linear1's output), u (the depthwise output), g = gelu(u + b) - and neither
+    # gelu(pre) nor the gradient with respect to it ever reaches HBM: the first GELU is applied by the depthwise kernels on load, its
+    # backward (and Linear1's bias gradient) by the depthwise backward on store, the second GELU leaves the depthwise forward as a
+    # second output.  15 hidden-wide passes per LeFF instead of 20.
+    pre, u, g, y = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
     n = pfx
-    rec.gemm(n + "linear1+gelu", x, W1, t, N=hid, K=C_, w_sn=C_, w_sk=1, bias=b1, act=L.ACT_GELU, pre_out=pre)
-    _dwconv_wide(rec, n + "dwconv", t, Wdw, u, hid, dims)
-    _gate(rec, n + "dwconv.gelu", hid, u, bdw, None, G=g)
+    rec.gemm(n + "linear1", x, W1, pre, N=hid, K=C_, w_sn=C_, w_sk=1, bias=b1)
+    _dwconv_wide(rec, n + "gelu.dwconv.gelu", pre, Wdw, u, hid, dims, act_in=1, bias=bdw, G=g)
     rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
 
     def backward(dy: torch.Tensor) -> torch.Tensor:
-        dg, du, dt, dpre, dx = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
+        dg, du, dpre, dx = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
         with rec.bulk():
             rec.gram(n + "linear2.dW", dy, g, Gr("linear2.0.weight"), N=C_, K=hid, o_sn=hid, o_sk=1)
             _colsum_wide(rec, n + "linear2.db", dy, C_, Gr("linear2.0.bias"))
         rec.gemm(n + "linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
         _gate(rec, n + "dwconv.gelu.bwd", hid, u, bdw, None, dG=dg, dU=du, dbias=Gr("dwconv.0.bias"))
-        _dwconv_bwd_wide(rec, n + "dwconv.bwd", du, t, Wdw, dt, Gr("dwconv.0.weight"), hid, dims)
-        _act(rec, n + "linear1.gelu.bwd", pre, None, hid, bwd_dt=dt, dpre=dpre, dbias=Gr("linear1.0.bias"))
+        _dwconv_bwd_wide(rec, n + "dwconv.bwd+gelu.bwd", du, pre, Wdw, dpre, Gr("dwconv.0.weight"), hid, dims, act=1,
+                         dbias=Gr("linear1.0.bias"))
         with rec.bulk():
             rec.gram(n + "linear1.dW", dpre, x, Gr("linear1.0.weight"), N=hid, K=C_, o_sn=C_, o_sk=1)
         rec.gemm(n + "linear1.dX", dpre, W1, dx, N=C_, K=hid, w_sn=1, w_sk=C_)
