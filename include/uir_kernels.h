@@ -545,6 +545,10 @@ typedef struct UirFrfnGateArgs {
   int hid;
   int ldu, ldv, ldg, lddu, lddv;
   int db_blocks;       /* workgroups of the backward launch when db_slab is given (256 % (hid/4) == 0 required) */
+  int v_act;           /* 1: V holds the PRE-activation of the x2 half (Linear1's output, block.py:271-273): the gate uses gelu(V), and
+                          dV is the gradient with respect to that pre-activation (dG gelu(U + bias) gelu'(V)) - no activated copy of
+                          Linear1's output is stored and no separate GELU-backward pass runs */
+  float* dbv_slab;     /* backward, optional, with db_slab: per-workgroup column sums of dV (Linear1's bias gradient, x2 half) */
 } UirFrfnGateArgs;
 int uir_frfn_gate_fwd(const UirFrfnGateArgs* args, void* stream);
 int uir_frfn_gate_bwd(const UirFrfnGateArgs* args, void* stream);

@@ -376,7 +376,8 @@ class InputProj(TokenModule):
             return _TokenFunction.apply(x, self, *self.parameters())
         plan = self._plan_for(x, want_backward=False)
         self._serial += 1
-        return plan.forward(x).clone().view(self._out_shape(x, plan))
+        y = plan.forward(x)
+        return (y if self._alias_io else y.clone()).view(self._out_shape(x, plan))
 
 
 class OutputProj(TokenModule):
@@ -405,9 +406,9 @@ class AST(nn.Module):
     only, bottleneck and decoders with sparse window attention, every second block shifted), stochastic depth 0 ... 0.1."""
 
     # device memory the 28 launch plans keep per input pixel (measured, tests/test_ast.py holds it): ModuleTrainStep sizes micro-batches with it
-    # (tools/measure_module_plans.py: 3.2 / 12.1 / 21.9 GiB at 1 x 128^2 / 2 x 256^2 / 1 x 512^2 = 81 KB per pixel + 2.2 GiB of per-plan scratch)
-    PLAN_BYTES_PER_PIXEL_TRAIN, PLAN_BYTES_FIXED_TRAIN = 82_000, 2_600_000_000
-    PLAN_BYTES_PER_PIXEL_EVAL, PLAN_BYTES_FIXED_EVAL = 39_000, 2_200_000_000
+    # (tools/measure_module_plans.py, round 3 with the activations of LeFF fused away: 3.0 / 10.6 / 19.0 GiB at 1 x 128^2 / 2 x 256^2 / 1 x 512^2 = 69 KB per pixel + 2.3 GB of per-plan scratch)
+    PLAN_BYTES_PER_PIXEL_TRAIN, PLAN_BYTES_FIXED_TRAIN = 70_000, 2_300_000_000
+    PLAN_BYTES_PER_PIXEL_EVAL, PLAN_BYTES_FIXED_EVAL = 33_000, 2_000_000_000
 
     def __init__(self, img_size=256, in_chans=3, dd_in=3, embed_dim=32, depths=[2, 2, 2, 2, 2, 2, 2, 2, 2],
                  num_heads=[1, 2, 4, 8, 16, 16, 8, 4, 2], win_size=8, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0.,

@@ -162,7 +162,7 @@ class ReduceDesc(C.Structure):
 class FrfnGateArgs(C.Structure):
     _fields_ = [("U", fp), ("bias", fp), ("V", fp), ("G", fp), ("dG", fp), ("dU", fp), ("dV", fp), ("db_slab", fp), ("M", C.c_long),
                 ("hid", C.c_int), ("ldu", C.c_int), ("ldv", C.c_int), ("ldg", C.c_int), ("lddu", C.c_int), ("lddv", C.c_int),
-                ("db_blocks", C.c_int)]
+                ("db_blocks", C.c_int), ("v_act", C.c_int), ("dbv_slab", fp)]
 
 
 class WinAttnArgs(C.Structure):

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void frfn_gate_fwd_kernel(const UirFrfnGateArg
     const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
     float4 v = make_float4(1.f, 1.f, 1.f, 1.f);        // V == NULL: plain GELU(u + bias) (LeFF, block.py:228,240)
     if (a.V) v = *reinterpret_cast<const float4*>(a.V + m * a.ldv + c);
+    if (a.v_act) v = make_float4(uir_gelu(v.x), uir_gelu(v.y), uir_gelu(v.z), uir_gelu(v.w));
     float4 o;
     o.x = uir_gelu(u.x + b.x) * v.x; o.y = uir_gelu(u.y + b.y) * v.y; o.z = uir_gelu(u.z + b.z) * v.z; o.w = uir_gelu(u.w + b.w) * v.w;
     *reinterpret_cast<float4*>(a.G + m * a.ldg + c) = o;
@@ -78,15 +79,19 @@ __global__ __launch_bounds__(256) void frfn_gate_fwd_kernel(const UirFrfnGateArg
 __global__ __launch_bounds__(256) void frfn_gate_bwd_kernel(const UirFrfnGateArgs a) {
   const int cols4 = a.hid / 4;
   const long total = a.M * cols4;
-  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), accv = acc;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
     const long m = e / cols4;
     const int c = (int)(e - m * cols4) * 4;
     const float4 u = *reinterpret_cast<const float4*>(a.U + m * a.ldu + c);
     const float4 b = *reinterpret_cast<const float4*>(a.bias + c);
     const float4 d = *reinterpret_cast<const float4*>(a.dG + m * a.ldg + c);
-    float4 v = make_float4(1.f, 1.f, 1.f, 1.f);
+    float4 v = make_float4(1.f, 1.f, 1.f, 1.f), va = v;       // va: gelu'(V) when V is a pre-activation
     if (a.V) v = *reinterpret_cast<const float4*>(a.V + m * a.ldv + c);
+    if (a.v_act) {
+      const float4 p = v;
+      uir_gelu_pair(p.x, v.x, va.x); uir_gelu_pair(p.y, v.y, va.y); uir_gelu_pair(p.z, v.z, va.z); uir_gelu_pair(p.w, v.w, va.w);
+    }
     float4 du, dv;
     float g, dg;
     uir_gelu_pair(u.x + b.x, g, dg); du.x = d.x * v.x * dg; dv.x = d.x * g;
@@ -94,10 +99,16 @@ __global__ __launch_bounds__(256) void frfn_gate_bwd_kernel(const UirFrfnGateArg
     uir_gelu_pair(u.z + b.z, g, dg); du.z = d.z * v.z * dg; dv.z = d.z * g;
     uir_gelu_pair(u.w + b.w, g, dg); du.w = d.w * v.w * dg; dv.w = d.w * g;
     *reinterpret_cast<float4*>(a.dU + m * a.lddu + c) = du;
+    dv = make_float4(dv.x * va.x, dv.y * va.y, dv.z * va.z, dv.w * va.w);
     if (a.dV) *reinterpret_cast<float4*>(a.dV + m * a.lddv + c) = dv;
     acc.x += du.x; acc.y += du.y; acc.z += du.z; acc.w += du.w;
+    accv.x += dv.x; accv.y += dv.y; accv.z += dv.z; accv.w += dv.w;
   }
   if (a.db_slab) frfn_col_partials(acc, cols4, a.db_slab);
+  if (a.dbv_slab) {
+    __syncthreads();                                           // the helper's LDS buffer is read by the first call's last phase
+    frfn_col_partials(accv, cols4, a.dbv_slab);
+  }
 }
 
 // dz = dy * (y > 0 ? 1 : slope): backward of an in-place LeakyReLU given its OUTPUT (InputProjection, block.py:50)
@@ -150,7 +161,9 @@ static int frfn_gate_check(const UirFrfnGateArgs& a, bool bwd) {
     UIR_REQUIRE(a.dG && a.dU && a.lddu >= a.hid && (a.lddu & 3) == 0 && uir_aligned16(a.dG) && uir_aligned16(a.dU));
     UIR_REQUIRE((a.dV != nullptr) == (a.V != nullptr) && (!a.dV || (a.lddv >= a.hid && (a.lddv & 3) == 0 && uir_aligned16(a.dV))));
     UIR_REQUIRE(!a.db_slab || (a.db_blocks > 0 && a.hid <= 1024 && 256 % (a.hid / 4) == 0 && uir_aligned16(a.db_slab)));
+    UIR_REQUIRE(!a.dbv_slab || (a.db_slab && a.dV && uir_aligned16(a.dbv_slab)));
   }
+  UIR_REQUIRE((a.v_act == 0 || a.v_act == 1) && (!a.v_act || a.V));
   return UIR_OK;
 }
 

@@ -54,11 +54,13 @@ def _act(rec, name, pre, t, cols, bwd_dt=None, dpre=None, dbias=None):
                 _colsum_wide(rec, name + ".db", dpre, cols, dbias)
 
 
-def _gate(rec, name, hid, U, bias, V, G=None, dG=None, dU=None, dV=None, dbias=None):
-    """V = None: no gate (LeFF): G = GELU(U + bias)."""
+def _gate(rec, name, hid, U, bias, V, G=None, dG=None, dU=None, dV=None, dbias=None, v_act=0, dbias_v=None):
+    """V = None: no gate (LeFF): G = GELU(U + bias).  v_act = 1: V is the pre-activation of the x2 half (the gate uses gelu(V), dV is
+    the gradient with respect to the pre-activation and dbias_v receives its column sums)."""
     rec._hold(U, bias, V, G, dG, dU, dV)
     a = L.FrfnGateArgs()
     a.U, a.bias = _ptr(U), _ptr(bias)
+    a.v_act = v_act
     a.V = _ptr(V) if V is not None else None
     a.M, a.hid = U.shape[0], hid
     a.ldu, a.ldv = _ld(U), (_ld(V) if V is not None else 0)
@@ -72,8 +74,11 @@ def _gate(rec, name, hid, U, bias, V, G=None, dG=None, dU=None, dV=None, dbias=N
     if dV is not None:
         a.dV, a.lddv = _ptr(dV), _ld(dV)
     slab = rec.alloc(_DB_BLOCKS, hid) if dbias is not None and _fused_db(hid) else None
+    slab_v = rec.alloc(_DB_BLOCKS, hid) if dbias_v is not None and slab is not None else None
     if slab is not None:
         a.db_slab, a.db_blocks = _ptr(slab), _DB_BLOCKS
+    if slab_v is not None:
+        a.dbv_slab = _ptr(slab_v)
     rec._op(name, lib.uir_frfn_gate_bwd, C.byref(a), nbytes=(20 if V is not None else 12) * a.M * a.hid)
     if dbias is not None:
         with rec.bulk():
@@ -81,6 +86,12 @@ def _gate(rec, name, hid, U, bias, V, G=None, dG=None, dU=None, dV=None, dbias=N
                 rec._reduce(name + ".db", _ptr(slab), _DB_BLOCKS, hid, _ptr(dbias), hid)
             else:
                 _colsum_wide(rec, name + ".db", dU, hid, dbias)
+    if dbias_v is not None:
+        with rec.bulk():
+            if slab_v is not None:
+                rec._reduce(name + ".dbv", _ptr(slab_v), _DB_BLOCKS, hid, _ptr(dbias_v), hid)
+            else:
+                _colsum_wide(rec, name + ".dbv", dV, hid, dbias_v)
 
 
 _DW_MAX = 1024       # channels per depthwise launch: the kernels keep the 9-tap weights of their channels in LDS (<= 64 KB)
@@ -117,29 +128,33 @@ def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     Wdw, bdw = P("dwconv.0.weight"), P("dwconv.0.bias")
     W2, b2 = P("linear2.0.weight"), P("linear2.0.bias")
     Wpc = P("partial_conv3.weight")
-    xc, pre, t = rec.alloc(M, C_), rec.alloc(M, 2 * hid), rec.alloc(M, 2 * hid)
+    xc, pre = rec.alloc(M, C_), rec.alloc(M, 2 * hid)
     u, g, y = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
     n = pfx
     # partial_conv3 on channels [0, C/4), the rest passes through (block.py:267-270)
     rec.copy_cols(n + "pc3.pass", x, c4, xc, c4, C_ - c4)
     rec.gemm(n + "pc3", x[:, :c4], Wpc, xc[:, :c4], N=c4, K=c4, w_sn=c4 * 9, w_sk=9, w_st=1, taps=9, hw=(H, W))
-    # Linear + bias + GELU in one pass: the GEMM epilogue stores the pre-activation (for the backward) and GELU of it
-    rec.gemm(n + "linear1+gelu", xc, W1, t, N=2 * hid, K=C_, w_sn=C_, w_sk=1, bias=b1, act=L.ACT_GELU, pre_out=pre)
-    _dwconv_wide(rec, n + "dwconv", t[:, :hid], Wdw, u, hid, dims)
-    _gate(rec, n + "dwconv.gelu*x2", hid, u, bdw, t[:, hid:], G=g)
+    # Linear1's output is stored once, as the pre-activation: the GELU of its x1 half is applied by the depthwise kernel on load, that
+    # of its x2 half by the gate kernel, and both backward GELUs (and Linear1's bias gradient) happen where the gradient is produced -
+    # 22 hidden-wide passes per FRFN instead of 30
+    rec.gemm(n + "linear1", xc, W1, pre, N=2 * hid, K=C_, w_sn=C_, w_sk=1, bias=b1)
+    _dwconv_wide(rec, n + "gelu.dwconv", pre[:, :hid], Wdw, u, hid, dims, act_in=1)
+    _gate(rec, n + "dwconv.gelu*gelu(x2)", hid, u, bdw, pre[:, hid:], G=g, v_act=1)
     rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
 
     def backward(dy: torch.Tensor) -> torch.Tensor:
         dx = rec.alloc(M, C_)
-        dg, du, dt = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, 2 * hid)
+        dg, du = rec.alloc(M, hid), rec.alloc(M, hid)
         dpre, dxc = rec.alloc(M, 2 * hid), rec.alloc(M, C_)
+        db1 = Gr("linear1.0.bias")
         with rec.bulk():
             rec.gram(n + "linear2.dW", dy, g, Gr("linear2.0.weight"), N=C_, K=hid, o_sn=hid, o_sk=1)
             _colsum_wide(rec, n + "linear2.db", dy, C_, Gr("linear2.0.bias"))
         rec.gemm(n + "linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
-        _gate(rec, n + "gate.bwd", hid, u, bdw, t[:, hid:], dG=dg, dU=du, dV=dt[:, hid:], dbias=Gr("dwconv.0.bias"))
-        _dwconv_bwd_wide(rec, n + "dwconv.bwd", du, t[:, :hid], Wdw, dt[:, :hid], Gr("dwconv.0.weight"), hid, dims)
-        _act(rec, n + "linear1.gelu.bwd", pre, None, 2 * hid, bwd_dt=dt, dpre=dpre, dbias=Gr("linear1.0.bias"))
+        _gate(rec, n + "gate.bwd", hid, u, bdw, pre[:, hid:], dG=dg, dU=du, dV=dpre[:, hid:], dbias=Gr("dwconv.0.bias"), v_act=1,
+              dbias_v=db1[hid:])
+        _dwconv_bwd_wide(rec, n + "dwconv.bwd+gelu.bwd", du, pre[:, :hid], Wdw, dpre[:, :hid], Gr("dwconv.0.weight"), hid, dims, act=1,
+                         dbias=db1[:hid])
         with rec.bulk():
             rec.gram(n + "linear1.dW", dpre, xc, Gr("linear1.0.weight"), N=2 * hid, K=C_, o_sn=C_, o_sk=1)
         rec.gemm(n + "linear1.dX", dpre, W1, dxc, N=C_, K=2 * hid, w_sn=1, w_sk=C_)
@@ -633,7 +648,10 @@ class _TokenFunction(torch.autograd.Function):
     def forward(ctx, x, module, *params):
         plan = module._plan_for(x)
         module._before_forward(plan)
-        y = plan.forward(x).clone().view(module._out_shape(x, plan))
+        y = plan.forward(x)
+        if not module._alias_io:
+            y = y.clone()
+        y = y.view(module._out_shape(x, plan))
         module._serial += 1
         ctx.module, ctx.plan, ctx.serial, ctx.shape = module, plan, module._serial, tuple(x.shape)
         return y
@@ -645,7 +663,7 @@ class _TokenFunction(torch.autograd.Function):
             raise RuntimeError(f"{type(m).__name__}(HIP): a later forward overwrote the saved activations; call backward before "
                                "the next forward")
         dx = ctx.plan.backward(dy.contiguous())
-        dx = None if dx is None else dx.clone().view(ctx.shape)
+        dx = None if dx is None else (dx if m._alias_io else dx.clone()).view(ctx.shape)
         fp = m._flat
         if m._flat_grads_only:       # a fused optimizer reads the module's flat gradient buffer directly (trainer.ModuleTrainStep)
             return (dx, None) + (None,) * len(m._names)
@@ -658,6 +676,10 @@ class TokenModule(nn.Module):
 
     _dead: frozenset = frozenset()        # parameters the reference never uses (their .grad stays None, as there)
     _flat_grads_only = False              # True: backward leaves the gradients in the flat buffer only (no per-parameter .grad)
+    # True (set by trainer.ModuleTrainStep on the modules of the network it drives): forward / backward return views of the plan's own
+    # output buffers instead of clones.  Inside one network step every module output is consumed (copied into the next plan's input, or
+    # summed by autograd) before that module runs again; a standalone module keeps the safe default, a fresh tensor per call.
+    _alias_io = False
 
     def _init_plumbing(self):
         self._flat: "FlatParams | None" = None
@@ -727,7 +749,8 @@ class TokenModule(nn.Module):
         plan = self._plan_for(x, want_backward=False)
         self._before_forward(plan)
         self._serial += 1
-        return plan.forward(x).clone().view(self._out_shape(x, plan))
+        y = plan.forward(x)
+        return (y if self._alias_io else y.clone()).view(self._out_shape(x, plan))
 
 
 class FRFN(TokenModule):
@@ -967,7 +990,8 @@ class InputProjection(TokenModule):
             return _TokenFunction.apply(x, self, *self.parameters())
         plan = self._plan_for(x, want_backward=False)
         self._serial += 1
-        return plan.forward(x).clone().view(self._out_shape(x, plan))
+        y = plan.forward(x)
+        return (y if self._alias_io else y.clone()).view(self._out_shape(x, plan))
 
 
 class OutputProjection(TokenModule):

@@ -287,9 +287,9 @@ class MyBigFRFNModel(nn.Module):
     (:628) is not emitted."""
 
     # device memory the 27 launch plans keep per input pixel (measured, tests/test_frfn_net.py holds it): ModuleTrainStep sizes micro-batches with it
-    # (tools/measure_module_plans.py: 4.4 / 6.9 / 22.8 GiB at 1 x 128^2 / 2 x 128^2 / 2 x 256^2 = 174 KB per pixel + 1.6 GiB of per-plan scratch)
-    PLAN_BYTES_PER_PIXEL_TRAIN, PLAN_BYTES_FIXED_TRAIN = 176_000, 2_000_000_000
-    PLAN_BYTES_PER_PIXEL_EVAL, PLAN_BYTES_FIXED_EVAL = 84_000, 1_900_000_000
+    # (tools/measure_module_plans.py, round 3 with the activations of FRFN fused away: 4.0 / 6.1 / 19.5 GiB at 1 x 128^2 / 2 x 128^2 / 2 x 256^2 = 147 KB per pixel + 1.7 GB of per-plan scratch)
+    PLAN_BYTES_PER_PIXEL_TRAIN, PLAN_BYTES_FIXED_TRAIN = 147_000, 1_900_000_000
+    PLAN_BYTES_PER_PIXEL_EVAL, PLAN_BYTES_FIXED_EVAL = 69_000, 1_750_000_000
 
 
     def __init__(self, img_size=512, dd_in=3, embed_dim=32, dropout_rate=0., drop_path_rate=0.1, use_dwt="Fourier"):

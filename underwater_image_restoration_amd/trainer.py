@@ -234,6 +234,7 @@ class ModuleTrainStep:
         for m in self.mods:
             m._ensure_flat(dev)
             m._flat_grads_only = True
+            m._alias_io = True
         self.flats = [m._flat for m in self.mods]
         # ONE gradient bucket for the whole network: every module's flat gradient buffer becomes a view of it, so data parallelism
         # is one all-reduce per step (AST: 28 modules, 80 MB) instead of one per module.  Plans record raw gradient
