@@ -9,6 +9,7 @@ ONE JSON line:
   cpu_baseline the oracle (torch CPU restatement pinned to the reference's own outputs) on the host cores, bounded sample
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -20,6 +21,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from underwater_image_restoration_amd.model.block import FRFN  # noqa: E402
 from underwater_image_restoration_amd.model.model import DecoderBlock, EncoderBlock  # noqa: E402
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 MFMA_F32_PEAK = 157.3e12
 HBM_PEAK = 8.0e12
 
@@ -67,6 +69,19 @@ def bench_net(args):
                          "plan_flops": flops, "mfma_frac_fp32": flops / (ms * 1e-3) / MFMA_F32_PEAK,
                          "note": "bytes / flops as the launch plans count them (every launch's operands once); the network is a chain of "
                                  "separate HBM-bound launches this round"}}
+    # HBM bytes per step from PMC passes of THIS command (tools/round_end.sh -> tools/pmc_traffic.py), quoted only while the kernels
+    # and launch plans still hash to what was measured
+    tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"*{args.what}_hbm_counters.json")))
+    if tfiles and (B, S) == ((4, 512) if arch == "AST" else (8, 256)):
+        from underwater_image_restoration_amd import build as _build
+        with open(tfiles[-1]) as tf:
+            tj = json.load(tf)
+        rel = os.path.relpath(tfiles[-1], ROOT)
+        if tj.get("source_sha") == _build.source_sha():
+            line["roofline"]["traffic"] = tj["hbm_bytes_per_step"]
+            line["roofline"]["traffic_source"] = rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
+        else:
+            line["roofline"]["traffic_note"] = f"{rel} was measured on other sources ({tj.get('source_sha')}): stale, not quoted"
     if not args.no_cpu:
         from oracle import decoder_ref as D, ast_ref as OA
         net_fn = OA.ast_net if arch == "AST" else D.frfn_net

@@ -1,5 +1,5 @@
 """Sum FETCH_SIZE / WRITE_SIZE (rocprofv3 --pmc, separate passes) over the kernels of the bench run.
-usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps_in_run> <out.json>
+usage: python tools/pmc_traffic.py <fetch_dir> <write_dir> <steps_in_run> <out.json> [fixed]
 Units/corrections per MI355X_MICROARCH.md (HBM section): counters are in KiB-like units of 1024 B... the
 tool reports kilobytes; on gfx950 FETCH_SIZE counts 128-B requests as 64 B for wide coalesced reads -> x2."""
 import csv, glob, json, os, sys, collections
@@ -22,7 +22,7 @@ write, nw = load(wd, "WRITE_SIZE")
 adam = 0
 for f in glob.glob(os.path.join(fd, "**", "*counter_collection.csv"), recursive=True):
     adam += sum(1 for row in csv.DictReader(open(f)) if row["Counter_Name"] == "FETCH_SIZE" and "clip_adam_kernel" in row["Kernel_Name"])
-if adam > 0:
+if adam > 0 and not (len(sys.argv) > 5 and sys.argv[5] == "fixed"):   # module networks run the kernel once per module: their callers pass the step count
     steps = adam
 KB = 1024.0
 res = {"steps_in_profiled_run": steps, "dispatches_fetch_pass": nf, "dispatches_write_pass": nw,

@@ -12,7 +12,15 @@ mkdir -p profiles/$RD && cp $O/prof/traffic.json profiles/$RD/zz_${T}_pmc_traffi
 python bench.py --breakdown-file $O/op_breakdown.csv --timeline-file $O/stage_timeline.csv > $O/bench.json 2> $O/bench.err && echo bench-ok
 python tools/bench_dwln.py 20 > $O/bench_dwln.txt 2>&1 && echo dwln-ok
 python tools/bench_deep.py 30 > $O/bench_deep.txt 2>&1 && echo deep-ok
+# module networks (BASELINE configs[3] / configs[4]): the same two PMC passes over THEIR bench command first, then the bench line that quotes them
+for W in net ast; do
+  ( cd /tmp && export TMPDIR=/tmp && A="$R/tools/bench_frfn.py --what $W --steps 2 --warmup 1 --no-cpu" && \
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_$W/fetch -- python3 $A > $O/prof_$W.fetch.log 2>&1 && \
+    timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/prof_$W/write -- python3 $A > $O/prof_$W.write.log 2>&1 && \
+    timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$W/stats -- python3 $A > $O/prof_$W.stats.log 2>&1 ) && echo pmc-$W-ok
+  python3 tools/pmc_traffic.py $O/prof_$W/fetch $O/prof_$W/write 3 $O/prof_$W/traffic.json fixed > $O/prof_$W.traffic.log 2>&1 && cp $O/prof_$W/traffic.json profiles/$RD/zz_${T}_${W}_hbm_counters.json
+done
 python tools/bench_frfn.py --what net > $O/frfnnet_bench.json 2> $O/frfnnet.err && echo frfnnet-ok
 python tools/bench_frfn.py --what ast > $O/ast_bench.json 2> $O/ast.err && echo ast-ok
 python tools/bench_uiqm.py > $O/uiqm_bench.json 2> $O/uiqm.err && echo uiqm-ok
-find $O/prof -name "*kernel_trace.csv" -delete; find $O/prof -name "*counter_collection.csv" -delete
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
