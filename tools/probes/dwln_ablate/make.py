@@ -27,6 +27,15 @@ VARIANTS = {
         "        DWA[ci * 288 + e] += (WR[e] + WR[288 + e]) + (WR[576 + e] + WR[864 + e]);\n", "        DWA[ci * 288 + e] += 0.f;\n#endif\n"),
         "#pragma unroll\n          for (int dx = 0; dx < 3; ++dx) dwa[dx] =", "          // p0 is free now").replace(
         "            dwa[3 + kx] = __builtin_elementwise_fma(xc, p1[kx], dwa[3 + kx]);\n            dwa[6 + kx] = __builtin_elementwise_fma(xc, p2[kx], dwa[6 + kx]);\n", ""),
+    # (b) removed: no depthwise walk (dP in LDS stays whatever it was; the prefetched operands are kept alive through dwa)
+    "no_b": lambda s: cut(s, "      // ---- (b) transposed depthwise 3x3", "      load_xp(cn, cp, sx, last ? tn : tc);",
+                          "      f32x2 dwa[9];\n#pragma unroll\n      for (int t = 0; t < 9; ++t) dwa[t] = xpv[t & 7] * wf[t] * xm;\n"),
+    # (b), (c), (d) removed: loads, LDS staging, barriers, reductions and the epilogue only
+    "mem_only": lambda s: cut(cut(cut(s, "      // ---- (d) dW1 chunk granule", "    // ---- tile epilogue", "    }\n\n"),
+                                  "      // ---- (c) dT += dP chunk", "      // ---- (d) dW1 chunk granule" if False else "    }\n\n    // ---- tile epilogue",
+                                  "      acc[0] += w1v[0] + w1v[5] + w1v[10] + w1v[15];\n"),
+                              "      // ---- (b) transposed depthwise 3x3", "      load_xp(cn, cp, sx, last ? tn : tc);",
+                              "      f32x2 dwa[9];\n#pragma unroll\n      for (int t = 0; t < 9; ++t) dwa[t] = xpv[t & 7] * wf[t] * xm;\n"),
     # tile epilogue (LayerNorm backward) removed
     "no_epi": lambda s: cut(s, "    // ---- tile epilogue", "  // ---- slab row of this workgroup", "    for (int r = 0; r < 16; ++r) dgam += acc[r];\n  }\n\n"),
 }

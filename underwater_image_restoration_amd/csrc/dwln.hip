@@ -266,6 +266,14 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         w1v[s] = ldg_off(a.W1, ok ? (unsigned)(row * C + li) * 4u : 0u);
       }
       const f32x2 xm = f32x2{colok && colA(ci) + cp < chcols ? 1.f : 0.f, colok && colB(ci) + cp < chcols ? 1.f : 0.f};
+      // the next unit's G rows (24 of the ~40 KB a chunk moves per workgroup) leave NOW, behind w1v in issue order: their registers
+      // were freed by the LDS stores above, and they get the walk + (c) + (d) to land instead of (c) + (d) alone - with two workgroups
+      // per CU the bytes in flight bound the bandwidth (Little's law), not the issue rate
+      if (last) {                                            // (uniform branch, no loads inside: the load count per chunk stays static)
+#pragma unroll
+        for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it, tn);
+      }
+      load_g(cn, t_);
 
       // ---- (b) transposed depthwise 3x3 + depthwise weight-gradient terms ----
       f32x2 dwa[9];
@@ -312,11 +320,6 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         step(rw[0], rw[1], rw[2], xpv[6] * (xm * keep_of(6)), keep_of(6));
         step(rw[1], rw[2], rw[0], xpv[7] * (xm * keep_of(7)), keep_of(7));
       }
-      if (last) {                                            // (uniform branch, no loads inside: the load count per chunk stays static)
-#pragma unroll
-        for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it, tn);
-      }
-      load_g(cn, t_);
       load_xp(cn, cp, sx, last ? tn : tc);
       load_wf(cn, cp);
       // sum over the wave's four strips (lanes cp, cp + 16, cp + 32, cp + 48), then one row per wave in LDS

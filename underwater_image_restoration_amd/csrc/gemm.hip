@@ -834,8 +834,11 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // one launch on the LDS-tiled kernel instead of tap-group launches / the un-staged fallback.  UIR_TILED_CONV_MINK (default 256; 0 off);
     // the SpectralTransformer's own 3 x 3 convolutions (K <= 256 on <= 16 384 pixels, side lane) stay on the tap-group path they were
     // tuned and measured on
+    // (round 3: ups_1.Sups itself, K = 128 -> N = 256 forward, 146 us here against 193 us as tap groups; its and ups_2's input
+    // gradients - flipped taps, K = 256 / 128 - measured 352 / 240 us here against 226 / 166 us and stay on the tap-group path)
     constexpr int cmink = 256;
-    if (cmink > 0 && a.taps == 9 && a.ntap <= 0 && a.K >= cmink && (a.K >= 512 || a.M > 16384) && a.N >= 64 && a.batches == 1 && a.pro == UIR_PRO_NONE &&
+    const bool ups1_fwd = a.taps == 9 && !a.flip && a.K >= 128 && a.N >= 256;
+    if (cmink > 0 && a.taps == 9 && a.ntap <= 0 && (ups1_fwd || (a.K >= cmink && (a.K >= 512 || a.M > 16384))) && a.N >= 64 && a.batches == 1 && a.pro == UIR_PRO_NONE &&
         a.epi == UIR_EPI_PLAIN && a.act == UIR_ACT_NONE && a.n_grp_pad <= 0 && a.k_grp_pad <= 0 && (a.K & 3) == 0) {
       UirTiledArgs t{};
       t.A = a.X; t.sa_i = a.ldx; t.sa_k = 1;
