@@ -169,6 +169,13 @@ typedef struct UirDwBwdArgs {
    * (optional, [nblocks][creal]) then receives the partial column sums of dX = the gradient of Linear1's bias. */
   int act;
   float* db_slab;
+  /* U != NULL (with act = 1; LeFF, src/model/block.py:240-244): dY is the gradient of G = gelu(U + gbias), the second GELU behind the
+   * convolution: dY is multiplied by gelu'(U + gbias) as it is loaded, so the gradient of the convolution output is never stored;
+   * dbu_slab (optional, [nblocks][creal]) receives its partial column sums = the gradient of the depthwise bias. */
+  const float* U;
+  const float* gbias;
+  float* dbu_slab;
+  int ldu;
 } UirDwBwdArgs;
 int uir_dwconv_bwd_fused(const UirDwBwdArgs* args, void* stream);
 

@@ -375,6 +375,21 @@ def test_dwconv_with_fused_gelus(B, H, W, C):
     assert rel(chw(dP, B, H, W), dpre) < TOL
     assert rel(dW.reshape(C, 1, 3, 3), dw) < TOL
     assert rel(dB, dpre.sum((0, 2, 3))) < TOL
+    # ... and with the second GELU's backward on load: the incoming gradient is that of g = gelu(u + b)
+    dg = rnd(*u.shape, seed=6)
+    pre2 = pre.detach().clone().requires_grad_(True)
+    w2, b2 = w.detach().clone().requires_grad_(True), b.clone().requires_grad_(True)
+    g2 = F.gelu(F.conv2d(F.gelu(pre2), w2, padding=1, groups=C) + b2.view(1, -1, 1, 1))
+    dpre2, dw2, db2 = torch.autograd.grad((g2 * dg).sum(), (pre2, w2, b2))
+    r2 = rec()
+    dP2, dW2, dB1, dBu = r2.alloc(B * H * W, C), r2.alloc(C, 9), r2.alloc(C), r2.alloc(C)
+    r2.dwconv_bwd("bg", dev(hwc(dg)), P, Wt, dP2, dW2, C_=C, creal=C, dims=(B, H, W), act=1, dbias=dB1, gate_u=U, gate_bias=dev(b),
+                  dbias_gate=dBu)
+    r2.run(r2.fwd)
+    assert rel(chw(dP2, B, H, W), dpre2) < TOL
+    assert rel(dW2.reshape(C, 1, 3, 3), dw2) < TOL
+    assert rel(dB1, dpre2.sum((0, 2, 3))) < TOL
+    assert rel(dBu, db2) < TOL
 
 
 def test_dwconv_padded_groups():

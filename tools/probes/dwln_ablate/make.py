@@ -36,6 +36,12 @@ VARIANTS = {
                                   "      acc[0] += w1v[0] + w1v[5] + w1v[10] + w1v[15];\n"),
                               "      // ---- (b) transposed depthwise 3x3", "      load_xp(cn, cp, sx, last ? tn : tc);",
                               "      f32x2 dwa[9];\n#pragma unroll\n      for (int t = 0; t < 9; ++t) dwa[t] = xpv[t & 7] * wf[t] * xm;\n"),
+    # depthwise weight-gradient FMAs kept, their cross-lane / cross-wave reduction removed (the sums are folded into dbet to stay alive)
+    "no_dwdw_reduce": lambda s: cut(s, "      // sum over the wave's four strips", "      // ---- (c) dT += dP chunk",
+                                    "#pragma unroll\n      for (int t = 0; t < 9; ++t) dbet += dwa[t].x + dwa[t].y;\n      lds_barrier2();\n"),
+    # reduction kept, the FMAs removed
+    "no_dwdw_fma": lambda s: cut(s, "#pragma unroll\n          for (int dx = 0; dx < 3; ++dx) dwa[dx] =", "          // p0 is free now").replace(
+        "            dwa[3 + kx] = __builtin_elementwise_fma(xc, p1[kx], dwa[3 + kx]);\n            dwa[6 + kx] = __builtin_elementwise_fma(xc, p2[kx], dwa[6 + kx]);\n", ""),
     # tile epilogue (LayerNorm backward) removed
     "no_epi": lambda s: cut(s, "    // ---- tile epilogue", "  // ---- slab row of this workgroup", "    for (int r = 0; r < 16; ++r) dgam += acc[r];\n  }\n\n"),
 }

@@ -68,7 +68,7 @@ class DwBwdArgs(C.Structure):
                 ("ldy", C.c_int), ("ldx", C.c_int), ("ldo", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
                 ("grp_real", C.c_int), ("grp_pad", C.c_int), ("creal", C.c_int), ("nblocks", C.c_int),
-                ("act", C.c_int), ("db_slab", fp)]
+                ("act", C.c_int), ("db_slab", fp), ("U", fp), ("gbias", fp), ("dbu_slab", fp), ("ldu", C.c_int)]
 
 
 class GdfnFwdArgs(C.Structure):

@@ -143,10 +143,14 @@ __device__ __forceinline__ void load_row_t(float4 (&v)[RR + 2], const float* bas
 // ACT (with DX): X is the pre-activation p of the GELU in front of the convolution: gelu(p) enters the weight gradient, dX leaves
 // multiplied by gelu'(p) (both from one uir_gelu_pair of the centre value that is loaded anyway) and its column sums (the bias
 // gradient of the Linear that produced p) join the partial slab - the separate GELU-backward pass (read p, read dX, write) is gone.
-template <int RR, bool DX, bool ACT = false>
+// GATE (with ACT): dY is the gradient of gelu(U + gbias) BEHIND the convolution; every loaded dY row is multiplied by
+// gelu'(U + gbias) of the same pixels (U read through the same clamped window: each value is evaluated (RR + 2) / RR times), the
+// centre run's products are also the depthwise bias gradient.  The whole backward of LeFF's  GELU -> dwconv + bias -> GELU  is this
+// one pass: reads dG, U, pre; writes d(pre).
+template <int RR, bool DX, bool ACT = false, bool GATE = false>
 __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBwdArgs a, const int HS) {
   extern __shared__ __attribute__((aligned(16))) float sm[];   // [9][C] weights (DX only), then [ny][c4n][RS] reduction
-  constexpr int RS = ACT ? 40 : 36;
+  constexpr int RS = GATE ? 44 : (ACT ? 40 : 36);
   const int c4n = a.C >> 2;
   const int c4 = threadIdx.x, py = threadIdx.y, ny = blockDim.y;
   const int tid = threadIdx.y * blockDim.x + threadIdx.x, nthr = blockDim.x * blockDim.y;
@@ -167,9 +171,24 @@ __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBw
   float4 acc[9];
 #pragma unroll
   for (int t = 0; t < 9; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 dbs = make_float4(0.f, 0.f, 0.f, 0.f), dbu = dbs;
   if (c4 < c4n) {
     const float* gb = a.dY + c4 * 4;
+    const float* ub = GATE ? a.U + c4 * 4 : nullptr;
+    float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (GATE) gbv = *reinterpret_cast<const float4*>(a.gbias + c4 * 4);
+    // one dY row of the window; GATE: times gelu'(U + gbias) (rows / columns outside the image are zero in dY already)
+    auto load_g = [&](float4 (&g)[RR + 2], int hh, int b, int w0) {
+      load_row_t<RR>(g, gb, a.ldy, b, hh, w0, a.H, a.Wd);
+      if (GATE) {
+        float4 u[RR + 2];
+        load_row_t<RR>(u, ub, a.ldu, b, hh, w0, a.H, a.Wd);
+#pragma unroll
+        for (int j = 0; j < RR + 2; ++j)
+          g[j] = make_float4(g[j].x * uir_gelu_grad(u[j].x + gbv.x), g[j].y * uir_gelu_grad(u[j].y + gbv.y),
+                             g[j].z * uir_gelu_grad(u[j].z + gbv.z), g[j].w * uir_gelu_grad(u[j].w + gbv.w));
+      }
+    };
     for (long it = (long)blockIdx.x * ny + py; it < items; it += (long)gridDim.x * ny) {
       const int run = (int)(it % runs);
       long t = it / runs;
@@ -178,11 +197,16 @@ __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBw
       const int w0 = run * RR, h0 = sp * HS;
       const int hend = min(h0 + HS, a.H);
       float4 g0[RR + 2], g1[RR + 2], g2[RR + 2];
-      load_row_t<RR>(g0, gb, a.ldy, b, h0 - 1, w0, a.H, a.Wd);
-      load_row_t<RR>(g1, gb, a.ldy, b, h0, w0, a.H, a.Wd);
+      load_g(g0, h0 - 1, b, w0);
+      load_g(g1, h0, b, w0);
       // gm = dY row h-1, gc = row h, gp = row h+1 (loaded here)
       auto step = [&](float4 (&gm)[RR + 2], float4 (&gc)[RR + 2], float4 (&gp)[RR + 2], int h) {
-        load_row_t<RR>(gp, gb, a.ldy, b, h + 1, w0, a.H, a.Wd);
+        load_g(gp, h + 1, b, w0);
+        if (GATE) {                                           // centre run of row h: each pixel of the strip exactly once
+#pragma unroll
+          for (int j = 0; j < RR; ++j)
+            if (w0 + j < a.Wd) dbu = make_float4(dbu.x + gc[j + 1].x, dbu.y + gc[j + 1].y, dbu.z + gc[j + 1].z, dbu.w + gc[j + 1].w);
+        }
         float4 x[RR];
         const float* xp = a.X + ((long)(b * a.H + h) * a.Wd) * a.ldx + c4 * 4;
 #pragma unroll
@@ -252,8 +276,18 @@ __global__ __launch_bounds__(256) void uir_dwconv_bwd_fused_kernel(const UirDwBw
       rp[0 * 9 + t] = acc[t].x; rp[1 * 9 + t] = acc[t].y; rp[2 * 9 + t] = acc[t].z; rp[3 * 9 + t] = acc[t].w;
     }
     if (ACT) { rp[36] = dbs.x; rp[37] = dbs.y; rp[38] = dbs.z; rp[39] = dbs.w; }
+    if (GATE) { rp[40] = dbu.x; rp[41] = dbu.y; rp[42] = dbu.z; rp[43] = dbu.w; }
   }
   __syncthreads();
+  if (GATE && a.dbu_slab) {
+    for (int c = tid; c < a.C; c += nthr) {
+      const int cr = uir_colmap(c, a.grp_real, a.grp_pad);
+      if (cr < 0) continue;
+      float sb = 0.f;
+      for (int y = 0; y < ny; ++y) sb += red[((long)y * c4n + (c >> 2)) * RS + 40 + (c & 3)];
+      a.dbu_slab[(long)blockIdx.x * a.creal + cr] = sb;
+    }
+  }
   if (ACT && a.db_slab) {
     for (int c = tid; c < a.C; c += nthr) {
       const int cr = uir_colmap(c, a.grp_real, a.grp_pad);
@@ -333,9 +367,13 @@ extern "C" int uir_dwconv_bwd_fused(const UirDwBwdArgs* p, void* stream) {
   UIR_REQUIRE(c4n <= 256);
   const int ny = 256 / c4n;
   UIR_REQUIRE(a.act == 0 || a.act == 1);
-  const size_t lds = ((size_t)9 * a.C + (size_t)ny * c4n * (a.act ? 40 : 36)) * sizeof(float);
+  UIR_REQUIRE(!a.U || (a.act == 1 && a.gbias && a.ldu >= a.C && (a.ldu & 3) == 0 && uir_aligned16(a.U) && uir_aligned16(a.gbias)));
+  const size_t lds = ((size_t)9 * a.C + (size_t)ny * c4n * (a.U ? 44 : (a.act ? 40 : 36))) * sizeof(float);
   UIR_REQUIRE(lds <= 96 * 1024);
-  if (a.act)
+  if (a.U)
+    hipLaunchKernelGGL((uir_dwconv_bwd_fused_kernel<2, true, true, true>), dim3(a.nblocks), dim3(c4n, ny), lds,
+                       static_cast<hipStream_t>(stream), a, uir_dw_strip(a.B, a.H, a.Wd, a.C));
+  else if (a.act)
     hipLaunchKernelGGL((uir_dwconv_bwd_fused_kernel<2, true, true>), dim3(a.nblocks), dim3(c4n, ny), lds,
                        static_cast<hipStream_t>(stream), a, uir_dw_strip(a.B, a.H, a.Wd, a.C));
   else

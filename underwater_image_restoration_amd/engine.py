@@ -793,9 +793,12 @@ class Recorder:
         self._op(name, lib.uir_dwconv_wgrad, C.byref(a), nbytes=8 * rows * C_, flops=18 * rows * C_)
         self._reduce(name + ".red", _ptr(slab), a.nblocks, creal * 9, _ptr(out), creal * 9)
 
-    def dwconv_bwd(self, name, dY, X, Wt, dX, dW, *, C_, creal, dims, grp=(0, 0), min_rows=None, act=0, dbias=None):
+    def dwconv_bwd(self, name, dY, X, Wt, dX, dW, *, C_, creal, dims, grp=(0, 0), min_rows=None, act=0, dbias=None, gate_u=None,
+                   gate_bias=None, dbias_gate=None):
         """Fused input-gradient + weight-gradient of a depthwise 3x3 (dY read once).  act = 1: X is the pre-activation p of a GELU
         in front of the convolution: dW uses gelu(p), dX = conv^T(dY) * gelu'(p), dbias (optional) = column sums of dX."""
+        # gate_u / gate_bias (with act): dY is the gradient of gelu(gate_u + gate_bias) behind the convolution and is multiplied by that
+        # GELU's derivative on load; dbias_gate = the depthwise bias gradient
         if act:
             min_rows = 0              # the activation-fused form exists as one pass only
         # fused only where bytes bind (full and half resolution); at the deep levels the chain is latency-bound and the
@@ -828,17 +831,26 @@ class Recorder:
         slab = self.alloc(a.nblocks * creal * 9)
         a.slab = _ptr(slab)
         a.act = act
-        dbs = None
+        dbs = dbu = None
         if act and dbias is not None:
             dbs = self.alloc(a.nblocks * creal)
             a.db_slab = _ptr(dbs)
+        if gate_u is not None:
+            assert act == 1 and gate_bias is not None
+            self._hold(gate_u, gate_bias)
+            a.U, a.gbias, a.ldu = _ptr(gate_u), _ptr(gate_bias), _ld(gate_u)
+            if dbias_gate is not None:
+                dbu = self.alloc(a.nblocks * creal)
+                a.dbu_slab = _ptr(dbu)
         self.keep.append(a)
         rows = dims[0] * dims[1] * dims[2]
-        self._op(name, lib.uir_dwconv_bwd_fused, C.byref(a), nbytes=12 * rows * C_, flops=36 * rows * C_)
+        self._op(name, lib.uir_dwconv_bwd_fused, C.byref(a), nbytes=(12 + (4 if gate_u is not None else 0)) * rows * C_, flops=36 * rows * C_)
         with self.bulk():
             self._reduce(name + ".red", _ptr(slab), a.nblocks, creal * 9, _ptr(dW), creal * 9)
             if dbs is not None:
                 self._reduce(name + ".db", _ptr(dbs), a.nblocks, creal, _ptr(dbias), creal)
+            if dbu is not None:
+                self._reduce(name + ".dbu", _ptr(dbu), a.nblocks, creal, _ptr(dbias_gate), creal)
 
     def ln_bwd(self, name, dT, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_):
         self._hold(dT, X, stats, gamma, dRes, dX, dgamma, dbeta)

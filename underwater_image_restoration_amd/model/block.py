@@ -104,11 +104,13 @@ def _dwconv_wide(rec, name, X, Wt, Y, C_, dims, act_in=0, bias=None, G=None):
                    act_in=act_in, bias=None if bias is None else bias[c0:c0 + n], G=None if G is None else G[:, c0:c0 + n])
 
 
-def _dwconv_bwd_wide(rec, name, dY, X, Wt, dX, dW, C_, dims, act=0, dbias=None):
+def _dwconv_bwd_wide(rec, name, dY, X, Wt, dX, dW, C_, dims, act=0, dbias=None, gate_u=None, gate_bias=None, dbias_gate=None):
     for c0 in range(0, C_, _DW_MAX):
         n = min(_DW_MAX, C_ - c0)
+        sl = (lambda t, rows=False: None if t is None else (t[:, c0:c0 + n] if rows else t[c0:c0 + n]))
         rec.dwconv_bwd(f"{name}[{c0}]" if C_ > _DW_MAX else name, dY[:, c0:c0 + n], X[:, c0:c0 + n], Wt[c0:c0 + n], dX[:, c0:c0 + n],
-                       dW[c0:c0 + n], C_=n, creal=n, dims=dims, act=act, dbias=None if dbias is None else dbias[c0:c0 + n])
+                       dW[c0:c0 + n], C_=n, creal=n, dims=dims, act=act, dbias=sl(dbias), gate_u=sl(gate_u, True),
+                       gate_bias=sl(gate_bias), dbias_gate=sl(dbias_gate))
 
 
 def _colsum_wide(rec, name, src, cols, out):
@@ -178,7 +180,7 @@ def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     # Three hidden-wide tensors are stored - pre (Linear1's output), u (the depthwise output), g = gelu(u + b) - and neither
     # gelu(pre) nor the gradient with respect to it ever reaches HBM: the first GELU is applied by the depthwise kernels on load, its
     # backward (and Linear1's bias gradient) by the depthwise backward on store, the second GELU leaves the depthwise forward as a
-    # second output.  15 hidden-wide passes per LeFF instead of 20.
+    # second output, and its backward is applied by the depthwise backward on load.  13 hidden-wide passes per LeFF instead of 20.
     pre, u, g, y = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
     n = pfx
     rec.gemm(n + "linear1", x, W1, pre, N=hid, K=C_, w_sn=C_, w_sk=1, bias=b1)
@@ -186,14 +188,14 @@ def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
 
     def backward(dy: torch.Tensor) -> torch.Tensor:
-        dg, du, dpre, dx = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
+        dg, dpre, dx = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
         with rec.bulk():
             rec.gram(n + "linear2.dW", dy, g, Gr("linear2.0.weight"), N=C_, K=hid, o_sn=hid, o_sk=1)
             _colsum_wide(rec, n + "linear2.db", dy, C_, Gr("linear2.0.bias"))
         rec.gemm(n + "linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
-        _gate(rec, n + "dwconv.gelu.bwd", hid, u, bdw, None, dG=dg, dU=du, dbias=Gr("dwconv.0.bias"))
-        _dwconv_bwd_wide(rec, n + "dwconv.bwd+gelu.bwd", du, pre, Wdw, dpre, Gr("dwconv.0.weight"), hid, dims, act=1,
-                         dbias=Gr("linear1.0.bias"))
+        # gelu'(u + b) on the way in, conv^T, gelu'(pre) on the way out: reads dg, u, pre, writes d(pre) - and all three small gradients
+        _dwconv_bwd_wide(rec, n + "gelu.bwd+dwconv.bwd+gelu.bwd", dg, pre, Wdw, dpre, Gr("dwconv.0.weight"), hid, dims, act=1,
+                         dbias=Gr("linear1.0.bias"), gate_u=u, gate_bias=bdw, dbias_gate=Gr("dwconv.0.bias"))
         with rec.bulk():
             rec.gram(n + "linear1.dW", dpre, x, Gr("linear1.0.weight"), N=hid, K=C_, o_sn=C_, o_sk=1)
         rec.gemm(n + "linear1.dX", dpre, W1, dx, N=C_, K=hid, w_sn=1, w_sk=C_)
