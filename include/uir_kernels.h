@@ -23,7 +23,7 @@ extern "C" {
 /* ---------------------------------------------------------------- uir_gemm */
 enum { UIR_PRO_NONE = 0, UIR_PRO_LN = 1, UIR_PRO_GATE = 2 };
 #define UIR_GEMM_SLAB_ROWS 512   /* max workgroups (= slab rows) of the GEMM variants with fused reductions */
-enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2, UIR_EPI_GATE_BWD_DW = 3, UIR_EPI_LN_BWD = 4 };
+enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2, UIR_EPI_GATE_BWD_DW = 3 };
 enum { UIR_ACT_NONE = 0, UIR_ACT_LEAKY = 1, UIR_ACT_GELU = 2 };   /* GELU: exact-erf form; plain epilogue only */
 
 /* Dense channel contraction over HWC rows, 1 or 9 (3x3, pad 1) taps:
@@ -59,10 +59,6 @@ typedef struct UirGemmArgs {
   float* dw_slab;      /* GATE_BWD_DW: per-workgroup partials [gridDim.x][dw_stride] of the project_out     */
   long dw_stride;      /* weight gradient dW[k][n] = sum_m X[m][k] * gate(G)[m][n], summed by uir_reduce_slab;*/
                        /* gridDim.x = min(M/128, UIR_GEMM_SLAB_ROWS).  Requires K <= 32, N <= 96, M % 128 == 0 */
-                       /* LN_BWD: the GEMM result is the gradient of a LayerNorm output; the epilogue applies  */
-                       /* the LayerNorm backward (G = LN input [M][ldg], stats, ln_g = gamma, R = residual-   */
-                       /* path gradient or NULL), writes dX to Y and per-workgroup rows [dgamma(N) | dbeta(N)] */
-                       /* to dw_slab.  Requires N <= 96 in one column group, M % 128 == 0                    */
   int tap0, ntap;      /* taps == 9 only: contract taps [tap0, tap0 + ntap) (ntap <= 0: all nine).  uir_gemm  */
                        /* itself uses this to run a 3x3 convolution whose weight panel exceeds LDS as a few   */
                        /* launches over tap groups that accumulate into Y (R = Y)                             */
@@ -241,26 +237,6 @@ typedef struct UirAttnvFwdArgs {
 } UirAttnvFwdArgs;
 int uir_attnv_fwd(const UirAttnvFwdArgs* args, void* stream);
 
-/* Tile-fused input-gradient chain of the GDFN (everything between dY and the gradient of the
- * norm2 output):  dg = dY . W_out;  dt2 = gate'(dg, t2);  dt1 = dw3x3^T(dt2);  dT = dt1 . W_in.
- * Replaces autograd's backward of SpectralTransformer.py:127-130 (conv1x1 / depthwise conv /
- * gelu-gate input gradients).  DT2 and DT1 are written for the weight-gradient kernels
- * (uir_dwconv_wgrad, uir_gram); same column layout as T1/T2 of uir_gdfn_fwd. */
-typedef struct UirGdfnBwdArgs {
-  const float* dY;     /* [B*H*W][ldy] gradient of the block output, float4-aligned rows          */
-  const float* T2;     /* [B*H*W][ldt] post-depthwise tensor saved by the forward                 */
-  const float* Wout;   /* project_out [C][h]                                                      */
-  const float* Wdw;    /* conv        [2h][1][3][3]                                               */
-  const float* Win;    /* project_in  [2h][C]                                                     */
-  float* DT2;          /* [B*H*W][ldt] gradient of the depthwise output                           */
-  float* DT1;          /* [B*H*W][ldt] gradient of the depthwise input                            */
-  float* dT;           /* [B*H*W][ldo] gradient of the norm2 output                               */
-  int ldy, ldt, ldo;
-  int B, H, Wd;
-  int C;               /* in {16,32}                                                              */
-  int h, hp;
-} UirGdfnBwdArgs;
-int uir_gdfn_bwd(const UirGdfnBwdArgs* args, void* stream);
 
 /* ------------------------------------------------------------- uir_dwln_bwd */
 /* Backward of  LayerNorm -> 1x1 conv (C -> CH, no bias) -> depthwise 3x3 (no bias)  in one pass over the pixels (csrc/dwln.hip):

@@ -491,42 +491,6 @@ def test_qkv_fwd_fused(B, H, W, C):
     assert rel(st[:, 0], rows.mean(1)) < TOL and rel(st[:, 1], (rows.var(1, unbiased=False) + 1e-5).rsqrt()) < TOL
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 12, 16, 16), (1, 19, 37, 32), (1, 1, 1, 32), (1, 40, 24, 16), (2, 5, 3, 32)])
-def test_gdfn_bwd_fused(B, H, W, C):
-    """Tile-fused GDFN input-gradient chain vs torch autograd (fp64): dt2, dt1 and the gradient of the norm2 output."""
-    h = int(C * 2.66)
-    hp = (h + 15) & ~15
-    ldt = (2 * hp + 31) & ~31
-    xn = rnd(B, C, H, W, seed=1).requires_grad_(True)
-    win, wdw, wout = rnd(2 * h, C, 1, 1, seed=4, scale=C ** -0.5), rnd(2 * h, 1, 3, 3, seed=5, scale=1 / 3), rnd(C, h, 1, 1, seed=6, scale=h ** -0.5)
-    t1 = F.conv2d(xn, win)
-    t1.retain_grad()
-    t2 = F.conv2d(t1, wdw, padding=1, groups=2 * h)
-    t2.retain_grad()
-    y = F.conv2d(F.gelu(t2[:, :h]) * t2[:, h:], wout)
-    dy = rnd(*y.shape, seed=7)
-    (y * dy).sum().backward()
-    M = B * H * W
-
-    def pad(t):  # [B,2h,H,W] -> padded rows [M, ldt]
-        rows = hwc(t.detach())
-        out = torch.zeros(M, ldt, dtype=torch.float64)
-        out[:, :h], out[:, hp:hp + h] = rows[:, :h], rows[:, h:]
-        return out
-    r = rec()
-    DT2, DT1, dT = r.alloc(M, ldt)[:, :2 * hp], r.alloc(M, ldt)[:, :2 * hp], r.alloc(M, C)
-    DT2.fill_(7.0)
-    DT1.fill_(7.0)
-    r.gdfn_bwd("g", dev(hwc(dy)), dev(pad(t2))[:, :2 * hp], dev(wout), dev(wdw), dev(win), DT2, DT1, dT, C_=C, h=h, hp=hp,
-               dims=(B, H, W))
-    r.run(r.fwd)
-    for T, t in ((DT2, t2.grad), (DT1, t1.grad)):
-        tr = hwc(t)
-        assert rel(T[:, :h], tr[:, :h]) < TOL and rel(T[:, hp:hp + h], tr[:, h:]) < TOL
-        assert float(T[:, h:hp].abs().max()) == 0 and float(T[:, hp + h:2 * hp].abs().max()) == 0
-    assert rel(chw(dT, B, H, W), xn.grad) < TOL
-
-
 # ------------------------------------------------------------- uir_layernorm
 @pytest.mark.parametrize("M,C", [(1000, 16), (333, 32), (129, 64), (70, 128)])
 def test_layernorm_bwd(M, C):

@@ -47,21 +47,6 @@ def main():
                 r.gdfn_fwd("g", x, (gam, bet), win, wdw, wout, Y, C_=C, h=h, hp=hp, dims=(B, S, S),
                            T1=T1 if st_ else None, T2=T2 if st_ else None, stats=st)
             res[mode] = timeit(r)
-        if C <= 32:
-            for mode in ("bwd_fused", "bwd_three"):
-                r = Recorder(DEV, scratch_floats=1 << 20)
-                dy = torch.rand(M, C, generator=g).to(DEV)
-                T2 = r.alloc(M, ldt)[:, :2 * hp]
-                T2.copy_(torch.rand(M, 2 * hp, generator=g) - 0.5)
-                DT2, DT1, dT = r.alloc(M, ldt)[:, :2 * hp], r.alloc(M, ldt)[:, :2 * hp], r.alloc(M, C)
-                if mode == "bwd_fused":
-                    r.gdfn_bwd("g", dy, T2, wout, wdw, win, DT2, DT1, dT, C_=C, h=h, hp=hp, dims=(B, S, S))
-                else:
-                    r.gemm("dgate", dy, wout, DT2, N=hp, K=C, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=T2, g_off=hp)
-                    r.dwconv("dX", DT2, wdw, DT1, C_=2 * hp, dims=(B, S, S), grp=(h, hp), flip=1)
-                    r.gemm("dt2", DT1, win, dT, N=C, K=2 * hp, w_sn=1, w_sk=C, k_grp=(h, hp))
-                res[mode] = timeit(r)
-            print(f"C={C:3d} S={S:3d}: bwd fused {res['bwd_fused']*1e3:7.1f} us  bwd three kernels {res['bwd_three']*1e3:7.1f} us", flush=True)
         print(f"C={C:3d} S={S:3d}: fused+store {res['store']*1e3:7.1f} us  fused {res['nostore']*1e3:7.1f} us  three kernels {res['three']*1e3:7.1f} us", flush=True)
 
 

@@ -15,7 +15,7 @@ fp = C.c_void_p  # device pointers travel as integers
 
 # enums (mirror include/uir_kernels.h)
 PRO_NONE, PRO_LN, PRO_GATE = 0, 1, 2
-EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW, EPI_LN_BWD = 0, 1, 2, 3, 4
+EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW = 0, 1, 2, 3
 ACT_NONE, ACT_LEAKY, ACT_GELU = 0, 1, 2
 # L1ColorLum has the same formula as L1withColor in the reference (src/Losses/losses.py:59-66 vs :67-75)
 LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4, "LuminanceCharbonnier": 5,
@@ -89,12 +89,6 @@ class AttnvFwdArgs(C.Structure):
     _fields_ = [("V", fp), ("WA", fp), ("WB", fp), ("Wdw", fp), ("R", fp), ("U", fp), ("VF", fp), ("Y", fp),
                 ("ldv", C.c_int), ("ldr", C.c_int), ("ldu", C.c_int), ("ldf", C.c_int), ("ldy", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int)]
-
-
-class GdfnBwdArgs(C.Structure):
-    _fields_ = [("dY", fp), ("T2", fp), ("Wout", fp), ("Wdw", fp), ("Win", fp), ("DT2", fp), ("DT1", fp), ("dT", fp),
-                ("ldy", C.c_int), ("ldt", C.c_int), ("ldo", C.c_int),
-                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int), ("h", C.c_int), ("hp", C.c_int)]
 
 
 class DwLnBwdArgs(C.Structure):
@@ -197,7 +191,6 @@ SIGNATURES = {
     "uir_dwconv_wgrad": [C.POINTER(DwWgradArgs), fp],
     "uir_dwconv_bwd_fused": [C.POINTER(DwBwdArgs), fp],
     "uir_gdfn_fwd": [C.POINTER(GdfnFwdArgs), fp],
-    "uir_gdfn_bwd": [C.POINTER(GdfnBwdArgs), fp],
     "uir_qkv_fwd": [C.POINTER(QkvFwdArgs), fp],
     "uir_attnv_fwd": [C.POINTER(AttnvFwdArgs), fp],
     "uir_dwln_bwd": [C.POINTER(DwLnBwdArgs), fp],
@@ -259,7 +252,7 @@ SIGNATURES = {
 # C struct name -> ctypes mirror (every argument struct of include/uir_kernels.h)
 STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirDwArgs": DwArgs, "UirDwWgradArgs": DwWgradArgs,
            "UirDwBwdArgs": DwBwdArgs, "UirGdfnFwdArgs": GdfnFwdArgs, "UirQkvFwdArgs": QkvFwdArgs,
-           "UirAttnvFwdArgs": AttnvFwdArgs, "UirGdfnBwdArgs": GdfnBwdArgs, "UirDwLnBwdArgs": DwLnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
+           "UirAttnvFwdArgs": AttnvFwdArgs, "UirDwLnBwdArgs": DwLnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
            "UirAttnFwdArgs": AttnFwdArgs, "UirAttnBwdArgs": AttnBwdArgs, "UirDftArgs": DftArgs, "UirDft2Args": Dft2Args,
            "UirAdamArgs": AdamArgs, "UirResizeImage": ResizeImage, "UirResizeArgs": ResizeArgs, "UirSsimArgs": SsimArgs,
            "UirUiqmArgs": UiqmArgs, "UirReduceDesc": ReduceDesc,

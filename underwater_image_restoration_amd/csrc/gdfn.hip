@@ -875,310 +875,6 @@ int attnv_fwd_launch(const UirAttnvFwdArgs& a, hipStream_t st) {
   return uir_launch_status();
 }
 
-// ------------------------------------------------------------------------------------------------
-// uir_gdfn_bwd: the input-gradient chain of the GDFN in one pass over the pixels
-//   dg   = dY . W_out                      (a)  f32 MFMA, K = C, on tile + ring        -> LDS
-//   dt2a = dg * t2b * gelu'(t2a), dt2b = dg * gelu(t2a)        (b1) VALU, in place over the staged t2 chunk
-//   dt1  = depthwise 3x3 transposed of dt2 (b2) packed-fp32 VALU                     -> LDS
-//   dT  += dt1 . W_in                      (c)  f32 MFMA, K = 32, accumulators live across chunks
-// dt2 and dt1 are written to HBM once (the weight-gradient kernels of the bulk lane read them) and
-// never re-read on the main lane.  Same tile / chunk skeleton as the forward kernel.
-template <int C, int TH, int TW>
-struct GdfnBwdTile {
-  static constexpr int RW = TW + 2, RH = TH + 2;
-  static constexpr int NPX1 = RW * RH;
-  static constexpr int NRT1 = (NPX1 + 31) / 32;
-  static constexpr int RTW = (NRT1 + 3) / 4;
-  static constexpr int NI = TH * TW;
-  static constexpr int NRTI = NI / 32;
-  static constexpr int NT = (C + 31) / 32;
-  static constexpr int UNITS = NRTI * NT;
-  static constexpr int UPW = (UNITS + 3) / 4;
-  static constexpr int S2 = 40;                      // t2 / dt2 chunk rows over tile + ring (32 cols + 8)
-  static constexpr int SD = 20;                      // dg rows over tile + ring (16 cols + 4)
-  static constexpr int S1 = 36;                      // dt1 rows over the interior (32 cols + 4)
-  static constexpr int KJ = C / 8;
-  static constexpr int SEG = 16 / TW;
-  static constexpr int ROWS = TH / SEG;
-  static constexpr int NLD = (NRT1 * 32 * 8) / 256;  // float4 passes staging the t2 chunk (8 lanes per ring pixel)
-  static constexpr int NST = (NI * 8 + 255) / 256;
-  static constexpr int DGF = NRT1 * 32 * SD, D1F = NI * S1;
-  static constexpr int LDS_FLOATS = NRT1 * 32 * S2 + (DGF > D1F ? DGF : D1F);   // dg and dt1 share a region
-  static_assert(NI % 32 == 0 && (16 % TW) == 0 && TH % SEG == 0 && C % 8 == 0 && 4 % NT == 0, "tile shape");
-};
-
-template <int C, int TH, int TW>
-__global__ __launch_bounds__(256, 2) void uir_gdfn_bwd_kernel(const UirGdfnBwdArgs a) {
-  using T = GdfnBwdTile<C, TH, TW>;
-  extern __shared__ float smem[];
-  float* T2s = smem;                          // t2 chunk, overwritten in place by dt2
-  float* DGs = smem + T::NRT1 * 32 * T::S2;   // dg chunk ...
-  float* D1s = DGs;                           // ... then the dt1 chunk (barrier in between)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
-  const int tiles_x = (a.Wd + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
-  int bid = blockIdx.x;
-  const int tx = bid % tiles_x;
-  bid /= tiles_x;
-  const int ty = bid % tiles_y;
-  const int b = bid / tiles_y;
-  const int y0 = ty * TH, x0 = tx * TW;
-  const long img = (long)b * a.H * a.Wd;
-  const int h = a.h, hp = a.hp;
-
-  // ---- phase 0: dY on tile + ring in A-operand registers (k = 8jj + 4h2 + e), zero outside the image ----
-  float A[T::RTW][C / 2];
-#pragma unroll
-  for (int q = 0; q < T::RTW; ++q) {
-    const int r = wave + 4 * q;
-    if (r < T::NRT1) {
-      const int p = r * 32 + li;
-      const int ry = p / T::RW, rx = p - ry * T::RW;
-      const int iy = y0 + ry - 1, ix = x0 + rx - 1;
-      const bool valid = p < T::NPX1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
-      const long m = valid ? img + (long)iy * a.Wd + ix : img;
-      const float* yr = a.dY + m * a.ldy + 4 * h2;
-      const float keep = valid ? 1.f : 0.f;
-#pragma unroll
-      for (int jj = 0; jj < T::KJ; ++jj) {
-        const float4 v = *reinterpret_cast<const float4*>(yr + 8 * jj);
-        A[q][4 * jj + 0] = keep * v.x;
-        A[q][4 * jj + 1] = keep * v.y;
-        A[q][4 * jj + 2] = keep * v.z;
-        A[q][4 * jj + 3] = keep * v.w;
-      }
-    }
-  }
-
-  f32x16 acc[T::UPW];
-#pragma unroll
-  for (int j = 0; j < T::UPW; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  const int my_n = (wave % T::NT) * 32 + li;
-
-  const int cp = tid & 15;
-  const int strip = (tid >> 6) * 4 + (((lane >> 4) & 1) << 1 | (lane >> 5));   // see the forward kernel
-  const int sx = strip % TW, ys = (strip / TW) * T::ROWS;
-
-  // staging slots of the t2 chunk (tile + ring) and write-out slots (interior): byte offsets without the chunk term
-  unsigned ld_off[T::NLD], st_off[T::NST];
-#pragma unroll
-  for (int it = 0; it < T::NLD; ++it) {
-    const int e = tid + 256 * it, p = e >> 3, j = e & 7;
-    const int ry = p / T::RW, rx = p - ry * T::RW;
-    const int iy = y0 + ry - 1, ix = x0 + rx - 1;
-    const bool ok = p < T::NPX1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
-    ld_off[it] = ok ? (unsigned)(((img + (long)iy * a.Wd + ix) * a.ldt + (j < 4 ? 4 * j : hp + 4 * (j - 4))) * 4) : ~0u;
-  }
-#pragma unroll
-  for (int it = 0; it < T::NST; ++it) {
-    const int e = tid + 256 * it, p = e >> 3, j = e & 7;
-    const int py = p / TW, px = p - py * TW;
-    const int iy = y0 + py, ix = x0 + px;
-    const bool ok = p < T::NI && iy < a.H && ix < a.Wd;
-    st_off[it] = ok ? (unsigned)(((img + (long)iy * a.Wd + ix) * a.ldt + (j < 4 ? 4 * j : hp + 4 * (j - 4))) * 4) : ~0u;
-  }
-
-  // per-chunk weights; every group is reloaded into the SAME registers right after its last use, one phase ahead
-  float wo[C / 2];   // (a) B operand: W_out[k][c0 + li] for the 16 hidden channels of the chunk (lanes li >= 16: zero)
-  float wi[16];      // (c) B operand: W_in[row(k)][my_n], k over the 32 dt1 columns of the chunk
-  f32x2 wv[9];       // depthwise taps (x1 | x2 channel of the pair), flipped
-  auto load_wo = [&](int c0) {
-    const int cc = c0 + (li & 15);
-    const bool ok = li < 16 && cc < h;
-#pragma unroll
-    for (int s = 0; s < C / 2; ++s) {
-      const int k = 8 * (s >> 2) + 4 * h2 + (s & 3);
-      const float t = a.Wout[ok ? (long)k * h + cc : 0];
-      wo[s] = ok ? t : 0.f;
-    }
-  };
-  auto load_wi = [&](int c0) {
-#pragma unroll
-    for (int s = 0; s < 16; ++s) {
-      const int k = 8 * (s >> 2) + 4 * h2 + (s & 3);
-      const int cc = c0 + (k & 15);
-      const bool ok = cc < h && my_n < C;
-      const float t = a.Win[ok ? (long)(k < 16 ? cc : h + cc) * C + my_n : 0];
-      wi[s] = ok ? t : 0.f;
-    }
-  };
-  auto load_wd = [&](int c0) {
-    const int cc = c0 + cp;
-    const bool ok = cc < h;
-    const float* p1 = a.Wdw + (long)(ok ? cc : 0) * 9;
-    const float* p2 = a.Wdw + (long)(ok ? h + cc : 0) * 9;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float u1 = p1[8 - t], u2 = p2[8 - t];   // transposed conv: tap 8 - t
-      wv[t] = f32x2{ok ? u1 : 0.f, ok ? u2 : 0.f};
-    }
-  };
-  float4 t2n[T::NLD];
-  auto load_t2 = [&](int c0) {
-#pragma unroll
-    for (int it = 0; it < T::NLD; ++it) {
-      const bool ok = ld_off[it] != ~0u;
-      const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(a.T2) + (ok ? ld_off[it] + (unsigned)c0 * 4u : 0u));
-      t2n[it] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  };
-  auto put_t2 = [&]() {
-#pragma unroll
-    for (int it = 0; it < T::NLD; ++it) {
-      const int e = tid + 256 * it;
-      *reinterpret_cast<float4*>(T2s + (e >> 3) * T::S2 + 4 * (e & 7)) = t2n[it];
-    }
-  };
-  load_t2(0);
-  load_wo(0);
-  load_wd(0);
-  put_t2();
-
-  for (int c0 = 0; c0 < hp; c0 += 16) {
-    const int cn = c0 + 16 < hp ? c0 + 16 : c0;
-    load_wi(c0);   // used in (c): in flight across (a), (b1)
-
-    // ---- (a) dg chunk on tile + ring ----
-#pragma unroll
-    for (int q = 0; q < T::RTW; ++q) {
-      const int r = wave + 4 * q;
-      if (r < T::NRT1) {
-        f32x16 d;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) d[i] = 0.f;
-#pragma unroll
-        for (int s = 0; s < C / 2; ++s) d = uir_mfma(A[q][s], wo[s], d);
-        if (li < 16) {
-          float* dst = DGs + (r * 32 + 4 * h2) * T::SD + li;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::SD] = d[i];
-        }
-      }
-    }
-    load_wo(cn);   // next chunk's (a) operand, into the registers (a) just released
-    lds_barrier();
-
-    // ---- (b1) gate backward, in place over the staged t2 chunk (tile + ring) ----
-#pragma unroll 2
-    for (int i = 0; i < T::NRT1 * 2; ++i) {
-      const int p = strip + 16 * i;
-      const float dg = DGs[p * T::SD + cp];
-      float* tp = T2s + p * T::S2 + cp;
-      const float ta = tp[0], tb = tp[16];
-      float g, dgl;
-      uir_gelu_pair(ta, g, dgl);
-      tp[0] = dg * tb * dgl;
-      tp[16] = dg * g;
-    }
-    lds_barrier();
-
-    // the weights loaded a phase ago must be complete BEFORE this chunk's stores are issued (see the forward kernel)
-#pragma unroll
-    for (int s = 0; s < 16; ++s) pin(wi[s]);
-#pragma unroll
-    for (int s = 0; s < C / 2; ++s) pin(wo[s]);
-    // ---- dt2 write-out: interior rows of the LDS chunk, 16-byte stores ----
-#pragma unroll
-    for (int it = 0; it < T::NST; ++it)
-      if (st_off[it] != ~0u) {
-        const int e = tid + 256 * it, p = e >> 3;
-        const float4 v = *reinterpret_cast<const float4*>(T2s + ((p / TW + 1) * T::RW + p % TW + 1) * T::S2 + 4 * (e & 7));
-        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.DT2) + (st_off[it] + (unsigned)c0 * 4u)) = v;
-      }
-
-    // ---- (b2) transposed depthwise 3x3 of dt2 -> dt1 (interior) ----
-    {
-      const float* rp = T2s + (ys * T::RW + sx) * T::S2 + cp;
-      f32x2 rw[3][3];
-#pragma unroll
-      for (int rr = 0; rr < 3; ++rr)
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx)
-          rw[rr][dx] = f32x2{rp[(rr * T::RW + dx) * T::S2], rp[(rr * T::RW + dx) * T::S2 + 16]};
-      rp += 3 * T::RW * T::S2;
-      float* ddst = D1s + ((ys * TW + sx) * T::S1 + cp);
-      auto step = [&](f32x2 (&p0)[3], f32x2 (&p1)[3], f32x2 (&p2)[3]) {
-        f32x2 t = wv[0] * p0[0];
-        t = __builtin_elementwise_fma(wv[1], p0[1], t);
-        t = __builtin_elementwise_fma(wv[2], p0[2], t);
-#pragma unroll
-        for (int dx = 0; dx < 3; ++dx) p0[dx] = f32x2{rp[dx * T::S2], rp[dx * T::S2 + 16]};
-        rp += T::RW * T::S2;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-          t = __builtin_elementwise_fma(wv[3 + kx], p1[kx], t);
-          t = __builtin_elementwise_fma(wv[6 + kx], p2[kx], t);
-        }
-        ddst[0] = t.x;
-        ddst[16] = t.y;
-        ddst += TW * T::S1;
-      };
-#pragma unroll 1
-      for (int yb = 0; yb < T::ROWS; yb += 3) {
-        step(rw[0], rw[1], rw[2]);
-        if (yb + 1 < T::ROWS) step(rw[1], rw[2], rw[0]);
-        if (yb + 2 < T::ROWS) step(rw[2], rw[0], rw[1]);
-      }
-    }
-    lds_barrier();
-
-    load_t2(cn);    // the dt2 buffer is free: fetch the next chunk's t2 (lands during the write-out and (c))
-    load_wd(cn);    // next chunk's taps, into the registers (b2) just released
-    // ---- dt1 write-out ----
-#pragma unroll
-    for (int it = 0; it < T::NST; ++it)
-      if (st_off[it] != ~0u) {
-        const int e = tid + 256 * it;
-        const float4 v = *reinterpret_cast<const float4*>(D1s + (e >> 3) * T::S1 + 4 * (e & 7));
-        *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.DT1) + (st_off[it] + (unsigned)c0 * 4u)) = v;
-      }
-
-    // ---- (c) dT += dt1 . W_in over the 32 dt1 columns of the chunk ----
-#pragma unroll
-    for (int j = 0; j < T::UPW; ++j) {
-      const int u = wave + 4 * j;
-      if (u < T::UNITS) {
-        const int rt = u / T::NT;
-        const float* dr = D1s + (rt * 32 + li) * T::S1 + 4 * h2;
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const float4 v = *reinterpret_cast<const float4*>(dr + 8 * jj);
-          acc[j] = uir_mfma(v.x, wi[4 * jj + 0], acc[j]);
-          acc[j] = uir_mfma(v.y, wi[4 * jj + 1], acc[j]);
-          acc[j] = uir_mfma(v.z, wi[4 * jj + 2], acc[j]);
-          acc[j] = uir_mfma(v.w, wi[4 * jj + 3], acc[j]);
-        }
-      }
-    }
-    put_t2();
-    lds_barrier();   // dg of the next chunk overwrites the dt1 region
-  }
-
-  // ---- epilogue ----
-#pragma unroll
-  for (int j = 0; j < T::UPW; ++j) {
-    const int u = wave + 4 * j;
-    if (u < T::UNITS && my_n < C) {
-      const int rt = u / T::NT;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int p = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
-        const int iy = y0 + p / TW, ix = x0 + p % TW;
-        if (iy < a.H && ix < a.Wd) a.dT[(img + (long)iy * a.Wd + ix) * a.ldo + my_n] = acc[j][i];
-      }
-    }
-  }
-}
-
-template <int C, int TH, int TW>
-int gdfn_bwd_launch(const UirGdfnBwdArgs& a, hipStream_t st) {
-  using T = GdfnBwdTile<C, TH, TW>;
-  const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
-  hipLaunchKernelGGL((uir_gdfn_bwd_kernel<C, TH, TW>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
-  return uir_launch_status();
-}
-
 template <int C, int TH, int TW>
 int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
@@ -1208,21 +904,6 @@ extern "C" int uir_gdfn_fwd(const UirGdfnFwdArgs* p, void* stream) {
     case 64: return gdfn_fwd_launch<64, 8, 16>(a, st);
     case 128: return gdfn_fwd_launch<128, 8, 8>(a, st);
     default: return UIR_EINVAL;
-  }
-}
-
-extern "C" int uir_gdfn_bwd(const UirGdfnBwdArgs* p, void* stream) {
-  const UirGdfnBwdArgs& a = *p;
-  UIR_REQUIRE(a.dY && a.T2 && a.Wout && a.Wdw && a.Win && a.DT2 && a.DT1 && a.dT);
-  UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0 && a.h > 0 && a.hp >= a.h && (a.hp & 15) == 0);
-  UIR_REQUIRE(a.ldy >= a.C && (a.ldy & 3) == 0 && a.ldo >= a.C && uir_aligned16(a.dY));
-  UIR_REQUIRE(a.ldt >= 2 * a.hp && (a.ldt & 3) == 0 && uir_aligned16(a.T2) && uir_aligned16(a.DT2) && uir_aligned16(a.DT1));
-  UIR_REQUIRE((long)a.B * a.H * a.Wd * a.ldt < (1L << 30));
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (a.C) {
-    case 16: return gdfn_bwd_launch<16, 12, 16>(a, st);
-    case 32: return gdfn_bwd_launch<32, 12, 16>(a, st);
-    default: return UIR_EINVAL;   // wider levels: the per-lane W_out / dY operands alone exceed the register file
   }
 }
 

@@ -308,84 +308,6 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
   }
 }
 
-// LayerNorm-backward as the epilogue of the GEMM that produces the LayerNorm output's gradient (EPI_LN_BWD):
-//   dT = acc (never written), g = dT * gamma, xhat = (x - mean) * rstd,
-//   dX = rstd * (g - mean_c(g) - xhat * mean_c(g * xhat)) + dRes,   dgamma += dT * xhat,  dbeta += dT.
-// The accumulator layout has the channel on the lane and 16 pixels in registers: the two per-pixel means are
-// xor-shuffle sums inside each 32-lane half (plus the sum over the NT column tiles held by the same lane), and
-// dgamma / dbeta are plain per-lane sums over the registers.  Needs all N <= 96 channels in ONE workgroup.
-// operands of the LayerNorm-backward epilogue, issued before the last K chunk's MFMAs so they are in flight with them
-template <int NT>
-__device__ __forceinline__ void uir_gemm1x1_load_ln(const UirGemmArgs& a, float (&xl)[NT][16], float (&rl)[NT][16], float2 (&st)[16],
-                                                     int m0, int n0, int r, int h2) {
-  const long row0 = (long)min(m0, a.M - 32) + 4 * h2;
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) st[reg] = *reinterpret_cast<const float2*>(a.stats + (row0 + (reg & 3) + 8 * (reg >> 2)) * 2);
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + 32 * nt + r;
-    const int nn = n < a.N ? n : a.N - 1;
-    const float* xp = a.G + row0 * a.ldg + nn;
-    const float* rp = a.R ? a.R + row0 * a.ldr + nn : xp;
-    const long rld = a.R ? a.ldr : a.ldg;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const long dr = (reg & 3) + 8 * (reg >> 2);
-      xl[nt][reg] = xp[dr * a.ldg];
-      rl[nt][reg] = rp[dr * rld];
-    }
-  }
-}
-
-template <int NT>
-__device__ __forceinline__ void uir_gemm1x1_store_ln_bwd(const UirGemmArgs& a, const f32x16 (&acc)[NT], float (&dgam)[NT],
-                                                          float (&dbet)[NT], const float (&xl)[NT][16], const float (&rl)[NT][16],
-                                                          const float2 (&st)[16], int m0, int n0, int r, int h2) {
-  const float invc = 1.0f / (float)a.N;
-  const long row0 = (long)m0 + 4 * h2;
-  float s1[16], s2[16];
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) { s1[reg] = 0.f; s2[reg] = 0.f; }
-  float xh[NT][16], gd[NT][16];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + 32 * nt + r;
-    const bool nok = n < a.N;
-    const float gam = nok ? a.ln_g[nok ? n : 0] : 0.f;
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      xh[nt][reg] = nok ? (xl[nt][reg] - st[reg].x) * st[reg].y : 0.f;
-      gd[nt][reg] = acc[nt][reg] * gam;
-      s1[reg] += gd[nt][reg];
-      s2[reg] = fmaf(gd[nt][reg], xh[nt][reg], s2[reg]);
-    }
-  }
-#pragma unroll
-  for (int reg = 0; reg < 16; ++reg) {
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) {
-      s1[reg] += __shfl_xor(s1[reg], o);
-      s2[reg] += __shfl_xor(s2[reg], o);
-    }
-    s1[reg] *= invc;
-    s2[reg] *= invc;
-  }
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) {
-    const int n = n0 + 32 * nt + r;
-    const bool nok = n < a.N;
-    float* yp = a.Y + row0 * a.ldy + (nok ? n : a.N - 1);
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      float dx = st[reg].y * (gd[nt][reg] - s1[reg] - xh[nt][reg] * s2[reg]);
-      if (a.R) dx += rl[nt][reg];
-      if (nok) yp[(long)((reg & 3) + 8 * (reg >> 2)) * a.ldy] = dx;
-      dgam[nt] = fmaf(acc[nt][reg], xh[nt][reg], dgam[nt]);   // xhat is 0 on pad lanes
-      dbet[nt] += nok ? acc[nt][reg] : 0.f;
-    }
-  }
-}
-
 // Gate-backward epilogue that ALSO accumulates the project_out weight gradient (EPI_GATE_BWD_DW, K <= 32, full tiles):
 //   dW_out[c][j] = sum_px dY[px][c] * g[px][j],   g = gelu(t2a) * t2b  (computed here anyway).
 // The accumulator layout of the main MFMA (lane = hidden column j, register = pixel) IS the B-operand layout of a
@@ -438,7 +360,7 @@ __device__ __forceinline__ void uir_gemm1x1_store_gate_dw(const UirGemmArgs& a, 
 }
 
 template <int NT, int PRO, int EPI, bool HAS_R>
-__global__ __launch_bounds__(256, (EPI == UIR_EPI_GATE_BWD_DW || EPI == UIR_EPI_LN_BWD) ? 2 : 3) void uir_gemm1x1_kernel(const UirGemmArgs a, const int Kp, const int tiles) {
+__global__ __launch_bounds__(256, EPI == UIR_EPI_GATE_BWD_DW ? 2 : 3) void uir_gemm1x1_kernel(const UirGemmArgs a, const int Kp, const int tiles) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int r = lane & 31, h2 = lane >> 5;
@@ -601,11 +523,6 @@ __global__ __launch_bounds__(256, (EPI == UIR_EPI_GATE_BWD_DW || EPI == UIR_EPI_
 #pragma unroll
       for (int q = 0; q < 16; ++q) gacc[nt][q] = 0.f;
   }
-  float dgam[EPI == UIR_EPI_LN_BWD ? NT : 1], dbet[EPI == UIR_EPI_LN_BWD ? NT : 1];   // fused LayerNorm-backward sums
-  if constexpr (EPI == UIR_EPI_LN_BWD) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { dgam[nt] = 0.f; dbet[nt] = 0.f; }
-  }
 
   auto step = [&](float4 (&an)[4], float4 (&un)[NU], const bool anok, float4 (&nx)[4], float4 (&nu)[NU], bool& nxok) -> bool {
     const int m0 = tile * 128 + wave * 32;
@@ -680,12 +597,6 @@ __global__ __launch_bounds__(256, (EPI == UIR_EPI_GATE_BWD_DW || EPI == UIR_EPI_
     if constexpr (HAS_R) {
       if (last) uir_gemm1x1_load_res<NT>(a, rv, z, m0, n0, r, h2);
     }
-    constexpr int LNT = (EPI == UIR_EPI_LN_BWD) ? NT : 1, LNR = (EPI == UIR_EPI_LN_BWD) ? 16 : 1;
-    float lnx[LNT][LNR], lnr[LNT][LNR];
-    float2 lnst[LNR];
-    if constexpr (EPI == UIR_EPI_LN_BWD) {
-      if (last) uir_gemm1x1_load_ln<NT>(a, lnx, lnr, lnst, m0, n0, r, h2);
-    }
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int k0 = 32 * cin + 8 * s;
@@ -704,7 +615,6 @@ __global__ __launch_bounds__(256, (EPI == UIR_EPI_GATE_BWD_DW || EPI == UIR_EPI_
     }
     if (last && m0 < a.M) {
       if constexpr (EPI == UIR_EPI_GATE_BWD_DW) uir_gemm1x1_store_gate_dw<NT>(a, acc, gacc, m0, n0, r, h2);
-      else if constexpr (EPI == UIR_EPI_LN_BWD) uir_gemm1x1_store_ln_bwd<NT>(a, acc, dgam, dbet, lnx, lnr, lnst, m0, n0, r, h2);
       else uir_gemm1x1_store<NT, EPI, HAS_R>(a, acc, bias, rv, z, m0, n0, r, h2);
     }
     tile = tn;
@@ -716,30 +626,6 @@ __global__ __launch_bounds__(256, (EPI == UIR_EPI_GATE_BWD_DW || EPI == UIR_EPI_
     while (true) {
       if (!step(P0, U0, ok0, P1, U1, ok1)) break;
       if (!step(P1, U1, ok1, P0, U0, ok0)) break;
-    }
-  }
-  if constexpr (EPI == UIR_EPI_LN_BWD) {
-    // dgamma | dbeta of this workgroup: halves of a wave, then the 4 waves (fixed order), one slab row [2N]
-    __syncthreads();
-    float* red = wl;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const float g = dgam[nt] + __shfl_xor(dgam[nt], 32), b = dbet[nt] + __shfl_xor(dbet[nt], 32);
-      if (h2 == 0) {
-        red[(wave * 2 + 0) * (NT * 32) + nt * 32 + r] = g;
-        red[(wave * 2 + 1) * (NT * 32) + nt * 32 + r] = b;
-      }
-    }
-    __syncthreads();
-    float* slab = a.dw_slab + (long)blockIdx.x * a.dw_stride;
-    for (int e = threadIdx.x; e < 2 * NT * 32; e += 256) {
-      const int which = e / (NT * 32), col = e - which * (NT * 32);
-      const int n = n0 + col;
-      if (n < a.N) {
-        float sum = 0.f;
-        for (int w = 0; w < 4; ++w) sum += red[(w * 2 + which) * (NT * 32) + col];
-        slab[which * a.N + n] = sum;
-      }
     }
   }
   if constexpr (EPI == UIR_EPI_GATE_BWD_DW) {
@@ -785,12 +671,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   if (a.pro == UIR_PRO_GATE) UIR_REQUIRE((a.gate_off & 3) == 0 && a.ldx >= a.gate_off + ((a.K + 3) & ~3));
   if (a.epi == UIR_EPI_GATE_BWD) UIR_REQUIRE(a.G && a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N && !a.R);
   if (a.epi == UIR_EPI_LEAKY_BWD) UIR_REQUIRE(a.G && a.ldg >= a.N && !a.R);
-  if (a.epi == UIR_EPI_LN_BWD) {
-    // fused LayerNorm backward: every channel of a pixel in one workgroup (N <= 96), whole 128-row tiles
-    UIR_REQUIRE(a.G && a.ldg >= a.N && a.stats && a.ln_g && a.dw_slab && a.dw_stride >= 2L * a.N && !a.bias && a.act == UIR_ACT_NONE);
-    UIR_REQUIRE(a.N <= 96 && a.taps == 1 && a.batches == 1 && (a.M & 127) == 0 && a.pro == UIR_PRO_NONE && a.n_grp_pad <= 0);
-    UIR_REQUIRE(!a.R || a.ldr >= a.N);
-  }
+  UIR_REQUIRE(a.epi >= UIR_EPI_PLAIN && a.epi <= UIR_EPI_GATE_BWD_DW);
   if (a.epi == UIR_EPI_GATE_BWD_DW) {
     // fused dW_out: one column group (N <= 96), K <= 32 channels, whole 128-row tiles, pads only at the tail (N = hp)
     UIR_REQUIRE(a.G && a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N && !a.R && !a.bias && a.act == UIR_ACT_NONE);
@@ -879,14 +760,11 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // small problems (deep U-Net levels): favour many narrow column groups over A re-use - the
     // row panel is L2-resident there and parallelism is what is missing
     if ((long)((a.M + 127) / 128) * groups1 * a.batches < 1024) nt1 = 1;
-    if (a.epi == UIR_EPI_LN_BWD) nt1 = tiles;          // the row reductions need every channel in one workgroup
     while (nt1 > 1 && (size_t)nt1 * 32 * Kp * 4 > 60 * 1024) { --nt1; }
     groups1 = (tiles + nt1 - 1) / nt1;
-    if (a.epi == UIR_EPI_LN_BWD) UIR_REQUIRE(groups1 == 1 && tiles <= 3);
     // (a float4 epilogue through a per-wave LDS transpose was tried and measured slower: profiles/r01/d_ab_notes.md)
     size_t lds = (size_t)nt1 * 32 * Kp * 4 + (size_t)2 * K8 * 4 + (size_t)(nt1 * 32 + K8) * 4;
     if (a.epi == UIR_EPI_GATE_BWD_DW && lds < (size_t)nt1 * 1024 * 4) lds = (size_t)nt1 * 1024 * 4;   // 4-wave dW sum
-    if (a.epi == UIR_EPI_LN_BWD && lds < (size_t)8 * nt1 * 32 * 4) lds = (size_t)8 * nt1 * 32 * 4;
     const bool combo_ok = (a.pro == UIR_PRO_NONE) || (a.epi == UIR_EPI_PLAIN && !(a.pro == UIR_PRO_LN && a.R));
     if (lds <= 100 * 1024 && combo_ok) {
       const int rtiles = (a.M + 127) / 128;
@@ -896,7 +774,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
       // the variants with fused reductions run 2 workgroups per CU (launch bounds): 512 resident workgroups take all
       // the tiles, and every workgroup writes one slab row for uir_reduce_slab - no point in more rows than that
       constexpr int slab_rows = UIR_GEMM_SLAB_ROWS;
-      if ((a.epi == UIR_EPI_GATE_BWD_DW || a.epi == UIR_EPI_LN_BWD) && gx > slab_rows) gx = slab_rows;
+      if (a.epi == UIR_EPI_GATE_BWD_DW && gx > slab_rows) gx = slab_rows;
       if (gx > rtiles) gx = rtiles;
       dim3 grid1(gx, groups1, a.batches);
 #define UIR_L1(NTV, PROV, EPIV, RV) \
@@ -905,7 +783,6 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   do {                                                                              \
     if (a.epi == UIR_EPI_GATE_BWD) UIR_L1(NTV, PROV, UIR_EPI_GATE_BWD, false);      \
     else if (a.epi == UIR_EPI_GATE_BWD_DW) UIR_L1(NTV, PROV, UIR_EPI_GATE_BWD_DW, false); \
-    else if (a.epi == UIR_EPI_LN_BWD) UIR_L1(NTV, PROV, UIR_EPI_LN_BWD, false);       \
     else if (a.epi == UIR_EPI_LEAKY_BWD) UIR_L1(NTV, PROV, UIR_EPI_LEAKY_BWD, false); \
     else if (a.R) UIR_L1(NTV, PROV, UIR_EPI_PLAIN, true);                           \
     else UIR_L1(NTV, PROV, UIR_EPI_PLAIN, false);                                   \

@@ -514,8 +514,6 @@ class Recorder:
         if pro == L.PRO_LN:
             a.ln_g, a.ln_b = _ptr(ln[0]), _ptr(ln[1])
             a.stats = _ptr(stats)
-        if epi == L.EPI_LN_BWD:      # LayerNorm backward in the epilogue: gamma, the forward statistics, G = the LN input
-            a.ln_g, a.stats = _ptr(ln[0]), _ptr(stats)
         a.epi, a.g_off, a.act = epi, g_off, act
         if G is not None:
             a.G, a.ldg = _ptr(G), _ld(G)
@@ -706,35 +704,6 @@ class Recorder:
         assert V.shape[0] == rows and C_ in (16, 32, 64, 128)
         self.keep.append(a)
         self._op(name, lib.uir_attnv_fwd, C.byref(a), nbytes=rows * 4 * 5 * C_, flops=rows * (4 * C_ * C_ + 18 * C_))
-
-    def gdfn_bwd(self, name, dY, T2, Wout, Wdw, Win, DT2, DT1, dT, *, C_, h, hp, dims):
-        """Tile-fused GDFN input-gradient chain (csrc/gdfn.hip): dY -> dt2 -> dt1 -> gradient of the norm2 output."""
-        self._hold(dY, T2, Wout, Wdw, Win, DT2, DT1, dT)
-        a = L.GdfnBwdArgs()
-        a.dY, a.T2, a.Wout, a.Wdw, a.Win = _ptr(dY), _ptr(T2), _ptr(Wout), _ptr(Wdw), _ptr(Win)
-        a.DT2, a.DT1, a.dT = _ptr(DT2), _ptr(DT1), _ptr(dT)
-        a.ldy, a.ldt, a.ldo = _ld(dY), _ld(T2), _ld(dT)
-        a.B, a.H, a.Wd = dims
-        a.C, a.h, a.hp = C_, h, hp
-        rows = dims[0] * dims[1] * dims[2]
-        assert dY.shape[0] == rows and C_ in (16, 32) and hp % 16 == 0 and hp >= h
-        assert _ld(DT2) == _ld(T2) == _ld(DT1) and _ld(T2) >= 2 * hp
-        self.keep.append(a)
-        self._op(name, lib.uir_gdfn_bwd, C.byref(a), nbytes=rows * (8 * C_ + 24 * hp),
-                 flops=rows * (2 * C_ * hp + 18 * 2 * hp + 2 * 2 * hp * C_))
-
-    def gemm_ln_bwd(self, name, A, W, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_, K, k_grp=(0, 0)):
-        """dX = LayerNorm'(A . W) + dRes with the LayerNorm backward as the GEMM epilogue (the gradient of the LN output
-        never reaches HBM); dgamma / dbeta as per-workgroup slab rows, summed on the bulk lane."""
-        slab = torch.zeros(GEMM_SLAB_ROWS, 2 * C_, device=self.dev, dtype=torch.float32)   # rows past gridDim.x stay zero
-        self.gemm(name, A, W, dX, N=C_, K=K, w_sn=1, w_sk=C_, k_grp=k_grp, epi=L.EPI_LN_BWD, G=X, stats=stats,
-                  ln=(gamma, None), R=dRes, dw_slab=slab)
-        with self.bulk():
-            if dbeta.data_ptr() == dgamma.data_ptr() + 4 * C_:
-                self._reduce(name + ".dgb", _ptr(slab), GEMM_SLAB_ROWS, 2 * C_, _ptr(dgamma), 2 * C_)
-            else:
-                self._reduce(name + ".dg", _ptr(slab), GEMM_SLAB_ROWS, 2 * C_, _ptr(dgamma), C_)
-                self._reduce(name + ".db", slab.data_ptr() + 4 * C_, GEMM_SLAB_ROWS, 2 * C_, _ptr(dbeta), C_)
 
     def dwln_bwd(self, name, G, XP, Wdw, W1, X, stats, gamma, beta, dRes, dX, dWdw, dW1, dgamma, dbeta, *, C_, dims, h=0, hp=0, ch=0,
                  nblocks=512):
