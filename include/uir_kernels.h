@@ -23,7 +23,7 @@ extern "C" {
 /* ---------------------------------------------------------------- uir_gemm */
 enum { UIR_PRO_NONE = 0, UIR_PRO_LN = 1, UIR_PRO_GATE = 2 };
 #define UIR_GEMM_SLAB_ROWS 512   /* max workgroups (= slab rows) of the GEMM variants with fused reductions */
-enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2, UIR_EPI_GATE_BWD_DW = 3 };
+enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2, UIR_EPI_GATE_BWD_DW = 3, UIR_EPI_GELU_BWD = 4 };
 enum { UIR_ACT_NONE = 0, UIR_ACT_LEAKY = 1, UIR_ACT_GELU = 2 };   /* GELU: exact-erf form; plain epilogue only */
 
 /* Dense channel contraction over HWC rows, 1 or 9 (3x3, pad 1) taps:
@@ -59,6 +59,9 @@ typedef struct UirGemmArgs {
   float* dw_slab;      /* GATE_BWD_DW: per-workgroup partials [gridDim.x][dw_stride] of the project_out     */
   long dw_stride;      /* weight gradient dW[k][n] = sum_m X[m][k] * gate(G)[m][n], summed by uir_reduce_slab;*/
                        /* gridDim.x = min(M/128, UIR_GEMM_SLAB_ROWS).  Requires K <= 32, N <= 96, M % 128 == 0 */
+                       /* GELU_BWD: Y = (X.W^T) * gelu'(G + bias) (bias = the bias INSIDE the GELU, not added to the  */
+                       /* product) and per-workgroup column sums of Y to dw_slab rows: LeFF's Linear2 input gradient   */
+                       /* with the second GELU's backward and the depthwise bias gradient (src/model/block.py:240-246) */
   int tap0, ntap;      /* taps == 9 only: contract taps [tap0, tap0 + ntap) (ntap <= 0: all nine).  uir_gemm  */
                        /* itself uses this to run a 3x3 convolution whose weight panel exceeds LDS as a few   */
                        /* launches over tap groups that accumulate into Y (R = Y)                             */

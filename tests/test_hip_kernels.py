@@ -147,6 +147,25 @@ def test_gemm_leaky_bwd_epilogue():
     assert rel(out, want) < TOL
 
 
+@pytest.mark.parametrize("M,K,N", [(1000, 32, 128), (517, 64, 256), (256, 128, 96)])
+def test_gemm_gelu_bwd_epilogue_with_bias_gradient(M, K, N):
+    """out = (dy . W) * gelu'(u + b) and db = column sums of out: LeFF's Linear2 input gradient with the second GELU's backward
+    (src/model/block.py:240-246)"""
+    dy, w, u, b = rnd(M, K, seed=1), rnd(K, N, seed=2), rnd(M, N, seed=3, scale=2), rnd(N, seed=4)
+    ug = (u + b).requires_grad_(True)
+    (dgelu,) = torch.autograd.grad(F.gelu(ug).sum(), ug)
+    want = (dy @ w) * dgelu
+    r = rec()
+    out = r.alloc(M, N)
+    slab = torch.zeros(512, N, device=DEV)
+    db = r.alloc(N)
+    r.gemm("g", dev(dy), dev(w), out, N=N, K=K, w_sn=1, w_sk=N, epi=L.EPI_GELU_BWD, G=dev(u), bias=dev(b), dw_slab=slab)
+    r._reduce("db", slab.data_ptr(), 512, N, db.data_ptr(), N)
+    r.run(r.fwd)
+    assert rel(out, want) < TOL
+    assert rel(db, want.sum(0)) < TOL
+
+
 def test_gemm_per_batch_weights():
     B, HW, C = 3, 70, 32
     x, w, res = rnd(B * HW, 3 * C, seed=1), rnd(B, C, C, seed=2), rnd(B * HW, C, seed=3)

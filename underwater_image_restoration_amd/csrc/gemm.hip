@@ -308,6 +308,40 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
   }
 }
 
+// GELU-backward epilogue with the bias gradient (EPI_GELU_BWD; LeFF's Linear2 input gradient, src/model/block.py:240-246):
+//   out = acc * gelu'(G + bias),  db[n] += out  - the gradient of the depthwise output u and of the depthwise bias, given
+//   G = u and the gradient acc of gelu(u + bias).  One GELU evaluation per element, where the accumulator already sits.
+template <int NT>
+__device__ __forceinline__ void uir_gemm1x1_store_gelu_bwd(const UirGemmArgs& a, const f32x16 (&acc)[NT], const float (&biasv)[NT],
+                                                            float (&dbacc)[NT], int z, int m0, int n0, int r, int h2) {
+  const bool full = (m0 + 32 <= a.M);
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + 32 * nt + r;
+    if (n >= a.N) continue;
+    const long row0 = (long)m0 + 4 * h2;
+    float* yp = a.Y + (long)z * a.y_bs + row0 * a.ldy + n;
+    const float* gp = a.G + (long)z * a.g_bs + n;
+    float g1[16];
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {                       // all operand loads first (see uir_gemm1x1_store)
+      const long row = row0 + (reg & 3) + 8 * (reg >> 2);
+      g1[reg] = gp[(full || row < a.M ? row : (long)a.M - 1) * a.ldg];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int dr = (reg & 3) + 8 * (reg >> 2);
+      const float o = acc[nt][reg] * uir_gelu_grad(g1[reg] + biasv[nt]);
+      if (full || row0 + dr < a.M) {
+        yp[(long)dr * a.ldy] = o;
+        s += o;
+      }
+    }
+    dbacc[nt] += s;
+  }
+}
+
 // Gate-backward epilogue that ALSO accumulates the project_out weight gradient (EPI_GATE_BWD_DW, K <= 32, full tiles):
 //   dW_out[c][j] = sum_px dY[px][c] * g[px][j],   g = gelu(t2a) * t2b  (computed here anyway).
 // The accumulator layout of the main MFMA (lane = hidden column j, register = pixel) IS the B-operand layout of a
@@ -517,6 +551,9 @@ __global__ __launch_bounds__(256, EPI == UIR_EPI_GATE_BWD_DW ? 2 : 3) void uir_g
   float mean = 0.f, rstd = 0.f;
   f32x16 acc[NT];
   f32x16 gacc[EPI == UIR_EPI_GATE_BWD_DW ? NT : 1];   // fused weight-gradient accumulators (live across row tiles)
+  float dbacc[EPI == UIR_EPI_GELU_BWD ? NT : 1];       // fused bias-gradient sums (column = lane)
+#pragma unroll
+  for (int nt = 0; nt < (EPI == UIR_EPI_GELU_BWD ? NT : 1); ++nt) dbacc[nt] = 0.f;
   if constexpr (EPI == UIR_EPI_GATE_BWD_DW) {
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
@@ -615,6 +652,7 @@ __global__ __launch_bounds__(256, EPI == UIR_EPI_GATE_BWD_DW ? 2 : 3) void uir_g
     }
     if (last && m0 < a.M) {
       if constexpr (EPI == UIR_EPI_GATE_BWD_DW) uir_gemm1x1_store_gate_dw<NT>(a, acc, gacc, m0, n0, r, h2);
+      else if constexpr (EPI == UIR_EPI_GELU_BWD) uir_gemm1x1_store_gelu_bwd<NT>(a, acc, bias, dbacc, z, m0, n0, r, h2);
       else uir_gemm1x1_store<NT, EPI, HAS_R>(a, acc, bias, rv, z, m0, n0, r, h2);
     }
     tile = tn;
@@ -626,6 +664,22 @@ __global__ __launch_bounds__(256, EPI == UIR_EPI_GATE_BWD_DW ? 2 : 3) void uir_g
     while (true) {
       if (!step(P0, U0, ok0, P1, U1, ok1)) break;
       if (!step(P1, U1, ok1, P0, U0, ok0)) break;
+    }
+  }
+  if constexpr (EPI == UIR_EPI_GELU_BWD) {
+    // bias-gradient partials of this workgroup's columns: lane halves, then the 4 waves in a fixed order, one slab row
+    __syncthreads();
+    float* red = wl;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const float g = dbacc[nt] + __shfl_xor(dbacc[nt], 32);
+      if (h2 == 0) red[wave * (NT * 32) + nt * 32 + r] = g;
+    }
+    __syncthreads();
+    float* slab = a.dw_slab + (long)blockIdx.x * a.dw_stride;
+    for (int e = threadIdx.x; e < NT * 32; e += 256) {
+      const int n = n0 + e;
+      if (n < a.N) slab[n] = (red[e] + red[NT * 32 + e]) + (red[2 * NT * 32 + e] + red[3 * NT * 32 + e]);
     }
   }
   if constexpr (EPI == UIR_EPI_GATE_BWD_DW) {
@@ -671,7 +725,12 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   if (a.pro == UIR_PRO_GATE) UIR_REQUIRE((a.gate_off & 3) == 0 && a.ldx >= a.gate_off + ((a.K + 3) & ~3));
   if (a.epi == UIR_EPI_GATE_BWD) UIR_REQUIRE(a.G && a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N && !a.R);
   if (a.epi == UIR_EPI_LEAKY_BWD) UIR_REQUIRE(a.G && a.ldg >= a.N && !a.R);
-  UIR_REQUIRE(a.epi >= UIR_EPI_PLAIN && a.epi <= UIR_EPI_GATE_BWD_DW);
+  UIR_REQUIRE(a.epi >= UIR_EPI_PLAIN && a.epi <= UIR_EPI_GELU_BWD);
+  if (a.epi == UIR_EPI_GELU_BWD) {
+    // out = acc * gelu'(G + bias), per-workgroup column sums of out to dw_slab rows [gridDim.x][dw_stride]
+    UIR_REQUIRE(a.G && a.ldg >= a.N && a.bias && a.dw_slab && a.dw_stride >= a.N && !a.R && a.act == UIR_ACT_NONE);
+    UIR_REQUIRE(a.taps == 1 && a.batches == 1 && a.pro == UIR_PRO_NONE && a.n_grp_pad <= 0);
+  }
   if (a.epi == UIR_EPI_GATE_BWD_DW) {
     // fused dW_out: one column group (N <= 96), K <= 32 channels, whole 128-row tiles, pads only at the tail (N = hp)
     UIR_REQUIRE(a.G && a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N && !a.R && !a.bias && a.act == UIR_ACT_NONE);
@@ -765,6 +824,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // (a float4 epilogue through a per-wave LDS transpose was tried and measured slower: profiles/r01/d_ab_notes.md)
     size_t lds = (size_t)nt1 * 32 * Kp * 4 + (size_t)2 * K8 * 4 + (size_t)(nt1 * 32 + K8) * 4;
     if (a.epi == UIR_EPI_GATE_BWD_DW && lds < (size_t)nt1 * 1024 * 4) lds = (size_t)nt1 * 1024 * 4;   // 4-wave dW sum
+    if (a.epi == UIR_EPI_GELU_BWD && lds < (size_t)4 * nt1 * 32 * 4) lds = (size_t)4 * nt1 * 32 * 4;      // 4-wave bias-gradient sum
     const bool combo_ok = (a.pro == UIR_PRO_NONE) || (a.epi == UIR_EPI_PLAIN && !(a.pro == UIR_PRO_LN && a.R));
     if (lds <= 100 * 1024 && combo_ok) {
       const int rtiles = (a.M + 127) / 128;
@@ -774,7 +834,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
       // the variants with fused reductions run 2 workgroups per CU (launch bounds): 512 resident workgroups take all
       // the tiles, and every workgroup writes one slab row for uir_reduce_slab - no point in more rows than that
       constexpr int slab_rows = UIR_GEMM_SLAB_ROWS;
-      if (a.epi == UIR_EPI_GATE_BWD_DW && gx > slab_rows) gx = slab_rows;
+      if ((a.epi == UIR_EPI_GATE_BWD_DW || a.epi == UIR_EPI_GELU_BWD) && gx > slab_rows) gx = slab_rows;
       if (gx > rtiles) gx = rtiles;
       dim3 grid1(gx, groups1, a.batches);
 #define UIR_L1(NTV, PROV, EPIV, RV) \
@@ -784,6 +844,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     if (a.epi == UIR_EPI_GATE_BWD) UIR_L1(NTV, PROV, UIR_EPI_GATE_BWD, false);      \
     else if (a.epi == UIR_EPI_GATE_BWD_DW) UIR_L1(NTV, PROV, UIR_EPI_GATE_BWD_DW, false); \
     else if (a.epi == UIR_EPI_LEAKY_BWD) UIR_L1(NTV, PROV, UIR_EPI_LEAKY_BWD, false); \
+    else if (a.epi == UIR_EPI_GELU_BWD) UIR_L1(NTV, PROV, UIR_EPI_GELU_BWD, false);   \
     else if (a.R) UIR_L1(NTV, PROV, UIR_EPI_PLAIN, true);                           \
     else UIR_L1(NTV, PROV, UIR_EPI_PLAIN, false);                                   \
   } while (0)
@@ -805,6 +866,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     }
   }
   UIR_REQUIRE(a.ntap <= 0);          // tap ranges exist only on the LDS-panel path above
+  UIR_REQUIRE(a.epi != UIR_EPI_GELU_BWD);   // ... and so does the GELU-backward epilogue (the caller keeps K <= 128)
   const int groups = (tiles + 3) / 4;
   const int nt = (tiles + groups - 1) / groups;
   dim3 grid((a.M + 127) / 128, groups, a.batches), block(256);

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib as L
-from ..engine import FlatParams, Recorder, _ptr, _ld
+from ..engine import GEMM_SLAB_ROWS, FlatParams, Recorder, _ptr, _ld
 import ctypes as C
 
 lib = L.lib
@@ -192,10 +192,20 @@ def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
         with rec.bulk():
             rec.gram(n + "linear2.dW", dy, g, Gr("linear2.0.weight"), N=C_, K=hid, o_sn=hid, o_sk=1)
             _colsum_wide(rec, n + "linear2.db", dy, C_, Gr("linear2.0.bias"))
-        rec.gemm(n + "linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
-        # gelu'(u + b) on the way in, conv^T, gelu'(pre) on the way out: reads dg, u, pre, writes d(pre) - and all three small gradients
-        _dwconv_bwd_wide(rec, n + "gelu.bwd+dwconv.bwd+gelu.bwd", dg, pre, Wdw, dpre, Gr("dwconv.0.weight"), hid, dims, act=1,
-                         dbias=Gr("linear1.0.bias"), gate_u=u, gate_bias=bdw, dbias_gate=Gr("dwconv.0.bias"))
+        if C_ <= 128:
+            # the byte-heavy levels: the second GELU's backward (and the depthwise bias gradient) as the epilogue of Linear2's input
+            # gradient - one GELU evaluation per element where the accumulator already sits - then conv^T and gelu'(pre) on store
+            slab = torch.zeros(GEMM_SLAB_ROWS, hid, device=rec.dev, dtype=torch.float32)     # rows past gridDim.x stay zero
+            rec.gemm(n + "linear2.dX+gelu.bwd", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid, epi=L.EPI_GELU_BWD, G=u, bias=bdw, dw_slab=slab)
+            with rec.bulk():
+                rec._reduce(n + "dwconv.db", _ptr(slab), GEMM_SLAB_ROWS, hid, _ptr(Gr("dwconv.0.bias")), hid)
+            _dwconv_bwd_wide(rec, n + "dwconv.bwd+gelu.bwd", dg, pre, Wdw, dpre, Gr("dwconv.0.weight"), hid, dims, act=1,
+                             dbias=Gr("linear1.0.bias"))
+        else:
+            rec.gemm(n + "linear2.dX", dy, W2, dg, N=hid, K=C_, w_sn=1, w_sk=hid)
+            # wide levels (Linear2 on the LDS-tiled kernel): gelu'(u + b) on the way into the depthwise backward instead
+            _dwconv_bwd_wide(rec, n + "gelu.bwd+dwconv.bwd+gelu.bwd", dg, pre, Wdw, dpre, Gr("dwconv.0.weight"), hid, dims, act=1,
+                             dbias=Gr("linear1.0.bias"), gate_u=u, gate_bias=bdw, dbias_gate=Gr("dwconv.0.bias"))
         with rec.bulk():
             rec.gram(n + "linear1.dW", dpre, x, Gr("linear1.0.weight"), N=hid, K=C_, o_sn=C_, o_sk=1)
         rec.gemm(n + "linear1.dX", dpre, W1, dx, N=C_, K=hid, w_sn=1, w_sk=C_)
