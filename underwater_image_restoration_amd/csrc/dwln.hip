@@ -24,6 +24,7 @@
 // and the tile ends with the LayerNorm backward on the dT accumulators (channel on the lane: row means by xor-shuffles).
 // Partial sums leave as one slab row per workgroup (fixed summation order everywhere: bitwise run-to-run).
 #include "uir_common.h"
+#include <type_traits>
 #include "../../include/uir_kernels.h"
 
 namespace {
@@ -90,7 +91,7 @@ struct DwLn {
   int t_ = threadIdx.x;                                                                                                   \
   asm volatile("" : "+v"(t_));                                                                                            \
   const int lane = t_ & 63, wave = __builtin_amdgcn_readfirstlane(t_ >> 6), li = lane & 31, h2 = lane >> 5;              \
-  const int cp = t_ & 15, sx = wave * 4 + ((((lane >> 4) & 1) << 1) | (lane >> 5));                                       \
+  const int cp = lane >> 2, sx = wave * 4 + (lane & 3);    /* a wave's four strips of a channel pair = one lane quad */        \
   const int l16 = lane & 15, j16 = lane >> 4;                                                                             \
   const int gr_k = (T::NG == 4) ? (wave >> 1) : (wave & 1), gr_n = (T::NG == 4) ? (wave & 1) : 0;                         \
   const int part = (T::NG == 4) ? 0 : (wave >> 1), n16 = 16 * gr_n + l16;                                                 \
@@ -242,14 +243,26 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       const bool colok = x0 + sx < a.Wd;
       const bool last = ci + 1 == NCH;
       const int cn = last ? 0 : ci + 1;                      // next unit: chunk ci + 1 of this tile, or chunk 0 of the next tile
+      // `plain` (uniform): the tile's ring lies inside the image and all 32 channels of the chunk exist - 2/3 of the (tile, chunk) units
+      // at 256 x 256, C = 32.  No value needs masking there: the masks below (~90 VALU per chunk) are skipped
+      const bool plain = y0 >= 1 && x0 >= 1 && y0 + T::TH + 1 <= a.H && x0 + T::TW + 1 <= a.Wd &&
+                         (SPLIT ? 16 * ci + 16 <= h : 32 * ci + 32 <= ch);
       // ---- (a) this chunk's G (tile + ring) -> LDS ----
+      if (plain) {
 #pragma unroll
-      for (int it = 0; it < T::NLD; ++it) {
-        const int e = t_ + 256 * it;
-        const float k = (goff[it] != ~0u && g_col(ci, e) + 4 <= chcols) ? 1.f : 0.f;
-        *reinterpret_cast<float4*>(GS1 + (e >> 3) * T::S1 + 4 * (e & 7)) = make_float4(gv[it].x * k, gv[it].y * k, gv[it].z * k, gv[it].w * k);
-      }
-      {
+        for (int it = 0; it < T::NLD; ++it) {
+          const int e = t_ + 256 * it;
+          *reinterpret_cast<float4*>(GS1 + (e >> 3) * T::S1 + 4 * (e & 7)) = gv[it];       // (rows >= NPX1: unused filler)
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wf[t] = wf_n[t];
+      } else {
+#pragma unroll
+        for (int it = 0; it < T::NLD; ++it) {
+          const int e = t_ + 256 * it;
+          const float k = (goff[it] != ~0u && g_col(ci, e) + 4 <= chcols) ? 1.f : 0.f;
+          *reinterpret_cast<float4*>(GS1 + (e >> 3) * T::S1 + 4 * (e & 7)) = make_float4(gv[it].x * k, gv[it].y * k, gv[it].z * k, gv[it].w * k);
+        }
         const f32x2 wm = f32x2{okA(ci, cp) ? 1.f : 0.f, okB(ci, cp) ? 1.f : 0.f};
 #pragma unroll
         for (int t = 0; t < 9; ++t) wf[t] = wf_n[t] * wm;
@@ -257,13 +270,27 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       lds_barrier2();
       // issue order = need order (vmcnt retires in order): this chunk's 1x1 weights now (used after the walk); the next chunk's
       // G, XP and depthwise taps after the walk, when its window / tap / accumulator registers are free - they land during (c), (d)
-      float w1v[16];                                        // (c) B operand: W1[row of k-slot 8 jj + 4 h2 + e][n = li], raw
+      // (c) B operand: W1[row of k-slot 8 jj + 4 h2 + e][n = li].  k-slots 0..15 are channels i = 8 (jj & 1) + 4 h2 + e of group A,
+      // 16..31 the same i of group B: a uniform row base per group + one per-lane offset + compile-time immediates.  Rows past the
+      // real channel count (last chunk only) are re-pointed at row 0: their dP is exactly zero (masked taps), any finite weight does.
+      float w1v[16];
+      {
+        const int baseA = SPLIT ? 16 * ci : 32 * ci, baseB = SPLIT ? h + 16 * ci : 32 * ci + 16;
+        const int limA = SPLIT ? h - 16 * ci : ch - 32 * ci, limB = SPLIT ? limA : limA - 16;       // valid channels i < lim
+        const float* wA = a.W1 + (size_t)(unsigned)(baseA * C);                                       // uniform: scalar bases
+        const float* wB = a.W1 + (size_t)(unsigned)(baseB * C);
+        const unsigned lo = (unsigned)(4 * h2 * C + (li < C ? li : C - 1)) * 4u;
+        if (limA >= 16 && limB >= 16) {
 #pragma unroll
-      for (int s = 0; s < 16; ++s) {
-        const int kk = 8 * (s >> 2) + 4 * h2 + (s & 3);
-        const bool ok = li < C && (kk < 16 ? okA(ci, kk) : okB(ci, kk - 16));
-        const int row = kk < 16 ? rowA(ci, kk) : rowB(ci, kk - 16);
-        w1v[s] = ldg_off(a.W1, ok ? (unsigned)(row * C + li) * 4u : 0u);
+          for (int s = 0; s < 16; ++s) w1v[s] = ldg_off(s < 8 ? wA : wB, lo + (unsigned)((8 * ((s >> 2) & 1) + (s & 3)) * C) * 4u);
+        } else {
+#pragma unroll
+          for (int s = 0; s < 16; ++s) {
+            const int i = 8 * ((s >> 2) & 1) + 4 * h2 + (s & 3);
+            const bool ok = i < (s < 8 ? limA : limB);
+            w1v[s] = ldg_off(ok ? (s < 8 ? wA : wB) : a.W1, ok ? lo + (unsigned)((8 * ((s >> 2) & 1) + (s & 3)) * C) * 4u : 0u);
+          }
+        }
       }
       const f32x2 xm = f32x2{colok && colA(ci) + cp < chcols ? 1.f : 0.f, colok && colB(ci) + cp < chcols ? 1.f : 0.f};
       // the next unit's G rows (24 of the ~40 KB a chunk moves per workgroup) leave NOW, behind w1v in issue order: their registers
@@ -279,7 +306,8 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       f32x2 dwa[9];
 #pragma unroll
       for (int t = 0; t < 9; ++t) dwa[t] = f32x2{0.f, 0.f};
-      {
+      auto walk = [&](auto plain_c) {
+        constexpr bool PL = decltype(plain_c)::value;
         const float* rp = GS1 + sx * T::S1 + cp;
         f32x2 rw[3][3];
 #pragma unroll
@@ -289,7 +317,9 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
             rw[rr][dx] = f32x2{rp[(rr * T::RW + dx) * T::S1], rp[(rr * T::RW + dx) * T::S1 + 16]};
         rp += 3 * T::RW * T::S1;
         float* gdst = Gs + sx * T::SG + cp;
-        auto step = [&](f32x2 (&p0)[3], f32x2 (&p1)[3], f32x2 (&p2)[3], const f32x2 xc, const float keep) {
+        auto step = [&](f32x2 (&p0)[3], f32x2 (&p1)[3], f32x2 (&p2)[3], const int y) {
+          const float keep = PL ? 1.f : ((colok && y < nrows) ? 1.f : 0.f);
+          const f32x2 xc = PL ? xpv[y] : xpv[y] * (xm * keep);
           f32x2 t = wf[0] * p0[0];
           t = __builtin_elementwise_fma(wf[1], p0[1], t);
           t = __builtin_elementwise_fma(wf[2], p0[2], t);
@@ -306,27 +336,30 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
             dwa[3 + kx] = __builtin_elementwise_fma(xc, p1[kx], dwa[3 + kx]);
             dwa[6 + kx] = __builtin_elementwise_fma(xc, p2[kx], dwa[6 + kx]);
           }
-          gdst[0] = t.x * keep;                             // pixels outside the image contribute nothing to dW1 / dT
-          gdst[16] = t.y * keep;
+          gdst[0] = PL ? t.x : t.x * keep;                  // pixels outside the image contribute nothing to dW1 / dT
+          gdst[16] = PL ? t.y : t.y * keep;
           gdst += T::TW * T::SG;
         };
-        auto keep_of = [&](int y) { return (colok && y < nrows) ? 1.f : 0.f; };
-        step(rw[0], rw[1], rw[2], xpv[0] * (xm * keep_of(0)), keep_of(0));
-        step(rw[1], rw[2], rw[0], xpv[1] * (xm * keep_of(1)), keep_of(1));
-        step(rw[2], rw[0], rw[1], xpv[2] * (xm * keep_of(2)), keep_of(2));
-        step(rw[0], rw[1], rw[2], xpv[3] * (xm * keep_of(3)), keep_of(3));
-        step(rw[1], rw[2], rw[0], xpv[4] * (xm * keep_of(4)), keep_of(4));
-        step(rw[2], rw[0], rw[1], xpv[5] * (xm * keep_of(5)), keep_of(5));
-        step(rw[0], rw[1], rw[2], xpv[6] * (xm * keep_of(6)), keep_of(6));
-        step(rw[1], rw[2], rw[0], xpv[7] * (xm * keep_of(7)), keep_of(7));
-      }
+        step(rw[0], rw[1], rw[2], 0);
+        step(rw[1], rw[2], rw[0], 1);
+        step(rw[2], rw[0], rw[1], 2);
+        step(rw[0], rw[1], rw[2], 3);
+        step(rw[1], rw[2], rw[0], 4);
+        step(rw[2], rw[0], rw[1], 5);
+        step(rw[0], rw[1], rw[2], 6);
+        step(rw[1], rw[2], rw[0], 7);
+      };
+      if (plain) walk(std::true_type{});
+      else walk(std::false_type{});
       load_xp(cn, cp, sx, last ? tn : tc);
       load_wf(cn, cp);
-      // sum over the wave's four strips (lanes cp, cp + 16, cp + 32, cp + 48), then one row per wave in LDS
+      // sum over the wave's four strips = the four lanes of a quad: two DPP adds per value (quad_perm [1,0,3,2], [2,3,0,1]); the strips
+      // on lanes 16 apart needed a v_permlane16_swap + v_permlane32_swap pair with its register copies (~110 VALU per chunk instead
+      // of ~40).  Then one row per wave in LDS
 #pragma unroll
       for (int t = 0; t < 9; ++t) {
-        const float vx = swap32_sum(swap16_sum(dwa[t].x)), vy = swap32_sum(swap16_sum(dwa[t].y));
-        if (lane < 16) {
+        const float vx = dpp_add<0x4E>(dpp_add<0xB1>(dwa[t].x)), vy = dpp_add<0x4E>(dpp_add<0xB1>(dwa[t].y));
+        if ((lane & 3) == 0) {
           WR[(wave * 16 + cp) * 18 + t] = vx;
           WR[(wave * 16 + cp) * 18 + 9 + t] = vy;
         }
@@ -342,11 +375,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         for (int jj = 0; jj < 4; ++jj) {
           const f32x4v v = *reinterpret_cast<const f32x4v*>(gr + 8 * jj);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int kk = 8 * jj + 4 * h2 + e;
-            const float m = (li < C && (kk < 16 ? okA(ci, kk) : okB(ci, kk - 16))) ? 1.f : 0.f;
-            acc = uir_mfma(v[e], w1v[4 * jj + e] * m, acc);
-          }
+          for (int e = 0; e < 4; ++e) acc = uir_mfma(v[e], w1v[4 * jj + e], acc);
         }
       }
       // ---- (d) dW1 chunk granule += dP^T . (xhat gamma + beta) over this wave's pixels.  k-slot j of step s is pixel
