@@ -34,6 +34,8 @@ def source_sha() -> str:
     import hashlib
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
     files += [os.path.join(HERE, "..", "include", "uir_kernels.h"), os.path.join(HERE, "engine.py")]
+    # ... and the launch-plan recorders of the module networks (their bench lines quote traffic files under the same rule)
+    files += [os.path.join(HERE, "model", "block.py"), os.path.join(HERE, "model", "model.py"), os.path.join(HERE, "Models", "AST.py")]
     h = hashlib.sha256()
     for f in files:
         h.update(os.path.basename(f).encode())

@@ -120,7 +120,7 @@ def _colsum_wide(rec, name, src, cols, out):
         rec.colsum(f"{name}[{c0}]", src, c0, n, out[c0:c0 + n])
 
 
-def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims):
+def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims, owns_input: bool = False):
     """Record FRFN.forward (block.py:262-282) on token rows x [M, dim] into `rec` (parameters `pfx + name` of rec.fp).
     Returns (y, backward) with backward(dy) -> dx recording the backward launches."""
     B, H, W = dims
@@ -130,12 +130,21 @@ def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     Wdw, bdw = P("dwconv.0.weight"), P("dwconv.0.bias")
     W2, b2 = P("linear2.0.weight"), P("linear2.0.bias")
     Wpc = P("partial_conv3.weight")
-    xc, pre = rec.alloc(M, C_), rec.alloc(M, 2 * hid)
+    pre = rec.alloc(M, 2 * hid)
     u, g, y = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
     n = pfx
-    # partial_conv3 on channels [0, C/4), the rest passes through (block.py:267-270)
-    rec.copy_cols(n + "pc3.pass", x, c4, xc, c4, C_ - c4)
-    rec.gemm(n + "pc3", x[:, :c4], Wpc, xc[:, :c4], N=c4, K=c4, w_sn=c4 * 9, w_sk=9, w_st=1, taps=9, hw=(H, W))
+    # partial_conv3 on channels [0, C/4), the rest passes through (block.py:267-270).  owns_input (the caller's x is a private
+    # intermediate nothing else reads - a LayerNorm / FFT output, a plan's input copy): the convolution result REPLACES columns
+    # [0, C/4) of x, read from a copy of just those columns - a quarter of the bytes of copying the pass-through three quarters
+    if owns_input:
+        xq = rec.alloc(M, c4)
+        rec.copy_cols(n + "pc3.in", x, 0, xq, 0, c4)
+        rec.gemm(n + "pc3", xq, Wpc, x[:, :c4], N=c4, K=c4, w_sn=c4 * 9, w_sk=9, w_st=1, taps=9, hw=(H, W))
+        xc = x
+    else:
+        xq, xc = x[:, :c4], rec.alloc(M, C_)
+        rec.copy_cols(n + "pc3.pass", x, c4, xc, c4, C_ - c4)
+        rec.gemm(n + "pc3", xq, Wpc, xc[:, :c4], N=c4, K=c4, w_sn=c4 * 9, w_sk=9, w_st=1, taps=9, hw=(H, W))
     # Linear1's output is stored once, as the pre-activation: the GELU of its x1 half is applied by the depthwise kernel on load, that
     # of its x2 half by the gate kernel, and both backward GELUs (and Linear1's bias gradient) happen where the gradient is produced -
     # 22 hidden-wide passes per FRFN instead of 30
@@ -145,7 +154,6 @@ def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
 
     def backward(dy: torch.Tensor) -> torch.Tensor:
-        dx = rec.alloc(M, C_)
         dg, du = rec.alloc(M, hid), rec.alloc(M, hid)
         dpre, dxc = rec.alloc(M, 2 * hid), rec.alloc(M, C_)
         db1 = Gr("linear1.0.bias")
@@ -160,16 +168,17 @@ def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
         with rec.bulk():
             rec.gram(n + "linear1.dW", dpre, xc, Gr("linear1.0.weight"), N=2 * hid, K=C_, o_sn=C_, o_sk=1)
         rec.gemm(n + "linear1.dX", dpre, W1, dxc, N=C_, K=2 * hid, w_sn=1, w_sk=C_)
-        rec.copy_cols(n + "pc3.pass.bwd", dxc, c4, dx, c4, C_ - c4)
+        # the pass-through three quarters of dxc ARE the input gradient; only the convolved quarter is replaced (from a copy of it)
+        dq = rec.alloc(M, c4)
+        rec.copy_cols(n + "pc3.dY", dxc, 0, dq, 0, c4)
         with rec.bulk():
-            rec.gram(n + "pc3.dW", dxc[:, :c4], x[:, :c4], Gr("partial_conv3.weight"), N=c4, K=c4, o_sn=c4 * 9, o_sk=9, o_st=1,
-                     taps=9, hw=(H, W))
-        rec.gemm(n + "pc3.dX", dxc[:, :c4], Wpc, dx[:, :c4], N=c4, K=c4, w_sn=9, w_sk=c4 * 9, w_st=1, taps=9, flip=1, hw=(H, W))
-        return dx
+            rec.gram(n + "pc3.dW", dq, xq, Gr("partial_conv3.weight"), N=c4, K=c4, o_sn=c4 * 9, o_sk=9, o_st=1, taps=9, hw=(H, W))
+        rec.gemm(n + "pc3.dX", dq, Wpc, dxc[:, :c4], N=c4, K=c4, w_sn=9, w_sk=c4 * 9, w_st=1, taps=9, flip=1, hw=(H, W))
+        return dxc
     return y, backward
 
 
-def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims):
+def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims, owns_input: bool = False):   # (owns_input: unused, same call shape as record_frfn)
     """Record LeFF.forward (block.py:234-247): Linear C -> hidden + GELU, depthwise 3x3 + bias + GELU, Linear hidden -> C."""
     B, H, W = dims
     M, C_ = B * H * W, dim
@@ -458,7 +467,7 @@ def record_decoder_block(rec: Recorder, pfx: str, xcat: torch.Tensor, dim: int, 
     y = _add_rows(rec, n + "res1", m, xcat, mdim)
     x2, n2_bw = record_layernorm(rec, n + "norm2.", y, mdim)
     mlp = record_frfn if token_mlp == "frfn" else record_leff
-    x3, mlp_bw = mlp(rec, n + "mlp.", x2, mdim, 4 * mdim, dims)
+    x3, mlp_bw = mlp(rec, n + "mlp.", x2, mdim, 4 * mdim, dims, owns_input=True)        # x2 = norm2's output: nothing else reads it
     x4 = _add_rows(rec, n + "res2", y, x3, mdim)
     Wp, bp = rec.P(n + "mlp_proj.weight"), rec.P(n + "mlp_proj.bias")
     out = rec.alloc(M, dim)
@@ -632,7 +641,7 @@ class FrfnPlan(TokenPlan):
         super().__init__(fp, dim, B, H, W, want_backward)
 
     def _record(self, x):
-        return record_frfn(self, "", x, self.dim, self.hidden, (self.B, self.H, self.W))
+        return record_frfn(self, "", x, self.dim, self.hidden, (self.B, self.H, self.W), owns_input=True)   # x = the plan's input copy
 
 
 class LeffPlan(TokenPlan):

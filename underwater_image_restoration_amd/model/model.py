@@ -128,9 +128,9 @@ class EncoderPlan(TokenPlan):
         self._hold(g1, b1)
         self._op("norm1", lib.uir_layernorm_fwd, _ptr(x), C_, _ptr(g1), _ptr(b1), _ptr(xn), C_, _ptr(stats), M, C_, 1e-5,
                  nbytes=8 * M * C_)
-        x1, bw1 = _MLP_RECORDERS[self.token_mlp](self, "mlp.", xn, C_, self.hidden, dims)
+        x1, bw1 = _MLP_RECORDERS[self.token_mlp](self, "mlp.", xn, C_, self.hidden, dims, owns_input=True)     # xn, f1: private intermediates
         f1 = record_token_fft(self, "fftn", x1, dims, C_, 1.0)
-        f2, bw2 = _MLP_RECORDERS[self.freq_mlp](self, "freq_mlp.", f1, C_, self.hidden, dims)
+        f2, bw2 = _MLP_RECORDERS[self.freq_mlp](self, "freq_mlp.", f1, C_, self.hidden, dims, owns_input=True)
         f3 = record_token_fft(self, "ifftn", f2, dims, C_, 1.0 / (Ltok * C_))
         # x = shortcut + drop_path2(freq_x) + drop_path(x)  (model.py:91): per-sample factors (1 in eval mode / for drop_path 0)
         self.dp_scale = self.alloc(2, self.B)          # row 0: drop_path2 (frequency branch), row 1: drop_path (token branch)
