@@ -405,7 +405,13 @@ enum { UIR_LOSS_L1 = 0, UIR_LOSS_L2 = 1, UIR_LOSS_CHARBONNIER = 2, UIR_LOSS_LUMI
        UIR_LOSS_LUM_CHARBONNIER = 5, /* "LuminanceCharbonnier" = LuminanceLoss + CharbonnierLoss, losses.py:118-123 */
        UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER = 6, /* "AdaptiveLuminanceCharbonnier", losses.py:130-140: 0.5 * softmax(-log(losses + 1e-6))
                                                * weights (detached) over (Charbonnier, Luminance) */
-       UIR_LOSS_GRADIENT = 7 /* "gradient" = Gradient_Loss, losses.py:162-181: L1 between the valid 3x3 Laplacians of pred and truth */ };
+       UIR_LOSS_GRADIENT = 7, /* "gradient" = Gradient_Loss, losses.py:162-181: L1 between the valid 3x3 Laplacians of pred and truth */
+       /* with FocalFrequencyLoss(loss_weight 1, alpha 1) terms (losses.py:45-46; the focal_frequency_loss package is not vendored and
+        * not in the image: its published algorithm - v0.3.0, patch_factor 1, ave_spectrum / log_matrix / batch_matrix False - is
+        * restated by the uir_ffl_* kernels below, PARITY UNPINNED); the FFL mean is read from sums[6] */
+       UIR_LOSS_FFL_CHARBONNIER = 8,      /* "fflCharbonnier" = ffl + charbonnier (:97-98) */
+       UIR_LOSS_LUM_FFL = 9,              /* "LuminanceFFL" = ffl + luminance (:148-151) */
+       UIR_LOSS_ADAPTIVE_LUM_FFL = 10     /* "AdaptiveLuminanceFFL" (:137-147): the adaptive pair of kind 6 with ffl in place of charbonnier */ };
 /* Partial sums over NCHW [B,3,H,W] pred/truth: slab[block][8] =
  * (sum|d|, sum d^2, sum sqrt(d^2+1e-6), sum lum^2, sum (clamp01(p)-clamp01(t))^2, 0,0,0).
  * Replaces nn.L1Loss / MSELoss / CharbonnierLoss / ColorLoss / LuminanceLoss
@@ -425,6 +431,19 @@ int uir_loss_bwd(const float* pred, const float* truth, const float* gscale, con
 int uir_gradloss_partials(const float* pred, const float* truth, float* slab, int nblocks, int B, int H, int Wd, void* stream);
 /* dpred = gscale[0] / (B*3*(H-2)*(W-2)) * lap^T(sign(lap(pred - truth))) */
 int uir_gradloss_bwd(const float* pred, const float* truth, const float* gscale, float* dpred, int B, int H, int Wd, void* stream);
+/* FocalFrequencyLoss pieces around the 2-D DFT (which the host runs with uir_dft_axis* on HWC4 rows; ortho-normalised):
+ *   uir_ffl_diff           d4[b][p][c] = pred[b][c][p] - truth[b][c][p] (c < 3), 0 in the pad channel: NCHW3 -> HWC4
+ *   uir_ffl_max            mx2[b][c] = max_p |D[b][p][c]|^2 (slab: [B][nblk][4] scratch)
+ *   uir_ffl_partials       slab[b * nblk + k] = partial sums of w |D|^2, w = |D| / sqrt(mx2) (0 where mx2 = 0: the package's
+ *                          NaN -> 0), i.e. FFL = sum / (B 3 HW) - the spectrum weight matrix is detached in the package
+ *   uir_ffl_spectrum_grad  G = coef * gscale[0] * (wdev ? wdev[0] : 1) * w * conj(D): its DFT (same sign) real part is dFFL/dd
+ *   uir_ffl_add_grad       dpred[b][c][p] (+)= dd4[b][p][c]: HWC4 -> NCHW3 */
+int uir_ffl_diff(const float* pred, const float* truth, float* d4, int B, int HW, void* stream);
+int uir_ffl_max(const float* Dr, const float* Di, float* mx2, float* slab, int nblk, int B, int HW, void* stream);
+int uir_ffl_partials(const float* Dr, const float* Di, const float* mx2, float* slab, int nblk, int B, int HW, void* stream);
+int uir_ffl_spectrum_grad(const float* Dr, const float* Di, const float* mx2, const float* gscale, const float* wdev, float coef, float* Gr,
+                          float* Gi, int B, int HW, void* stream);
+int uir_ffl_add_grad(const float* dd4, float* dpred, int B, int HW, int accumulate, void* stream);
 
 /* --------------------------------------------------------------- uir_optim */
 /* slab[block] = partial sum of squares of g[0..n) */

@@ -528,9 +528,10 @@ def test_rccl_allreduce_call_path_world1(monkeypatch):
 def test_micro_batched_step_equals_full_batch():
     """Gradient accumulation over micro-batches of one plan (how 16 x 1024 x 1024, the reference's default run, fits in
     HBM): B = 4 as 2 x 2 and as 4 x 1 must reproduce the full-batch step - loss, clip norm and updated parameters - for
-    a loss the reference divides by the batch size (L1withColor) and one it does not (charbonnier)."""
+    a loss the reference divides by the batch size (L1withColor), one it does not (charbonnier) and one with a FocalFrequencyLoss
+    term (fflCharbonnier: per-image spectrum weights, so the batch mean splits exactly)."""
     raw, ref = O.closed_form_images(4, 64, 61).to(DEV), O.closed_form_images(4, 64, 62).to(DEV)
-    for loss in ("L1withColor", "charbonnier"):
+    for loss in ("L1withColor", "charbonnier", "fflCharbonnier"):
         model, step = _fresh_step(loss)
         l0, n0 = step(raw, ref)
         l0, n0 = l0.clone(), n0.clone()            # the norm is a view of the optimizer's persistent buffer: the next step rewrites it

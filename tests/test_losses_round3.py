@@ -67,3 +67,44 @@ def test_unavailable_reference_losses_say_why():
         LossFunction("fflMix", "cuda").getloss(x, x)
     with pytest.raises(ValueError, match="Unsupported loss"):
         LossFunction("nope", "cuda").getloss(x, x)
+
+
+# ------------------------------------------------------------------ FocalFrequencyLoss terms (restated package: parity unpinned)
+def test_ffl_oracle_properties():
+    """(CPU) the restatement behaves like the published loss: zero for equal inputs (0/0 weights -> 0), quadratic in the error's
+    scale (the spectrum weights are scale-invariant), invariant to a constant offset of BOTH images, and its weights are detached
+    (gradient = 2 w D / count through the orthonormal transform)."""
+    from oracle import ffl_ref
+    g = torch.Generator().manual_seed(3)
+    p, t = torch.rand(2, 3, 12, 20, generator=g, dtype=torch.float64), torch.rand(2, 3, 12, 20, generator=g, dtype=torch.float64)
+    assert float(ffl_ref.ffl(p, p)) == 0.0
+    l1, l3 = float(ffl_ref.ffl(p, t)), float(ffl_ref.ffl(t + 3.0 * (p - t), t))
+    assert abs(l3 - 9.0 * l1) < 1e-12 * l3
+    assert abs(float(ffl_ref.ffl(p + 0.25, t + 0.25)) - l1) < 1e-12
+    pr = p.clone().requires_grad_(True)
+    (gr,) = torch.autograd.grad(ffl_ref.ffl(pr, t), pr)
+    d = torch.fft.fft2(p - t, norm="ortho")
+    w = d.abs() / d.abs().amax(dim=(-2, -1), keepdim=True)
+    want = torch.fft.ifft2(2.0 * w * d / p.numel(), norm="ortho").real
+    assert float((gr - want).abs().max()) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 32, 48), (1, 3, 256, 256), (3, 3, 20, 64)])
+@pytest.mark.parametrize("name", ["fflCharbonnier", "LuminanceFFL", "AdaptiveLuminanceFFL"])
+def test_ffl_losses_match_the_cpu_restatement(name, shape):
+    """HIP value and input gradient of the three FocalFrequencyLoss losses vs oracle/ffl_ref.py in fp64 (the fast MFMA DFT lengths, the
+    256 = 2 x 128 split and the dense fallback)."""
+    from oracle import ffl_ref
+    from underwater_image_restoration_amd.Losses.losses import LossFunction
+    pred, truth = recipe(shape, 21), recipe(shape, 22)
+    truth = 0.6 * truth + 0.4 * pred
+    p64 = pred.double().requires_grad_(True)
+    want = ffl_ref.loss(name, p64, truth.double())
+    (gwant,) = torch.autograd.grad(want, p64)
+    pg = pred.cuda().requires_grad_(True)
+    got = LossFunction(name, "cuda").getloss(pg, truth.cuda())
+    got.backward()
+    assert abs(float(got) - float(want)) < 5e-6 * abs(float(want)), (float(got), float(want))
+    err = float((pg.grad.cpu().double() - gwant).abs().max())
+    assert err < 2e-5 * float(gwant.abs().max()), (err, float(gwant.abs().max()))

@@ -13,6 +13,10 @@ truth)`` (src/Losses/losses.py:30-160), for the loss names on the SpectralTransf
   LuminanceCharbonnier          LuminanceLoss + CharbonnierLoss                                  (:118-123)
   AdaptiveLuminanceCharbonnier  sum_i loss_i * 0.5 * softmax(-log(loss + 1e-6))_i, weights detached (:130-140)
   gradient      nn.L1Loss between the valid 3x3 Laplacians of pred and truth (Gradient_Loss, :162-181)
+  fflCharbonnier / LuminanceFFL / AdaptiveLuminanceFFL   FocalFrequencyLoss(loss_weight=1, alpha=1) + Charbonnier / + Luminance /
+                the adaptive pair with Luminance (:97-98, :137-151).  focal_frequency_loss is an un-vendored pip package that is not in
+                this image: its published algorithm (v0.3.0 defaults) is restated on the GPU (ops._FflPlan) and checked against a CPU
+                restatement (oracle/ffl_ref.py) - PARITY UNPINNED, no value of the package itself exists here to hold it to.
 
 Forward and backward are HIP reductions (uir_loss_*).  Other reference loss names need
 third-party packages / pretrained VGG weights that are outside this build's scope.
@@ -26,10 +30,9 @@ from .. import ops
 
 # names the reference defines on top of packages / weights that are not in the image: torchvision's pretrained VGG16 (a download,
 # losses.py:219-222: "perceptual" and every mix), pytorch_msssim.MS_SSIM and focal_frequency_loss.FocalFrequencyLoss (un-vendored,
-# unpinned pip packages, requirements.txt:14-15).  "fflMix" (:108-117) needs all three: its pinnable terms - Charbonnier and
-# Gradient_Loss - are the losses above; the other three terms cannot be held to the reference here.
-_REFERENCE_OTHER = ("perceptual", "ms_ssim", "ffl", "mix", "fflMixTV", "bigMix", "fflCharbonnier", "fflMix",
-                    "AdaptiveLuminanceFFL", "LuminanceFFL", "ssimFFLCharbonnier")
+# unpinned pip packages, requirements.txt:14-15).  "fflMix" (:108-117) needs all three: its Charbonnier, Gradient_Loss and (restated,
+# unpinned) FocalFrequencyLoss terms exist above; the VGG16 and MS-SSIM terms cannot be built here.
+_REFERENCE_OTHER = ("perceptual", "ms_ssim", "ffl", "mix", "fflMixTV", "bigMix", "fflMix", "ssimFFLCharbonnier")
 
 
 class _LossFn(torch.autograd.Function):
@@ -58,7 +61,7 @@ class LossFunction:
         if name in _REFERENCE_OTHER:
             raise NotImplementedError(f"loss '{name}' needs torchvision's pretrained VGG16 and / or the pytorch_msssim and "
                                       f"focal_frequency_loss packages, none of which exist in this image (DESIGN.md section 16); "
-                                      f"its Charbonnier / Luminance / Gradient_Loss terms are available as 'charbonnier', 'Luminance', 'gradient'")
+                                      f"its Charbonnier / Luminance / Gradient_Loss / FocalFrequencyLoss terms are available through 'charbonnier', 'Luminance', 'gradient', 'fflCharbonnier'")
         raise ValueError(f"Unsupported loss: {self.loss_name}")
 
 

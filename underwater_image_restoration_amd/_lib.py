@@ -19,8 +19,12 @@ EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW, EPI_GELU_BWD = 0, 1, 2,
 ACT_NONE, ACT_LEAKY, ACT_GELU = 0, 1, 2
 # L1ColorLum has the same formula as L1withColor in the reference (src/Losses/losses.py:59-66 vs :67-75)
 LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4, "LuminanceCharbonnier": 5,
-              "AdaptiveLuminanceCharbonnier": 6, "gradient": 7}
+              "AdaptiveLuminanceCharbonnier": 6, "gradient": 7,
+              # with a FocalFrequencyLoss term (src/Losses/losses.py:45-46,97-98,137-151; the package's algorithm restated: parity unpinned)
+              "fflCharbonnier": 8, "LuminanceFFL": 9, "AdaptiveLuminanceFFL": 10}
 LOSS_GRADIENT = 7
+LOSS_FFL_KINDS = (8, 9, 10)
+LOSS_ADAPTIVE_KINDS = (6, 10)      # term weights from the detached loss values: aux of loss_sums -> loss_grad
 
 
 class GemmArgs(C.Structure):
@@ -220,6 +224,11 @@ SIGNATURES = {
     "uir_loss_bwd": [fp, fp, fp, fp, fp, i32, i32, i32, fp],
     "uir_gradloss_partials": [fp, fp, fp, i32, i32, i32, i32, fp],
     "uir_gradloss_bwd": [fp, fp, fp, fp, i32, i32, i32, fp],
+    "uir_ffl_diff": [fp, fp, fp, i32, i32, fp],
+    "uir_ffl_max": [fp, fp, fp, fp, i32, i32, i32, fp],
+    "uir_ffl_partials": [fp, fp, fp, fp, i32, i32, i32, fp],
+    "uir_ffl_spectrum_grad": [fp, fp, fp, fp, fp, C.c_float, fp, fp, i32, i32, fp],
+    "uir_ffl_add_grad": [fp, fp, i32, i32, i32, fp],
     "uir_sumsq_partials": [fp, i64, fp, i32, fp],
     "uir_clip_adam_step": [C.POINTER(AdamArgs), fp],
     "uir_adam_set_hyper": [fp, f32, f32, f32, f32, fp],

@@ -60,6 +60,15 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __re
     case UIR_LOSS_LUMINANCE: loss = lum; break;
     case UIR_LOSS_LUM_CHARBONNIER: loss = lum + ch; break;          // losses.py:118-123
     case UIR_LOSS_GRADIENT: loss = sums[5]; break;                  // mean |lap(d)| (uir_gradloss_partials, scaled by its reduction)
+    case UIR_LOSS_FFL_CHARBONNIER: loss = sums[6] + ch; break;      // sums[6] = the FocalFrequencyLoss mean (uir_ffl_partials + reduction)
+    case UIR_LOSS_LUM_FFL: loss = sums[6] + lum; break;
+    case UIR_LOSS_ADAPTIVE_LUM_FFL: {                               // losses.py:137-147
+      const float a = 1.f / (sums[6] + 1e-6f), b = 1.f / (lum + 1e-6f);
+      w0 = 0.5f * a / (a + b);
+      w1 = 0.5f * b / (a + b);
+      loss = sums[6] * w0 + lum * w1;
+      break;
+    }
     case UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER: {                       // losses.py:130-140: weights 0.5 * softmax(-log(loss_i + 1e-6)), detached
       const float a = 1.f / (ch + 1e-6f), b = 1.f / (lum + 1e-6f);  // softmax(-log x) = (1/x) / sum(1/x)
       w0 = 0.5f * a / (a + b);
@@ -78,7 +87,8 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __re
 __global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ truth, const float* __restrict__ gscale,
                                 const float* __restrict__ aux, float* __restrict__ dpred, int kind, int B, long HW, long n) {
   const float gs = gscale[0];
-  const float w0 = kind == UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER ? aux[2] : 0.f, w1 = kind == UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER ? aux[3] : 0.f;
+  const bool adaptive = kind == UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER || kind == UIR_LOSS_ADAPTIVE_LUM_FFL;
+  const float w0 = adaptive ? aux[2] : 0.f, w1 = adaptive ? aux[3] : 0.f;
   const float nn = (float)B * 3.f * (float)HW;
   const float npix = (float)B * (float)HW;
   const float bc = (float)B * 3.f;
@@ -102,6 +112,10 @@ __global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __r
         case UIR_LOSS_LUMINANCE: g = 2.f * lum * yc / npix; break;
         case UIR_LOSS_LUM_CHARBONNIER: g = 2.f * lum * yc / npix + d[c] / sqrtf(d[c] * d[c] + CHARB_EPS2) / nn; break;
         case UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER: g = w1 * 2.f * lum * yc / npix + w0 * d[c] / sqrtf(d[c] * d[c] + CHARB_EPS2) / nn; break;
+        // the FocalFrequencyLoss term of these three arrives separately (uir_ffl_spectrum_grad -> DFT -> uir_ffl_add_grad, accumulating)
+        case UIR_LOSS_FFL_CHARBONNIER: g = d[c] / sqrtf(d[c] * d[c] + CHARB_EPS2) / nn; break;
+        case UIR_LOSS_LUM_FFL: g = 2.f * lum * yc / npix; break;
+        case UIR_LOSS_ADAPTIVE_LUM_FFL: g = w1 * 2.f * lum * yc / npix; break;
         default: g = (0.5f * 2.f * d[c] / nn + 0.25f * sg / nn + 0.25f * 2.f * lum * yc / npix) / bc; break;
       }
       dpred[b * 3 * HW + c * HW + p] = g * gs;
@@ -150,6 +164,94 @@ __global__ __launch_bounds__(256) void gradloss_bwd_kernel(const float* __restri
   }
 }
 
+// ---- FocalFrequencyLoss (focal_frequency_loss v0.3.0 as the reference constructs it, losses.py:45-46; restated: parity unpinned) ----
+__global__ void ffl_diff_kernel(const float* __restrict__ pred, const float* __restrict__ truth, float* __restrict__ d4, long HW, long n) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const long b = idx / HW, p = idx - b * HW;
+    const float* pp = pred + b * 3 * HW + p;
+    const float* tp = truth + b * 3 * HW + p;
+    *reinterpret_cast<float4*>(d4 + idx * 4) = make_float4(pp[0] - tp[0], pp[HW] - tp[HW], pp[2 * HW] - tp[2 * HW], 0.f);
+  }
+}
+
+// grid (nblk, B): squared-magnitude maxima of one image's chunk, 4 channels
+__global__ __launch_bounds__(256) void ffl_max_partials_kernel(const float* __restrict__ Dr, const float* __restrict__ Di, float* __restrict__ slab,
+                                                               long HW) {
+  __shared__ float4 red[256];
+  const long b = blockIdx.y;
+  float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const float4 r = *reinterpret_cast<const float4*>(Dr + (b * HW + p) * 4), i = *reinterpret_cast<const float4*>(Di + (b * HW + p) * 4);
+    m.x = fmaxf(m.x, r.x * r.x + i.x * i.x); m.y = fmaxf(m.y, r.y * r.y + i.y * i.y);
+    m.z = fmaxf(m.z, r.z * r.z + i.z * i.z); m.w = fmaxf(m.w, r.w * r.w + i.w * i.w);
+  }
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int s_ = 128; s_ > 0; s_ >>= 1) {
+    if ((int)threadIdx.x < s_) {
+      const float4 o = red[threadIdx.x + s_];
+      float4& t = red[threadIdx.x];
+      t.x = fmaxf(t.x, o.x); t.y = fmaxf(t.y, o.y); t.z = fmaxf(t.z, o.z); t.w = fmaxf(t.w, o.w);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *reinterpret_cast<float4*>(slab + (b * gridDim.x + blockIdx.x) * 4) = red[0];
+}
+__global__ void ffl_max_final_kernel(const float* __restrict__ slab, float* __restrict__ mx2, int nblk) {
+  const int b = blockIdx.x, c = threadIdx.x;                 // 4 threads
+  float m = 0.f;
+  for (int k = 0; k < nblk; ++k) m = fmaxf(m, slab[((long)b * nblk + k) * 4 + c]);
+  mx2[b * 4 + c] = m;
+}
+
+// w |D|^2 with w = |D| / max|D| per (image, channel): |D|^3 / sqrt(mx2); fixed-order sums (bitwise run-to-run)
+__global__ __launch_bounds__(256) void ffl_partials_kernel(const float* __restrict__ Dr, const float* __restrict__ Di, const float* __restrict__ mx2,
+                                                           float* __restrict__ slab, long HW) {
+  __shared__ float red[256];
+  const long b = blockIdx.y;
+  const float4 mx = *reinterpret_cast<const float4*>(mx2 + b * 4);
+  const float ix = mx.x > 0.f ? 1.f / sqrtf(mx.x) : 0.f, iy = mx.y > 0.f ? 1.f / sqrtf(mx.y) : 0.f, iz = mx.z > 0.f ? 1.f / sqrtf(mx.z) : 0.f;
+  float acc = 0.f;
+  for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const float4 r = *reinterpret_cast<const float4*>(Dr + (b * HW + p) * 4), i = *reinterpret_cast<const float4*>(Di + (b * HW + p) * 4);
+    const float a = r.x * r.x + i.x * i.x, c = r.y * r.y + i.y * i.y, e = r.z * r.z + i.z * i.z;
+    acc += (a * fminf(sqrtf(a) * ix, 1.f) + c * fminf(sqrtf(c) * iy, 1.f)) + e * fminf(sqrtf(e) * iz, 1.f);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s_ = 128; s_ > 0; s_ >>= 1) {
+    if ((int)threadIdx.x < s_) red[threadIdx.x] += red[threadIdx.x + s_];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) slab[b * gridDim.x + blockIdx.x] = red[0];
+}
+
+__global__ void ffl_spectrum_grad_kernel(const float* __restrict__ Dr, const float* __restrict__ Di, const float* __restrict__ mx2,
+                                         const float* __restrict__ gscale, const float* __restrict__ wdev, float coef, float* __restrict__ Gr,
+                                         float* __restrict__ Gi, long HW, long n) {
+  const float k = coef * gscale[0] * (wdev ? wdev[0] : 1.f);
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const long b = idx / HW;
+    const float4 mx = *reinterpret_cast<const float4*>(mx2 + b * 4);
+    const float4 r = *reinterpret_cast<const float4*>(Dr + idx * 4), i = *reinterpret_cast<const float4*>(Di + idx * 4);
+    const float wx = mx.x > 0.f ? fminf(sqrtf((r.x * r.x + i.x * i.x) / mx.x), 1.f) * k : 0.f;
+    const float wy = mx.y > 0.f ? fminf(sqrtf((r.y * r.y + i.y * i.y) / mx.y), 1.f) * k : 0.f;
+    const float wz = mx.z > 0.f ? fminf(sqrtf((r.z * r.z + i.z * i.z) / mx.z), 1.f) * k : 0.f;
+    *reinterpret_cast<float4*>(Gr + idx * 4) = make_float4(wx * r.x, wy * r.y, wz * r.z, 0.f);
+    *reinterpret_cast<float4*>(Gi + idx * 4) = make_float4(-wx * i.x, -wy * i.y, -wz * i.z, 0.f);
+  }
+}
+
+__global__ void ffl_add_grad_kernel(const float* __restrict__ dd4, float* __restrict__ dpred, long HW, long n, int accumulate) {
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x) {
+    const long b = idx / HW, p = idx - b * HW;
+    const float4 v = *reinterpret_cast<const float4*>(dd4 + idx * 4);
+    float* o = dpred + b * 3 * HW + p;
+    if (accumulate) { o[0] += v.x; o[HW] += v.y; o[2 * HW] += v.z; }
+    else { o[0] = v.x; o[HW] = v.y; o[2 * HW] = v.z; }
+  }
+}
+
 }  // namespace
 
 extern "C" int uir_gradloss_partials(const float* pred, const float* truth, float* slab, int nblocks, int B, int H, int Wd, void* stream) {
@@ -172,17 +274,54 @@ extern "C" int uir_loss_partials(const float* pred, const float* truth, float* s
   return uir_launch_status();
 }
 extern "C" int uir_loss_finalize(const float* sums, float* out, int kind, int B, int HW, void* stream) {
-  UIR_REQUIRE(sums && out && kind >= 0 && kind <= UIR_LOSS_GRADIENT && B > 0 && HW > 0);
+  UIR_REQUIRE(sums && out && kind >= 0 && kind <= UIR_LOSS_ADAPTIVE_LUM_FFL && B > 0 && HW > 0);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), sums, out, kind, B, (long)HW);
   return uir_launch_status();
 }
 extern "C" int uir_loss_bwd(const float* pred, const float* truth, const float* gscale, const float* aux, float* dpred, int kind, int B, int HW,
                             void* stream) {
-  UIR_REQUIRE(pred && truth && gscale && dpred && kind >= 0 && kind <= UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER && B > 0 && HW > 0);
-  UIR_REQUIRE(kind != UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER || aux);
+  UIR_REQUIRE(pred && truth && gscale && dpred && kind >= 0 && kind <= UIR_LOSS_ADAPTIVE_LUM_FFL && kind != UIR_LOSS_GRADIENT && B > 0 && HW > 0);
+  UIR_REQUIRE((kind != UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER && kind != UIR_LOSS_ADAPTIVE_LUM_FFL) || aux);
   const long n = (long)B * HW;
   long blocks = (n + 255) / 256;
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(loss_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), pred, truth, gscale, aux, dpred, kind, B, (long)HW, n);
+  return uir_launch_status();
+}
+
+static unsigned ffl_grid(long n) {
+  long g = (n + 255) / 256;
+  return (unsigned)(g > 4096 ? 4096 : (g < 1 ? 1 : g));
+}
+extern "C" int uir_ffl_diff(const float* pred, const float* truth, float* d4, int B, int HW, void* stream) {
+  UIR_REQUIRE(pred && truth && d4 && B > 0 && HW > 0 && uir_aligned16(d4));
+  const long n = (long)B * HW;
+  hipLaunchKernelGGL(ffl_diff_kernel, dim3(ffl_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), pred, truth, d4, (long)HW, n);
+  return uir_launch_status();
+}
+extern "C" int uir_ffl_max(const float* Dr, const float* Di, float* mx2, float* slab, int nblk, int B, int HW, void* stream) {
+  UIR_REQUIRE(Dr && Di && mx2 && slab && nblk > 0 && B > 0 && HW > 0 && uir_aligned16(Dr) && uir_aligned16(Di) && uir_aligned16(slab) && uir_aligned16(mx2));
+  hipLaunchKernelGGL(ffl_max_partials_kernel, dim3(nblk, B), dim3(256), 0, static_cast<hipStream_t>(stream), Dr, Di, slab, (long)HW);
+  hipLaunchKernelGGL(ffl_max_final_kernel, dim3(B), dim3(4), 0, static_cast<hipStream_t>(stream), slab, mx2, nblk);
+  return uir_launch_status();
+}
+extern "C" int uir_ffl_partials(const float* Dr, const float* Di, const float* mx2, float* slab, int nblk, int B, int HW, void* stream) {
+  UIR_REQUIRE(Dr && Di && mx2 && slab && nblk > 0 && B > 0 && HW > 0 && uir_aligned16(Dr) && uir_aligned16(Di) && uir_aligned16(mx2));
+  hipLaunchKernelGGL(ffl_partials_kernel, dim3(nblk, B), dim3(256), 0, static_cast<hipStream_t>(stream), Dr, Di, mx2, slab, (long)HW);
+  return uir_launch_status();
+}
+extern "C" int uir_ffl_spectrum_grad(const float* Dr, const float* Di, const float* mx2, const float* gscale, const float* wdev, float coef,
+                                     float* Gr, float* Gi, int B, int HW, void* stream) {
+  UIR_REQUIRE(Dr && Di && mx2 && gscale && Gr && Gi && B > 0 && HW > 0);
+  UIR_REQUIRE(uir_aligned16(Dr) && uir_aligned16(Di) && uir_aligned16(Gr) && uir_aligned16(Gi) && uir_aligned16(mx2));
+  const long n = (long)B * HW;
+  hipLaunchKernelGGL(ffl_spectrum_grad_kernel, dim3(ffl_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), Dr, Di, mx2, gscale, wdev, coef,
+                     Gr, Gi, (long)HW, n);
+  return uir_launch_status();
+}
+extern "C" int uir_ffl_add_grad(const float* dd4, float* dpred, int B, int HW, int accumulate, void* stream) {
+  UIR_REQUIRE(dd4 && dpred && B > 0 && HW > 0 && uir_aligned16(dd4));
+  const long n = (long)B * HW;
+  hipLaunchKernelGGL(ffl_add_grad_kernel, dim3(ffl_grid(n)), dim3(256), 0, static_cast<hipStream_t>(stream), dd4, dpred, (long)HW, n, accumulate);
   return uir_launch_status();
 }

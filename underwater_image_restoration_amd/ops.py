@@ -25,6 +25,71 @@ def _req(t: torch.Tensor, what: str) -> torch.Tensor:
     return t.contiguous()
 
 
+class _FflPlan:
+    """FocalFrequencyLoss(loss_weight=1, alpha=1) of the reference (src/Losses/losses.py:45-46; focal_frequency_loss v0.3.0 with its
+    defaults patch_factor 1, ave_spectrum / log_matrix / batch_matrix False) for one (B, H, W):
+        D = fft2(pred - truth, norm="ortho");  w = |D| / max_{H,W}|D| per (image, channel), detached, NaN -> 0, clamped to [0, 1]
+        loss = mean(w |D|^2)
+    The package is not in the image and not vendored by the reference: this restates its published algorithm (PARITY UNPINNED).
+    The two DFT axes run on the plan's own HWC4 buffers (uir_dft_axis*; |D| does not depend on the transform's sign convention, and
+    the gradient of a real input is Re DFT(w conj(D)) with the SAME sign), everything else is five small kernels of csrc/loss.hip.
+    The backward recomputes the spectrum: nothing is assumed about which tensors the forward last saw."""
+
+    _cache: dict = {}
+
+    @classmethod
+    def get(cls, B, H, W, device):
+        key = (B, H, W, str(device))
+        if key not in cls._cache:
+            if len(cls._cache) >= 4:
+                cls._cache.pop(next(iter(cls._cache)))
+            cls._cache[key] = cls(B, H, W, device)
+        return cls._cache[key]
+
+    def __init__(self, B, H, W, device):
+        from .engine import Recorder
+        from .model.block import record_axis_dft
+        self.B, self.H, self.W = B, H, W
+        r = self.rec = Recorder(device, scratch_floats=1 << 16)
+        M, s = B * H * W, 1.0 / float(H * W) ** 0.5
+        self.d4 = r.alloc(M, 4)
+        ar, ai = record_axis_dft(r, "ffl.W", self.d4, None, B * H, W, 1, 4, 1.0, real_out=False)
+        self.Dr, self.Di = record_axis_dft(r, "ffl.H", ar, ai, B, H, W, 4, s, real_out=False)
+        self.nblk = max(1, min(64, (H * W + 4095) // 4096))
+        self.mslab, self.mx2, self.sslab = r.alloc(B * self.nblk * 4), r.alloc(B * 4), r.alloc(B * self.nblk)
+        self.Gr, self.Gi = r.alloc(M, 4), r.alloc(M, 4)
+        r.cur = r.bwd
+        hr, hi = record_axis_dft(r, "ffl.bwd.H", self.Gr, self.Gi, B, H, W, 4, 1.0, real_out=False)
+        self.dd4, _ = record_axis_dft(r, "ffl.bwd.W", hr, hi, B * H, W, 1, 4, s, real_out=True)
+        r.cur = r.fwd
+
+    def _spectrum(self, pred, truth, st):
+        B, HW = self.B, self.H * self.W
+        L.check(lib.uir_ffl_diff(pred.data_ptr(), truth.data_ptr(), self.d4.data_ptr(), B, HW, st), "uir_ffl_diff")
+        self.rec.run(self.rec.fwd)
+        L.check(lib.uir_ffl_max(self.Dr.data_ptr(), self.Di.data_ptr(), self.mx2.data_ptr(), self.mslab.data_ptr(), self.nblk, B, HW, st), "uir_ffl_max")
+
+    def forward(self, pred, truth, out_ptr: int):
+        """writes the FFL mean to the device float at out_ptr"""
+        st = _stream()
+        B, HW = self.B, self.H * self.W
+        self._spectrum(pred, truth, st)
+        L.check(lib.uir_ffl_partials(self.Dr.data_ptr(), self.Di.data_ptr(), self.mx2.data_ptr(), self.sslab.data_ptr(), self.nblk, B, HW, st),
+                "uir_ffl_partials")
+        L.check(lib.uir_reduce_slab(self.sslab.data_ptr(), B * self.nblk, 1, out_ptr, 1, 0, 1.0 / (B * 3 * HW), st), "uir_reduce_slab")
+
+    def backward(self, pred, truth, gscale_ptr: int, w_ptr, dpred, accumulate: bool):
+        """dpred (+)= gscale * (w or 1) * dFFL/dpred"""
+        st = _stream()
+        B, HW = self.B, self.H * self.W
+        self._spectrum(pred, truth, st)
+        coef = 2.0 / (B * 3 * HW)                 # d mean(w |D|^2) / dD = 2 w D / count (w detached); the DFT scale sits in the plan
+        L.check(lib.uir_ffl_spectrum_grad(self.Dr.data_ptr(), self.Di.data_ptr(), self.mx2.data_ptr(), gscale_ptr, w_ptr, coef,
+                                          self.Gr.data_ptr(), self.Gi.data_ptr(), B, HW, st), "uir_ffl_spectrum_grad")
+        self.rec.run(self.rec.bwd)
+        L.check(lib.uir_ffl_add_grad(self.dd4.data_ptr(), dpred.data_ptr(), B, HW, 1 if accumulate else 0, st), "uir_ffl_add_grad")
+
+
 def loss_sums(pred: torch.Tensor, truth: torch.Tensor, kind: int) -> torch.Tensor:
     """-> device tensor [4] = (loss(kind), PSNR, and the two detached weights of AdaptiveLuminanceCharbonnier - pass it to
     loss_grad as `aux`)."""
@@ -45,6 +110,8 @@ def loss_sums(pred: torch.Tensor, truth: torch.Tensor, kind: int) -> torch.Tenso
         L.check(lib.uir_gradloss_partials(pred.data_ptr(), truth.data_ptr(), gslab.data_ptr(), _LOSS_BLOCKS, B, H, W, st), "uir_gradloss_partials")
         L.check(lib.uir_reduce_slab(gslab.data_ptr(), _LOSS_BLOCKS, 1, sums.data_ptr() + 20, 1, 0, 1.0 / (B * 3 * (H - 2) * (W - 2)), st),
                 "uir_reduce_slab")
+    if kind in L.LOSS_FFL_KINDS:         # FocalFrequencyLoss mean -> sums[6]
+        _FflPlan.get(B, H, W, pred.device).forward(pred, truth, sums.data_ptr() + 24)
     L.check(lib.uir_loss_finalize(sums.data_ptr(), out.data_ptr(), kind, B, H * W, st), "uir_loss_finalize")
     return out
 
@@ -86,10 +153,13 @@ def loss_grad(pred: torch.Tensor, truth: torch.Tensor, gscale: torch.Tensor, kin
     if kind == L.LOSS_GRADIENT:
         L.check(lib.uir_gradloss_bwd(pred.data_ptr(), truth.data_ptr(), gs.data_ptr(), dpred.data_ptr(), B, H, W, _stream()), "uir_gradloss_bwd")
         return dpred
-    if kind == L.LOSS_KINDS["AdaptiveLuminanceCharbonnier"] and aux is None:
+    if kind in L.LOSS_ADAPTIVE_KINDS and aux is None:
         aux = loss_sums(pred, truth, kind)
     L.check(lib.uir_loss_bwd(pred.data_ptr(), truth.data_ptr(), gs.data_ptr(), aux.data_ptr() if aux is not None else None, dpred.data_ptr(),
                              kind, B, H * W, _stream()), "uir_loss_bwd")
+    if kind in L.LOSS_FFL_KINDS:         # + the FocalFrequencyLoss term (weighted by aux[2] in the adaptive pair)
+        wp = aux.data_ptr() + 8 if kind in L.LOSS_ADAPTIVE_KINDS else None
+        _FflPlan.get(B, H, W, pred.device).backward(pred, truth, gs.data_ptr(), wp, dpred, accumulate=True)
     return dpred
 
 

@@ -76,8 +76,8 @@ class TrainStep:
     def _weights(self, mb: int, B: int) -> float:
         """Weight of one micro-batch's loss in the full-batch loss: b/B for plain means; (b/B)^2 for the losses the
         reference also divides by the batch size (L1, L2, L1withColor / L1ColorLum: src/Losses/losses.py:57,65,74,78)."""
-        if self.kind == L.LOSS_KINDS["AdaptiveLuminanceCharbonnier"] and mb != B:
-            raise NotImplementedError("AdaptiveLuminanceCharbonnier weights its two terms by their values over the WHOLE batch "
+        if self.kind in L.LOSS_ADAPTIVE_KINDS and mb != B:
+            raise NotImplementedError("the Adaptive* losses weight their two terms by their values over the WHOLE batch "
                                       "(losses.py:135-138): it cannot be accumulated over micro-batches")
         f = mb / B
         return f * f if self.kind in (0, 1, 4) else f
@@ -295,7 +295,7 @@ class ModuleTrainStep:
         return mb
 
     def _weights(self, mb: int, B: int) -> float:
-        if self.kind == L.LOSS_KINDS["AdaptiveLuminanceCharbonnier"] and mb != B:
+        if self.kind in L.LOSS_ADAPTIVE_KINDS and mb != B:
             raise NotImplementedError("AdaptiveLuminanceCharbonnier cannot be accumulated over micro-batches (losses.py:135-138)")
         f = mb / B                                # see TrainStep._weights (losses the reference also divides by the batch size)
         return f * f if self.kind in (0, 1, 4) else f
