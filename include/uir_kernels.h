@@ -411,7 +411,11 @@ enum { UIR_LOSS_L1 = 0, UIR_LOSS_L2 = 1, UIR_LOSS_CHARBONNIER = 2, UIR_LOSS_LUMI
         * restated by the uir_ffl_* kernels below, PARITY UNPINNED); the FFL mean is read from sums[6] */
        UIR_LOSS_FFL_CHARBONNIER = 8,      /* "fflCharbonnier" = ffl + charbonnier (:97-98) */
        UIR_LOSS_LUM_FFL = 9,              /* "LuminanceFFL" = ffl + luminance (:148-151) */
-       UIR_LOSS_ADAPTIVE_LUM_FFL = 10     /* "AdaptiveLuminanceFFL" (:137-147): the adaptive pair of kind 6 with ffl in place of charbonnier */ };
+       UIR_LOSS_ADAPTIVE_LUM_FFL = 10,    /* "AdaptiveLuminanceFFL" (:137-147): the adaptive pair of kind 6 with ffl in place of charbonnier */
+       /* with MS_SSIM(win 11, sigma 1.5, data_range 1, size_average, channel 3) (losses.py:43-44; pytorch_msssim is not vendored and not
+        * in the image: restated by the uir_msssim_* functions below, PARITY UNPINNED); the MS-SSIM mean is read from sums[7] */
+       UIR_LOSS_MS_SSIM = 11,             /* "ms_ssim" = 1 - ms_ssim (:86-87) */
+       UIR_LOSS_SSIM_FFL_CHARBONNIER = 12 /* "ssimFFLCharbonnier" = 0.025 ffl + 0.025 charbonnier + (1 - ms_ssim) (:152-156) */ };
 /* Partial sums over NCHW [B,3,H,W] pred/truth: slab[block][8] =
  * (sum|d|, sum d^2, sum sqrt(d^2+1e-6), sum lum^2, sum (clamp01(p)-clamp01(t))^2, 0,0,0).
  * Replaces nn.L1Loss / MSELoss / CharbonnierLoss / ColorLoss / LuminanceLoss
@@ -444,6 +448,29 @@ int uir_ffl_partials(const float* Dr, const float* Di, const float* mx2, float* 
 int uir_ffl_spectrum_grad(const float* Dr, const float* Di, const float* mx2, const float* gscale, const float* wdev, float coef, float* Gr,
                           float* Gi, int B, int HW, void* stream);
 int uir_ffl_add_grad(const float* dd4, float* dpred, int B, int HW, int accumulate, void* stream);
+
+/* MS-SSIM as a training loss (pytorch_msssim.MS_SSIM restated: parity unpinned), NCHW planes [planes = B * 3][H][W]:
+ *   uir_msssim_level      means[plane] = (mean ssim_map, mean cs_map) of one level: the 11-tap Gaussian as its outer-product window,
+ *                         VALID positions only (slab: [planes][nblk][2] scratch)
+ *   uir_avgpool2(_bwd)    F.avg_pool2d(x, 2, padding = size % 2) between levels (zeros counted) and its adjoint
+ *   uir_msssim_combine    ms_out[0] = mean_planes prod_i relu(v_i)^w_i, v_i = cs mean of level i < levels - 1, ssim mean of the last;
+ *                         dmeans[level][plane][2] = d ms / d(those means), 0 for the unused mean of each level
+ *   uir_msssim_level_bwd  dX (+)= gradient of one level through its ssim / cs maps (A, Bm, Cm: [planes][(H-10)(W-10)] scratch)
+ *   uir_axpy_dev          y += coef * gscale[0] * x */
+typedef struct UirMsSsimArgs {
+  const float* X; const float* Y;   /* [planes][H][W] */
+  float* slab;                      /* uir_msssim_level only */
+  int planes, H, W, nblk;
+  float C1, C2;                     /* (0.01 * data_range)^2, (0.03 * data_range)^2 */
+  float win[11];                    /* _fspecial_gauss_1d(11, 1.5), fp32 */
+} UirMsSsimArgs;
+typedef struct UirMsSsimWeights { float w[5]; } UirMsSsimWeights;
+int uir_msssim_level(const UirMsSsimArgs* args, float* means, void* stream);
+int uir_msssim_combine(const float* means, float* dmeans, float* ms_out, int levels, int planes, const UirMsSsimWeights* w, void* stream);
+int uir_msssim_level_bwd(const UirMsSsimArgs* args, const float* dmeans, float* A, float* Bm, float* Cm, float* dX, int accumulate, void* stream);
+int uir_avgpool2(const float* X, float* Y, int planes, int H, int W, void* stream);
+int uir_avgpool2_bwd(const float* dY, float* dX, int planes, int H, int W, int accumulate, void* stream);
+int uir_axpy_dev(const float* x, const float* gscale, float coef, float* y, long n, void* stream);
 
 /* --------------------------------------------------------------- uir_optim */
 /* slab[block] = partial sum of squares of g[0..n) */

@@ -108,3 +108,45 @@ def test_ffl_losses_match_the_cpu_restatement(name, shape):
     assert abs(float(got) - float(want)) < 5e-6 * abs(float(want)), (float(got), float(want))
     err = float((pg.grad.cpu().double() - gwant).abs().max())
     assert err < 2e-5 * float(gwant.abs().max()), (err, float(gwant.abs().max()))
+
+
+# ------------------------------------------------------------------ MS-SSIM terms (restated package: parity unpinned)
+def test_msssim_oracle_properties():
+    """(CPU) the restatement: 1 for identical images, symmetric, below 1 otherwise, and equal to its single-level SSIM factors
+    recombined by hand."""
+    from oracle import msssim_ref as R
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand(1, 3, 176, 208, generator=g, dtype=torch.float64)      # sides that halve evenly four times
+    y = (x + 0.2 * torch.rand(1, 3, 176, 208, generator=g, dtype=torch.float64)).clamp(0, 1)
+    assert abs(float(R.ms_ssim(x, x)) - 1.0) < 1e-12
+    a, b = float(R.ms_ssim(x, y)), float(R.ms_ssim(y, x))
+    assert abs(a - b) < 1e-12 and 0.0 < a < 1.0
+    gw = R._gauss(torch.float64)
+    X, Y, f = x, y, []
+    for i in range(5):
+        s, c = R._ssim(X, Y, gw)
+        f.append((s if i == 4 else c).clamp_min(0))
+        X, Y = torch.nn.functional.avg_pool2d(X, 2), torch.nn.functional.avg_pool2d(Y, 2)
+    want = torch.stack([v ** w for v, w in zip(f, R.WEIGHTS)]).prod(0).mean()
+    assert abs(float(want) - a) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 3, 176, 192), (1, 3, 256, 256), (1, 3, 163, 171)])
+@pytest.mark.parametrize("name", ["ms_ssim", "ssimFFLCharbonnier"])
+def test_msssim_losses_match_the_cpu_restatement(name, shape):
+    """HIP value and input gradient of the two MS-SSIM losses vs oracle/msssim_ref.py in fp64 (even sizes, and odd sizes that take
+    the padded average pooling)."""
+    from oracle import msssim_ref as R
+    from underwater_image_restoration_amd.Losses.losses import LossFunction
+    pred = 0.5 + 0.5 * recipe(shape, 31)
+    truth = (0.8 * pred + 0.2 * (0.5 + 0.5 * recipe(shape, 32)))
+    p64 = pred.double().requires_grad_(True)
+    want = R.loss(name, p64, truth.double())
+    (gwant,) = torch.autograd.grad(want, p64)
+    pg = pred.cuda().requires_grad_(True)
+    got = LossFunction(name, "cuda").getloss(pg, truth.cuda())
+    got.backward()
+    assert abs(float(got) - float(want)) < 2e-5 * max(abs(float(want)), 1e-3), (float(got), float(want))
+    err = float((pg.grad.cpu().double() - gwant).abs().max())
+    assert err < 1e-4 * float(gwant.abs().max()), (err, float(gwant.abs().max()))

@@ -17,6 +17,9 @@ truth)`` (src/Losses/losses.py:30-160), for the loss names on the SpectralTransf
                 the adaptive pair with Luminance (:97-98, :137-151).  focal_frequency_loss is an un-vendored pip package that is not in
                 this image: its published algorithm (v0.3.0 defaults) is restated on the GPU (ops._FflPlan) and checked against a CPU
                 restatement (oracle/ffl_ref.py) - PARITY UNPINNED, no value of the package itself exists here to hold it to.
+  ms_ssim / ssimFFLCharbonnier   1 - MS_SSIM(win 11, sigma 1.5, data_range 1, size_average, channel 3) (:43-44, :86-87) and
+                0.025 ffl + 0.025 charbonnier + (1 - ms_ssim) (:152-156).  pytorch_msssim is likewise absent: its published algorithm is
+                restated (ops._MsSsimPlan, csrc/msssim.hip; oracle/msssim_ref.py) - PARITY UNPINNED.  Needs min(H, W) > 160.
 
 Forward and backward are HIP reductions (uir_loss_*).  Other reference loss names need
 third-party packages / pretrained VGG weights that are outside this build's scope.
@@ -28,11 +31,11 @@ import torch
 from .. import _lib as L
 from .. import ops
 
-# names the reference defines on top of packages / weights that are not in the image: torchvision's pretrained VGG16 (a download,
-# losses.py:219-222: "perceptual" and every mix), pytorch_msssim.MS_SSIM and focal_frequency_loss.FocalFrequencyLoss (un-vendored,
-# unpinned pip packages, requirements.txt:14-15).  "fflMix" (:108-117) needs all three: its Charbonnier, Gradient_Loss and (restated,
+# names the reference defines on top of torchvision's pretrained VGG16 (a weight download, losses.py:219-222: "perceptual" and every
+# mix; "ffl" alone raises AttributeError in the reference, :30-48 never builds self.ffl for it).  pytorch_msssim.MS_SSIM and
+# focal_frequency_loss.FocalFrequencyLoss are un-vendored, unpinned pip packages (requirements.txt:14-15) restated above.  "fflMix" (:108-117) needs all three: its Charbonnier, Gradient_Loss and (restated,
 # unpinned) FocalFrequencyLoss terms exist above; the VGG16 and MS-SSIM terms cannot be built here.
-_REFERENCE_OTHER = ("perceptual", "ms_ssim", "ffl", "mix", "fflMixTV", "bigMix", "fflMix", "ssimFFLCharbonnier")
+_REFERENCE_OTHER = ("perceptual", "ffl", "mix", "fflMixTV", "bigMix", "fflMix")
 
 
 class _LossFn(torch.autograd.Function):
@@ -59,9 +62,9 @@ class LossFunction:
         if name in L.LOSS_KINDS:
             return _LossFn.apply(predicted_data, truth_data.detach(), L.LOSS_KINDS[name])
         if name in _REFERENCE_OTHER:
-            raise NotImplementedError(f"loss '{name}' needs torchvision's pretrained VGG16 and / or the pytorch_msssim and "
-                                      f"focal_frequency_loss packages, none of which exist in this image (DESIGN.md section 16); "
-                                      f"its Charbonnier / Luminance / Gradient_Loss / FocalFrequencyLoss terms are available through 'charbonnier', 'Luminance', 'gradient', 'fflCharbonnier'")
+            raise NotImplementedError(f"loss '{name}' needs torchvision's pretrained VGG16 weights (a download that does not exist in "
+                                      f"this image; 'ffl' alone is an AttributeError in the reference) (DESIGN.md section 18); "
+                                      f"its Charbonnier / Luminance / Gradient_Loss / FocalFrequencyLoss terms are available through 'charbonnier', 'Luminance', 'gradient', 'fflCharbonnier', 'ms_ssim'")
         raise ValueError(f"Unsupported loss: {self.loss_name}")
 
 

@@ -21,9 +21,12 @@ ACT_NONE, ACT_LEAKY, ACT_GELU = 0, 1, 2
 LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4, "LuminanceCharbonnier": 5,
               "AdaptiveLuminanceCharbonnier": 6, "gradient": 7,
               # with a FocalFrequencyLoss term (src/Losses/losses.py:45-46,97-98,137-151; the package's algorithm restated: parity unpinned)
-              "fflCharbonnier": 8, "LuminanceFFL": 9, "AdaptiveLuminanceFFL": 10}
+              "fflCharbonnier": 8, "LuminanceFFL": 9, "AdaptiveLuminanceFFL": 10,
+              # with an MS_SSIM term (:43-44,86-87,152-156; pytorch_msssim restated: parity unpinned)
+              "ms_ssim": 11, "ssimFFLCharbonnier": 12}
 LOSS_GRADIENT = 7
-LOSS_FFL_KINDS = (8, 9, 10)
+LOSS_FFL_KINDS = (8, 9, 10, 12)
+LOSS_MSSSIM_KINDS = (11, 12)
 LOSS_ADAPTIVE_KINDS = (6, 10)      # term weights from the detached loss values: aux of loss_sums -> loss_grad
 
 
@@ -163,6 +166,15 @@ class FrfnGateArgs(C.Structure):
                 ("db_blocks", C.c_int), ("v_act", C.c_int), ("dbv_slab", fp)]
 
 
+class MsSsimArgs(C.Structure):
+    _fields_ = [("X", fp), ("Y", fp), ("slab", fp), ("planes", C.c_int), ("H", C.c_int), ("W", C.c_int), ("nblk", C.c_int),
+                ("C1", C.c_float), ("C2", C.c_float), ("win", C.c_float * 11)]
+
+
+class MsSsimWeights(C.Structure):
+    _fields_ = [("w", C.c_float * 5)]
+
+
 class WinAttnArgs(C.Structure):
     _fields_ = [("Q", fp), ("K", fp), ("V", fp), ("table", fp), ("w", fp), ("O", fp), ("dO", fp), ("dQ", fp), ("dK", fp), ("dV", fp),
                 ("dtable_slab", fp), ("dw_slab", fp),
@@ -229,6 +241,12 @@ SIGNATURES = {
     "uir_ffl_partials": [fp, fp, fp, fp, i32, i32, i32, fp],
     "uir_ffl_spectrum_grad": [fp, fp, fp, fp, fp, C.c_float, fp, fp, i32, i32, fp],
     "uir_ffl_add_grad": [fp, fp, i32, i32, i32, fp],
+    "uir_msssim_level": [C.POINTER(MsSsimArgs), fp, fp],
+    "uir_msssim_combine": [fp, fp, fp, i32, i32, C.POINTER(MsSsimWeights), fp],
+    "uir_msssim_level_bwd": [C.POINTER(MsSsimArgs), fp, fp, fp, fp, fp, i32, fp],
+    "uir_avgpool2": [fp, fp, i32, i32, i32, fp],
+    "uir_avgpool2_bwd": [fp, fp, i32, i32, i32, i32, fp],
+    "uir_axpy_dev": [fp, fp, C.c_float, fp, C.c_long, fp],
     "uir_sumsq_partials": [fp, i64, fp, i32, fp],
     "uir_clip_adam_step": [C.POINTER(AdamArgs), fp],
     "uir_adam_set_hyper": [fp, f32, f32, f32, f32, fp],
@@ -265,7 +283,7 @@ STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirDwArgs": DwArgs
            "UirAttnFwdArgs": AttnFwdArgs, "UirAttnBwdArgs": AttnBwdArgs, "UirDftArgs": DftArgs, "UirDft2Args": Dft2Args,
            "UirAdamArgs": AdamArgs, "UirResizeImage": ResizeImage, "UirResizeArgs": ResizeArgs, "UirSsimArgs": SsimArgs,
            "UirUiqmArgs": UiqmArgs, "UirReduceDesc": ReduceDesc,
-           "UirFrfnGateArgs": FrfnGateArgs, "UirWinAttnArgs": WinAttnArgs}
+           "UirFrfnGateArgs": FrfnGateArgs, "UirWinAttnArgs": WinAttnArgs, "UirMsSsimArgs": MsSsimArgs, "UirMsSsimWeights": MsSsimWeights}
 
 
 def abi_layout(lib_, cname: str):

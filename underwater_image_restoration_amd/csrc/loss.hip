@@ -62,6 +62,8 @@ __global__ void loss_finalize_kernel(const float* __restrict__ sums, float* __re
     case UIR_LOSS_GRADIENT: loss = sums[5]; break;                  // mean |lap(d)| (uir_gradloss_partials, scaled by its reduction)
     case UIR_LOSS_FFL_CHARBONNIER: loss = sums[6] + ch; break;      // sums[6] = the FocalFrequencyLoss mean (uir_ffl_partials + reduction)
     case UIR_LOSS_LUM_FFL: loss = sums[6] + lum; break;
+    case UIR_LOSS_MS_SSIM: loss = 1.f - sums[7]; break;             // sums[7] = the MS-SSIM mean (uir_msssim_combine)
+    case UIR_LOSS_SSIM_FFL_CHARBONNIER: loss = 0.025f * sums[6] + 0.025f * ch + (1.f - sums[7]); break;
     case UIR_LOSS_ADAPTIVE_LUM_FFL: {                               // losses.py:137-147
       const float a = 1.f / (sums[6] + 1e-6f), b = 1.f / (lum + 1e-6f);
       w0 = 0.5f * a / (a + b);
@@ -116,6 +118,8 @@ __global__ void loss_bwd_kernel(const float* __restrict__ pred, const float* __r
         case UIR_LOSS_FFL_CHARBONNIER: g = d[c] / sqrtf(d[c] * d[c] + CHARB_EPS2) / nn; break;
         case UIR_LOSS_LUM_FFL: g = 2.f * lum * yc / npix; break;
         case UIR_LOSS_ADAPTIVE_LUM_FFL: g = w1 * 2.f * lum * yc / npix; break;
+        case UIR_LOSS_MS_SSIM: g = 0.f; break;                     // (the MS-SSIM term arrives through uir_msssim_level_bwd + uir_axpy_dev)
+        case UIR_LOSS_SSIM_FFL_CHARBONNIER: g = 0.025f * d[c] / sqrtf(d[c] * d[c] + CHARB_EPS2) / nn; break;
         default: g = (0.5f * 2.f * d[c] / nn + 0.25f * sg / nn + 0.25f * 2.f * lum * yc / npix) / bc; break;
       }
       dpred[b * 3 * HW + c * HW + p] = g * gs;
@@ -274,13 +278,13 @@ extern "C" int uir_loss_partials(const float* pred, const float* truth, float* s
   return uir_launch_status();
 }
 extern "C" int uir_loss_finalize(const float* sums, float* out, int kind, int B, int HW, void* stream) {
-  UIR_REQUIRE(sums && out && kind >= 0 && kind <= UIR_LOSS_ADAPTIVE_LUM_FFL && B > 0 && HW > 0);
+  UIR_REQUIRE(sums && out && kind >= 0 && kind <= UIR_LOSS_SSIM_FFL_CHARBONNIER && B > 0 && HW > 0);
   hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), sums, out, kind, B, (long)HW);
   return uir_launch_status();
 }
 extern "C" int uir_loss_bwd(const float* pred, const float* truth, const float* gscale, const float* aux, float* dpred, int kind, int B, int HW,
                             void* stream) {
-  UIR_REQUIRE(pred && truth && gscale && dpred && kind >= 0 && kind <= UIR_LOSS_ADAPTIVE_LUM_FFL && kind != UIR_LOSS_GRADIENT && B > 0 && HW > 0);
+  UIR_REQUIRE(pred && truth && gscale && dpred && kind >= 0 && kind <= UIR_LOSS_SSIM_FFL_CHARBONNIER && kind != UIR_LOSS_GRADIENT && B > 0 && HW > 0);
   UIR_REQUIRE((kind != UIR_LOSS_ADAPTIVE_LUM_CHARBONNIER && kind != UIR_LOSS_ADAPTIVE_LUM_FFL) || aux);
   const long n = (long)B * HW;
   long blocks = (n + 255) / 256;

@@ -78,16 +78,102 @@ class _FflPlan:
                 "uir_ffl_partials")
         L.check(lib.uir_reduce_slab(self.sslab.data_ptr(), B * self.nblk, 1, out_ptr, 1, 0, 1.0 / (B * 3 * HW), st), "uir_reduce_slab")
 
-    def backward(self, pred, truth, gscale_ptr: int, w_ptr, dpred, accumulate: bool):
-        """dpred (+)= gscale * (w or 1) * dFFL/dpred"""
+    def backward(self, pred, truth, gscale_ptr: int, w_ptr, dpred, accumulate: bool, scale: float = 1.0):
+        """dpred (+)= scale * gscale * (w or 1) * dFFL/dpred"""
         st = _stream()
         B, HW = self.B, self.H * self.W
         self._spectrum(pred, truth, st)
-        coef = 2.0 / (B * 3 * HW)                 # d mean(w |D|^2) / dD = 2 w D / count (w detached); the DFT scale sits in the plan
+        coef = scale * 2.0 / (B * 3 * HW)         # d mean(w |D|^2) / dD = 2 w D / count (w detached); the DFT scale sits in the plan
         L.check(lib.uir_ffl_spectrum_grad(self.Dr.data_ptr(), self.Di.data_ptr(), self.mx2.data_ptr(), gscale_ptr, w_ptr, coef,
                                           self.Gr.data_ptr(), self.Gi.data_ptr(), B, HW, st), "uir_ffl_spectrum_grad")
         self.rec.run(self.rec.bwd)
         L.check(lib.uir_ffl_add_grad(self.dd4.data_ptr(), dpred.data_ptr(), B, HW, 1 if accumulate else 0, st), "uir_ffl_add_grad")
+
+
+class _MsSsimPlan:
+    """MS_SSIM(win_size=11, win_sigma=1.5, data_range=1, size_average=True, channel=3) of the reference (src/Losses/losses.py:43-44) as a
+    differentiable loss term for one (B, H, W); pytorch_msssim is not in the image and not vendored: its published algorithm is restated
+    (PARITY UNPINNED, checked against oracle/msssim_ref.py).  Five levels, weights (0.0448, 0.2856, 0.3001, 0.2363, 0.1333), K = (0.01,
+    0.03); needs min(H, W) > 160 like the package.  The backward recomputes the forward (pooled images, level means)."""
+
+    WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+    _cache: dict = {}
+
+    @classmethod
+    def get(cls, B, H, W, device):
+        key = (B, H, W, str(device))
+        if key not in cls._cache:
+            if len(cls._cache) >= 4:
+                cls._cache.pop(next(iter(cls._cache)))
+            cls._cache[key] = cls(B, H, W, device)
+        return cls._cache[key]
+
+    def __init__(self, B, H, W, device):
+        if min(H, W) <= (11 - 1) * 2 ** 4:
+            raise ValueError(f"MS-SSIM: image sides must exceed {(11 - 1) * 2 ** 4} (4 downsamplings of an 11-tap window), got {H} x {W}")
+        self.B, self.planes = B, B * 3
+        f32 = dict(dtype=torch.float32, device=device)
+        coords = torch.arange(11, dtype=torch.float32) - 5            # _fspecial_gauss_1d(11, 1.5), fp32 as in the package
+        g = torch.exp(-(coords ** 2) / (2 * 1.5 ** 2))
+        self.win = [float(v) for v in (g / g.sum())]
+        self.sizes = [(H, W)]
+        for _ in range(4):
+            h, w = self.sizes[-1]
+            ph, pw = h % 2, w % 2
+            self.sizes.append(((h + 2 * ph - 2) // 2 + 1, (w + 2 * pw - 2) // 2 + 1))
+        P = self.planes
+        self.X = [None] + [torch.empty(P * h * w, **f32) for h, w in self.sizes[1:]]        # level 0 = the caller's tensors
+        self.Y = [None] + [torch.empty(P * h * w, **f32) for h, w in self.sizes[1:]]
+        self.dX = [torch.empty(P * h * w, **f32) for h, w in self.sizes]
+        self.nblk = [max(1, min(64, ((h - 10) * (w - 10) + 4095) // 4096)) for h, w in self.sizes]
+        self.slab = torch.empty(P * 64 * 2, **f32)
+        self.means, self.dmeans, self.ms = torch.empty(5 * P * 2, **f32), torch.empty(5 * P * 2, **f32), torch.empty(1, **f32)
+        n0 = P * (H - 10) * (W - 10)
+        self.A, self.Bm, self.Cm = torch.empty(n0, **f32), torch.empty(n0, **f32), torch.empty(n0, **f32)
+        self.wts = L.MsSsimWeights()
+        for i, v in enumerate(self.WEIGHTS):
+            self.wts.w[i] = v
+
+    def _args(self, lvl, pred, truth):
+        a = L.MsSsimArgs()
+        a.X = pred.data_ptr() if lvl == 0 else self.X[lvl].data_ptr()
+        a.Y = truth.data_ptr() if lvl == 0 else self.Y[lvl].data_ptr()
+        a.slab = self.slab.data_ptr()
+        a.planes, (a.H, a.W), a.nblk = self.planes, self.sizes[lvl], self.nblk[lvl]
+        a.C1, a.C2 = 0.01 ** 2, 0.03 ** 2
+        for i, v in enumerate(self.win):
+            a.win[i] = v
+        return a
+
+    def _forward(self, pred, truth, st, ms_ptr=None):
+        P = self.planes
+        for lvl in range(5):
+            a = self._args(lvl, pred, truth)
+            L.check(lib.uir_msssim_level(C.byref(a), self.means.data_ptr() + 4 * (lvl * P * 2), st), "uir_msssim_level")
+            if lvl < 4:
+                h, w = self.sizes[lvl]
+                L.check(lib.uir_avgpool2(a.X, self.X[lvl + 1].data_ptr(), P, h, w, st), "uir_avgpool2")
+                L.check(lib.uir_avgpool2(a.Y, self.Y[lvl + 1].data_ptr(), P, h, w, st), "uir_avgpool2")
+        L.check(lib.uir_msssim_combine(self.means.data_ptr(), self.dmeans.data_ptr(), ms_ptr or self.ms.data_ptr(), 5, P, C.byref(self.wts), st),
+                "uir_msssim_combine")
+
+    def forward(self, pred, truth, out_ptr: int):
+        """writes ms_ssim(pred, truth) to the device float at out_ptr"""
+        self._forward(pred, truth, _stream(), out_ptr)
+
+    def backward(self, pred, truth, gscale_ptr: int, coef: float, dpred):
+        """dpred += coef * gscale * d ms_ssim / d pred"""
+        st = _stream()
+        P = self.planes
+        self._forward(pred, truth, st)
+        for lvl in range(4, -1, -1):
+            a = self._args(lvl, pred, truth)
+            L.check(lib.uir_msssim_level_bwd(C.byref(a), self.dmeans.data_ptr() + 4 * (lvl * P * 2), self.A.data_ptr(), self.Bm.data_ptr(),
+                                             self.Cm.data_ptr(), self.dX[lvl].data_ptr(), 0, st), "uir_msssim_level_bwd")
+            if lvl < 4:
+                h, w = self.sizes[lvl]
+                L.check(lib.uir_avgpool2_bwd(self.dX[lvl + 1].data_ptr(), self.dX[lvl].data_ptr(), P, h, w, 1, st), "uir_avgpool2_bwd")
+        L.check(lib.uir_axpy_dev(self.dX[0].data_ptr(), gscale_ptr, coef, dpred.data_ptr(), self.dX[0].numel(), st), "uir_axpy_dev")
 
 
 def loss_sums(pred: torch.Tensor, truth: torch.Tensor, kind: int) -> torch.Tensor:
@@ -112,6 +198,8 @@ def loss_sums(pred: torch.Tensor, truth: torch.Tensor, kind: int) -> torch.Tenso
                 "uir_reduce_slab")
     if kind in L.LOSS_FFL_KINDS:         # FocalFrequencyLoss mean -> sums[6]
         _FflPlan.get(B, H, W, pred.device).forward(pred, truth, sums.data_ptr() + 24)
+    if kind in L.LOSS_MSSSIM_KINDS:      # MS-SSIM mean -> sums[7]
+        _MsSsimPlan.get(B, H, W, pred.device).forward(pred, truth, sums.data_ptr() + 28)
     L.check(lib.uir_loss_finalize(sums.data_ptr(), out.data_ptr(), kind, B, H * W, st), "uir_loss_finalize")
     return out
 
@@ -157,9 +245,12 @@ def loss_grad(pred: torch.Tensor, truth: torch.Tensor, gscale: torch.Tensor, kin
         aux = loss_sums(pred, truth, kind)
     L.check(lib.uir_loss_bwd(pred.data_ptr(), truth.data_ptr(), gs.data_ptr(), aux.data_ptr() if aux is not None else None, dpred.data_ptr(),
                              kind, B, H * W, _stream()), "uir_loss_bwd")
-    if kind in L.LOSS_FFL_KINDS:         # + the FocalFrequencyLoss term (weighted by aux[2] in the adaptive pair)
+    if kind in L.LOSS_FFL_KINDS:         # + the FocalFrequencyLoss term (weighted by aux[2] in the adaptive pair, 0.025 in ssimFFLCharbonnier)
         wp = aux.data_ptr() + 8 if kind in L.LOSS_ADAPTIVE_KINDS else None
-        _FflPlan.get(B, H, W, pred.device).backward(pred, truth, gs.data_ptr(), wp, dpred, accumulate=True)
+        _FflPlan.get(B, H, W, pred.device).backward(pred, truth, gs.data_ptr(), wp, dpred, accumulate=True,
+                                                    scale=0.025 if kind == L.LOSS_KINDS["ssimFFLCharbonnier"] else 1.0)
+    if kind in L.LOSS_MSSSIM_KINDS:      # + the (1 - ms_ssim) term
+        _MsSsimPlan.get(B, H, W, pred.device).backward(pred, truth, gs.data_ptr(), -1.0, dpred)
     return dpred
 
 
