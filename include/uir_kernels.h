@@ -472,6 +472,25 @@ int uir_avgpool2(const float* X, float* Y, int planes, int H, int W, void* strea
 int uir_avgpool2_bwd(const float* dY, float* dX, int planes, int H, int W, int accumulate, void* stream);
 int uir_axpy_dev(const float* x, const float* gscale, float coef, float* y, long n, void* stream);
 
+/* Pieces of VGGPerceptualLoss (src/Losses/losses.py:215-255) and TVLoss (:11-28) around the convolution stack, which is uir_gemm
+ * (taps = 9, bias, ReLU = UIR_ACT_LEAKY with slope 0) / uir_leaky_bwd + uir_gemm (flipped taps) on HWC rows.  The VGG16 weights are
+ * the USER's torchvision-format file (the reference downloads them; this build cannot and does not ship or fake them).
+ *   uir_vgg_prep(_bwd)         out4[b][oy][ox][c] = (bilinear_{align_corners=False}(img)[b][c][oy][ox] - mean[c]) / std[c], S x S, pad
+ *                              channel 0;  backward: dimg += coef * gscale[0] * adjoint(d4), gathered per source pixel (no atomics)
+ *   uir_maxpool2_hwc(_bwd)     nn.MaxPool2d(2, 2) on rows [B*H*W][C]; gradient to the first maximum of each window in scan order
+ *   uir_l1_feat_partials/_bwd  partial sums of |x - y| over n floats (n % 4 == 0); dX (+)= k * sign(x - y)
+ *   uir_tv_partials/_bwd       slab[blk] = (sum of squared vertical, horizontal differences) of [planes][H][W];
+ *                              dX += gscale[0] * (kh * d(sum_h)/dX + kw * d(sum_w)/dX) */
+int uir_vgg_prep(const float* img, float* out4, int B, int H, int W, int S, void* stream);
+int uir_vgg_prep_bwd(const float* d4, float* dimg, const float* gscale, float coef, int B, int H, int W, int S, void* stream);
+int uir_maxpool2_hwc(const float* X, float* Y, int B, int H, int W, int C, void* stream);
+int uir_maxpool2_hwc_bwd(const float* X, const float* dY, float* dX, int B, int H, int W, int C, int accumulate, void* stream);
+int uir_l1_feat_partials(const float* X, const float* Y, float* slab, int nblocks, long n, void* stream);
+int uir_l1_feat_bwd(const float* X, const float* Y, float* dX, float k, long n, int accumulate, void* stream);
+int uir_tv_partials(const float* X, float* slab, int nblocks, int planes, int H, int W, void* stream);
+int uir_tv_bwd(const float* X, float* dX, const float* gscale, float kh, float kw, int planes, int H, int W, void* stream);
+int uir_relu_inplace(float* x, long n, void* stream);   /* x = max(x, 0), n % 4 == 0 */
+
 /* --------------------------------------------------------------- uir_optim */
 /* slab[block] = partial sum of squares of g[0..n) */
 int uir_sumsq_partials(const float* g, long n, float* slab, int nblocks, void* stream);

@@ -300,3 +300,39 @@ def test_ast_data_parallel_two_ranks(tmp_path):
     flat = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).cpu()
     d = float((flat - r0["flat"]).abs().max())
     assert d <= 2e-4, d
+
+
+@pytest.mark.gpu
+def test_ast_train_step_with_the_fflmix_loss_of_baseline_config_4():
+    """BASELINE configs[4] = --arch AST with the "perceptual+ffl mix" loss (fflMix, src/Losses/losses.py:108-117), here at 256 x 256,
+    bs 1, fp32 and RANDOM VGG16 weights in torchvision's layout (the pretrained file is the user's to supply): the fused step's loss
+    and pre-clip gradient norm equal the autograd path's with LossFunction("fflMix"), and two steps stay finite."""
+    from oracle import perceptual_ref as R
+    from underwater_image_restoration_amd.Losses import perceptual
+    from underwater_image_restoration_amd.Losses.losses import LossFunction
+    from underwater_image_restoration_amd.Models import init_model
+    from underwater_image_restoration_amd.trainer import make_train_step
+    perceptual.set_vgg16_weights(R.random_vgg16_state(5))
+    try:
+        N = 256
+        raw = (0.5 + 0.5 * O.closed_form_input(1, 3, N * N, 291).reshape(1, 3, N, N)).cuda()
+        ref = (0.5 + 0.5 * O.closed_form_input(1, 3, N * N, 292).reshape(1, 3, N, N)).cuda()
+        nets = []
+        for _ in range(2):
+            m = init_model("AST", drop_path_rate=0.0)
+            shapes = {k: tuple(v.shape) for k, v in m.state_dict().items() if v.is_floating_point()}
+            m.load_state_dict(O.closed_form_params(shapes, "astfflmix"), strict=False)
+            nets.append(m.cuda().train())
+        step = make_train_step(nets[0], "fflMix", 3e-4)
+        l0, n0 = step(raw, ref)
+        l0, n0 = float(l0), float(n0)
+        tup = LossFunction("fflMix", "cuda").getloss(nets[1](raw), ref)
+        tup[0].backward()
+        norm = torch.nn.utils.clip_grad_norm_(nets[1].parameters(), 1.0)
+        assert len(tup) == 6 and abs(float(tup[0]) - l0) < 1e-5 * abs(l0), (float(tup[0]), l0)
+        assert abs(float(norm) - n0) < 2e-4 * n0, (float(norm), n0)
+        l1, n1 = step(raw, ref)
+        assert np.isfinite(float(l1)) and np.isfinite(float(n1))
+    finally:
+        perceptual._weights_sd = None
+        perceptual._VggPlan._cache.clear()

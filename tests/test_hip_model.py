@@ -696,3 +696,32 @@ def test_data_parallel_two_ranks_real_step(tmp_path):
     torch.cuda.synchronize()
     d = float((model.flat_params().flat.cpu() - r0["flat"]).abs().max())
     assert d <= 1e-4, d                               # Adam's sign-like first steps amplify 1e-5 gradient noise (see the micro-batch test)
+
+
+def test_fused_train_step_with_the_fflmix_loss_equals_the_autograd_path():
+    """BASELINE configs[4]'s loss ("perceptual+ffl mix" = fflMix, src/Losses/losses.py:108-117) through the fused train step: the
+    loss value and the pre-clip gradient norm equal those of the module's autograd path with LossFunction("fflMix") - every term
+    (Charbonnier, VGG perceptual with the user's weights - random ones here -, Gradient_Loss, FocalFrequencyLoss, MS-SSIM) reaches
+    the network's parameters the same way."""
+    from oracle import perceptual_ref as R
+    from underwater_image_restoration_amd.Losses import perceptual
+    perceptual.set_vgg16_weights(R.random_vgg16_state(3))
+    try:
+        raw, ref = O.closed_form_images(2, 176, 301).to(DEV), O.closed_form_images(2, 176, 302).to(DEV)
+        model, step = _fresh_step("fflMix")
+        l0, n0 = step(raw, ref)
+        l0, n0 = float(l0), float(n0)
+        assert np.isfinite(l0) and np.isfinite(n0)
+        model2 = init_model("SpectralTransformer")
+        model2.load_state_dict(O.closed_form_state())
+        model2 = model2.to(DEV)
+        out = model2(raw)
+        tup = LossFunction("fflMix", DEV).getloss(out, ref)
+        assert len(tup) == 6
+        tup[0].backward()
+        norm = torch.nn.utils.clip_grad_norm_(model2.parameters(), 1.0)
+        assert abs(float(tup[0]) - l0) < 1e-5 * abs(l0), (float(tup[0]), l0)
+        assert abs(float(norm) - n0) < 1e-4 * n0, (float(norm), n0)
+    finally:
+        perceptual._weights_sd = None
+        perceptual._VggPlan._cache.clear()

@@ -150,3 +150,53 @@ def test_msssim_losses_match_the_cpu_restatement(name, shape):
     assert abs(float(got) - float(want)) < 2e-5 * max(abs(float(want)), 1e-3), (float(got), float(want))
     err = float((pg.grad.cpu().double() - gwant).abs().max())
     assert err < 1e-4 * float(gwant.abs().max()), (err, float(gwant.abs().max()))
+
+
+# ------------------------------------------------------------------ VGG perceptual loss and the mixes around it
+def test_perceptual_losses_refuse_without_the_users_weights(monkeypatch, tmp_path):
+    """(CPU) no weight file, no fake: the names that contain VGGPerceptualLoss say what is missing and where it is looked for."""
+    from underwater_image_restoration_amd.Losses import perceptual
+    monkeypatch.setattr(perceptual, "_weights_sd", None)
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path))
+    monkeypatch.delenv("UIR_VGG16_WEIGHTS", raising=False)
+    with pytest.raises(NotImplementedError, match="vgg16-397923af.pth"):
+        perceptual._find_weights()
+    with pytest.raises(KeyError):
+        perceptual.set_vgg16_weights({"features.0.weight": torch.zeros(64, 3, 3, 3)})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,shape", [("perceptual", (1, 3, 64, 80)), ("perceptual", (2, 3, 256, 240)), ("fflMix", (1, 3, 176, 192)),
+                                        ("fflMixTV", (1, 3, 176, 192)), ("bigMix", (1, 3, 176, 192)), ("mix", (1, 3, 176, 192))])
+def test_perceptual_mixes_match_the_cpu_restatement(name, shape):
+    """Preprocessing, the VGG16 feature stack (random weights in torchvision's layout), the four L1 feature losses, their backward to
+    the image, and the reference's mixes (fflMix as its 6-tuple) vs oracle/perceptual_ref.py in fp64.  The L1 feature losses have sign
+    kinks: the gradient is compared in the L2 sense."""
+    from oracle import perceptual_ref as R
+    from underwater_image_restoration_amd.Losses import perceptual
+    from underwater_image_restoration_amd.Losses.losses import LossFunction
+    sd = R.random_vgg16_state(7)
+    perceptual.set_vgg16_weights(sd)
+    try:
+        pred = 0.5 + 0.45 * recipe(shape, 41)
+        truth = 0.7 * pred + 0.3 * (0.5 + 0.45 * recipe(shape, 42))
+        p64 = pred.double().requires_grad_(True)
+        want = R.loss(name, p64, truth.double(), {k: v.double() for k, v in sd.items()})
+        wtot = want[0] if isinstance(want, tuple) else want
+        (gwant,) = torch.autograd.grad(wtot, p64)
+        pg = pred.cuda().requires_grad_(True)
+        got = LossFunction(name, "cuda").getloss(pg, truth.cuda())
+        gtot = got[0] if isinstance(got, tuple) else got
+        gtot.backward()
+        if name == "fflMix":
+            assert len(got) == 6
+            for a, b in zip(got, want):
+                assert abs(float(a) - float(b)) < 2e-4 * max(abs(float(b)), 1e-3), (float(a), float(b))
+        assert abs(float(gtot) - float(wtot)) < 2e-4 * abs(float(wtot)), (float(gtot), float(wtot))
+        diff = pg.grad.cpu().double() - gwant
+        # a fraction f of feature differences within fp32 noise of zero flips its sign between fp32 and fp64: ~2 sqrt(f) in this norm
+        # (measured 2e-3 ... 6e-3); a wrong convolution / pooling / resize adjoint is an O(1) error
+        assert float(diff.norm()) < 2e-2 * float(gwant.norm()), (float(diff.norm()), float(gwant.norm()))
+    finally:
+        perceptual._weights_sd = None
+        perceptual._VggPlan._cache.clear()

@@ -20,6 +20,10 @@ truth)`` (src/Losses/losses.py:30-160), for the loss names on the SpectralTransf
   ms_ssim / ssimFFLCharbonnier   1 - MS_SSIM(win 11, sigma 1.5, data_range 1, size_average, channel 3) (:43-44, :86-87) and
                 0.025 ffl + 0.025 charbonnier + (1 - ms_ssim) (:152-156).  pytorch_msssim is likewise absent: its published algorithm is
                 restated (ops._MsSsimPlan, csrc/msssim.hip; oracle/msssim_ref.py) - PARITY UNPINNED.  Needs min(H, W) > 160.
+  perceptual / mix / bigMix / fflMix / fflMixTV   VGGPerceptualLoss (:215-255) alone and the reference's mixes around it (:82-117;
+                fflMix returns the reference's 6-tuple): the preprocessing, the frozen VGG16 feature stack, the L1 feature losses and the
+                backward to the image run on the HIP kernels (Losses/perceptual.py), composed with the terms above and TVLoss (:11-28).
+                They need the USER's torchvision VGG16 weight file (a download in the reference) and refuse without it.
 
 Forward and backward are HIP reductions (uir_loss_*).  Other reference loss names need
 third-party packages / pretrained VGG weights that are outside this build's scope.
@@ -35,7 +39,7 @@ from .. import ops
 # mix; "ffl" alone raises AttributeError in the reference, :30-48 never builds self.ffl for it).  pytorch_msssim.MS_SSIM and
 # focal_frequency_loss.FocalFrequencyLoss are un-vendored, unpinned pip packages (requirements.txt:14-15) restated above.  "fflMix" (:108-117) needs all three: its Charbonnier, Gradient_Loss and (restated,
 # unpinned) FocalFrequencyLoss terms exist above; the VGG16 and MS-SSIM terms cannot be built here.
-_REFERENCE_OTHER = ("perceptual", "ffl", "mix", "fflMixTV", "bigMix", "fflMix")
+_REFERENCE_OTHER = ("ffl",)
 
 
 class _LossFn(torch.autograd.Function):
@@ -52,6 +56,24 @@ class _LossFn(torch.autograd.Function):
         return ops.loss_grad(pred, truth, g, ctx.kind, aux=out), None, None
 
 
+class _MixFn(torch.autograd.Function):
+    """fflMix: the total (differentiable) and its five terms (values only, like the reference's logging use of them)."""
+
+    @staticmethod
+    def forward(ctx, pred, truth, kind):
+        out = ops.loss_sums(pred, truth, kind)
+        ctx.save_for_backward(pred, truth, out)
+        ctx.kind = kind
+        terms = tuple(out[i].clone() for i in (4, 5, 6, 7, 8))
+        ctx.mark_non_differentiable(*terms)
+        return (out[0].clone(),) + terms
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        pred, truth, out = ctx.saved_tensors
+        return ops.loss_grad(pred, truth, g, ctx.kind, aux=out), None, None
+
+
 class LossFunction:
     def __init__(self, loss_name, device):
         self.loss_name = loss_name
@@ -59,11 +81,12 @@ class LossFunction:
 
     def getloss(self, predicted_data, truth_data):
         name = self.loss_name
+        if name == "fflMix":                      # the reference returns (loss, charb, perc, grad, ffl, ssim) here (:108-117)
+            return _MixFn.apply(predicted_data, truth_data.detach(), L.LOSS_KINDS[name])
         if name in L.LOSS_KINDS:
             return _LossFn.apply(predicted_data, truth_data.detach(), L.LOSS_KINDS[name])
         if name in _REFERENCE_OTHER:
-            raise NotImplementedError(f"loss '{name}' needs torchvision's pretrained VGG16 weights (a download that does not exist in "
-                                      f"this image; 'ffl' alone is an AttributeError in the reference) (DESIGN.md section 18); "
+            raise NotImplementedError(f"loss '{name}' is an AttributeError in the reference (losses.py:30-48 never builds self.ffl for it); "
                                       f"its Charbonnier / Luminance / Gradient_Loss / FocalFrequencyLoss terms are available through 'charbonnier', 'Luminance', 'gradient', 'fflCharbonnier', 'ms_ssim'")
         raise ValueError(f"Unsupported loss: {self.loss_name}")
 

@@ -23,10 +23,14 @@ LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor":
               # with a FocalFrequencyLoss term (src/Losses/losses.py:45-46,97-98,137-151; the package's algorithm restated: parity unpinned)
               "fflCharbonnier": 8, "LuminanceFFL": 9, "AdaptiveLuminanceFFL": 10,
               # with an MS_SSIM term (:43-44,86-87,152-156; pytorch_msssim restated: parity unpinned)
-              "ms_ssim": 11, "ssimFFLCharbonnier": 12}
+              "ms_ssim": 11, "ssimFFLCharbonnier": 12,
+              # with the VGG16 perceptual term (:82-83,88-117; composed on the host from the terms above, Losses/perceptual.py): they need the
+              # USER's torchvision weight file and refuse without it
+              "perceptual": 100, "mix": 101, "fflMixTV": 102, "bigMix": 103, "fflMix": 104}
 LOSS_GRADIENT = 7
 LOSS_FFL_KINDS = (8, 9, 10, 12)
 LOSS_MSSSIM_KINDS = (11, 12)
+LOSS_MIX_FIRST = 100             # kinds >= this are host-composed mixes
 LOSS_ADAPTIVE_KINDS = (6, 10)      # term weights from the detached loss values: aux of loss_sums -> loss_grad
 
 
@@ -247,6 +251,15 @@ SIGNATURES = {
     "uir_avgpool2": [fp, fp, i32, i32, i32, fp],
     "uir_avgpool2_bwd": [fp, fp, i32, i32, i32, i32, fp],
     "uir_axpy_dev": [fp, fp, C.c_float, fp, C.c_long, fp],
+    "uir_vgg_prep": [fp, fp, i32, i32, i32, i32, fp],
+    "uir_vgg_prep_bwd": [fp, fp, fp, C.c_float, i32, i32, i32, i32, fp],
+    "uir_maxpool2_hwc": [fp, fp, i32, i32, i32, i32, fp],
+    "uir_maxpool2_hwc_bwd": [fp, fp, fp, i32, i32, i32, i32, i32, fp],
+    "uir_l1_feat_partials": [fp, fp, fp, i32, C.c_long, fp],
+    "uir_l1_feat_bwd": [fp, fp, fp, C.c_float, C.c_long, i32, fp],
+    "uir_tv_partials": [fp, fp, i32, i32, i32, i32, fp],
+    "uir_tv_bwd": [fp, fp, fp, C.c_float, C.c_float, i32, i32, i32, fp],
+    "uir_relu_inplace": [fp, C.c_long, fp],
     "uir_sumsq_partials": [fp, i64, fp, i32, fp],
     "uir_clip_adam_step": [C.POINTER(AdamArgs), fp],
     "uir_adam_set_hyper": [fp, f32, f32, f32, f32, fp],

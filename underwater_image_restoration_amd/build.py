@@ -16,11 +16,11 @@ OBJ = os.path.join(CSRC, "_build")
 LIB = os.path.join(HERE, "libuir_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"]
-SOURCES = ["gemm", "conv3s", "tiled", "gram", "dwconv", "gdfn", "dwln", "layernorm", "attn", "spectral", "shuffle", "resize", "colsum", "loss", "msssim", "ssim", "uiqm", "frfn", "tokenfft", "winattn", "optim", "abi_layout"]
+SOURCES = ["gemm", "conv3s", "tiled", "gram", "dwconv", "gdfn", "dwln", "layernorm", "attn", "spectral", "shuffle", "resize", "colsum", "loss", "msssim", "vgg", "ssim", "uiqm", "frfn", "tokenfft", "winattn", "optim", "abi_layout"]
 # Per-source flags.  -fno-slp-vectorize: in these files hipcc's SLP vectoriser forms packed-f32 instructions whose src1 is half-swapped
 # (op_sel[1] = 1), the form the gfx950 erratum of DESIGN.md section 17 corrupts next to bf16 MFMA waves; explicit f32x2 code keeps
 # its v_pk_fma_f32.  lint_isa() below is what actually enforces the rule - a file missing here fails the build, it does not slip through.
-EXTRA_FLAGS = {n: ["-fno-slp-vectorize"] for n in ("gemm", "gdfn", "attn", "ssim", "uiqm", "winattn", "dwconv", "msssim")}
+EXTRA_FLAGS = {n: ["-fno-slp-vectorize"] for n in ("gemm", "gdfn", "attn", "ssim", "uiqm", "winattn", "dwconv", "msssim", "vgg")}
 LLVM_BIN = os.environ.get("UIR_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 # packed-f32 VOP3P with op_sel set on src1 or src2 (the low result reads a HIGH half): wrong low halves in lanes 48-63 whenever a
 # wave issuing v_mfma_f32_32x32x16_bf16 shares the SIMD (tools/probes/pkfma/, profiles/r03/pkfma_*.txt).  op_sel on src0 and every

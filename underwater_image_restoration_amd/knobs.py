@@ -22,6 +22,16 @@ KNOBS = {
 PLUMBING = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HIPCC", "UIR_LLVM_BIN")
 
 
+# file locations (not numerics): where the user's torchvision VGG16 weights may be found for the perceptual loss (Losses/perceptual.py);
+# TORCH_HOME is torch's own variable for the hub cache the reference's vgg16(pretrained=True) would have filled
+PATHS = ("UIR_VGG16_WEIGHTS", "TORCH_HOME")
+
+
+def path(name: str) -> "str | None":
+    assert name in PATHS, f"{name} is not a documented path variable (knobs.py)"
+    return os.environ.get(name) or None
+
+
 def get(name: str) -> str:
     assert name in KNOBS, f"{name} is not a documented knob (knobs.py)"
     return os.environ.get(name, KNOBS[name][0])
@@ -44,6 +54,6 @@ def report() -> None:
         v = os.environ.get(k)
         if v is not None and v != default:
             print(f"[uir] {k}={v} (default {default}): {what}", flush=True)
-    stray = sorted(k for k in os.environ if k.startswith("UIR_") and k not in KNOBS and k not in PLUMBING and k not in ("UIR_CPU_THREADS", "UIR_CPU_BATCH"))
+    stray = sorted(k for k in os.environ if k.startswith("UIR_") and k not in KNOBS and k not in PLUMBING and k not in PATHS and k not in ("UIR_CPU_THREADS", "UIR_CPU_BATCH"))
     if stray:
         print(f"[uir] ignored environment variables (not knobs of this build): {', '.join(stray)}", flush=True)

@@ -182,6 +182,9 @@ def loss_sums(pred: torch.Tensor, truth: torch.Tensor, kind: int) -> torch.Tenso
     pred, truth = _req(pred, "loss"), _req(truth, "loss")
     if pred.shape != truth.shape or pred.dim() != 4 or pred.shape[1] != 3:
         raise ValueError(f"loss expects matching [B,3,H,W] tensors, got {tuple(pred.shape)} / {tuple(truth.shape)}")
+    if kind >= L.LOSS_MIX_FIRST:         # the mixes around the VGG16 perceptual term: composed from the single-term paths
+        from .Losses import perceptual
+        return perceptual.mix_sums(pred, truth, kind)
     B, _, H, W = pred.shape
     slab = torch.empty(_LOSS_BLOCKS * 8, dtype=torch.float32, device=pred.device)
     sums = torch.empty(8, dtype=torch.float32, device=pred.device)
@@ -235,6 +238,9 @@ def loss_grad(pred: torch.Tensor, truth: torch.Tensor, gscale: torch.Tensor, kin
     """dL/dpred * gscale.  aux = the tensor loss_sums returned for the same pair (needed by AdaptiveLuminanceCharbonnier: its weights
     are functions of the two loss values, detached - src/Losses/losses.py:135-138)."""
     pred, truth = _req(pred, "loss"), _req(truth, "loss")
+    if kind >= L.LOSS_MIX_FIRST:
+        from .Losses import perceptual
+        return perceptual.mix_grad(pred, truth, gscale, kind, aux)
     B, _, H, W = pred.shape
     gs = _req(gscale.reshape(1), "loss")
     dpred = torch.empty_like(pred)
