@@ -90,11 +90,11 @@ def test_ffl_oracle_properties():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("shape", [(2, 3, 32, 48), (1, 3, 256, 256), (3, 3, 20, 64)])
+@pytest.mark.parametrize("shape", [(2, 3, 32, 48), (1, 3, 256, 256), (3, 3, 20, 64), (1, 3, 512, 512)])
 @pytest.mark.parametrize("name", ["fflCharbonnier", "LuminanceFFL", "AdaptiveLuminanceFFL"])
 def test_ffl_losses_match_the_cpu_restatement(name, shape):
     """HIP value and input gradient of the three FocalFrequencyLoss losses vs oracle/ffl_ref.py in fp64 (the fast MFMA DFT lengths, the
-    256 = 2 x 128 split and the dense fallback)."""
+    256 = 2 x 128 split, 512 = 2 x (2 x 128) and the dense fallback)."""
     from oracle import ffl_ref
     from underwater_image_restoration_amd.Losses.losses import LossFunction
     pred, truth = recipe(shape, 21), recipe(shape, 22)

@@ -43,7 +43,17 @@ def bench_net(args):
     with contextlib.redirect_stdout(sys.stderr):
         model = init_model(arch).cuda()
     model.train()
-    step = make_train_step(model, "charbonnier", 3e-4)
+    vgg_note = None
+    if args.loss in ("perceptual", "mix", "bigMix", "fflMix", "fflMixTV"):
+        from underwater_image_restoration_amd.Losses import perceptual
+        try:
+            perceptual._find_weights()
+            vgg_note = "VGG16 weights: the user's torchvision file"
+        except NotImplementedError:            # timing only: the arithmetic does not depend on the values
+            from oracle import perceptual_ref
+            perceptual.set_vgg16_weights(perceptual_ref.random_vgg16_state(0))
+            vgg_note = "VGG16 weights: RANDOM values in torchvision's layout (no pretrained file on this box) - a timing of the loss's arithmetic, not a training result"
+    step = make_train_step(model, args.loss, 3e-4)
     g = torch.Generator().manual_seed(1000)
     raw = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).cuda()
     ref = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).cuda()
@@ -57,10 +67,11 @@ def bench_net(args):
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     plans = [p for m in model.plan_modules() for p in m._plans.values()]
     nbytes, flops, launches = sum(p.alg_bytes() for p in plans), sum(p.flops() for p in plans), sum(len(p.fwd) + len(p.bwd) for p in plans)
-    line = {"metric": f"train images/sec, {arch} {S}x{S} bs={B}/GPU, Charbonnier (BASELINE {cfg}, one GPU)",
+    lname = "Charbonnier" if args.loss == "charbonnier" else args.loss
+    line = {"metric": f"train images/sec, {arch} {S}x{S} bs={B}/GPU, {lname} (BASELINE {cfg}, one GPU)",
             "value": B / (ms * 1e-3), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{arch} {S}x{S} bs={B}, charbonnier, clip 1.0 + Adam 3e-4, DropPath as the reference sets it",
+            "config": {"workload": f"{arch} {S}x{S} bs={B}, {args.loss}, clip 1.0 + Adam 3e-4, DropPath as the reference sets it" + (f"; {vgg_note}" if vgg_note else ""),
                        "params": sum(p.numel() for p in model.parameters()), "launches_per_step": launches,
                        "final_loss": float(loss), "grad_norm": float(norm),
                        "plan_memory_GB": sum(p.bytes for p in plans) / 1e9},
@@ -106,6 +117,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--loss", default="charbonnier", help="loss name of the network benches (--what net / ast), e.g. fflMix = BASELINE configs[4]'s")
     ap.add_argument("--what", default="frfn", choices=("frfn", "encoder", "decoder", "net", "ast"),
                     help="frfn: one FRFN (block.py:249-282); encoder: one EncoderBlock = LN + 2 FRFN + 2 (L,C) transforms (model.py:16-93); "
                          "decoder: one DecoderBlock(dim, enc_out=True) = 2 LN + MDASSA (2 window attentions + FDFP) + FRFN(2 dim) + proj (model.py:96-160)")

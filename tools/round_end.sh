@@ -22,5 +22,7 @@ for W in net ast; do
 done
 python tools/bench_frfn.py --what net > $O/frfnnet_bench.json 2> $O/frfnnet.err && echo frfnnet-ok
 python tools/bench_frfn.py --what ast > $O/ast_bench.json 2> $O/ast.err && echo ast-ok
+python tools/bench_frfn.py --what ast --loss fflMix --no-cpu > $O/ast_fflmix_bench.json 2> $O/ast_fflmix.err && echo ast-fflmix-ok
+python tools/bench_losses.py 4 512 > $O/bench_losses.txt 2>&1 && python tools/bench_losses.py 16 256 >> $O/bench_losses.txt 2>&1 && echo losses-ok
 python tools/bench_uiqm.py > $O/uiqm_bench.json 2> $O/uiqm.err && echo uiqm-ok
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete

@@ -227,8 +227,14 @@ _FAST_DFT = (128, 64, 32)            # lengths of the two-stage MFMA DFT kernel 
 
 
 def _axis_factors(N: int):
-    """(N,) when one launch handles the axis, else (2, N/2) with N/2 on the fast kernel (256 = 2 * 128)."""
-    if N % 2 == 0 and N // 2 in _FAST_DFT and N not in _FAST_DFT:
+    """(N,) when one launch handles the axis, else (2, N/2): radix-2 splits down to a length of the fast kernel (256 = 2 * 128,
+    512 = 2 * (2 * 128), ...); lengths that do not reduce to one (odd factors) take the dense kernel in one launch."""
+    if N in _FAST_DFT:
+        return (N,)
+    n = N
+    while n % 2 == 0 and n > max(_FAST_DFT):
+        n //= 2
+    if n in _FAST_DFT and n != N:
         return (2, N // 2)
     return (N,)
 
@@ -262,8 +268,11 @@ def record_axis_dft(rec: Recorder, name: str, in_re, in_im, O: int, N: int, I: i
         rec.dft(name, in_re, in_im, o_re, o_im, O=O, N=N, I=I, C_=C_, sign=1.0, scale=scale)
         return o_re, o_im
     N2 = f[1]
-    yr, yi = rec.alloc(M, C_), rec.alloc(M, C_)
-    rec.dft(name + ".n2", in_re, in_im, yr, yi, O=O, N=N2, I=2 * I, C_=C_, sign=1.0, scale=1.0)
+    if N2 in _FAST_DFT:
+        yr, yi = rec.alloc(M, C_), rec.alloc(M, C_)
+        rec.dft(name + ".n2", in_re, in_im, yr, yi, O=O, N=N2, I=2 * I, C_=C_, sign=1.0, scale=1.0)
+    else:                              # N = 4 * 128, ...: the half-length transforms split again (the dense kernel at N = 512 took 5x longer)
+        yr, yi = record_axis_dft(rec, name + ".n2", in_re, in_im, O, N2, 2 * I, C_, 1.0, real_out=False)
     twr, twi = _axis_twiddle(N, rec.dev)
     rec._hold(twr, twi, yr, yi, o_re, o_im)
     rec._op(name + ".radix2", lib.uir_radix2_combine, _ptr(yr), _ptr(yi), _ptr(o_re), _ptr(o_im), _ptr(twr), _ptr(twi), O, N2, I, C_,
