@@ -383,6 +383,12 @@ int uir_gather_even(const float* src, int lds, int scol, float* dst, int ldd, in
  * dst [B,2H,2W,C] (channel c*4 + dy*2 + dx -> pixel (2h+dy, 2w+dx)); unshuffle is the inverse. */
 int uir_pixel_shuffle(const float* src, int lds, float* dst, int ldd, int dcol, int B, int H, int Wd, int C, void* stream);
 int uir_pixel_unshuffle(const float* src, int lds, int scol, float* dst, int ldd, int B, int H, int Wd, int C, void* stream);
+/* Patches of Conv2d(kernel 4, stride 2, padding 1) (Downsample, src/Models/AST.py:408-424) in the weight's own k order:
+ * P[(b,oy,ox)][c*16 + ky*4 + kx] = x[(b, 2oy-1+ky, 2ox-1+kx)][c], 0 outside; x is [B, 2H, 2Wd, C] rows, P [B*H*Wd, 16*C]
+ * (H, Wd: OUTPUT sides), so the convolution is one GEMM against weight.view(Cout, Cin*16).  _bwd is the adjoint
+ * (dx[pixel][c] = the <= 4 patch entries holding it, summed in (ky, kx) order). */
+int uir_patch4s2(const float* x, int ldx, float* P, int ldp, int B, int H, int Wd, int C, void* stream);
+int uir_patch4s2_bwd(const float* dP, int ldp, float* dx, int ldx, int B, int H, int Wd, int C, void* stream);
 /* dst[i] = sum_{g < group} src[idx[i * group + g]], entries with idx < 0 count as 0 (i < n; idx is device int32).  Weight
  * re-layouts of the AST samplers (src/Models/AST.py:408-443): the 4 x 4 stride-2 kernel of Downsample laid out as a 3 x 3
  * kernel over the 2 x 2-unshuffled image (and its gradient gathered back), the per-channel bias of the ConvTranspose2d of

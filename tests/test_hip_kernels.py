@@ -690,6 +690,28 @@ def test_spectral_elementwise_and_adjoints():
 
 
 # --------------------------------------------------------------- uir_shuffle
+@pytest.mark.parametrize("B,H,W,C", [(2, 3, 5, 8), (1, 1, 1, 4), (1, 4, 2, 36)])
+def test_patch4s2_is_unfold_and_its_adjoint(B, H, W, C):
+    """uir_patch4s2 == F.unfold(kernel 4, stride 2, padding 1) in the weight's k order (bit-exact: a gather), uir_patch4s2_bwd ==
+    F.fold of the same geometry; Conv2d(4, 2, 1) == patches @ weight.view(Cout, 16 C)^T (AST.py:408-424)."""
+    x = rnd(B, C, 2 * H, 2 * W, seed=1)
+    src = dev(hwc(x))
+    P = torch.full((B * H * W, 16 * C + 4), 7.0, device=DEV)
+    assert lib.uir_patch4s2(src.data_ptr(), C, P.data_ptr(), 16 * C + 4, B, H, W, C, None) == 0
+    torch.cuda.synchronize()
+    want = F.unfold(x.float(), 4, stride=2, padding=1).transpose(1, 2).reshape(B * H * W, 16 * C)
+    assert torch.equal(P[:, :16 * C].cpu(), want) and float(P[:, 16 * C:].min()) == 7.0
+    w = rnd(6, C, 4, 4, seed=2)
+    y = P[:, :16 * C].cpu().double() @ w.reshape(6, -1).double().t()
+    assert rel(chw(y, B, H, W), F.conv2d(x.float().double(), w.double(), stride=2, padding=1)) < 1e-12
+    dP = rnd(B * H * W, 16 * C, seed=3)
+    dx = torch.full((B * 4 * H * W, C + 2), 7.0, device=DEV)
+    assert lib.uir_patch4s2_bwd(dev(dP).data_ptr(), 16 * C, dx.data_ptr(), C + 2, B, H, W, C, None) == 0
+    torch.cuda.synchronize()
+    fold = F.fold(dP.float().double().reshape(B, H * W, 16 * C).transpose(1, 2), (2 * H, 2 * W), 4, stride=2, padding=1)
+    assert rel(chw(dx[:, :C], B, 2 * H, 2 * W), fold) < 1e-6 and float(dx[:, C:].min()) == 7.0
+
+
 def test_shuffle_family():
     B, H, W, C = 2, 3, 5, 8
     x = rnd(B, 4 * C, H, W, seed=1)

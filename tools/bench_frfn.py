@@ -93,6 +93,31 @@ def bench_net(args):
             line["roofline"]["traffic_source"] = rel + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, FETCH x2)"
         else:
             line["roofline"]["traffic_note"] = f"{rel} was measured on other sources ({tj.get('source_sha')}): stale, not quoted"
+    if args.breakdown_file:
+        # every module's launch lists timed one launch at a time (HIP event pairs, serial): where a step's kernel time is,
+        # module by module; the overlapped step is shorter than the sum (weight-gradient lane)
+        named = {id(m): n for n, m in model.named_modules()}
+        with open(args.breakdown_file, "w") as f:
+            f.write(f"# {arch} {S}x{S} bs={B}: step {ms:.2f} ms; serial per-launch times, one pass\n")
+            f.write("module,fwd_ms,bwd_ms,launches\n")
+            allrows = []
+            for m in model.plan_modules():
+                for key, p in m._plans.items():
+                    rf, rb = p.run_timed(p.fwd), p.run_timed(p.bwd)
+                    lf = list(p.lanes[id(p.fwd)]) + list(p.lanes[id(p.bwd)])
+                    mn = named.get(id(m), type(m).__name__) or type(m).__name__
+                    f.write(f"{mn}{list(key[:3])},{sum(r[4] for r in rf):.3f},{sum(r[4] for r in rb):.3f},{len(rf) + len(rb)}\n")
+                    allrows += [(mn, key[1], r, ln) for r, ln in zip(rf + rb, lf)]
+            agg = {}
+            for mn, side, (name, sym, nb, fl, t), ln in allrows:
+                a = agg.setdefault((sym, side, ln), [0, 0.0, 0, 0])
+                a[0] += 1; a[1] += t; a[2] += nb; a[3] += fl
+            f.write("\nsymbol,token grid side,lane,launches,ms,alg_GB,GB/s,TFLOP/s\n")
+            for (sym, side, ln), (c, t, nb, fl) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                f.write(f"{sym},{side},{ln},{c},{t:.3f},{nb / 1e9:.3f},{nb / max(t, 1e-9) / 1e6:.0f},{fl / max(t, 1e-9) / 1e9:.1f}\n")
+            f.write("\nmodule,op,symbol,lane,ms,alg_MB,GFLOP\n")
+            for mn, side, (name, sym, nb, fl, t), ln in sorted(allrows, key=lambda r: -r[2][4])[:150]:
+                f.write(f"{mn},{name},{sym},{ln},{t:.4f},{nb / 1e6:.1f},{fl / 1e9:.2f}\n")
     if not args.no_cpu:
         from oracle import decoder_ref as D, ast_ref as OA
         net_fn = OA.ast_net if arch == "AST" else D.frfn_net
@@ -117,6 +142,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--breakdown-file", default="", help="--what net / ast: per-module and per-launch serial times (csv)")
     ap.add_argument("--loss", default="charbonnier", help="loss name of the network benches (--what net / ast), e.g. fflMix = BASELINE configs[4]'s")
     ap.add_argument("--what", default="frfn", choices=("frfn", "encoder", "decoder", "net", "ast"),
                     help="frfn: one FRFN (block.py:249-282); encoder: one EncoderBlock = LN + 2 FRFN + 2 (L,C) transforms (model.py:16-93); "

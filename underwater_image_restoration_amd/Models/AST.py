@@ -4,9 +4,8 @@ values - with every forward / backward a launch list over the C ABI (include/uir
 
     InputProj (:447-466)            conv3x3 3 -> C + bias + LeakyReLU           uir_gemm taps=9 (+ uir_leaky_bwd)
     OutputProj (:470-493)           conv3x3 C -> 3 + bias on the token image    uir_gemm taps=9
-    Downsample (:408-424)           Conv2d(k 4, s 2, p 1)                       uir_pixel_unshuffle + uir_gemm taps=9 over the 4C-channel
-                                                                                half-resolution image (the 4 x 4 kernel re-laid out by
-                                                                                uir_gather_sum as a 3 x 3 one with structural zeros)
+    Downsample (:408-424)           Conv2d(k 4, s 2, p 1)                       uir_patch4s2 (16-tap patches in the weight's k order)
+                                                                                + uir_gemm against weight.view(Cout, 16 Cin) in place
     Upsample (:428-443)             ConvTranspose2d(k 2, s 2)                   uir_gemm C -> 4 C_out + uir_pixel_shuffle
     LeFF (:294-326)                 = src/model/block.py's LeFF                 model.block.record_leff
     WindowAttention_sparse          q/kv Linears, proj                          uir_gemm
@@ -45,42 +44,30 @@ def _idx(rec, a: np.ndarray) -> torch.Tensor:
     return t
 
 
-def _down_layout(Cout: int, Cin: int):
-    """Index tables between Conv2d(k 4, s 2, p 1)'s weight [Cout][Cin][4][4] and the 3 x 3 kernel over the PixelUnshuffle(2) image
-    [Cout][4 Cin][3][3]: input row 2i - 1 + u is row i + ty of phase dy with u = 0, 1, 2, 3 -> (ty, dy) = (-1, 1), (0, 0), (0, 1),
-    (1, 0); the other (ty, dy) pairs are structural zeros.  -> (expanded <- native or -1, native -> expanded)."""
-    T, D = (-1, 0, 0, 1), (1, 0, 1, 0)
-    o, c, u, v = np.meshgrid(np.arange(Cout), np.arange(Cin), np.arange(4), np.arange(4), indexing="ij")
-    native = ((o * Cin + c) * 4 + u) * 4 + v
-    ty, dy, tx, dx = np.take(T, u), np.take(D, u), np.take(T, v), np.take(D, v)
-    expanded = ((o * (4 * Cin) + (c * 4 + dy * 2 + dx)) * 3 + (ty + 1)) * 3 + (tx + 1)
-    fwd = np.full(Cout * 4 * Cin * 9, -1, dtype=np.int64)
-    fwd[expanded.ravel()] = native.ravel()
-    return fwd, expanded.ravel()
-
-
 def record_ast_downsample(rec, pfx: str, x: torch.Tensor, Cin: int, Cout: int, dims):
-    """Downsample.forward (AST.py:417-424): [B*H*W, Cin] -> [B*H*W/4, Cout]."""
+    """Downsample.forward (AST.py:417-424): [B*H*W, Cin] -> [B*H*W/4, Cout].  Conv2d(k 4, s 2, p 1) as ONE dense contraction: the
+    16-tap patches of every output pixel in the weight's own k order (uir_patch4s2) against weight.view(Cout, Cin * 16) - the weight
+    and its gradient are used in place.  (Until round 3 this was a 3 x 3 kernel over the PixelUnshuffle(2) image: 36 taps per
+    input channel of which 20 are structural zeros, 2.25 x the arithmetic.)"""
     B, H, W = dims
     H2, W2 = H // 2, W // 2
+    M2, K = B * H2 * W2, 16 * Cin
     Wn, bn = rec.P(pfx + "conv.0.weight"), rec.P(pfx + "conv.0.bias")
-    fwd, back = _down_layout(Cout, Cin)
-    ifwd, iback = _idx(rec, fwd), _idx(rec, back)
-    xu, Wx = rec.alloc(B * H2 * W2, 4 * Cin), rec.alloc(Cout, 4 * Cin, 3, 3)
-    rec._hold(x, Wn)
-    rec._op(pfx + "unshuffle", lib.uir_pixel_unshuffle, _ptr(x), _ld(x), 0, _ptr(xu), _ld(xu), B, H2, W2, Cin, nbytes=8 * x.numel())
-    rec._op(pfx + "w.layout", lib.uir_gather_sum, _ptr(Wn), _ptr(ifwd), _ptr(Wx), Wx.numel(), 1, nbytes=8 * Wx.numel())
-    y, conv_bw = record_conv3x3(rec, pfx + "conv.0", xu, Wx, bn, 4 * Cin, Cout, (B, H2, W2))
+    P, y = rec.alloc(M2, K), rec.alloc(M2, Cout)
+    rec._hold(x, Wn, bn)
+    rec._op(pfx + "patches", lib.uir_patch4s2, _ptr(x), _ld(x), _ptr(P), _ld(P), B, H2, W2, Cin, nbytes=4 * (x.numel() + P.numel()))
+    rec.gemm(pfx + "conv.0", P, Wn, y, N=Cout, K=K, w_sn=K, w_sk=1, bias=bn)
 
     def backward(dy):
-        dWx = rec.alloc(Cout, 4 * Cin, 3, 3)
-        dxu = conv_bw(dy, dWx, rec.Gr(pfx + "conv.0.bias"))
-        with rec.bulk():                                   # the gradient of the re-laid-out kernel, gathered back once it is summed
+        dP, dx = rec.alloc(M2, K), rec.alloc(B * H * W, Cin)
+        rec._hold(dy)
+        with rec.bulk():
+            rec.gram(pfx + "conv.0.dW", dy, P, rec.Gr(pfx + "conv.0.weight"), N=Cout, K=K, o_sn=K, o_sk=1)
+            _colsum_wide(rec, pfx + "conv.0.db", dy, Cout, rec.Gr(pfx + "conv.0.bias"))
             rec.flush_reductions(pfx + "conv.0.dW")
-            gW = rec.Gr(pfx + "conv.0.weight")
-            rec._op(pfx + "dw.layout", lib.uir_gather_sum, _ptr(dWx), _ptr(iback), _ptr(gW), gW.numel(), 1, nbytes=8 * gW.numel())
-        dx = rec.alloc(B * H * W, Cin)
-        rec._op(pfx + "unshuffle.bwd", lib.uir_pixel_shuffle, _ptr(dxu), _ld(dxu), _ptr(dx), _ld(dx), 0, B, H2, W2, Cin, nbytes=8 * dx.numel())
+        rec.gemm(pfx + "conv.0.dX", dy, Wn, dP, N=K, K=Cout, w_sn=1, w_sk=K)
+        rec._op(pfx + "patches.bwd", lib.uir_patch4s2_bwd, _ptr(dP), _ld(dP), _ptr(dx), _ld(dx), B, H2, W2, Cin,
+                nbytes=4 * (dP.numel() + dx.numel()))
         return dx
     return y, backward
 

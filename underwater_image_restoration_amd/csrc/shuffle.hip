@@ -76,6 +76,65 @@ __global__ void pixel_unshuffle_kernel(const float* __restrict__ src, int lds, i
   }
 }
 
+// Patches of a 4 x 4, stride 2, padding 1 convolution (Conv2d of Downsample, src/Models/AST.py:408-424) in the weight's OWN k order:
+// P[(b, oy, ox)][c * 16 + ky * 4 + kx] = x[(b, 2 oy - 1 + ky, 2 ox - 1 + kx)][c] (0 outside the image), so the convolution is one
+// dense contraction against the native [Cout][Cin * 16] weight.  One thread per (output pixel, channel): 16 reads coalesced over the
+// channels of a pixel row, 64 contiguous bytes written.  H, Wd are the OUTPUT sides.
+__global__ void patch4s2_kernel(const float* __restrict__ x, int ldx, float* __restrict__ P, int ldp, int H, int Wd, int C, long n) {
+  GRID_STRIDE(idx, n) {  // idx over [B][H][W][C]
+    const int c = (int)(idx % C);
+    const long pix = idx / C;
+    const int ox = (int)(pix % Wd);
+    const long q = pix / Wd;
+    const int oy = (int)(q % H);
+    const long b = q / H;
+    float4 v[4];
+#pragma unroll
+    for (int ky = 0; ky < 4; ++ky) {
+      const int iy = 2 * oy - 1 + ky;
+      const bool yok = iy >= 0 && iy < 2 * H;
+      const float* row = x + ((b * 2 * H + (yok ? iy : 0)) * 2 * Wd) * (long)ldx + c;
+      float t[4];
+#pragma unroll
+      for (int kx = 0; kx < 4; ++kx) {
+        const int ix = 2 * ox - 1 + kx;
+        const bool ok = yok && ix >= 0 && ix < 2 * Wd;
+        const float u = row[(long)(ok ? ix : 0) * ldx];
+        t[kx] = ok ? u : 0.f;
+      }
+      v[ky] = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    float4* d = reinterpret_cast<float4*>(P + pix * ldp + 16 * c);
+    d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  }
+}
+
+// ... and its adjoint: dx[(b, iy, ix)][c] = sum of the (at most four) patch entries that hold this pixel, in (ky, kx) order.
+// H, Wd are the sides of the PATCH grid (dx has 2 H x 2 Wd pixels).
+__global__ void patch4s2_bwd_kernel(const float* __restrict__ dP, int ldp, float* __restrict__ dx, int ldx, int H, int Wd, int C, long n) {
+  GRID_STRIDE(idx, n) {  // idx over [B][2H][2W][C]
+    const int c = (int)(idx % C);
+    const long pix = idx / C;
+    const int ix = (int)(pix % (2 * Wd));
+    const long q = pix / (2 * Wd);
+    const int iy = (int)(q % (2 * H));
+    const long b = q / (2 * H);
+    float s = 0.f;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      const int ky = ((iy + 1) & 1) + 2 * a, oy = (iy + 1 - ky) >> 1;      // iy = 2 oy - 1 + ky
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        const int kx = ((ix + 1) & 1) + 2 * e, ox = (ix + 1 - kx) >> 1;
+        const bool ok = oy >= 0 && oy < H && ox >= 0 && ox < Wd;
+        const float u = dP[((b * H + (ok ? oy : 0)) * Wd + (ok ? ox : 0)) * (long)ldp + 16 * c + 4 * ky + kx];
+        s += ok ? u : 0.f;
+      }
+    }
+    dx[pix * ldx + c] = s;
+  }
+}
+
 __global__ void copy_cols_kernel(const float* __restrict__ src, int lds, int scol, float* __restrict__ dst, int ldd, int dcol,
                                  int C, int accumulate, long n) {
   GRID_STRIDE(idx, n) {
@@ -170,6 +229,18 @@ extern "C" int uir_pixel_unshuffle(const float* src, int lds, int scol, float* d
   UIR_REQUIRE(src && dst && B > 0 && H > 0 && Wd > 0 && C > 0 && lds >= scol + C && ldd >= 4 * C);
   const long n = (long)B * H * Wd * 4 * C;
   hipLaunchKernelGGL(pixel_unshuffle_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, scol, dst, ldd, H, Wd, C, n);
+  return uir_launch_status();
+}
+extern "C" int uir_patch4s2(const float* x, int ldx, float* P, int ldp, int B, int H, int Wd, int C, void* stream) {
+  UIR_REQUIRE(x && P && B > 0 && H > 0 && Wd > 0 && C > 0 && ldx >= C && ldp >= 16 * C && (ldp & 3) == 0 && uir_aligned16(P));
+  const long n = (long)B * H * Wd * C;
+  hipLaunchKernelGGL(patch4s2_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, P, ldp, H, Wd, C, n);
+  return uir_launch_status();
+}
+extern "C" int uir_patch4s2_bwd(const float* dP, int ldp, float* dx, int ldx, int B, int H, int Wd, int C, void* stream) {
+  UIR_REQUIRE(dP && dx && B > 0 && H > 0 && Wd > 0 && C > 0 && ldx >= C && ldp >= 16 * C);
+  const long n = (long)B * H * Wd * 4 * C;
+  hipLaunchKernelGGL(patch4s2_bwd_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), dP, ldp, dx, ldx, H, Wd, C, n);
   return uir_launch_status();
 }
 extern "C" int uir_copy_cols(const float* src, int lds, int scol, float* dst, int ldd, int dcol, long M, int C, int accumulate, void* stream) {
