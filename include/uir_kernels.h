@@ -389,6 +389,11 @@ int uir_pixel_unshuffle(const float* src, int lds, int scol, float* dst, int ldd
  * (dx[pixel][c] = the <= 4 patch entries holding it, summed in (ky, kx) order). */
 int uir_patch4s2(const float* x, int ldx, float* P, int ldp, int B, int H, int Wd, int C, void* stream);
 int uir_patch4s2_bwd(const float* dP, int ldp, float* dx, int ldx, int B, int H, int Wd, int C, void* stream);
+/* Patches of a 3 x 3, padding 1 convolution in the weight's own k order: P[(b,y,x)][c*9 + ky*3 + kx] = x[(b, y-1+ky, x-1+kx)][c],
+ * 0 outside (x [B*H*Wd, C] rows, P [B*H*Wd, 9*C]); _bwd is the adjoint.  The wide convolutions on few pixels (samplers of
+ * src/model/block.py:107-153 at the deep levels, the VGG16 stacks of src/Losses/losses.py:215-250) run as one K = 9 C GEMM on them. */
+int uir_patch3x3(const float* x, int ldx, float* P, int ldp, int B, int H, int Wd, int C, void* stream);
+int uir_patch3x3_bwd(const float* dP, int ldp, float* dx, int ldx, int B, int H, int Wd, int C, void* stream);
 /* dst[i] = sum_{g < group} src[idx[i * group + g]], entries with idx < 0 count as 0 (i < n; idx is device int32).  Weight
  * re-layouts of the AST samplers (src/Models/AST.py:408-443): the 4 x 4 stride-2 kernel of Downsample laid out as a 3 x 3
  * kernel over the 2 x 2-unshuffled image (and its gradient gathered back), the per-channel bias of the ConvTranspose2d of

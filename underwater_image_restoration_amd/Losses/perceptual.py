@@ -110,8 +110,12 @@ class _VggPlan:
                     kw = dict(k_grp=(3, 4)) if cin == 3 else {}
                     # bias in the convolution, ReLU as its own in-place pass: the launch paths of the wide 3x3 convolutions (tap groups,
                     # LDS-tiled kernel) carry a bias but no activation epilogue
-                    r.gemm(f"{tag}.conv{i}", x, Wc, y, N=cout, K=4 if cin == 3 else cin, w_sn=cin * 9, w_sk=9, w_st=1, taps=9, hw=(side, side),
-                           bias=bc, **kw)
+                    if r.conv_as_patches(B * side * side, cin, cout):          # conv3_2 ... conv4_3 on a small batch: one K = 9 Cin GEMM
+                        r.gemm(f"{tag}.conv{i}", r.patches3x3(f"{tag}.conv{i}.patches", x, cin, (B, side, side)), Wc, y, N=cout, K=9 * cin,
+                               w_sn=9 * cin, w_sk=1, bias=bc)
+                    else:
+                        r.gemm(f"{tag}.conv{i}", x, Wc, y, N=cout, K=4 if cin == 3 else cin, w_sn=cin * 9, w_sk=9, w_st=1, taps=9, hw=(side, side),
+                               bias=bc, **kw)
                     r._op(f"{tag}.relu{i}", lib.uir_relu_inplace, _ptr(y), y.numel(), nbytes=8 * y.numel())
                     layers.append((y, x, i, cin, cout, side))
                     x = y
@@ -151,7 +155,10 @@ class _VggPlan:
                       nbytes=12 * y.numel())
                 dx = r.alloc(y.shape[0], 4 if cin == 3 else cin)
                 kw = dict(n_grp=(3, 4)) if cin == 3 else {}
-                r.gemm(f"conv{i}.dX", dz, Wc, dx, N=4 if cin == 3 else cin, K=cout, w_sn=9, w_sk=cin * 9, w_st=1, taps=9, flip=1, hw=(side, side), **kw)
+                if r.conv_as_patches(y.shape[0], cin, cout):
+                    r.conv3x3_dx_from_patches(f"conv{i}.dX", dz, Wc, dx, cin, cout, (B, side, side))
+                else:
+                    r.gemm(f"conv{i}.dX", dz, Wc, dx, N=4 if cin == 3 else cin, K=cout, w_sn=9, w_sk=cin * 9, w_st=1, taps=9, flip=1, hw=(side, side), **kw)
                 d = dx
         self.dx0 = d
         r.cur = r.fwd

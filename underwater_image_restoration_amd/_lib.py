@@ -229,6 +229,8 @@ SIGNATURES = {
     "uir_gather_even": [fp, i32, i32, fp, i32, i32, i32, i32, i32, fp],
     "uir_pixel_shuffle": [fp, i32, fp, i32, i32, i32, i32, i32, i32, fp],
     "uir_pixel_unshuffle": [fp, i32, i32, fp, i32, i32, i32, i32, i32, fp],
+    "uir_patch3x3": [fp, i32, fp, i32, i32, i32, i32, i32, fp],
+    "uir_patch3x3_bwd": [fp, i32, fp, i32, i32, i32, i32, i32, fp],
     "uir_patch4s2": [fp, i32, fp, i32, i32, i32, i32, i32, fp],
     "uir_patch4s2_bwd": [fp, i32, fp, i32, i32, i32, i32, i32, fp],
     "uir_gather_sum": [fp, fp, fp, i64, i32, fp],

@@ -135,6 +135,46 @@ __global__ void patch4s2_bwd_kernel(const float* __restrict__ dP, int ldp, float
   }
 }
 
+// Patches of a 3 x 3, padding 1 convolution in the weight's own k order: P[(b, y, x)][c * 9 + ky * 3 + kx] = x[(b, y - 1 + ky,
+// x - 1 + kx)][c] (0 outside), and the adjoint.  For the WIDE convolutions on FEW pixels (samplers of the deep U-Net levels of
+// NewBigFRFNModel, block.py:107-153; VGG16's conv3 / conv4 stacks on a batch of 4): 128 x 128 output tiles of the in-place nine-tap
+// kernel leave most of the chip idle there (2 048 pixels x 1 024 channels = 128 workgroups, flipped-tap weights read 4 bytes at a
+// time), as patches the layer is one plain K = 9 Cin contraction with split-k (csrc/tiled.hip) and the patch matrix is a few MB.
+__global__ void patch3x3_kernel(const float* __restrict__ x, int ldx, float* __restrict__ P, int ldp, int H, int Wd, int C, long n) {
+  GRID_STRIDE(idx, n) {  // idx over [B][H][W][C]
+    const int c = (int)(idx % C);
+    const long pix = idx / C;
+    const int px = (int)(pix % Wd);
+    const int py = (int)((pix / Wd) % H);
+    float* d = P + pix * ldp + 9 * c;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      const int dy = t / 3 - 1, dx = t % 3 - 1;
+      const bool ok = py + dy >= 0 && py + dy < H && px + dx >= 0 && px + dx < Wd;
+      const float u = x[(pix + (ok ? (long)dy * Wd + dx : 0)) * ldx + c];
+      d[t] = ok ? u : 0.f;
+    }
+  }
+}
+
+__global__ void patch3x3_bwd_kernel(const float* __restrict__ dP, int ldp, float* __restrict__ dx, int ldx, int H, int Wd, int C, long n) {
+  GRID_STRIDE(idx, n) {  // idx over [B][H][W][C]
+    const int c = (int)(idx % C);
+    const long pix = idx / C;
+    const int px = (int)(pix % Wd);
+    const int py = (int)((pix / Wd) % H);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {                // patch (y - dy, x - dx) holds this pixel at tap t
+      const int dy = t / 3 - 1, dxx = t % 3 - 1;
+      const bool ok = py - dy >= 0 && py - dy < H && px - dxx >= 0 && px - dxx < Wd;
+      const float u = dP[(pix - (ok ? (long)dy * Wd + dxx : 0)) * ldp + 9 * c + t];
+      s += ok ? u : 0.f;
+    }
+    dx[pix * ldx + c] = s;
+  }
+}
+
 __global__ void copy_cols_kernel(const float* __restrict__ src, int lds, int scol, float* __restrict__ dst, int ldd, int dcol,
                                  int C, int accumulate, long n) {
   GRID_STRIDE(idx, n) {
@@ -241,6 +281,18 @@ extern "C" int uir_patch4s2_bwd(const float* dP, int ldp, float* dx, int ldx, in
   UIR_REQUIRE(dP && dx && B > 0 && H > 0 && Wd > 0 && C > 0 && ldx >= C && ldp >= 16 * C);
   const long n = (long)B * H * Wd * 4 * C;
   hipLaunchKernelGGL(patch4s2_bwd_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), dP, ldp, dx, ldx, H, Wd, C, n);
+  return uir_launch_status();
+}
+extern "C" int uir_patch3x3(const float* x, int ldx, float* P, int ldp, int B, int H, int Wd, int C, void* stream) {
+  UIR_REQUIRE(x && P && B > 0 && H > 0 && Wd > 0 && C > 0 && ldx >= C && ldp >= 9 * C);
+  const long n = (long)B * H * Wd * C;
+  hipLaunchKernelGGL(patch3x3_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, P, ldp, H, Wd, C, n);
+  return uir_launch_status();
+}
+extern "C" int uir_patch3x3_bwd(const float* dP, int ldp, float* dx, int ldx, int B, int H, int Wd, int C, void* stream) {
+  UIR_REQUIRE(dP && dx && B > 0 && H > 0 && Wd > 0 && C > 0 && ldx >= C && ldp >= 9 * C);
+  const long n = (long)B * H * Wd * C;
+  hipLaunchKernelGGL(patch3x3_bwd_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), dP, ldp, dx, ldx, H, Wd, C, n);
   return uir_launch_status();
 }
 extern "C" int uir_copy_cols(const float* src, int lds, int scol, float* dst, int ldd, int dcol, long M, int C, int accumulate, void* stream) {

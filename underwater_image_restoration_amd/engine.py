@@ -635,6 +635,30 @@ class Recorder:
                 t = extras[key]
                 self._reduce(name + ".red." + key, sp + 4 * off, nch, stride, _ptr(t), t.numel())
 
+    # ---- wide 3 x 3 convolutions on few pixels as ONE plain contraction over patches (uir_patch3x3: k = cin * 9 + tap, the native
+    # weight's own order, so weight.view(Cout, 9 Cin) and its gradient are used in place).  The in-place nine-tap kernels tile the
+    # OUTPUT (128 x 128): 2 048 pixels x 1 024 channels are 128 workgroups and the flipped-tap weights of an input gradient are read
+    # 4 bytes at a time (NewBigFRFNModel upsample_3: 0.55 / 1.39 ms forward / input gradient for 19 GFLOP each); the patch matrix
+    # is M x 9 Cin floats (38 MB there) and the K = 9 Cin GEMM splits k (csrc/tiled.hip).
+    @staticmethod
+    def conv_as_patches(M: int, Cin: int, Cout: int) -> bool:
+        return Cin >= 256 and Cin % 4 == 0 and Cout >= 128 and Cout % 4 == 0 and 256 <= M <= 16384
+
+    def patches3x3(self, name, x, Cin, dims):
+        B, H, W = dims
+        P = self.alloc(B * H * W, 9 * Cin)
+        self._hold(x)
+        self._op(name, lib.uir_patch3x3, _ptr(x), _ld(x), _ptr(P), _ld(P), B, H, W, Cin, nbytes=4 * (x.shape[0] * Cin + P.numel()))
+        return P
+
+    def conv3x3_dx_from_patches(self, name, dy, Wt, dx, Cin, Cout, dims):
+        """dx = the input gradient of a 3 x 3 convolution: dP = dy . weight.view(Cout, 9 Cin), folded back by uir_patch3x3_bwd."""
+        B, H, W = dims
+        dP = self.alloc(B * H * W, 9 * Cin)
+        self.gemm(name, dy, Wt, dP, N=9 * Cin, K=Cout, w_sn=1, w_sk=9 * Cin)
+        self._hold(dx)
+        self._op(name + ".fold", lib.uir_patch3x3_bwd, _ptr(dP), _ld(dP), _ptr(dx), _ld(dx), B, H, W, Cin, nbytes=4 * (dP.numel() + dx.shape[0] * Cin))
+
     def dwconv(self, name, X, Wt, Y, *, C_, dims, grp=(0, 0), flip=0, act_in=0, bias=None, G=None):
         """act_in = 1: X is the pre-activation of a GELU applied on load; G (with bias): second output gelu(Y + bias)."""
         self._hold(X, Wt, Y, bias, G)

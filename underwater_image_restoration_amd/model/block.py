@@ -543,6 +543,22 @@ def record_conv3x3(rec: Recorder, name: str, x: torch.Tensor, Wt, bias, Cin: int
     """Dense 3x3 convolution, pad 1, optional bias / LeakyReLU, on HWC rows (native weight [Cout][Cin][3][3]).
     Returns (y, backward(dy, dW, db) -> dx)."""
     M = x.shape[0]
+    if Kp is None and Np is None and act == L.ACT_NONE and rec.conv_as_patches(M, Cin, Cout):
+        # wide layer on few pixels (deep samplers): one K = 9 Cin contraction over patches, weight and gradient in place
+        P, y = rec.patches3x3(name + ".patches", x, Cin, dims), rec.alloc(M, Cout)
+        rec.gemm(name, P, Wt, y, N=Cout, K=9 * Cin, w_sn=9 * Cin, w_sk=1, bias=bias)
+
+        def backward_p(dy, dW, db):
+            with rec.bulk():
+                rec.gram(name + ".dW", dy, P, dW, N=Cout, K=9 * Cin, o_sn=9 * Cin, o_sk=1)
+                if db is not None:
+                    _colsum_wide(rec, name + ".db", dy, Cout, db)
+            if not need_dx:
+                return None
+            dx = rec.alloc(M, Cin)
+            rec.conv3x3_dx_from_patches(name + ".dX", dy, Wt, dx, Cin, Cout, dims)
+            return dx
+        return y, backward_p
     Kp, Np = Kp or Cin, Np or Cout
     y = rec.alloc(M, Np)
     rec.gemm(name, x, Wt, y, N=Np, K=Kp, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=dims[1:], k_grp=k_grp, n_grp=n_grp, bias=bias, act=act,
