@@ -276,6 +276,22 @@ def test_conv3x3_as_patches_for_wide_layers_on_few_pixels():
     assert rel(chw(got, B, H, W), fold) < 1e-6
 
 
+@pytest.mark.parametrize("M,K,N", [(6 * 50, 32, 32), (4 * 96, 64, 100), (4 * 128, 256, 128), (2 * 300, 512, 64)])
+def test_gemm_residual_with_per_sample_scale(M, K, N):
+    """UirGemmArgs.out_scale: Y = R + scale[row // rows_per_sample] * (X W^T + b) - a residual branch's DropPath factor as the
+    epilogue of its last Linear (AST.py:617,620), on the panel kernel (K < 256), the LDS-tiled kernel and with a zero factor."""
+    nb = {6 * 50: 6, 4 * 96: 4, 4 * 128: 4, 2 * 300: 2}[M]
+    x, w, b, res = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=K ** -0.5), rnd(N, seed=3), rnd(M, N, seed=4)
+    sc = torch.tensor([0.0, 1.25, 1.0, 2.5, 0.5, 1.0][:nb], dtype=torch.float64)
+    r = rec()
+    Y = r.alloc(M, N)
+    r.gemm("g", dev(x), dev(w), Y, N=N, K=K, w_sn=K, w_sk=1, bias=dev(b), R=dev(res), out_scale=dev(sc), scale_rows=M // nb)
+    r.run(r.fwd)
+    want = res + sc.repeat_interleave(M // nb)[:, None] * (x @ w.t() + b)
+    assert rel(Y, want) < TOL
+    assert torch.equal(Y[:M // nb].cpu(), res[:M // nb].float())          # factor 0: the shortcut alone, exactly
+
+
 def test_gemm_embed_and_output_padding():
     B, H, W = 2, 6, 5
     x = rnd(B, 3, H, W, seed=1)

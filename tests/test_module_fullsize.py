@@ -65,7 +65,7 @@ def test_full_size_properties(arch, B, S):
 
 
 def test_module_step_refuses_what_cannot_fit_with_the_numbers():
-    """AST at the reference's default 1024 x 1024 (DataLoader.py:14) keeps ~84 GB of plans per image: a batch of 8 must come back as
+    """AST at the reference's default 1024 x 1024 (DataLoader.py:14) keeps ~67 GB of plans per image: a batch of 8 must come back as
     micro-batches from check_memory (not as an allocator OOM deep inside plan recording), and an impossible size must raise up front."""
     m, step = _fresh("AST")
     mb = step.check_memory(8, 1024, 1024)

@@ -30,7 +30,7 @@ import torch.nn as nn
 
 from .. import _lib as L
 from ..engine import _ld, _ptr
-from ..model.block import (LeFF, TokenModule, TokenPlan, _SimplePlan, _add_rows, _colsum_wide, record_conv3x3, record_layernorm,
+from ..model.block import (LeFF, TokenModule, TokenPlan, _SimplePlan, _colsum_wide, record_conv3x3, record_layernorm,
                            record_leff, record_window_attention)
 from ..model.model import _ResidualImage
 
@@ -116,11 +116,12 @@ def record_ast_block(rec, x: torch.Tensor, dim: int, heads: int, shift: int, att
     y = x
     if att:
         xn, n1_bw = record_layernorm(rec, "norm1.", x, C_)
-        a, a_bw = record_window_attention(rec, "attn.", xn, None, dims, C_, heads, qname="qkv.to_q", kvname="qkv.to_kv", shift=shift)
-        y = _add_rows(rec, "res1=x+dp*attn", x, a, C_, scale=s_att, rows_per_sample=Ltok)
+        # x + drop_path(attn(...)), y + drop_path(mlp(...)) (AST.py:617,620): shortcut and per-sample factor are the epilogue of the
+        # branch's last Linear (proj / linear2)
+        y, a_bw = record_window_attention(rec, "attn.", xn, None, dims, C_, heads, qname="qkv.to_q", kvname="qkv.to_kv", shift=shift,
+                                          residual=(x, s_att, Ltok))
     x2, n2_bw = record_layernorm(rec, "norm2.", y, C_)
-    m, m_bw = record_leff(rec, "mlp.", x2, C_, 4 * C_, dims)
-    out = _add_rows(rec, "res2=y+dp*mlp", y, m, C_, scale=s_mlp, rows_per_sample=Ltok)
+    out, m_bw = record_leff(rec, "mlp.", x2, C_, 4 * C_, dims, residual=(y, s_mlp, Ltok))
 
     def backward(dout):
         dm = rec.alloc(M, C_)
@@ -393,9 +394,10 @@ class AST(nn.Module):
     only, bottleneck and decoders with sparse window attention, every second block shifted), stochastic depth 0 ... 0.1."""
 
     # device memory the 28 launch plans keep per input pixel (measured, tests/test_ast.py holds it): ModuleTrainStep sizes micro-batches with it
-    # (tools/measure_module_plans.py, round 3 with the activations of LeFF fused away: 3.0 / 10.6 / 19.0 GiB at 1 x 128^2 / 2 x 256^2 / 1 x 512^2 = 69 KB per pixel + 2.3 GB of per-plan scratch)
-    PLAN_BYTES_PER_PIXEL_TRAIN, PLAN_BYTES_FIXED_TRAIN = 70_000, 2_300_000_000
-    PLAN_BYTES_PER_PIXEL_EVAL, PLAN_BYTES_FIXED_EVAL = 33_000, 2_000_000_000
+    # (tools/measure_module_plans.py, round 3 with LeFF's activations fused away and the residual sums as GEMM epilogues: 2.8 / 9.6 /
+    # 17.3 GiB at 1 x 128^2 / 2 x 256^2 / 1 x 512^2, 61.2 GiB at 4 x 512^2 = 60 KB per pixel + 2.9 GB of per-plan scratch)
+    PLAN_BYTES_PER_PIXEL_TRAIN, PLAN_BYTES_FIXED_TRAIN = 61_000, 2_900_000_000
+    PLAN_BYTES_PER_PIXEL_EVAL, PLAN_BYTES_FIXED_EVAL = 30_800, 2_000_000_000
 
     def __init__(self, img_size=256, in_chans=3, dd_in=3, embed_dim=32, depths=[2, 2, 2, 2, 2, 2, 2, 2, 2],
                  num_heads=[1, 2, 4, 8, 16, 16, 8, 4, 2], win_size=8, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0.,

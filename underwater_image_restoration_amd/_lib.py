@@ -45,7 +45,8 @@ class GemmArgs(C.Structure):
                 ("n_grp_real", C.c_int), ("n_grp_pad", C.c_int), ("k_grp_real", C.c_int), ("k_grp_pad", C.c_int),
                 ("pro", C.c_int), ("gate_off", C.c_int), ("epi", C.c_int), ("g_off", C.c_int), ("act", C.c_int),
                 ("slope", C.c_float), ("ln_eps", C.c_float), ("dw_slab", fp), ("dw_stride", C.c_long),
-                ("tap0", C.c_int), ("ntap", C.c_int), ("pre_out", fp), ("ldpre", C.c_long)]
+                ("tap0", C.c_int), ("ntap", C.c_int), ("pre_out", fp), ("ldpre", C.c_long),
+                ("out_scale", fp), ("scale_rows", C.c_int)]
 
 
 class GramArgs(C.Structure):

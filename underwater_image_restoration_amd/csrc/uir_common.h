@@ -89,6 +89,8 @@ struct UirTiledArgs {
   long ldr, ldpre;
   int act;                 // UIR_ACT_NONE / UIR_ACT_GELU
   int allow_split;         // caller's mark for the split-bf16 variant (wide layers only), see uir_tiled_gemm
+  const float* out_scale;  // UirGemmArgs.out_scale / scale_rows (plain tiled kernel only), or null
+  int scale_rows;
   int H, Wd, flip;         // uir_tiled_conv3x3: image size of the pixel rows, weight taps mirrored (input gradient)
   long sb_t;               // uir_tiled_conv3x3: tap stride of the weight
 };

@@ -490,7 +490,7 @@ class Recorder:
     # ---------------------------------------------------------------- kernels
     def gemm(self, name, X, W, Y, *, N, K, w_sn, w_sk, w_st=0, w_bs=0, batches=1, bias=None, R=None,
              taps=1, flip=0, hw=None, n_grp=(0, 0), k_grp=(0, 0), pro=L.PRO_NONE, gate_off=0, ln=None, stats=None,
-             epi=L.EPI_PLAIN, G=None, g_off=0, act=L.ACT_NONE, dw_slab=None, pre_out=None, slope=0.1):
+             epi=L.EPI_PLAIN, G=None, g_off=0, act=L.ACT_NONE, dw_slab=None, pre_out=None, slope=0.1, out_scale=None, scale_rows=0):
         M_total = X.shape[0]
         assert M_total % batches == 0 and Y.shape[0] == M_total
         M = M_total // batches
@@ -526,6 +526,11 @@ class Recorder:
         if dw_slab is not None:
             self._hold(dw_slab)
             a.dw_slab, a.dw_stride = _ptr(dw_slab), dw_slab.stride(0)
+        if out_scale is not None:      # Y = R + out_scale[row // scale_rows] * (X.W^T + bias): a residual branch's DropPath factor
+            assert epi == L.EPI_PLAIN and taps == 1 and batches == 1 and pre_out is None and scale_rows > 0 and M % scale_rows == 0
+            assert out_scale.numel() * scale_rows == M
+            self._hold(out_scale)
+            a.out_scale, a.scale_rows = _ptr(out_scale), scale_rows
         assert a.ldx % 4 == 0 and a.ldx >= pad4(K) and a.ldy >= N, (name, a.ldx, K, a.ldy, N)
         assert Y.shape[1] >= N or epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW), (name, Y.shape, N)
         self.keep.append(a)

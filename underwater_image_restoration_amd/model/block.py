@@ -120,7 +120,7 @@ def _colsum_wide(rec, name, src, cols, out):
         rec.colsum(f"{name}[{c0}]", src, c0, n, out[c0:c0 + n])
 
 
-def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims, owns_input: bool = False):
+def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims, owns_input: bool = False, residual=None):
     """Record FRFN.forward (block.py:262-282) on token rows x [M, dim] into `rec` (parameters `pfx + name` of rec.fp).
     Returns (y, backward) with backward(dy) -> dx recording the backward launches."""
     B, H, W = dims
@@ -151,7 +151,7 @@ def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     rec.gemm(n + "linear1", xc, W1, pre, N=2 * hid, K=C_, w_sn=C_, w_sk=1, bias=b1)
     _dwconv_wide(rec, n + "gelu.dwconv", pre[:, :hid], Wdw, u, hid, dims, act_in=1)
     _gate(rec, n + "dwconv.gelu*gelu(x2)", hid, u, bdw, pre[:, hid:], G=g, v_act=1)
-    rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
+    rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2, **_res_kw(residual))      # residual: see record_leff
 
     def backward(dy: torch.Tensor) -> torch.Tensor:
         dg, du = rec.alloc(M, hid), rec.alloc(M, hid)
@@ -178,8 +178,18 @@ def record_frfn(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     return y, backward
 
 
-def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims, owns_input: bool = False):   # (owns_input: unused, same call shape as record_frfn)
-    """Record LeFF.forward (block.py:234-247): Linear C -> hidden + GELU, depthwise 3x3 + bias + GELU, Linear hidden -> C."""
+def _res_kw(residual):
+    """GEMM epilogue arguments of ``residual = (R, scale or None, rows per sample)``: Y = R + scale[sample] * (X.W^T + bias)."""
+    if residual is None:
+        return {}
+    R, scale, rows = residual
+    return dict(R=R) if scale is None else dict(R=R, out_scale=scale, scale_rows=rows)
+
+
+def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, dims, owns_input: bool = False, residual=None):   # (owns_input: unused, same call shape as record_frfn)
+    """Record LeFF.forward (block.py:234-247): Linear C -> hidden + GELU, depthwise 3x3 + bias + GELU, Linear hidden -> C.
+    ``residual = (R, scale, rows)``: the returned rows are R + scale[sample] * LeFF(x) (the block's shortcut and DropPath factor as
+    Linear2's epilogue); backward(dy) still takes the gradient of LeFF's own output."""
     B, H, W = dims
     M, C_ = B * H * W, dim
     P, Gr = (lambda n: rec.P(pfx + n)), (lambda n: rec.Gr(pfx + n))
@@ -194,7 +204,7 @@ def record_leff(rec: Recorder, pfx: str, x: torch.Tensor, dim: int, hid: int, di
     n = pfx
     rec.gemm(n + "linear1", x, W1, pre, N=hid, K=C_, w_sn=C_, w_sk=1, bias=b1)
     _dwconv_wide(rec, n + "gelu.dwconv.gelu", pre, Wdw, u, hid, dims, act_in=1, bias=bdw, G=g)
-    rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2)
+    rec.gemm(n + "linear2", g, W2, y, N=C_, K=hid, w_sn=hid, w_sk=1, bias=b2, **_res_kw(residual))
 
     def backward(dy: torch.Tensor) -> torch.Tensor:
         dg, dpre, dx = rec.alloc(M, hid), rec.alloc(M, hid), rec.alloc(M, C_)
@@ -330,7 +340,7 @@ def _winattn_args(q, k, v, table, w, dims, C_, heads, shift=0):
 
 
 def record_window_attention(rec: Recorder, pfx: str, xq: torch.Tensor, xkv: "torch.Tensor | None", dims, C_: int, heads: int,
-                            qname: str = "to_qkv.to_q", kvname: "str | None" = None, shift: int = 0):
+                            qname: str = "to_qkv.to_q", kvname: "str | None" = None, shift: int = 0, residual=None):
     """Record WindowAttention_Sparse.forward (block.py:336-373) applied to every 8 x 8 window of a token image, mask None;
     with ``shift`` > 0 the cyclically shifted windows and their region mask of AST's TransformerBlock (src/Models/AST.py:568-616;
     its LinearProjection names its Linears ``qkv.to_q`` / ``qkv.to_kv``: ``qname`` / ``kvname``).
@@ -358,7 +368,7 @@ def record_window_attention(rec: Recorder, pfx: str, xq: torch.Tensor, xkv: "tor
     rec.keep.append(fa)
     hd = C_ // heads
     rec._op(n + "attention", lib.uir_winattn_fwd, C.byref(fa), nbytes=16 * M * C_, flops=M * heads * (4 * 64 * hd))
-    rec.gemm(n + "proj", o, Wp, y, N=C_, K=C_, w_sn=C_, w_sk=1, bias=bp)
+    rec.gemm(n + "proj", o, Wp, y, N=C_, K=C_, w_sn=C_, w_sk=1, bias=bp, **_res_kw(residual))      # residual: see record_leff
 
     def backward(dy: torch.Tensor):
         do, dq, dkv, dxq = rec.alloc(M, C_), rec.alloc(M, C_), rec.alloc(M, 2 * C_), rec.alloc(M, C_)
@@ -476,8 +486,8 @@ def record_decoder_block(rec: Recorder, pfx: str, xcat: torch.Tensor, dim: int, 
     y = _add_rows(rec, n + "res1", m, xcat, mdim)
     x2, n2_bw = record_layernorm(rec, n + "norm2.", y, mdim)
     mlp = record_frfn if token_mlp == "frfn" else record_leff
-    x3, mlp_bw = mlp(rec, n + "mlp.", x2, mdim, 4 * mdim, dims, owns_input=True)        # x2 = norm2's output: nothing else reads it
-    x4 = _add_rows(rec, n + "res2", y, x3, mdim)
+    # x2 = norm2's output: nothing else reads it; the residual y + mlp(...) is Linear2's epilogue
+    x4, mlp_bw = mlp(rec, n + "mlp.", x2, mdim, 4 * mdim, dims, owns_input=True, residual=(y, None, 0))
     Wp, bp = rec.P(n + "mlp_proj.weight"), rec.P(n + "mlp_proj.bias")
     out = rec.alloc(M, dim)
     rec.gemm(n + "mlp_proj", x4, Wp, out, N=dim, K=mdim, w_sn=mdim, w_sk=1, bias=bp)

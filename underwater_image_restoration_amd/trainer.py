@@ -254,7 +254,7 @@ class ModuleTrainStep:
 
     # ---- memory: every module's plan keeps all its activations.  The per-pixel figure is a constant of the architecture
     # (model.PLAN_BYTES_PER_PIXEL_TRAIN / _EVAL, held to the real plan bytes by tests/test_frfn_net.py / test_ast.py): AST needs
-    # ~21 GB per 512 x 512 image, ~84 GB per image at the reference's default 1024 x 1024 (DataLoader.py:14), so a batch that does
+    # ~19 GB per 512 x 512 image, ~67 GB per image at the reference's default 1024 x 1024 (DataLoader.py:14), so a batch that does
     # not fit runs as micro-batches with gradient accumulation - exact in eval mode (no cross-sample statistics); in training mode
     # the stochastic-depth factors are drawn per micro-batch (another, equally valid draw).
     def plan_bytes(self) -> int:
