@@ -20,8 +20,8 @@ for W in net ast; do
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$W/stats -- python3 $A > $O/prof_$W.stats.log 2>&1 ) && echo pmc-$W-ok
   python3 tools/pmc_traffic.py $O/prof_$W/fetch $O/prof_$W/write 3 $O/prof_$W/traffic.json fixed > $O/prof_$W.traffic.log 2>&1 && cp $O/prof_$W/traffic.json profiles/$RD/zz_${T}_${W}_hbm_counters.json
 done
-python tools/bench_frfn.py --what net > $O/frfnnet_bench.json 2> $O/frfnnet.err && echo frfnnet-ok
-python tools/bench_frfn.py --what ast > $O/ast_bench.json 2> $O/ast.err && echo ast-ok
+python tools/bench_frfn.py --what net --breakdown-file $O/frfnnet_breakdown.csv > $O/frfnnet_bench.json 2> $O/frfnnet.err && echo frfnnet-ok
+python tools/bench_frfn.py --what ast --breakdown-file $O/ast_breakdown.csv > $O/ast_bench.json 2> $O/ast.err && echo ast-ok
 python tools/bench_frfn.py --what ast --loss fflMix --no-cpu > $O/ast_fflmix_bench.json 2> $O/ast_fflmix.err && echo ast-fflmix-ok
 python tools/bench_losses.py 4 512 > $O/bench_losses.txt 2>&1 && python tools/bench_losses.py 16 256 >> $O/bench_losses.txt 2>&1 && echo losses-ok
 python tools/bench_uiqm.py > $O/uiqm_bench.json 2> $O/uiqm.err && echo uiqm-ok
