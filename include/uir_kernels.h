@@ -68,7 +68,7 @@ typedef struct UirGemmArgs {
   float* pre_out;      /* UIR_ACT_GELU only, optional: the pre-activation X.W^T + bias is ALSO stored here (row stride */
   long ldpre;          /* ldpre) - what the GELU backward needs; one pass instead of GEMM + element-wise (FRFN / LeFF  */
                        /* linear1, block.py:252,273).  batches == 1                                                   */
-  const float* out_scale; /* optional (PLAIN epilogue, taps 1, batches 1): Y = R + out_scale[row / scale_rows] * act(X.W^T + bias) -  */
+  const float* out_scale; /* optional (with R; PLAIN epilogue, taps 1, batches 1): Y = R + out_scale[row / scale_rows] * act(X.W^T + bias) -  */
   int scale_rows;      /* (>= 32) the per-sample DropPath factor of a residual branch (timm drop_path: src/Models/AST.py:617,620,        */
                        /* src/model/model.py:91) folded into the branch's last Linear; scale_rows = token rows per sample        */
 } UirGemmArgs;

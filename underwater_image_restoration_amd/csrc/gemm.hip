@@ -241,13 +241,16 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
   const bool gelu = (a.act == UIR_ACT_GELU);
   const bool full = (m0 + 32 <= a.M);
   // per-sample output factor: a 32-row tile touches at most two samples (scale_rows >= 32) - one division per tile, not per element
+  // (only with a residual - its one use - so that the variants without one, the hot ones of the SpectralTransformer step, carry nothing)
   float sc0 = 1.f, sc1 = 1.f;
   int sc_bnd = 0;
-  if (a.out_scale) {
-    const int s0 = m0 / a.scale_rows;
-    sc_bnd = (s0 + 1) * a.scale_rows;
-    sc0 = a.out_scale[s0];
-    sc1 = a.out_scale[sc_bnd < a.M ? s0 + 1 : s0];
+  if constexpr (HAS_R) {
+    if (a.out_scale) {
+      const int s0 = m0 / a.scale_rows;
+      sc_bnd = (s0 + 1) * a.scale_rows;
+      sc0 = a.out_scale[s0];
+      sc1 = a.out_scale[sc_bnd < a.M ? s0 + 1 : s0];
+    }
   }
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
@@ -267,8 +270,10 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
           if (pp) pp[(long)dr * a.ldpre] = v;
           v = uir_gelu(v);
         }
-        if (a.out_scale) v *= ((int)row0 + dr < sc_bnd) ? sc0 : sc1;                          // uniform over the launch
-        if constexpr (HAS_R) v += rv[nt][reg];
+        if constexpr (HAS_R) {
+          if (a.out_scale) v *= ((int)row0 + dr < sc_bnd) ? sc0 : sc1;                        // uniform over the launch
+          v += rv[nt][reg];
+        }
         yp[(long)dr * a.ldy] = v;
       } else if constexpr (EPI == UIR_EPI_GATE_BWD) {
         const float g1 = gp[(long)dr * a.ldg], g2 = gp[(long)dr * a.ldg + a.g_off];
@@ -750,7 +755,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     UIR_REQUIRE((a.M & 127) == 0 && a.pro == UIR_PRO_NONE && (a.n_grp_pad <= 0 || a.n_grp_pad == a.N));
   }
   if (a.R) UIR_REQUIRE(a.ldr >= a.N);
-  if (a.out_scale) UIR_REQUIRE(a.scale_rows >= 32 && a.epi == UIR_EPI_PLAIN && a.taps == 1 && a.batches == 1 && !a.pre_out);
+  if (a.out_scale) UIR_REQUIRE(a.R && a.scale_rows >= 32 && a.epi == UIR_EPI_PLAIN && a.taps == 1 && a.batches == 1 && !a.pre_out);
   if (a.act == UIR_ACT_GELU) UIR_REQUIRE(a.epi == UIR_EPI_PLAIN && (!a.pre_out || (a.batches == 1 && a.ldpre >= a.N)));
   else UIR_REQUIRE(!a.pre_out);
   UIR_REQUIRE(a.ntap <= 0 || (a.taps == 9 && a.tap0 >= 0 && a.tap0 + a.ntap <= 9));

@@ -527,7 +527,7 @@ class Recorder:
             self._hold(dw_slab)
             a.dw_slab, a.dw_stride = _ptr(dw_slab), dw_slab.stride(0)
         if out_scale is not None:      # Y = R + out_scale[row // scale_rows] * (X.W^T + bias): a residual branch's DropPath factor
-            assert epi == L.EPI_PLAIN and taps == 1 and batches == 1 and pre_out is None and scale_rows > 0 and M % scale_rows == 0
+            assert R is not None and epi == L.EPI_PLAIN and taps == 1 and batches == 1 and pre_out is None and scale_rows >= 32 and M % scale_rows == 0
             assert out_scale.numel() * scale_rows == M
             self._hold(out_scale)
             a.out_scale, a.scale_rows = _ptr(out_scale), scale_rows
