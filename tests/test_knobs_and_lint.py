@@ -40,7 +40,7 @@ def test_knob_report_names_non_default_and_stray_variables():
     env = dict(os.environ, UIR_GRAPH="1", UIR_SKIP_SIDE="1")
     code = ("import importlib.util, sys; spec = importlib.util.spec_from_file_location('knobs', sys.argv[1]); "
             "m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m); m.report(); m.report()")
-    out = subprocess.run([sys.executable, "-c", code, os.path.join(PKG, "knobs.py")], env=env, capture_output=True, text=True, check=True).stdout
+    out = subprocess.run([sys.executable, "-c", code, os.path.join(PKG, "knobs.py")], env=env, capture_output=True, text=True, check=True).stderr
     assert out.count("UIR_GRAPH=1") == 1 and "UIR_SKIP_SIDE" in out and "ignored" in out
 
 

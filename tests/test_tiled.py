@@ -108,6 +108,83 @@ def test_split_bf16_mode_is_f32_accurate():
     assert out.stdout.count("ERR") == 3
 
 
+@pytest.mark.parametrize("kind", ["bf16", "fp16"])
+def test_mixed_mode_equals_the_rounded_operand_products(kind):
+    """UIR_MIXED=bf16 | fp16 (opt-in mixed precision, BASELINE configs[4]; csrc/tiled.hip uir_tiled_lp_kernel): every wide contraction
+    takes each f32 operand rounded ONCE, round-to-nearest-even, to the 16-bit type, multiplies exactly and accumulates in f32.  So the
+    result must equal the fp64 product of the ROUNDED operands (torch's .to(bfloat16 / float16) is the same rounding) to f32 accumulation
+    level - tolerance 5e-6 of the largest output, as for the f32 kernels - for the forward with bias + GELU + pre-activation copy, the
+    input gradient with a residual and a per-sample output factor, and the split-k weight gradient with ragged edges; and it must
+    differ from the unrounded product by the type's rounding level (the mode really is on).  Read once per process: run in a child."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import torch.nn.functional as F\n"
+        "from underwater_image_restoration_amd import _lib as L\n"
+        "from underwater_image_restoration_amd.engine import Recorder\n"
+        "lp = torch.bfloat16 if %r == 'bf16' else torch.float16\n"
+        "q = lambda t: t.float().cpu().to(lp).double()\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "rnd = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64) * 2 - 1\n"
+        "worst = 0.0\n"
+        "def check(got, ref, exact, lo, hi):\n"
+        "    e = float((got.double().cpu() - ref).abs().max() / ref.abs().max())\n"
+        "    d = float((got.double().cpu() - exact).abs().max() / exact.abs().max())\n"
+        "    print('ERR %%.3e vs rounded operands, %%.3e vs f32 operands' %% (e, d))\n"
+        "    assert e < 5e-6, e\n"
+        "    assert lo < d < hi, d\n"
+        "for (M, K, N) in ((4096, 1024, 512), (1000, 512, 200), (300, 260, 136)):\n"
+        "    x, w, b, dy, res = rnd(M, K), rnd(N, K) * K ** -0.5, rnd(N), rnd(M, N), rnd(M, K)\n"
+        "    sc = rnd(4).abs() + 0.5\n"
+        "    r = Recorder('cuda', scratch_floats=16 << 20)\n"
+        "    X, W, Bv, DY, R, SC = (t.float().cuda().contiguous() for t in (x, w, b, dy, res, sc))\n"
+        "    Y, PRE, DX, DW, DWT = r.alloc(M, N), r.alloc(M, N), r.alloc(M, K), r.alloc(N, K), r.alloc(K, N)\n"
+        "    r.gemm('f', X, W, Y, N=N, K=K, w_sn=K, w_sk=1, bias=Bv, act=L.ACT_GELU, pre_out=PRE)\n"
+        "    rows = M // 4\n"
+        "    if N >= 256:\n"
+        "        r.gemm('dx', DY, W, DX, N=K, K=N, w_sn=1, w_sk=K, R=R, out_scale=SC, scale_rows=rows)\n"
+        "    r.gram('dw', DY, X, DW, N=N, K=K, o_sn=K, o_sk=1, own_slab=True)\n"
+        "    r.gram('dwT', DY, X, DWT, N=N, K=K, o_sn=1, o_sk=N, own_slab=True)   # transposed output: the column-per-lane epilogue\n"
+        "    r.run(r.fwd); torch.cuda.synchronize()\n"
+        "    xd, wd, dyd = X.double().cpu(), W.double().cpu(), DY.double().cpu()\n"
+        "    pre_q, pre_x = q(X) @ q(W).T + Bv.double().cpu(), xd @ wd.T + Bv.double().cpu()\n"
+        "    check(PRE, pre_q, pre_x, 1e-5, 2e-2)\n"
+        "    check(Y, F.gelu(pre_q), F.gelu(pre_x), 1e-5, 2e-2)\n"
+        "    if N >= 256:\n"
+        "        f = SC.double().cpu()[torch.arange(M) // rows][:, None]\n"
+        "        check(DX, (q(DY) @ q(W)) * f + R.double().cpu(), (dyd @ wd) * f + R.double().cpu(), 1e-6, 2e-2)\n"
+        "    check(DW, q(DY).T @ q(X), dyd.T @ xd, 1e-6, 2e-2)\n"
+        "    check(DWT, (q(DY).T @ q(X)).T, (dyd.T @ xd).T, 1e-6, 2e-2)\n" % (root, kind))
+    env = dict(os.environ, UIR_MIXED=kind)
+    env.pop("UIR_TILED_SPLIT", None)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.count("ERR") == 13, out.stdout
+
+
+def test_mixed_mode_refuses_an_unknown_type():
+    """UIR_MIXED=<anything but bf16 / fp16 / 0>: the first wide contraction fails with an error instead of silently running in f32."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from underwater_image_restoration_amd.engine import Recorder\n"
+            "r = Recorder('cuda', scratch_floats=1 << 20)\n"
+            "X, W = torch.ones(512, 512, device='cuda'), torch.ones(256, 512, device='cuda')\n"
+            "Y = r.alloc(512, 256)\n"
+            "r.gemm('f', X, W, Y, N=256, K=512, w_sn=512, w_sk=1)\n"
+            "try:\n"
+            "    r.run(r.fwd); torch.cuda.synchronize()\n"
+            "except Exception as e:\n"
+            "    print('REFUSED', type(e).__name__)\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UIR_MIXED="fp8"), capture_output=True, text=True, timeout=300)
+    assert "REFUSED" in out.stdout, out.stdout + out.stderr
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 10, 6, 512, 72), (1, 16, 16, 512, 200), (5, 60, 56, 256, 128)])
 def test_wide_conv3x3_forward_and_input_gradient(B, H, W, Cin, Cout):
     """3 x 3 convolutions with >= 128 input channels (the sampler convolutions) as ONE launch of the tiled kernel: native weight

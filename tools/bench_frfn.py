@@ -17,6 +17,12 @@ import time
 
 import torch
 
+for _i, _a in enumerate(sys.argv):          # the library reads UIR_MIXED once per process: set it before anything launches
+    if _a == "--mixed" and _i + 1 < len(sys.argv):
+        os.environ["UIR_MIXED"] = sys.argv[_i + 1]
+    elif _a.startswith("--mixed="):
+        os.environ["UIR_MIXED"] = _a.split("=", 1)[1]
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from underwater_image_restoration_amd.model.block import FRFN  # noqa: E402
 from underwater_image_restoration_amd.model.model import DecoderBlock, EncoderBlock  # noqa: E402
@@ -35,7 +41,10 @@ def bench_net(args):
     from underwater_image_restoration_amd.Models import init_model
     from underwater_image_restoration_amd.trainer import make_train_step
     arch = "AST" if args.what == "ast" else "NewBigFRFNModel"
-    cfg = "configs[4], fp32" if arch == "AST" else "configs[3]"
+    mixed = os.environ.get("UIR_MIXED", "0")
+    mixed = "" if mixed in ("", "0") else mixed
+    cfg = ("configs[4], " + (f"MIXED {mixed}: wide contractions with {mixed} operands, f32 accumulation and master weights" if mixed else "fp32")) if arch == "AST" \
+        else ("configs[3]" + (f", MIXED {mixed}" if mixed else ""))
     if arch == "AST" and (args.batch, args.size) == (8, 256):
         args.batch, args.size = 4, 512
     B, S = args.batch, args.size
@@ -70,7 +79,7 @@ def bench_net(args):
     lname = "Charbonnier" if args.loss == "charbonnier" else args.loss
     line = {"metric": f"train images/sec, {arch} {S}x{S} bs={B}/GPU, {lname} (BASELINE {cfg}, one GPU)",
             "value": B / (ms * 1e-3), "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
-            "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "dtype": f"{mixed}-mixed" if mixed else "f32", "data": "synthetic",
             "config": {"workload": f"{arch} {S}x{S} bs={B}, {args.loss}, clip 1.0 + Adam 3e-4, DropPath as the reference sets it" + (f"; {vgg_note}" if vgg_note else ""),
                        "params": sum(p.numel() for p in model.parameters()), "launches_per_step": launches,
                        "final_loss": float(loss), "grad_norm": float(norm),
@@ -83,7 +92,7 @@ def bench_net(args):
     # HBM bytes per step from PMC passes of THIS command (tools/round_end.sh -> tools/pmc_traffic.py), quoted only while the kernels
     # and launch plans still hash to what was measured
     tfiles = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", f"*{args.what}_hbm_counters.json")))
-    if tfiles and (B, S) == ((4, 512) if arch == "AST" else (8, 256)):
+    if tfiles and not mixed and (B, S) == ((4, 512) if arch == "AST" else (8, 256)):
         from underwater_image_restoration_amd import build as _build
         with open(tfiles[-1]) as tf:
             tj = json.load(tf)
@@ -143,6 +152,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--breakdown-file", default="", help="--what net / ast: per-module and per-launch serial times (csv)")
+    ap.add_argument("--mixed", default="", choices=("", "bf16", "fp16"),
+                    help="--what net / ast: UIR_MIXED for this process - wide contractions with 16-bit operands, f32 accumulation (its own metric, never the f32 one)")
     ap.add_argument("--loss", default="charbonnier", help="loss name of the network benches (--what net / ast), e.g. fflMix = BASELINE configs[4]'s")
     ap.add_argument("--what", default="frfn", choices=("frfn", "encoder", "decoder", "net", "ast"),
                     help="frfn: one FRFN (block.py:249-282); encoder: one EncoderBlock = LN + 2 FRFN + 2 (L,C) transforms (model.py:16-93); "

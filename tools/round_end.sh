@@ -25,4 +25,6 @@ python tools/bench_frfn.py --what ast --breakdown-file $O/ast_breakdown.csv > $O
 python tools/bench_frfn.py --what ast --loss fflMix --no-cpu > $O/ast_fflmix_bench.json 2> $O/ast_fflmix.err && echo ast-fflmix-ok
 python tools/bench_losses.py 4 512 > $O/bench_losses.txt 2>&1 && python tools/bench_losses.py 16 256 >> $O/bench_losses.txt 2>&1 && echo losses-ok
 python tools/bench_uiqm.py > $O/uiqm_bench.json 2> $O/uiqm.err && echo uiqm-ok
+# opt-in mixed precision (UIR_MIXED, BASELINE configs[4]'s "mixed fp16"): its own lines, after and apart from every f32 number above
+bash tools/mixed_bench.sh $T/mixed
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete

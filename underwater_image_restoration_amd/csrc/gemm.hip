@@ -773,9 +773,12 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // Wide plain Linear layers (NewBigFRFNModel / AST: K, N up to 2048) on the LDS-tiled kernel of csrc/tiled.hip.  The panel
     // kernel below keeps ALL K of one column group in LDS (fine for the SpectralTransformer's K <= 340), its un-staged fallback
     // ran the K >= 1024 layers at 22-29 TFLOP/s.  UIR_TILED_MINK (default 256): smallest K sent there; 0 disables.
-    constexpr int mink = 256;
+    // UIR_MIXED: the 16-bit kernel has no MFMA time to lose on a short contraction - every Linear with >= 64 input channels goes there
+    // (AST's 64 -> 256 / 128 -> 512 LeFF layers on 1 M / 262 k tokens stream at the byte rate instead of 64-81 TFLOP/s of f32 MFMA)
+    const int mixed = uir_mixed_mode();
+    const int mink = mixed != 0 ? 64 : 256;
     const bool w_kc = a.w_sk == 1 && (a.w_sn & 3) == 0, w_nc = a.w_sn == 1 && (a.w_sk & 3) == 0 && (a.N & 3) == 0;
-    if (mink > 0 && a.K >= mink && a.N >= 128 && a.M >= 256 && a.taps == 1 && a.batches == 1 && a.pro == UIR_PRO_NONE &&
+    if (mink > 0 && a.K >= mink && a.N >= (mixed != 0 ? 64 : 128) && a.M >= 256 && a.taps == 1 && a.batches == 1 && a.pro == UIR_PRO_NONE &&
         a.epi == UIR_EPI_PLAIN && (a.act == UIR_ACT_NONE || a.act == UIR_ACT_GELU) && a.n_grp_pad <= 0 && a.k_grp_pad <= 0 &&
         (a.K & 3) == 0 && (w_kc || w_nc) && uir_aligned16(a.W)) {
       UirTiledArgs t{};

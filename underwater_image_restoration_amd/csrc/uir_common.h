@@ -89,11 +89,14 @@ struct UirTiledArgs {
   long ldr, ldpre;
   int act;                 // UIR_ACT_NONE / UIR_ACT_GELU
   int allow_split;         // caller's mark for the split-bf16 variant (wide layers only), see uir_tiled_gemm
+  int vec_epi;             // set by uir_tiled_gemm: D / R / pre_out rows are 16-byte addressable (row-major float4 epilogue of the 16-bit kernel)
   const float* out_scale;  // UirGemmArgs.out_scale / scale_rows (plain tiled kernel only), or null
   int scale_rows;
   int H, Wd, flip;         // uir_tiled_conv3x3: image size of the pixel rows, weight taps mirrored (input gradient)
   long sb_t;               // uir_tiled_conv3x3: tap stride of the weight
 };
 int uir_tiled_gemm(const UirTiledArgs& t, hipStream_t st);
+// UIR_MIXED (knobs.py), read once: 0 off, 1 bf16, 2 fp16, -1 an unknown value (uir_tiled_gemm refuses it)
+int uir_mixed_mode();
 // 3 x 3 convolution (uir_gemm's taps = 9 contract) with K >= 128 input channels: A k-contiguous pixel rows, any weight strides
 int uir_tiled_conv3x3(const UirTiledArgs& t, hipStream_t st);

@@ -7,6 +7,7 @@ ones that are set, so a stray variable cannot silently change what trains.
 from __future__ import annotations
 
 import os
+import sys
 
 KNOBS = {
     # name: (default, what it does, the test that holds results with it on)
@@ -15,6 +16,11 @@ KNOBS = {
     "UIR_TILED_SPLIT": ("0", "read by libuir_hip.so: 1 = every wide contraction of csrc/tiled.hip on split-bf16 MFMA (3 bf16 planes, 6 products, "
                         "f32-accurate); 3 = only the marked ones",
                         "tests/test_tiled.py::test_split_bf16_mode_is_f32_accurate"),
+    "UIR_MIXED": ("0", "read by libuir_hip.so: bf16 | fp16 = MIXED precision - every wide contraction of csrc/tiled.hip (the Linear layers of "
+                  "AST / NewBigFRFNModel with >= 256 input channels and their input / weight gradients) takes its operands rounded to that "
+                  "16-bit type on the bf16 / f16 matrix pipe, f32 accumulation, f32 master weights, everything else f32 (BASELINE "
+                  "configs[4]'s 'mixed fp16'); results are NOT f32-accurate and no f32 number is measured with it; any other value is refused",
+                  "tests/test_tiled.py::test_mixed_mode_equals_the_rounded_operand_products"),
     "UIR_FORCE_ALLREDUCE": ("0", "1: run the gradient all-reduce even in a world of one process (exercises the RCCL call path on a 1-GPU box)",
                             "tests/test_hip_model.py::test_rccl_allreduce_call_path_world1"),
 }
@@ -53,7 +59,7 @@ def report() -> None:
     for k, (default, what, _test) in KNOBS.items():
         v = os.environ.get(k)
         if v is not None and v != default:
-            print(f"[uir] {k}={v} (default {default}): {what}", flush=True)
+            print(f"[uir] {k}={v} (default {default}): {what}", file=sys.stderr, flush=True)
     stray = sorted(k for k in os.environ if k.startswith("UIR_") and k not in KNOBS and k not in PLUMBING and k not in PATHS and k not in ("UIR_CPU_THREADS", "UIR_CPU_BATCH"))
     if stray:
-        print(f"[uir] ignored environment variables (not knobs of this build): {', '.join(stray)}", flush=True)
+        print(f"[uir] ignored environment variables (not knobs of this build): {', '.join(stray)}", file=sys.stderr, flush=True)

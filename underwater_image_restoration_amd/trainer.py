@@ -34,6 +34,9 @@ class TrainStep:
         if self.world > 1:
             parallel.broadcast_flat_params(self.flat.flat, process_group)
         self._one = torch.ones(1, dtype=torch.float32, device=self.flat.device)
+        if knobs.get("UIR_MIXED") == "fp16":
+            raise NotImplementedError("UIR_MIXED=fp16 needs the loss scaling of the module networks' train step (AST / NewBigFRFNModel); "
+                                      "the SpectralTransformer step has none - use bf16, or unset it (its f32 path is the measured one)")
         self._graph_on = knobs.flag("UIR_GRAPH") and self.flat.device.type == "cuda"
         # opt-in (UIR_GRAPH=1): on ROCm 7.2 replaying the ~1400-node graph measured 62.2 ms/step vs 57.9 eager
         # a captured graph is stored ON its plan (plan._graph): it can never outlive the buffers it was recorded over
@@ -250,7 +253,13 @@ class ModuleTrainStep:
             for fp in self.flats:
                 parallel.broadcast_flat_params(fp.flat, process_group)
         self.opt = ops.MultiFlatClipAdam(self.flats, lr=lr, max_norm=max_norm, weight_decay=weight_decay)
-        self._one = torch.ones(1, dtype=torch.float32, device=dev)
+        # UIR_MIXED=fp16 (knobs.py): the gradient operands of the wide contractions are rounded to fp16, whose normal range ends at
+        # 6e-5 - a mean-type loss at 4 x 512 x 512 starts its backward at 3e-7.  Loss scaling as in torch.cuda.amp: the loss gradient
+        # is multiplied by GradScaler's initial scale 2^16 (exact in f32; every backward kernel is linear in it) and the optimizer's
+        # gradient factor divides it out before the norm and the clip.  The scale is STATIC: the fp16 conversion saturates at
+        # +-65504 instead of producing infinities (csrc/tiled.hip lp_pack2), there is no skip-and-back-off.  bf16 needs no scale.
+        self.loss_scale = 65536.0 if knobs.get("UIR_MIXED") == "fp16" else 1.0
+        self._one = torch.full((1,), self.loss_scale, dtype=torch.float32, device=dev)
 
     # ---- memory: every module's plan keeps all its activations.  The per-pixel figure is a constant of the architecture
     # (model.PLAN_BYTES_PER_PIXEL_TRAIN / _EVAL, held to the real plan bytes by tests/test_frfn_net.py / test_ast.py): AST needs
@@ -318,7 +327,7 @@ class ModuleTrainStep:
                 self._wdev = torch.zeros(1, dtype=torch.float32, device=self.bucket.device)
                 self._loss_acc = torch.zeros(1, dtype=torch.float32, device=self.bucket.device)
             w = self._weights(mb, B)
-            self._wdev.fill_(w)
+            self._wdev.fill_(w * self.loss_scale)
             n = self.bucket.numel()
             for i, o in enumerate(range(0, B, mb)):
                 out = self.model(raw[o:o + mb])
@@ -330,7 +339,7 @@ class ModuleTrainStep:
             ops.flat_accumulate(self._acc, self.bucket, n, accumulate=False)
             loss = self._loss_acc[0].clone()
         scale = parallel.allreduce_flat_grads(self.bucket, self.bucket.numel(), self.pg)
-        norm = self.opt.step(lr=lr, grad_scale=scale)
+        norm = self.opt.step(lr=lr, grad_scale=scale / self.loss_scale)
         return loss, norm[0]
 
     @torch.no_grad()
