@@ -638,35 +638,39 @@ template <bool F16>
 __device__ __forceinline__ void lp_store_row4(unsigned short* s, int row, int k, float x0, float x1, float x2, float x3) {
   *reinterpret_cast<uint2*>(s + swz(row, k >> 3) + (k & 7)) = make_uint2(lp_pack2<F16>(x0, x1), lp_pack2<F16>(x2, x3));
 }
-// SplitLoader's addressing; one rounded plane instead of three truncated ones.  (Measured on the ISA: applying the tail mask at
-// conversion time instead, to keep the loads in flight across the MFMAs, costs 10 more registers than three workgroups per CU allow.)
+// SplitLoader's addressing; one rounded plane instead of three truncated ones.  The loads are RAW (clamped addresses); the k-tail
+// mask is applied when the chunk is converted, AFTER the MFMAs of the chunk before it (the kernel pins that order with
+// sched_barriers): nothing waits on the loads before the matrix work they are meant to hide behind.
 template <bool KC, bool F16>
 struct LpLoader : SplitLoader<KC> {
-  // the tail mask as a bitwise AND: a select lets the compiler sink each load under its own exec branch (float4s through scratch)
-  __device__ __forceinline__ void load_lp(float4 (&v)[4], int k0, int ke, long s_k) const {
+  __device__ __forceinline__ void load_lp(uint4 (&v)[4], int k0, int ke, long s_k) const {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int k = k0 + this->kk[q];
       const int kc = k < ke ? k : ke - 4;
-      const uint4 t = *reinterpret_cast<const uint4*>(KC ? this->p[q] + kc : this->p[q] + (long)kc * s_k);
-      const uint32_t m = k < ke ? 0xffffffffu : 0u;
-      v[q] = make_float4(__uint_as_float(t.x & m), __uint_as_float(t.y & m), __uint_as_float(t.z & m), __uint_as_float(t.w & m));
+      v[q] = *reinterpret_cast<const uint4*>(KC ? this->p[q] + kc : this->p[q] + (long)kc * s_k);
     }
   }
-  __device__ __forceinline__ void store_lp(unsigned short* s, const float4 (&v)[4], int tid) const {
+  __device__ __forceinline__ void store_lp(unsigned short* s, const uint4 (&v)[4], int tid, int k0, int ke) const {
+#define UIR_F(x, q) __uint_as_float((x) & m##q)
     if (KC) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int e = tid + 256 * q;
-        lp_store_row4<F16>(s, e >> 3, 4 * (e & 7), v[q].x, v[q].y, v[q].z, v[q].w);
+        const uint32_t mq = k0 + this->kk[q] < ke ? 0xffffffffu : 0u;
+        lp_store_row4<F16>(s, e >> 3, 4 * (e & 7), __uint_as_float(v[q].x & mq), __uint_as_float(v[q].y & mq),
+                           __uint_as_float(v[q].z & mq), __uint_as_float(v[q].w & mq));
       }
     } else {
       const int k = 4 * (tid & 7);
-      lp_store_row4<F16>(s, this->row0, k, v[0].x, v[1].x, v[2].x, v[3].x);
-      lp_store_row4<F16>(s, this->row0 + 1, k, v[0].y, v[1].y, v[2].y, v[3].y);
-      lp_store_row4<F16>(s, this->row0 + 2, k, v[0].z, v[1].z, v[2].z, v[3].z);
-      lp_store_row4<F16>(s, this->row0 + 3, k, v[0].w, v[1].w, v[2].w, v[3].w);
+      const uint32_t m0 = k0 + this->kk[0] < ke ? 0xffffffffu : 0u, m1 = k0 + this->kk[1] < ke ? 0xffffffffu : 0u;
+      const uint32_t m2 = k0 + this->kk[2] < ke ? 0xffffffffu : 0u, m3 = k0 + this->kk[3] < ke ? 0xffffffffu : 0u;
+      lp_store_row4<F16>(s, this->row0, k, UIR_F(v[0].x, 0), UIR_F(v[1].x, 1), UIR_F(v[2].x, 2), UIR_F(v[3].x, 3));
+      lp_store_row4<F16>(s, this->row0 + 1, k, UIR_F(v[0].y, 0), UIR_F(v[1].y, 1), UIR_F(v[2].y, 2), UIR_F(v[3].y, 3));
+      lp_store_row4<F16>(s, this->row0 + 2, k, UIR_F(v[0].z, 0), UIR_F(v[1].z, 1), UIR_F(v[2].z, 2), UIR_F(v[3].z, 3));
+      lp_store_row4<F16>(s, this->row0 + 3, k, UIR_F(v[0].w, 0), UIR_F(v[1].w, 1), UIR_F(v[2].w, 2), UIR_F(v[3].w, 3));
     }
+#undef UIR_F
   }
 };
 
@@ -702,19 +706,20 @@ __global__ __launch_bounds__(256, 3) void uir_tiled_lp_kernel(const UirTiledArgs
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-  float4 va[4], vb[4];
+  uint4 va[4], vb[4];
   la.load_lp(va, ks, ke, t.sa_k);
   lb.load_lp(vb, ks, ke, t.sb_k);
-  la.store_lp(As, va, tid);
-  lb.store_lp(Bs, vb, tid);
+  la.store_lp(As, va, tid, ks, ke);
+  lb.store_lp(Bs, vb, tid, ks, ke);
   __syncthreads();
   int stage = 0;
   for (int k0 = ks; k0 < ke; k0 += TK) {
     const bool more = k0 + TK < ke;
-    if (more) {
-      la.load_lp(va, k0 + TK, ke, t.sa_k);
-      lb.load_lp(vb, k0 + TK, ke, t.sb_k);
-    }
+    // unconditional (past the end the addresses clamp into the operand and the values are never stored): a load under `if (more)`
+    // reaches the stores through loop-carried copies, and hipcc waits for it right there to make them
+    la.load_lp(va, k0 + TK, ke, t.sa_k);
+    lb.load_lp(vb, k0 + TK, ke, t.sb_k);
+    __builtin_amdgcn_sched_barrier(0);              // the loads are issued; nothing of their consumers may move up here
     const unsigned short* as = As + stage * SPLANE;
     const unsigned short* bs = Bs + stage * SPLANE;
 #pragma unroll
@@ -730,9 +735,10 @@ __global__ __launch_bounds__(256, 3) void uir_tiled_lp_kernel(const UirTiledArgs
 #pragma unroll
         for (int b = 0; b < 2; ++b) acc[a][b] = lp_mfma<F16>(fa[a], fb[b], acc[a][b]);
     }
+    __builtin_amdgcn_sched_barrier(0);              // mask + convert + LDS stores of the next chunk stay behind the MFMAs
     if (more) {
-      la.store_lp(As + (stage ^ 1) * SPLANE, va, tid);
-      lb.store_lp(Bs + (stage ^ 1) * SPLANE, vb, tid);
+      la.store_lp(As + (stage ^ 1) * SPLANE, va, tid, k0 + TK, ke);
+      lb.store_lp(Bs + (stage ^ 1) * SPLANE, vb, tid, k0 + TK, ke);
     }
     __syncthreads();                 // every wave has read this stage and written the other one
     stage ^= 1;
