@@ -355,7 +355,19 @@ l0, n0 = step(raw, ref)
 grad = step.bucket.detach().clone().cpu()
 l1, n1 = step(raw, ref)
 torch.cuda.synchronize()
-torch.save({"loss": [float(l0), float(l1)], "norm": [float(n0), float(n1)], "grad": grad}, sys.argv[1])
+# the same mode through gradient accumulation (the fp16 loss scale rides on the micro-batch weight): 2 x 1 image == 1 x 2 images
+pair = []
+raw2 = O.closed_form_input(2, 3, N * N, 303).reshape(2, 3, N, N).cuda()
+ref2 = O.closed_form_input(2, 3, N * N, 304).reshape(2, 3, N, N).cuda()
+for mb in (None, 1):
+    mm = init_model("AST", drop_path_rate=0.0)
+    mm.load_state_dict(O.closed_form_params(shapes, "astmixed"), strict=False)
+    st = make_train_step(mm.cuda().train(), "charbonnier", 3e-4)
+    st.micro_batch = mb
+    l, n = st(raw2, ref2)
+    pair += [float(l), float(n)]
+torch.cuda.synchronize()
+torch.save({"loss": [float(l0), float(l1)], "norm": [float(n0), float(n1)], "grad": grad, "pair": pair}, sys.argv[1])
 """
 
 
@@ -388,3 +400,6 @@ def test_ast_train_step_in_mixed_precision_stays_close_to_fp32(tmp_path):
         print(f"mixed {kind}: loss rel {dl:.2e}, norm rel {dn:.2e}, gradient cosine {cos:.6f}")
         assert dl < 1e-2 and dn < 5e-2 and cos > 0.99, (kind, dl, dn, cos)
         assert not torch.equal(r["grad"], f["grad"])
+    for kind, r in res.items():          # full batch == two micro-batches, in every mode (loss 1e-5, pre-clip gradient norm 1e-3)
+        lA, nA, lB, nB = r["pair"]
+        assert abs(lA - lB) <= 1e-5 * abs(lA) and abs(nA - nB) <= 1e-3 * nA, (kind, r["pair"])

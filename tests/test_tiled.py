@@ -74,10 +74,12 @@ def test_wide_weight_gradient(M, N, K):
     assert torch.equal(out, again)              # fixed summation order: bitwise run-to-run
 
 
-def test_split_bf16_mode_is_f32_accurate():
-    """UIR_TILED_SPLIT=1 (opt-in): the same contractions on the bf16 matrix pipe with every f32 operand split into three bf16 pieces
-    and six products per pair (csrc/tiled.hip): against fp64 the error must stay at the f32 kernel's level (<= 3e-6 of the largest
-    output here; measured 0.6-1.9e-6 for both).  The variable is read once per process: run in a child."""
+@pytest.mark.parametrize("mode", ["1", "0", "3"])
+def test_split_bf16_mode_is_f32_accurate(mode):
+    """UIR_TILED_SPLIT: 1 = every wide contraction on the bf16 matrix pipe with every f32 operand split into three bf16 pieces and six
+    products per pair (csrc/tiled.hip); 0 = f32 MFMA everywhere; 3 = the marked calls; (the default, 2, picks per shape - the other
+    tests of this file run under it).  Against fp64 the error must stay at the f32 kernel's level in EVERY mode (<= 3e-6 of the
+    largest output here; measured 0.6-1.9e-6 for both kernels).  The variable is read once per process: run in a child."""
     import os
     import subprocess
     import sys
@@ -102,7 +104,8 @@ def test_split_bf16_mode_is_f32_accurate():
         "    e = float((got.double().cpu() - ref).abs().max() / ref.abs().max())\n"
         "    print('ERR %%.3e' %% e)\n"
         "    assert e < 3e-6, e\n" % root)
-    env = dict(os.environ, UIR_TILED_SPLIT="1")
+    env = dict(os.environ, UIR_TILED_SPLIT=mode)
+    env.pop("UIR_MIXED", None)
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.count("ERR") == 3
