@@ -776,7 +776,9 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // UIR_MIXED: the 16-bit kernel has no MFMA time to lose on a short contraction - every Linear with >= 64 input channels goes there
     // (AST's 64 -> 256 / 128 -> 512 LeFF layers on 1 M / 262 k tokens stream at the byte rate instead of 64-81 TFLOP/s of f32 MFMA)
     const int mixed = uir_mixed_mode();
-    const int mink = mixed != 0 ? 64 : 256;
+    // f32: K >= 256; K >= 128 where the rows are very many (AST's 128 -> 512 LeFF / projection layers on 262 k tokens: the tiled
+    // kernels' split-bf16 form and row-major stores against this file's panel kernel at 81 TFLOP/s)
+    const int mink = mixed != 0 ? 64 : (a.M >= 524288 ? 64 : a.M >= 131072 ? 128 : 256);
     const bool w_kc = a.w_sk == 1 && (a.w_sn & 3) == 0, w_nc = a.w_sn == 1 && (a.w_sk & 3) == 0 && (a.N & 3) == 0;
     if (mink > 0 && a.K >= mink && a.N >= (mixed != 0 ? 64 : 128) && a.M >= 256 && a.taps == 1 && a.batches == 1 && a.pro == UIR_PRO_NONE &&
         a.epi == UIR_EPI_PLAIN && (a.act == UIR_ACT_NONE || a.act == UIR_ACT_GELU) && a.n_grp_pad <= 0 && a.k_grp_pad <= 0 &&

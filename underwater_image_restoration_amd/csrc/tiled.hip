@@ -852,7 +852,7 @@ int uir_tiled_gemm(const UirTiledArgs& t_in, hipStream_t st) {
   static const int mode = getenv("UIR_TILED_SPLIT") ? atoi(getenv("UIR_TILED_SPLIT")) : 2;
   UIR_REQUIRE(mode >= 0 && mode <= 3);
   const int kc_split = t.k_per_split < t.KK ? t.k_per_split : t.KK;
-  const bool auto_split = mode == 2 && t.MM >= TM && t.NN >= TN && kc_split >= 256 && (long)grid.x * nsplit >= 256;
+  const bool auto_split = mode == 2 && t.MM >= TM && t.NN >= TN && kc_split >= 64 && (long)grid.x * nsplit >= 256;
   // UIR_MIXED=bf16 | fp16 (opt-in, knobs.py): EVERY contraction that reaches this kernel family runs on uir_tiled_lp_kernel - operands
   // rounded to the named 16-bit type, f32 accumulation and epilogue.  Results are no longer f32-accurate (that is the point of the mode)
   // and no f32 number of this repository is measured with it.
