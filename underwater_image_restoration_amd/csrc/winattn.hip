@@ -144,7 +144,10 @@ __device__ __forceinline__ void score_pair(const float* __restrict__ A, int lda,
 // out[m][n] = sum over the 64 tokens t of p[m][t] X[t][ct * 32 + n]: p0 / p1 are accumulator tiles whose ROW index is the token
 // (tile 0 / 1), i.e. register r of a lane stands for token tile * 32 + (r / 4) * 8 + half * 4 + r % 4, and the lane's column of the tile
 // becomes the output row.  X is read channel-on-the-lane for exactly those tokens.
-template <int HD>
+// PIN (the forward kernel): all 32 operand loads are issued before the first MFMA.  Left to itself hipcc sinks each load next to the
+// MFMA that consumes it (fewer live registers: 97) - 32 serialised `global_load_dword; s_waitcnt vmcnt(0); v_mfma` round trips per
+// column tile; the backward kernel's uses are batched by the compiler already and stay as they are.
+template <int HD, bool PIN = false>
 __device__ __forceinline__ void acc_times(const f32x16& p0, const f32x16& p1, const float* __restrict__ X, int ldx, const WinGeo& g,
                                           int h, int ct, f32x16& out) {
   // head dim < 32: lanes past the head's channels re-read its last channel (their output columns are not stored).  The column keeps
@@ -166,6 +169,7 @@ __device__ __forceinline__ void acc_times(const f32x16& p0, const f32x16& p1, co
       const char* rb = reinterpret_cast<const char*>(X) + (size_t)((unsigned)g.rowp[t * 4 + r / 4] * ldx) * 4u;
       b[t * 16 + r] = *reinterpret_cast<const float*>(rb + vo[r % 4]);
     }
+  if (PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int r = 0; r < 16; ++r) out = mfma32(p0[r], b[r], out);
 #pragma unroll
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(256, 2) void winattn_fwd_kernel(const UirWinAttnArg
 #pragma unroll 1
     for (int ct = 0; ct < nct; ++ct) {
       f32x16 o;
-      acc_times<HD>(s0, s1, a.V, a.ldv, g, h, ct, o);
+      acc_times<HD, true>(s0, s1, a.V, a.ldv, g, h, ct, o);
       store_rows<HD>(a.O, a.ldo, g, h, ct, qt, o, 1.0f);
     }
   }
