@@ -131,6 +131,9 @@ __global__ __launch_bounds__(256) void uir_dft2_kernel(const UirDft2Args a, int 
       br[s] = a.in_re[off];
       bi[s] = imp[off];
     }
+    // all 16 loads of this n2 in flight before its MFMAs: hipcc sinks each imaginary-part load next to the MFMA that consumes it
+    // (`global_load_dword; s_waitcnt vmcnt(0); v_mfma`, eight serialised round trips per n2) when left to schedule freely
+    __builtin_amdgcn_sched_barrier(0);
     f32x16 d;
 #pragma unroll
     for (int q = 0; q < 16; ++q) d[q] = 0.f;
