@@ -60,3 +60,29 @@ def test_isa_lint_refuses_the_erratum_form_and_passes_the_library():
     build.build()
     scanned = {n: build.lint_isa(os.path.join(build.OBJ, n + ".o")) for n in build.SOURCES}
     assert scanned["abi_layout"] == 0 and min(v for k, v in scanned.items() if k != "abi_layout") > 50, scanned
+
+
+def test_pipelined_kernels_keep_their_loads_in_flight():
+    """tools/scan_isa_waits.py on the built library (CPU only, disassembly): the kernels whose operand loads were found serialised in
+    round 3 - one `global_load; s_waitcnt vmcnt(0)` round trip per MFMA - and were fixed with a sched_barrier between the load loop
+    and its consumers must not fall back, and the hot kernels of the headline step that were clean stay
+    clean: no chain of four or more single-load full waits."""
+    import importlib.util
+    import tempfile
+    spec = importlib.util.spec_from_file_location("scan_isa_waits", os.path.join(ROOT, "tools", "scan_isa_waits.py"))
+    scan = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(scan)
+    from underwater_image_restoration_amd import build
+    watched = {"winattn.o": ("winattn_fwd_kernel",), "spectral.o": ("uir_dft2_kernel",), "dwln.o": ("uir_dwln_bwd_kernel",),
+               "gdfn.o": ("uir_gdfn_fwd_kernel",), "gram.o": ("uir_gram_kernel",)}
+    seen = 0
+    with tempfile.TemporaryDirectory() as tmp:
+        for obj, names in watched.items():
+            path = os.path.join(build.OBJ, obj)
+            assert os.path.exists(path), f"{path}: build the library first (__graft_entry__.build())"
+            for name, body in scan.kernels(scan.disassemble(path, tmp)):
+                if any(n in name for n in names):
+                    seen += 1
+                    _nloads, prof = scan.wait_profile(body)
+                    assert scan.longest_chain(prof) < 4, (name, prof)
+    assert seen >= 10
