@@ -73,6 +73,7 @@ def test_pipelined_kernels_keep_their_loads_in_flight():
     scan = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(scan)
     from underwater_image_restoration_amd import build
+    build.build()                       # no-op when the objects are fresh; a fresh checkout compiles here (hipcc cross-compiles on CPU)
     watched = {"winattn.o": ("winattn_fwd_kernel",), "spectral.o": ("uir_dft2_kernel",), "dwln.o": ("uir_dwln_bwd_kernel",),
                "gdfn.o": ("uir_gdfn_fwd_kernel",), "gram.o": ("uir_gram_kernel",)}
     seen = 0
