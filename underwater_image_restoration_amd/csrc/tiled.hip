@@ -842,7 +842,7 @@ int uir_tiled_gemm(const UirTiledArgs& t_in, hipStream_t st) {
   // Split-bf16 operands on the bf16 matrix pipe (uir_tiled_split_kernel: three bf16 planes per f32 operand, six products, f32
   // accumulation - as accurate against fp64 as the f32 MFMA, tests/test_tiled.py).  Since its loads overlap its MFMAs (round 3) it
   // beats the f32 kernel wherever the tile grid fills the chip and the contraction is long enough to amortise the split:
-  //   UIR_TILED_SPLIT unset / 2 (default): AUTO - full 128 x 128 tiles (M, N >= 128), >= 256 workgroups, >= 256 k per split
+  //   UIR_TILED_SPLIT unset / 2 (default): AUTO - full 128 x 128 tiles (M, N >= 128), >= 256 workgroups, >= 64 k per split
   //                   (16 k x 512 -> 2048: 295 -> 212 us = 162 TFLOP/s, above the f32 MFMA peak; 65 k x 256 -> 1024: 328 -> 229 us);
   //                   narrow outputs, under-filled grids (the SpectralTransformer's own four deep-level calls) and short
   //                   contractions stay on the f32 kernel and its 128 x 64 / 64 x 128 variants

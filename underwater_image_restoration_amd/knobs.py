@@ -15,7 +15,7 @@ KNOBS = {
                   "tests/test_hip_model.py::test_adam_scalars_survive_an_unsynchronised_host"),
     "UIR_TILED_SPLIT": ("2", "read by libuir_hip.so: where the wide contractions of csrc/tiled.hip run on split-bf16 MFMA (3 bf16 planes per f32 "
                         "operand, 6 products, f32-accurate).  2 (default) = where it is faster: full 128 x 128 tiles, >= 256 workgroups, "
-                        ">= 256 k per split; 0 = never (f32 MFMA everywhere); 1 = every tiled call; 3 = only the calls the dispatchers mark",
+                        ">= 64 k per split; 0 = never (f32 MFMA everywhere); 1 = every tiled call; 3 = only the calls the dispatchers mark",
                         "tests/test_tiled.py::test_split_bf16_mode_is_f32_accurate"),
     "UIR_MIXED": ("0", "read by libuir_hip.so: bf16 | fp16 = MIXED precision - every wide contraction of csrc/tiled.hip (the Linear layers of "
                   "AST / NewBigFRFNModel with >= 256 input channels and their input / weight gradients) takes its operands rounded to that "
