@@ -919,3 +919,45 @@ def test_dwln_bwd_vs_autograd(B, H, W, C, split):
     r.run(r.fwd)
     torch.cuda.synchronize()
     assert all(torch.equal(a_, b_) for a_, b_ in zip(first, (dX, dWdw, dW1, dgb)))
+
+
+# ------------------------------------------------- UIR_FUSED_SPLIT (split-bf16 contractions inside the tile-fused kernels)
+def test_fused_kernels_agree_between_split_bf16_and_f32_mfma():
+    """UIR_FUSED_SPLIT (knobs.py): 1 / unset = uir_gdfn_fwd, uir_qkv_fwd, uir_attnv_fwd contract on split-bf16 in registers
+    (csrc/uir_common.h uir_mfma_split: three bf16 planes per f32 operand, six products, f32 accumulation); 0 = on the f32 MFMA.  Every
+    other test of this file runs under the default; here the SAME fp64 comparisons run in a child with the knob off (the variable is
+    read once per process), and both modes are held to the f32-MFMA error level on operands spanning 2^-6 .. 2^6 per pixel."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, UIR_FUSED_SPLIT="0")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_kernels.py"), "-m", "gpu", "-x", "-q", "-k",
+                          "gdfn_fwd_fused or attnv_fwd_fused or qkv_fwd_fused"], env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import torch.nn.functional as F\n"
+        "from underwater_image_restoration_amd.engine import Recorder\n"
+        "g = torch.Generator().manual_seed(0)\n"
+        "B, H, W, C = 2, 48, 64, 32\n"
+        "h = int(C * 2.66); hp = (h + 15) & ~15; ldt = (2 * hp + 31) & ~31; M = B * H * W\n"
+        "rnd = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64) * 2 - 1\n"
+        "x = rnd(M, C) * torch.exp2(torch.randint(-6, 7, (M, 1), generator=g).double())\n"
+        "gam, bet = 1 + 0.1 * rnd(C), 0.1 * rnd(C)\n"
+        "wq, wdw = rnd(3 * C, C) * C ** -0.5, rnd(3 * C, 1, 3, 3) / 3\n"
+        "xn = F.layer_norm(x, (C,), gam, bet, 1e-5).reshape(B, H, W, C).permute(0, 3, 1, 2)\n"
+        "pre = F.conv2d(xn, wq.reshape(3 * C, C, 1, 1)); out = F.conv2d(pre, wdw, padding=1, groups=3 * C)\n"
+        "r = Recorder('cuda', scratch_floats=1 << 20)\n"
+        "f = lambda t: t.float().cuda().contiguous()\n"
+        "Ypre, Y, st = r.alloc(M, 3 * C), r.alloc(M, 3 * C), r.alloc(M, 2)\n"
+        "r.qkv_fwd('q', f(x), (f(gam), f(bet)), f(wq), f(wdw), Ypre, Y, C_=C, dims=(B, H, W), stats=st)\n"
+        "r.run(r.fwd); torch.cuda.synchronize()\n"
+        "rows = lambda t: t.permute(0, 2, 3, 1).reshape(M, -1)\n"
+        "for got, ref in ((Ypre, rows(pre)), (Y, rows(out))):\n"
+        "    e = float((got.double().cpu() - ref).abs().max() / ref.abs().max())\n"
+        "    print('ERR %%.3e' %% e)\n"
+        "    assert e < 3e-6, e\n" % root)
+    for mode in ("0", "1"):
+        o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UIR_FUSED_SPLIT=mode), capture_output=True, text=True, timeout=300)
+        assert o.returncode == 0 and o.stdout.count("ERR") == 2, (mode, o.stdout + o.stderr)

@@ -58,7 +58,7 @@ __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }   
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 
-template <int C, int TH, int TW, bool STORE>
+template <int C, int TH, int TW, bool STORE, bool SB>
 __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdArgs a) {
   using T = GdfnTile<C, TH, TW>;
   extern __shared__ float smem[];
@@ -125,6 +125,18 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
           *reinterpret_cast<float2*>(a.stats + m * 2) = make_float2(mean, rstd);
       }
     }
+  }
+
+  // SB: the A operand as three bf16 planes per 16-deep k step, split ONCE per tile (it is the same for every chunk)
+  UirBf3 Ap[SB ? T::RTW : 1][SB ? C / 16 : 1];
+  if constexpr (SB) {
+#pragma unroll
+    for (int q = 0; q < T::RTW; ++q)
+#pragma unroll
+      for (int s = 0; s < C / 16; ++s) {
+        const float x[8] = {A[q][8 * s], A[q][8 * s + 1], A[q][8 * s + 2], A[q][8 * s + 3], A[q][8 * s + 4], A[q][8 * s + 5], A[q][8 * s + 6], A[q][8 * s + 7]};
+        Ap[q][s] = uir_split8(x);
+      }
   }
 
   // (c) work units (interior row tile, 32-column output tile): unit u = wave + 4 j -> rt = u / NT, nt = u % NT;
@@ -238,7 +250,29 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
       w2_[t] = ok ? u2 : 0.f;
     }
   };
-  if constexpr (PF) {
+  auto load_win = [&](int c0, float4 (&win_)[NPF]) {   // the W_in fragment alone (SB, C <= 32)
+    const int cc = c0 + (li & 15);
+    const bool ok = cc < h;
+    const float* wr = a.Win + (long)(ok ? (li < 16 ? cc : h + cc) : 0) * C + 4 * h2;
+#pragma unroll
+    for (int jj = 0; jj < NPF; ++jj) {
+      const float4 t = *reinterpret_cast<const float4*>(wr + 8 * jj);
+      win_[jj] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  // SB: only W_in is fetched a chunk ahead (it is needed first, at the top of (a)); W_out and the depthwise taps of the CURRENT chunk
+  // are loaded at its top and land under (a) - the bf16 planes of the A operand take the registers of the second small-weight set
+  if constexpr (SB) {
+    if constexpr (PF) {
+      load_win(0, win_n);
+#pragma unroll
+      for (int jj = 0; jj < NPF; ++jj) win[jj] = win_n[jj];
+    } else {
+      stage_load(0);
+      stage_store(0);
+      lds_barrier();
+    }
+  } else if constexpr (PF) {
     load_w(0, win, wo, w1, w2);
   } else {
     stage_load(0);
@@ -249,7 +283,11 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
 
   int wbuf = 0;
   for (int c0 = 0; c0 < hp; c0 += 16) {
-    if constexpr (PF) {
+    if constexpr (SB) {
+      if constexpr (PF) load_win(c0 + 16 < hp ? c0 + 16 : c0, win_n);
+      else stage_load(c0 + 16 < hp ? c0 + 16 : c0);
+      load_small(c0, wo, w1, w2);
+    } else if constexpr (PF) {
       // in flight across (a) and (b): the LDS-only barriers do not wait for them
       load_w(c0 + 16 < hp ? c0 + 16 : c0, win_n, wo_n, w1_n, w2_n);
     } else {
@@ -258,6 +296,33 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     }
 
     // ---- (a) t1 chunk on tile + ring ----
+    if constexpr (SB) {
+      // the chunk's W_in fragment is split once per 16-deep k step and meets every row tile of the wave
+      f32x16 d[T::RTW];
+#pragma unroll
+      for (int q = 0; q < T::RTW; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[q][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < C / 16; ++s) {
+        UirBf3 wp;
+        if constexpr (PF) wp = uir_split8(win[2 * s], win[2 * s + 1]);
+        else wp = uir_split8(*reinterpret_cast<const float4*>(Ws + wbuf * 32 * WS + li * WS + 16 * s + 4 * h2),
+                             *reinterpret_cast<const float4*>(Ws + wbuf * 32 * WS + li * WS + 16 * s + 8 + 4 * h2));
+#pragma unroll
+        for (int q = 0; q < T::RTW; ++q)
+          if (wave + 4 * q < T::NRT1) d[q] = uir_mfma_split(Ap[q][s], wp, d[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < T::RTW; ++q) {
+        const int r = wave + 4 * q;
+        if (r < T::NRT1) {
+          float* dst = T1s + (r * 32 + 4 * h2) * T::S1 + li;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::S1] = d[q][i];
+        }
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < T::RTW; ++q) {
       const int r = wave + 4 * q;
@@ -280,6 +345,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::S1] = d[i];
       }
     }
+    }
     lds_barrier();
 
     // The prefetched weights are needed only at the end of the chunk, but the compiler would wait for them with
@@ -292,10 +358,17 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     } else {
       stage_store(wbuf ^ 1);     // (a) of chunk c-1 was the last reader of that buffer; visible after the next barrier
     }
+    if constexpr (SB) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) pin(wo[t]);
+#pragma unroll
+      for (int t = 0; t < 9; ++t) { pin(w1[t]); pin(w2[t]); }
+    } else {
 #pragma unroll
     for (int t = 0; t < 8; ++t) pin(wo_n[t]);
 #pragma unroll
     for (int t = 0; t < 9; ++t) { pin(w1_n[t]); pin(w2_n[t]); }
+    }
 
     // ---- T1 write-out (training): interior rows of the LDS chunk as 16-byte stores, 8 lanes per pixel ----
     if (STORE) {
@@ -359,6 +432,8 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     }
 
     // ---- (c) y += (gelu(t2a) * t2b) . W_out^T over this chunk's 16 hidden channels ----
+    UirBf3 wop;
+    if constexpr (SB) wop = uir_split8(wo);
 #pragma unroll
     for (int j = 0; j < T::UPW; ++j) {
       const int u = wave + 4 * j;
@@ -369,6 +444,12 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         const float4 a1 = *reinterpret_cast<const float4*>(gr + 8);
         const float4 b0 = *reinterpret_cast<const float4*>(gr + 16);
         const float4 b1 = *reinterpret_cast<const float4*>(gr + 24);
+        if constexpr (SB) {
+          const float gv[8] = {uir_gelu(a0.x) * b0.x, uir_gelu(a0.y) * b0.y, uir_gelu(a0.z) * b0.z, uir_gelu(a0.w) * b0.w,
+                               uir_gelu(a1.x) * b1.x, uir_gelu(a1.y) * b1.y, uir_gelu(a1.z) * b1.z, uir_gelu(a1.w) * b1.w};
+          acc[j] = uir_mfma_split(uir_split8(gv), wop, acc[j]);
+          continue;
+        }
         acc[j] = uir_mfma(uir_gelu(a0.x) * b0.x, wo[0], acc[j]);
         acc[j] = uir_mfma(uir_gelu(a0.y) * b0.y, wo[1], acc[j]);
         acc[j] = uir_mfma(uir_gelu(a0.z) * b0.z, wo[2], acc[j]);
@@ -383,10 +464,12 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
 #pragma unroll
       for (int jj = 0; jj < T::KJ; ++jj) win[jj] = win_n[jj];
     }
+    if constexpr (!SB) {
 #pragma unroll
     for (int t = 0; t < 8; ++t) wo[t] = wo_n[t];
 #pragma unroll
     for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
+    }
     wbuf ^= 1;
     // no barrier: (a) of the next chunk writes T1s (all reads of it finished before the barrier
     // above) and Gs is rewritten only after the next barrier, which every wave reaches after its (c)
@@ -422,7 +505,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
 // (SpectralTransformer.py:93-94 with the norm1 of :144).  Same tile / chunk skeleton as uir_gdfn_fwd without the gate
 // and the second 1x1: chunks of 32 consecutive output channels, thread (cp, column) owns channels cp and cp + 16.
 // Both results are written once: the pre-depthwise tensor (only the backward reads it: streaming stores) and qkv.
-template <int C, int TH, int TW>
+template <int C, int TH, int TW, bool SB>
 __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs a) {
   using T = GdfnTile<C, TH, TW>;
   extern __shared__ float smem[];
@@ -490,6 +573,16 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
     }
   }
 
+  UirBf3 Ap[SB ? T::RTW : 1][SB ? C / 16 : 1];       // SB: A operand as bf16 planes, split once per tile (uir_gdfn_fwd_kernel)
+  if constexpr (SB) {
+#pragma unroll
+    for (int q = 0; q < T::RTW; ++q)
+#pragma unroll
+      for (int s = 0; s < C / 16; ++s) {
+        const float x[8] = {A[q][8 * s], A[q][8 * s + 1], A[q][8 * s + 2], A[q][8 * s + 3], A[q][8 * s + 4], A[q][8 * s + 5], A[q][8 * s + 6], A[q][8 * s + 7]};
+        Ap[q][s] = uir_split8(x);
+      }
+  }
   const int cp = tid & 15;
   const int strip = (tid >> 6) * 4 + (((lane >> 4) & 1) << 1 | (lane >> 5));
   const int sx = strip % TW, ys = (strip / TW) * T::ROWS;
@@ -546,6 +639,29 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
       load_w(c0, win, w1, w2);
     }
     // ---- (a) 32 output channels of the 1x1 on tile + ring ----
+    if constexpr (SB) {
+      f32x16 d[T::RTW];
+#pragma unroll
+      for (int q = 0; q < T::RTW; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[q][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < C / 16; ++s) {
+        const UirBf3 wp = uir_split8(win[2 * s], win[2 * s + 1]);
+#pragma unroll
+        for (int q = 0; q < T::RTW; ++q)
+          if (wave + 4 * q < T::NRT1) d[q] = uir_mfma_split(Ap[q][s], wp, d[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < T::RTW; ++q) {
+        const int r = wave + 4 * q;
+        if (r < T::NRT1) {
+          float* dst = T1s + (r * 32 + 4 * h2) * T::S1 + li;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::S1] = d[q][i];
+        }
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < T::RTW; ++q) {
       const int r = wave + 4 * q;
@@ -564,6 +680,7 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
 #pragma unroll
         for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::S1] = d[i];
       }
+    }
     }
     lds_barrier();
     if constexpr (PF) {   // see uir_gdfn_fwd_kernel: the prefetched weights must be complete before this chunk's stores
@@ -639,7 +756,8 @@ template <int C, int TH, int TW>
 int qkv_fwd_launch(const UirQkvFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
   const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
-  hipLaunchKernelGGL((uir_qkv_fwd_kernel<C, TH, TW>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
+  if (uir_fused_split()) hipLaunchKernelGGL((uir_qkv_fwd_kernel<C, TH, TW, true>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
+  else hipLaunchKernelGGL((uir_qkv_fwd_kernel<C, TH, TW, false>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
   return uir_launch_status();
 }
 
@@ -648,7 +766,7 @@ int qkv_fwd_launch(const UirQkvFwdArgs& a, hipStream_t st) {
 // algebraic folding of DESIGN.md section 5):  u = v . WA[b]^T,  vf = dw3x3(u),  x1 = vf . WB[b]^T + x
 // with the per-sample C x C matrices WA, WB from uir_attn_fwd.  Same skeleton as uir_gdfn_fwd (no LayerNorm, no gate):
 // chunks of 32 channels of u / vf; both are written once (the backward reads them).
-template <int C, int TH, int TW>
+template <int C, int TH, int TW, bool SB>
 __global__ __launch_bounds__(256, 2) void uir_attnv_fwd_kernel(const UirAttnvFwdArgs a) {
   using T = GdfnTile<C, TH, TW>;
   extern __shared__ float smem[];
@@ -688,6 +806,16 @@ __global__ __launch_bounds__(256, 2) void uir_attnv_fwd_kernel(const UirAttnvFwd
         A[q][4 * jj + 3] = keep * v.w;
       }
     }
+  }
+  UirBf3 Ap[SB ? T::RTW : 1][SB ? C / 16 : 1];       // SB: A operand as bf16 planes, split once per tile (uir_gdfn_fwd_kernel)
+  if constexpr (SB) {
+#pragma unroll
+    for (int q = 0; q < T::RTW; ++q)
+#pragma unroll
+      for (int s = 0; s < C / 16; ++s) {
+        const float x[8] = {A[q][8 * s], A[q][8 * s + 1], A[q][8 * s + 2], A[q][8 * s + 3], A[q][8 * s + 4], A[q][8 * s + 5], A[q][8 * s + 6], A[q][8 * s + 7]};
+        Ap[q][s] = uir_split8(x);
+      }
   }
   f32x16 acc[T::UPW];
 #pragma unroll
@@ -751,6 +879,29 @@ __global__ __launch_bounds__(256, 2) void uir_attnv_fwd_kernel(const UirAttnvFwd
       }
     }
     // ---- (a) u chunk on tile + ring ----
+    if constexpr (SB) {
+      f32x16 d[T::RTW];
+#pragma unroll
+      for (int q = 0; q < T::RTW; ++q)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[q][i] = 0.f;
+#pragma unroll
+      for (int s = 0; s < C / 16; ++s) {
+        const UirBf3 wp = uir_split8(wa[2 * s], wa[2 * s + 1]);
+#pragma unroll
+        for (int q = 0; q < T::RTW; ++q)
+          if (wave + 4 * q < T::NRT1) d[q] = uir_mfma_split(Ap[q][s], wp, d[q]);
+      }
+#pragma unroll
+      for (int q = 0; q < T::RTW; ++q) {
+        const int r = wave + 4 * q;
+        if (r < T::NRT1) {
+          float* dst = T1s + (r * 32 + 4 * h2) * T::S1 + li;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::S1] = d[q][i];
+        }
+      }
+    } else {
 #pragma unroll
     for (int q = 0; q < T::RTW; ++q) {
       const int r = wave + 4 * q;
@@ -769,6 +920,7 @@ __global__ __launch_bounds__(256, 2) void uir_attnv_fwd_kernel(const UirAttnvFwd
 #pragma unroll
         for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::S1] = d[i];
       }
+    }
     }
     lds_barrier();
 #pragma unroll
@@ -824,12 +976,20 @@ __global__ __launch_bounds__(256, 2) void uir_attnv_fwd_kernel(const UirAttnvFwd
         *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.VF) + (st_vf[it] + (unsigned)c0 * 4u)) = v;
       }
     // ---- (c) x1 += vf chunk . WB^T ----
+    UirBf3 wbp[SB ? 2 : 1];
+    if constexpr (SB) { wbp[0] = uir_split8(wb[0], wb[1]); wbp[1] = uir_split8(wb[2], wb[3]); }
 #pragma unroll
     for (int j = 0; j < T::UPW; ++j) {
       const int u = wave + 4 * j;
       if (u < T::UNITS) {
         const int rt = u / T::NT;
         const float* gr = Gs + (rt * 32 + li) * T::SG + 4 * h2;
+        if constexpr (SB) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s)
+            acc[j] = uir_mfma_split(uir_split8(*reinterpret_cast<const float4*>(gr + 16 * s), *reinterpret_cast<const float4*>(gr + 16 * s + 8)), wbp[s], acc[j]);
+          continue;
+        }
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const float4 v = *reinterpret_cast<const float4*>(gr + 8 * jj);
@@ -871,7 +1031,8 @@ template <int C, int TH, int TW>
 int attnv_fwd_launch(const UirAttnvFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
   const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
-  hipLaunchKernelGGL((uir_attnv_fwd_kernel<C, TH, TW>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
+  if (uir_fused_split()) hipLaunchKernelGGL((uir_attnv_fwd_kernel<C, TH, TW, true>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
+  else hipLaunchKernelGGL((uir_attnv_fwd_kernel<C, TH, TW, false>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
   return uir_launch_status();
 }
 
@@ -880,8 +1041,11 @@ int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
   const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
   const size_t lds = ((size_t)T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : 0)) * 4;   // + two staged W_in chunks
-  if (a.T1) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true>), dim3(tiles), dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false>), dim3(tiles), dim3(256), lds, st, a);
+  const bool sb = uir_fused_split() != 0;
+  if (a.T1) { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, true>), dim3(tiles), dim3(256), lds, st, a);
+              else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, false>), dim3(tiles), dim3(256), lds, st, a); }
+  else { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, true>), dim3(tiles), dim3(256), lds, st, a);
+         else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, false>), dim3(tiles), dim3(256), lds, st, a); }
   return uir_launch_status();
 }
 

@@ -812,6 +812,16 @@ int uir_mixed_mode() {
   return mode;
 }
 
+// UIR_FUSED_SPLIT (knobs.py): 1 / unset = the tile-fused kernels (csrc/gdfn.hip, csrc/dwln.hip) contract on split-bf16 in registers
+// (uir_mfma_split, f32-accurate); 0 = on the f32 MFMA (the round-1..3 arithmetic, kept for A/B measurements and the parity tests)
+int uir_fused_split() {
+  static const int mode = [] {
+    const char* v = getenv("UIR_FUSED_SPLIT");
+    return (v && v[0] == '0' && !v[1]) ? 0 : 1;
+  }();
+  return mode;
+}
+
 int uir_tiled_conv3x3(const UirTiledArgs& t, hipStream_t st) {
   UIR_REQUIRE(t.A && t.B && t.D && t.MM > 0 && t.NN > 0 && t.KK > 0 && (t.KK & 3) == 0 && t.sa_k == 1 && (t.sa_i & 3) == 0);
   UIR_REQUIRE(t.H > 0 && t.Wd > 0 && t.MM % (t.H * t.Wd) == 0 && uir_aligned16(t.A) && t.act == UIR_ACT_NONE && !t.pre_out);

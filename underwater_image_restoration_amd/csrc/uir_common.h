@@ -66,6 +66,52 @@ __device__ __forceinline__ f32x16 uir_mfma(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- split-bf16 contraction in registers (the construction of csrc/tiled.hip, DESIGN.md section 17, without the LDS planes) ----
+// An f32 value is the exact sum of three bf16 pieces (hi = its top 16 bits, mid = the top 16 bits of x - hi, lo = x - hi - mid, both
+// subtractions exact), a bf16 x bf16 product is exact in f32, and the six products (h,h) (h,m) (m,h) (h,l) (l,h) (m,m) reproduce
+// a b to 3 * 2^-24 |a b| - the rounding level of an f32 multiply - on v_mfma_f32_32x32x16_bf16, which runs at 16x the rate of
+// v_mfma_f32_32x32x2_f32 and, unlike it, beside the VALU.  A lane's 8 operand values of one 16-deep k step are the SAME 8 values it
+// feeds to eight consecutive f32 MFMAs (k = 8 j + 4 h2 + e for two consecutive j): any bijection lane slot <-> k is a valid
+// contraction order as long as both operands use it, so the f32 kernels' operand registers are packed as they stand.
+typedef __bf16 uir_bf16x8 __attribute__((ext_vector_type(8)));
+struct UirBf3 { uir_bf16x8 h, m, l; };
+
+__device__ __forceinline__ uint32_t uir_pack_hi16(uint32_t lo_elem, uint32_t hi_elem) {   // {lo_elem >> 16, hi_elem >> 16} as one dword
+  return __builtin_amdgcn_perm(hi_elem, lo_elem, 0x07060302u);
+}
+__device__ __forceinline__ UirBf3 uir_split8(const float (&x)[8]) {
+  uint32_t hh[8], mm[8], ll[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    hh[e] = __float_as_uint(x[e]) & 0xffff0000u;
+    const float r1 = x[e] - __uint_as_float(hh[e]);
+    mm[e] = __float_as_uint(r1) & 0xffff0000u;
+    ll[e] = __float_as_uint(r1 - __uint_as_float(mm[e]));       // at most 8 significant bits left: its top 16 bits hold it exactly
+  }
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  UirBf3 o;
+  o.h = __builtin_bit_cast(uir_bf16x8, (u32x4){uir_pack_hi16(hh[0], hh[1]), uir_pack_hi16(hh[2], hh[3]), uir_pack_hi16(hh[4], hh[5]), uir_pack_hi16(hh[6], hh[7])});
+  o.m = __builtin_bit_cast(uir_bf16x8, (u32x4){uir_pack_hi16(mm[0], mm[1]), uir_pack_hi16(mm[2], mm[3]), uir_pack_hi16(mm[4], mm[5]), uir_pack_hi16(mm[6], mm[7])});
+  o.l = __builtin_bit_cast(uir_bf16x8, (u32x4){uir_pack_hi16(ll[0], ll[1]), uir_pack_hi16(ll[2], ll[3]), uir_pack_hi16(ll[4], ll[5]), uir_pack_hi16(ll[6], ll[7])});
+  return o;
+}
+__device__ __forceinline__ UirBf3 uir_split8(const float4& a, const float4& b) {
+  const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+  return uir_split8(x);
+}
+// c += A . B over one 16-deep k step, f32-accurate; small terms first
+__device__ __forceinline__ f32x16 uir_mfma_split(const UirBf3& a, const UirBf3& b, f32x16 c) {
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.l, b.h, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.l, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.h, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.m, c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.h, b.h, c, 0, 0, 0);
+  return c;
+}
+// UIR_FUSED_SPLIT (knobs.py), read once: 1 (default) = the tile-fused kernels contract on split-bf16, 0 = on the f32 MFMA
+int uir_fused_split();
+
 __device__ __forceinline__ float uir_wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);

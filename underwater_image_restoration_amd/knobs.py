@@ -17,6 +17,10 @@ KNOBS = {
                         "operand, 6 products, f32-accurate).  2 (default) = where it is faster: full 128 x 128 tiles, >= 256 workgroups, "
                         ">= 64 k per split; 0 = never (f32 MFMA everywhere); 1 = every tiled call; 3 = only the calls the dispatchers mark",
                         "tests/test_tiled.py::test_split_bf16_mode_is_f32_accurate"),
+    "UIR_FUSED_SPLIT": ("1", "read by libuir_hip.so: 1 (default) = the tile-fused kernels of the SpectralTransformer step (uir_gdfn_fwd, uir_qkv_fwd, "
+                        "uir_attnv_fwd) run their channel contractions on split-bf16 MFMA in registers (3 bf16 planes per f32 operand, 6 products, "
+                        "f32-accurate: csrc/uir_common.h uir_mfma_split); 0 = on the f32 MFMA (the arithmetic of rounds 1-3)",
+                        "tests/test_hip_kernels.py::test_fused_kernels_agree_between_split_bf16_and_f32_mfma"),
     "UIR_MIXED": ("0", "read by libuir_hip.so: bf16 | fp16 = MIXED precision - every wide contraction of csrc/tiled.hip (the Linear layers of "
                   "AST / NewBigFRFNModel with >= 256 input channels and their input / weight gradients) takes its operands rounded to that "
                   "16-bit type on the bf16 / f16 matrix pipe, f32 accumulation, f32 master weights, everything else f32 (BASELINE "
