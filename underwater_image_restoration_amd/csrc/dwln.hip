@@ -26,6 +26,7 @@
 #include "uir_common.h"
 #include <type_traits>
 #include "../../include/uir_kernels.h"
+#include "uir_stamps.h"
 
 namespace {
 
@@ -209,6 +210,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     load_xp(0, cp, sx, c0);
   }
 
+  UIR_ST_DECL;
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const Tc tc = coords(tile), tn = coords(tile + gridDim.x);
     const int y0 = tc.y0, x0 = tc.x0, nrows = tc.nrows;
@@ -216,22 +218,35 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     {
       UIR_DWLN_COORDS;
       // ---- xhat of the tile's interior -> LDS (all waves are past the previous tile's reads of XH / RS after this barrier) ----
-      lds_barrier2();
+      // all loads of the tile in flight together, then the LDS stores: as one loop hipcc waited for each (x, stats) pair with
+      // vmcnt(0) before the next pair was issued - NXL exposed round trips per tile (tools/scan_isa_chains.py)
+      float4 xv[T::NXL];
+      float2 sv[T::NXL];
+      bool okv[T::NXL];
 #pragma unroll
       for (int it = 0; it < T::NXL; ++it) {
         const int e = t_ + 256 * it, p = e / (C / 4), q = e - p * (C / 4);
         const int py = p / T::TW, px = p - py * T::TW;
         const int iy = y0 + py, ix = x0 + px;
-        const bool ok = iy < a.H && ix < a.Wd;
-        const unsigned m = ok ? img + (unsigned)(iy * a.Wd + ix) : img;
-        const float4 v = *reinterpret_cast<const float4*>(a.X + (m * (unsigned)a.ldx + 4u * q));
-        const float2 st = *reinterpret_cast<const float2*>(a.stats + m * 2u);
-        const float rs = ok ? st.y : 0.f;
+        okv[it] = iy < a.H && ix < a.Wd;
+        const unsigned m = okv[it] ? img + (unsigned)(iy * a.Wd + ix) : img;
+        xv[it] = *reinterpret_cast<const float4*>(a.X + (m * (unsigned)a.ldx + 4u * q));
+        sv[it] = *reinterpret_cast<const float2*>(a.stats + m * 2u);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      lds_barrier2();
+#pragma unroll
+      for (int it = 0; it < T::NXL; ++it) {
+        const int e = t_ + 256 * it, p = e / (C / 4), q = e - p * (C / 4);
+        const float4 v = xv[it];
+        const float2 st = sv[it];
+        const float rs = okv[it] ? st.y : 0.f;
         *reinterpret_cast<float4*>(XH + p * T::SX + 4 * q) =
             make_float4((v.x - st.x) * rs, (v.y - st.x) * rs, (v.z - st.x) * rs, (v.w - st.x) * rs);
         if (q == 0) RS[p] = rs;
       }
     }
+    UIR_ST(0);
 
     f32x16 acc;
 #pragma unroll
@@ -268,6 +283,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         for (int t = 0; t < 9; ++t) wf[t] = wf_n[t] * wm;
       }
       lds_barrier2();
+      UIR_ST(1);
       // issue order = need order (vmcnt retires in order): this chunk's 1x1 weights now (used after the walk); the next chunk's
       // G, XP and depthwise taps after the walk, when its window / tap / accumulator registers are free - they land during (c), (d)
       // (c) B operand: W1[row of k-slot 8 jj + 4 h2 + e][n = li].  k-slots 0..15 are channels i = 8 (jj & 1) + 4 h2 + e of group A,
@@ -301,6 +317,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it, tn);
       }
       load_g(cn, t_);
+      UIR_ST(2);
 
       // ---- (b) transposed depthwise 3x3 + depthwise weight-gradient terms ----
       f32x2 dwa[9];
@@ -351,8 +368,10 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       };
       if (plain) walk(std::true_type{});
       else walk(std::false_type{});
+      UIR_ST(3);
       load_xp(cn, cp, sx, last ? tn : tc);
       load_wf(cn, cp);
+      UIR_ST(9);
       // sum over the wave's four strips = the four lanes of a quad: two DPP adds per value (quad_perm [1,0,3,2], [2,3,0,1]); the strips
       // on lanes 16 apart needed a v_permlane16_swap + v_permlane32_swap pair with its register copies (~110 VALU per chunk instead
       // of ~40).  Then one row per wave in LDS
@@ -364,9 +383,12 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
           WR[(wave * 16 + cp) * 18 + 9 + t] = vy;
         }
       }
+      UIR_ST(10);
       lds_barrier2();
+      UIR_ST(4);
       for (int e = t_; e < 16 * 18; e += 256)
         DWA[ci * 288 + e] += (WR[e] + WR[288 + e]) + (WR[576 + e] + WR[864 + e]);
+      UIR_ST(5);
 
       // ---- (c) dT += dP chunk . W1 chunk (row tile = wave) ----
       {
@@ -378,6 +400,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
           for (int e = 0; e < 4; ++e) acc = uir_mfma(v[e], w1v[4 * jj + e], acc);
         }
       }
+      UIR_ST(6);
       // ---- (d) dW1 chunk granule += dP^T . (xhat gamma + beta) over this wave's pixels.  k-slot j of step s is pixel
       //      8 (s >> 1) + 2 (s & 1) + (j >> 1) + 4 (j & 1): the two rows a 32-lane half reads sit 4 * 36 floats = 16 banks apart ----
       {
@@ -395,19 +418,25 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
             bo[s] = xb[p * T::SX];
           }
         };
+        // sched_barriers: as plain code hipcc sank every ds_read next to the MFMA that consumes it - one exposed LDS round trip per
+        // MFMA pair, 26 % of the kernel (tools/probes/stamps, tools/scan_isa_chains.py); pinned, a group's 16 reads land under the
+        // previous group's 8 MFMAs
         fetch(0, av[0], bv[0]);
 #pragma unroll
         for (int g = 0; g < NGR; ++g) {
           if (g + 1 < NGR) fetch(g + 1, av[(g + 1) & 1], bv[(g + 1) & 1]);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int s = 0; s < 8; s += 2) {
             d = mfma16(av[g & 1][s], fmaf(bv[g & 1][s], gam16, bet16), d);
             d1 = mfma16(av[g & 1][s + 1], fmaf(bv[g & 1][s + 1], gam16, bet16), d1);
           }
+          __builtin_amdgcn_sched_barrier(0);
         }
         d += d1;
         DW_PUT(ci, d);
       }
+      UIR_ST(7);
     }
 
     // ---- tile epilogue: LayerNorm backward on the dT accumulators (lane = channel, registers = pixels of row tile `wave`).
@@ -426,21 +455,44 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         mo[r] = (iy < a.H && ix < a.Wd && li < C) ? m : ~0u;
         rv[r] = ldg_off(a.dRes, (m * (unsigned)a.ldr + nn) * 4u);
       }
+      // Passes - LDS operands, arithmetic (two halves of 8 rows: registers), stores.  As one loop every store sat under its own
+      // branch, and since vmcnt retires in issue order and the compiler cannot count a store it may have skipped, each iteration's
+      // wait for rv[r] was vmcnt(0): it also waited for the PREVIOUS iteration's store to be acknowledged - 16 HBM round trips per
+      // tile, 11 % of the kernel.  The asm pins keep LLVM from sinking the arithmetic (and with it the rv waits) back into the
+      // store branches.
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int p = (2 * wave + (r >> 3)) * T::TW + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h2;
-        const float xq = li < C ? XH[p * T::SX + nn] : 0.f;
-        const float rs = RS[p];
-        const float dt = acc[r];
-        const float g = dt * gam_n;
-        const float s1 = swap16_sum(row_sum16(g)), s2 = swap16_sum(row_sum16(g * xq));   // over the 32 channel lanes of the half
-        const float dx = rs * (g - s1 * invc - xq * (s2 * invc)) + rv[r];
-        if (mo[r] != ~0u) a.dX[mo[r] * (unsigned)a.ldo + nn] = dx;
-        dgam = fmaf(dt, xq, dgam);
-        dbet += dt;
+      for (int hf = 0; hf < 2; ++hf) {
+        float xqv[8], rsv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = 8 * hf + q;
+          const int p = (2 * wave + (r >> 3)) * T::TW + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h2;
+          xqv[q] = XH[p * T::SX + nn];
+          rsv[q] = RS[p];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const int r = 8 * hf + q;
+          const float xq = li < C ? xqv[q] : 0.f;
+          const float dt = acc[r];
+          const float g = dt * gam_n;
+          const float s1 = swap16_sum(row_sum16(g)), s2 = swap16_sum(row_sum16(g * xq));   // over the 32 channel lanes of the half
+          float dx = rsv[q] * (g - s1 * invc - xq * (s2 * invc)) + rv[r];
+          asm volatile("" : "+v"(dx));
+          acc[r] = dx;
+          dgam = fmaf(dt, xq, dgam);
+          dbet += dt;
+        }
       }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (mo[r] != ~0u) a.dX[mo[r] * (unsigned)a.ldo + nn] = acc[r];
     }
+    UIR_ST(8);
   }
+  UIR_ST_FLUSH();
 
   // ---- slab row of this workgroup: dWdw (CHreal x 9) | dW1 (CHreal x C) | dgamma (C) | dbeta (C) ----
   UIR_DWLN_COORDS;
@@ -512,6 +564,7 @@ int dwln_launch(const UirDwLnBwdArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+UIR_ST_EXPORT
 
 extern "C" int uir_dwln_bwd(const UirDwLnBwdArgs* p, void* stream) {
   const UirDwLnBwdArgs& a = *p;

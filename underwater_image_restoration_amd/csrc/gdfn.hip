@@ -22,6 +22,7 @@
 // (project_in has no bias).
 #include "uir_common.h"
 #include "../../include/uir_kernels.h"
+#include "uir_stamps.h"
 
 namespace {
 
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
   const long img = (long)b * a.H * a.Wd;
   const int h = a.h, hp = a.hp;
 
+  UIR_ST_DECL;
   // ---- phase 0: x on tile + ring -> LayerNorm -> A-operand registers (k = 8jj + 4h2 + e) ----
   float A[T::RTW][C / 2];
   {
@@ -282,6 +284,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
   }
 
   int wbuf = 0;
+  UIR_ST(0);
   for (int c0 = 0; c0 < hp; c0 += 16) {
     if constexpr (SB) {
       if constexpr (PF) load_win(c0 + 16 < hp ? c0 + 16 : c0, win_n);
@@ -346,7 +349,9 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
       }
     }
     }
+    UIR_ST(1);
     lds_barrier();
+    UIR_ST(2);
 
     // The prefetched weights are needed only at the end of the chunk, but the compiler would wait for them with
     // vmcnt(0) AFTER this chunk's T1/T2 stores were issued (VMEM ops retire in issue order and it cannot count stores
@@ -380,6 +385,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         }
     }
 
+    UIR_ST(3);
     // ---- (b) depthwise 3x3: rolling three-row window (rotating register names, no shifts), row y+3
     //      loaded while row y is being computed; x1/x2 as packed pairs (v_pk_fma_f32) ----
     {
@@ -418,7 +424,9 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         if (yb + 2 < T::ROWS) step(rw[2], rw[0], rw[1]);
       }
     }
+    UIR_ST(4);
     lds_barrier();
+    UIR_ST(5);
 
     // ---- T2 write-out (training) ----
     if (STORE) {
@@ -431,6 +439,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         }
     }
 
+    UIR_ST(6);
     // ---- (c) y += (gelu(t2a) * t2b) . W_out^T over this chunk's 16 hidden channels ----
     UirBf3 wop;
     if constexpr (SB) wop = uir_split8(wo);
@@ -471,6 +480,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
     }
     wbuf ^= 1;
+    UIR_ST(7);
     // no barrier: (a) of the next chunk writes T1s (all reads of it finished before the barrier
     // above) and Gs is rewritten only after the next barrier, which every wave reaches after its (c)
   }
@@ -498,6 +508,8 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         if (ok[i]) a.Y[mm[i] * a.ldy + nn] = acc[j][i] + res[i];
     }
   }
+  UIR_ST(8);
+  UIR_ST_FLUSH();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1050,6 +1062,7 @@ int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
 }
 
 }  // namespace
+UIR_ST_EXPORT
 
 extern "C" int uir_gdfn_fwd(const UirGdfnFwdArgs* p, void* stream) {
   const UirGdfnFwdArgs& a = *p;
