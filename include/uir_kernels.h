@@ -71,6 +71,8 @@ typedef struct UirGemmArgs {
   const float* out_scale; /* optional (with R; PLAIN epilogue, taps 1, batches 1): Y = R + out_scale[row / scale_rows] * act(X.W^T + bias) -  */
   int scale_rows;      /* (>= 32) the per-sample DropPath factor of a residual branch (timm drop_path: src/Models/AST.py:617,620,        */
                        /* src/model/model.py:91) folded into the branch's last Linear; scale_rows = token rows per sample        */
+  int il16;            /* EPI_GATE_BWD / EPI_GATE_BWD_DW only: 1 = G and Y hold the GDFN tensors in the chunk-interleaved layout of      */
+                       /* UirGdfnFwdArgs.il (hidden channel n at column 32 (n / 16) + n % 16, its x2 partner g_off = 16 columns on)      */
 } UirGemmArgs;
 int uir_gemm(const UirGemmArgs* args, void* stream);
 
@@ -204,6 +206,11 @@ typedef struct UirGdfnFwdArgs {
   int C;               /* in {16,32,64,128}                                                      */
   int h, hp;           /* hidden = int(2.66 C); hp = h padded to a multiple of 16                */
   float ln_eps;
+  int il;              /* column layout of T1 / T2.  0: x1 half at column j, x2 half at hp + j.           */
+                       /* 1: interleaved by 16-channel chunk - hidden channel j's x1 value at column      */
+                       /* 32 (j / 16) + j % 16, its x2 value 16 columns on: every (pixel, chunk) access   */
+                       /* of this kernel, the gate-backward GEMM and uir_dwln_bwd is ONE 128-byte line    */
+                       /* instead of two 64-byte halves (3.5 vs 5-6.5 TB/s: tools/probes/vmem/halfline)   */
 } UirGdfnFwdArgs;
 int uir_gdfn_fwd(const UirGdfnFwdArgs* args, void* stream);
 
@@ -271,6 +278,7 @@ typedef struct UirDwLnBwdArgs {
   int h, hp;           /* GDFN layout (hp > 0, multiple of 16): (C, hp) in {(32, 96), (16, 48)}             */
   int ch;              /* consecutive layout (hp == 0): (C, ch) in {(32, 96), (16, 48)}                     */
   int nblocks;         /* persistent workgroups = slab rows                                                 */
+  int il;              /* GDFN layout only: 1 = G / XP columns interleaved by chunk (UirGdfnFwdArgs.il)             */
 } UirDwLnBwdArgs;
 int uir_dwln_bwd(const UirDwLnBwdArgs* args, void* stream);
 

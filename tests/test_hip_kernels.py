@@ -46,6 +46,17 @@ def hwc(x):  # [B,C,H,W] -> [B*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
 
 
+def to_il(rows_split, h, hp):
+    """GDFN tensor in the split column layout [x1 | pad | x2 | pad] -> the chunk-interleaved layout of UirGdfnFwdArgs.il: hidden channel
+    j's x1 value at column 32 (j // 16) + j % 16, its x2 value 16 columns on."""
+    j = torch.arange(hp)
+    c1 = 32 * (j // 16) + j % 16
+    out = torch.zeros_like(rows_split)
+    out[:, c1] = rows_split[:, :hp]
+    out[:, c1 + 16] = rows_split[:, hp:2 * hp]
+    return out
+
+
 def chw(rows, B, H, W):  # [B*H*W, C] -> [B,C,H,W]
     return rows.reshape(B, H, W, -1).permute(0, 3, 1, 2).contiguous()
 
@@ -491,7 +502,7 @@ def test_dwconv_padded_groups():
 # ---------------------------------------------------------------- uir_gdfn
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 16), (1, 19, 37, 32), (2, 8, 16, 64), (1, 11, 9, 128), (1, 1, 1, 32),
                                      (1, 40, 24, 16)])
-@pytest.mark.parametrize("store", [True, False])
+@pytest.mark.parametrize("store", [True, False, "il"])
 def test_gdfn_fwd_fused(B, H, W, C, store):
     """Tile-fused GDFN forward (+ norm2 + residual) vs torch fp64; ragged tiles, image edges, pad channels."""
     h = int(C * 2.66)
@@ -514,8 +525,9 @@ def test_gdfn_fwd_fused(B, H, W, C, store):
     if store:
         T1.fill_(7.0)
         T2.fill_(7.0)
+    il = store == "il"               # t1 / t2 written in the chunk-interleaved column layout
     r.gdfn_fwd("g", dev(rows), (dev(gam), dev(bet)), dev(win), dev(wdw), dev(wout), Y, C_=C, h=h, hp=hp, dims=(B, H, W),
-               T1=T1, T2=T2, stats=st)
+               T1=T1, T2=T2, stats=st, il=int(il))
     r.run(r.fwd)
     assert rel(chw(Y, B, H, W), y) < TOL
     mean = rows.mean(1)
@@ -524,6 +536,12 @@ def test_gdfn_fwd_fused(B, H, W, C, store):
     if store:
         for T, t in ((T1, t1), (T2, t2)):
             tr = hwc(t)
+            if il:
+                want = torch.zeros(M, 2 * hp, dtype=tr.dtype)
+                want[:, :h], want[:, hp:hp + h] = tr[:, :h], tr[:, h:]
+                want = to_il(want, h, hp)
+                assert rel(T, want) < TOL and float(T.cpu()[want == 0].abs().max()) == 0
+                continue
             assert rel(T[:, :h], tr[:, :h]) < TOL and rel(T[:, hp:hp + h], tr[:, h:]) < TOL
             assert float(T[:, h:hp].abs().max()) == 0 and float(T[:, hp + h:2 * hp].abs().max()) == 0
 
@@ -896,18 +914,55 @@ def _dwln_case(B, H, W, C, split, seed):
     return ref, ops_, dict(h=h, hp=hp, ch=0 if split else 3 * C, chreal=chreal, cols=cols)
 
 
+@pytest.mark.parametrize("M,C,fused_dw", [(384, 32, True), (256, 16, True), (300, 32, False), (257, 16, False)])
+def test_gemm_gate_bwd_in_the_interleaved_layout(M, C, fused_dw):
+    """UirGemmArgs.il16: the gate-backward epilogues (with and without the fused project_out weight gradient) on GDFN tensors in the
+    chunk-interleaved column layout give the split layout's results, column for column."""
+    h = int(C * 2.66)
+    hp = (h + 15) & ~15
+    g = rnd(M, 2 * hp, seed=1, scale=2)
+    g[:, h:hp] = 0
+    g[:, hp + h:] = 0
+    w, dy = rnd(C, h, seed=2), rnd(M, C, seed=4)
+    g1 = g[:, :h].clone().requires_grad_(True)
+    g2 = g[:, hp:hp + h].clone().requires_grad_(True)
+    gate = F.gelu(g1) * g2
+    d1, d2 = torch.autograd.grad(((gate @ w.T) * dy).sum(), (g1, g2))
+    want = torch.zeros(M, 2 * hp, dtype=torch.float64)
+    want[:, :h], want[:, hp:hp + h] = d1, d2
+    want = to_il(want, h, hp)
+    r = rec()
+    dG = r.alloc(M, 2 * hp)
+    dG.fill_(7.0)
+    kw = {}
+    if fused_dw:
+        dws = torch.zeros(512, C * h, device=DEV)
+        kw = dict(dw_slab=dws)
+    r.gemm("dgate", dev(dy), dev(w), dG, N=hp, K=C, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD_DW if fused_dw else L.EPI_GATE_BWD,
+           G=dev(to_il(g, h, hp)), g_off=16, il16=1, **kw)
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    assert rel(dG, want) < TOL and float(dG.cpu()[want == 0].abs().max()) == 0
+    if fused_dw:
+        assert rel(dws.sum(0).reshape(C, h), dy.T @ gate.detach()) < TOL
+
+
 @pytest.mark.parametrize("B,H,W,C,split", [(2, 16, 32, 32, True), (1, 24, 16, 32, False), (2, 8, 16, 16, True), (1, 16, 16, 16, False),
-                                           (1, 20, 24, 32, True), (3, 12, 40, 16, False), (1, 40, 72, 32, False)])
+                                           (1, 20, 24, 32, True), (3, 12, 40, 16, False), (1, 40, 72, 32, False),
+                                           (2, 16, 32, 32, "il"), (1, 20, 24, 16, "il"), (1, 40, 72, 32, "il")])
 def test_dwln_bwd_vs_autograd(B, H, W, C, split):
     """The fused backward of norm -> 1x1 -> depthwise 3x3 (SpectralTransformer.py:81-82,94,144 / :122-124,147) against fp64
     autograd: input gradient and all four parameter gradients; image sizes that are not multiples of the 8 x 16 tile included."""
-    ref, o, g = _dwln_case(B, H, W, C, split, seed=11)
+    il = split == "il"               # GDFN layout with the columns interleaved by chunk (UirDwLnBwdArgs.il)
+    ref, o, g = _dwln_case(B, H, W, C, bool(split), seed=11)
+    if il:
+        o["G"], o["XP"] = to_il(o["G"], g["h"], g["hp"]), to_il(o["XP"], g["h"], g["hp"])
     r = rec()
     M = B * H * W
     dX = r.alloc(M, C)
     dWdw, dW1, dgb = r.alloc(g["chreal"], 9), r.alloc(g["chreal"], C), r.alloc(2 * C)
     r.dwln_bwd("dwln", dev(o["G"]), dev(o["XP"]), dev(o["wdw"]), dev(o["w1"]), dev(o["X"]), dev(o["stats"]), dev(o["gam"]), dev(o["bet"]),
-               dev(o["dRes"]), dX, dWdw, dW1, dgb[:C], dgb[C:], C_=C, dims=(B, H, W), h=g["h"], hp=g["hp"], ch=g["ch"], nblocks=5)
+               dev(o["dRes"]), dX, dWdw, dW1, dgb[:C], dgb[C:], C_=C, dims=(B, H, W), h=g["h"], hp=g["hp"], ch=g["ch"], nblocks=5, il=int(il))
     r.run(r.fwd)
     torch.cuda.synchronize()
     assert rel(dX, ref["dx"]) < TOL

@@ -94,5 +94,5 @@ r.gdfn_fwd("g", x, (g1, b1), rnd(2 * h, Cc) * .2, rnd(2 * h, 9) * .3, rnd(Cc, h)
 _, args, _ = r.fwd[0]
 print(f"uir_gdfn_fwd C={Cc} {S}x{S} (UIR_FUSED_SPLIT={os.environ.get('UIR_FUSED_SPLIT', '1')})")
 run("libstamps_gdfn.so", "uir_gdfn_fwd", args, 1024,
-    ["phase0", "wload+(a)", "bar_a", "pin+T1st", "walk", "bar_b", "T2st", "(c)", "epi", "", "", ""])
+    ["phase0", "(a)T1s-writes", "bar_a", "pin+T1st", "walk", "bar_b", "T2st", "(c)", "epi", "wload-issue", "(a)split+mfma", ""])
 variants("gdfn", "uir_gdfn_fwd", args)

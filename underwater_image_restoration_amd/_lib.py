@@ -46,7 +46,7 @@ class GemmArgs(C.Structure):
                 ("pro", C.c_int), ("gate_off", C.c_int), ("epi", C.c_int), ("g_off", C.c_int), ("act", C.c_int),
                 ("slope", C.c_float), ("ln_eps", C.c_float), ("dw_slab", fp), ("dw_stride", C.c_long),
                 ("tap0", C.c_int), ("ntap", C.c_int), ("pre_out", fp), ("ldpre", C.c_long),
-                ("out_scale", fp), ("scale_rows", C.c_int)]
+                ("out_scale", fp), ("scale_rows", C.c_int), ("il16", C.c_int)]
 
 
 class GramArgs(C.Structure):
@@ -88,7 +88,7 @@ class GdfnFwdArgs(C.Structure):
                 ("Y", fp), ("T1", fp), ("T2", fp), ("stats", fp),
                 ("ldx", C.c_int), ("ldy", C.c_int), ("ldt", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
-                ("h", C.c_int), ("hp", C.c_int), ("ln_eps", C.c_float)]
+                ("h", C.c_int), ("hp", C.c_int), ("ln_eps", C.c_float), ("il", C.c_int)]
 
 
 class QkvFwdArgs(C.Structure):
@@ -108,7 +108,7 @@ class DwLnBwdArgs(C.Structure):
                 ("dRes", fp), ("dX", fp), ("slab", fp), ("slab_stride", C.c_long),
                 ("ldg", C.c_int), ("ldp", C.c_int), ("ldx", C.c_int), ("ldr", C.c_int), ("ldo", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int), ("h", C.c_int), ("hp", C.c_int),
-                ("ch", C.c_int), ("nblocks", C.c_int)]
+                ("ch", C.c_int), ("nblocks", C.c_int), ("il", C.c_int)]
 
 
 class LnBwdArgs(C.Structure):

@@ -114,8 +114,11 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
   const int chcols = SPLIT ? 2 * hp : ch;                 // columns of G / XP that exist
 
   // chunk geometry: two groups of 16 channels; column of the group in G / XP, real weight row, validity of channel i of the group
-  auto colA = [&](int ci) { return SPLIT ? 16 * ci : 32 * ci; };
-  auto colB = [&](int ci) { return SPLIT ? hp + 16 * ci : 32 * ci + 16; };
+  // a.il (GDFN layout): the chunk's 16 + 16 columns are consecutive in memory (UirGdfnFwdArgs.il) - only the COLUMNS change, the
+  // weight rows and the validity of a channel stay those of the split layout
+  const bool il = SPLIT && a.il != 0;
+  auto colA = [&](int ci) { return (SPLIT && !il) ? 16 * ci : 32 * ci; };
+  auto colB = [&](int ci) { return (SPLIT && !il) ? hp + 16 * ci : 32 * ci + 16; };
   auto rowA = [&](int ci, int i) { return (SPLIT ? 16 * ci : 32 * ci) + i; };
   auto rowB = [&](int ci, int i) { return SPLIT ? h + 16 * ci + i : 32 * ci + 16 + i; };
   auto okA = [&](int ci, int i) { return SPLIT ? 16 * ci + i < h : 32 * ci + i < ch; };
@@ -251,6 +254,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float rv[16];                                            // the epilogue's residual-gradient values: in flight from the last chunk's (c) on
 
 #pragma unroll 1
     for (int ci = 0; ci < NCH; ++ci) {
@@ -400,6 +404,15 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
           for (int e = 0; e < 4; ++e) acc = uir_mfma(v[e], w1v[4 * jj + e], acc);
         }
       }
+      if (last) {                                            // uniform; the 16 loads land under (d) instead of stalling the epilogue
+        const int nn = li < C ? li : 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int iy = y0 + 2 * wave + (r >> 3), ix = x0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h2;
+          const unsigned m = img + (unsigned)((iy < a.H ? iy : a.H - 1) * a.Wd + (ix < a.Wd ? ix : a.Wd - 1));
+          rv[r] = ldg_off(a.dRes, (m * (unsigned)a.ldr + nn) * 4u);
+        }
+      }
       UIR_ST(6);
       // ---- (d) dW1 chunk granule += dP^T . (xhat gamma + beta) over this wave's pixels.  k-slot j of step s is pixel
       //      8 (s >> 1) + 2 (s & 1) + (j >> 1) + 4 (j & 1): the two rows a 32-lane half reads sit 4 * 36 floats = 16 banks apart ----
@@ -440,20 +453,18 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     }
 
     // ---- tile epilogue: LayerNorm backward on the dT accumulators (lane = channel, registers = pixels of row tile `wave`).
-    //      Register r is tile row 2 wave + (r >> 3), column (r & 3) + 8 ((r >> 2) & 1) + 4 h2.  All 16 residual-gradient loads
-    //      are issued first: their latency runs under the 32 row reductions, which do not need them ----
+    //      Register r is tile row 2 wave + (r >> 3), column (r & 3) + 8 ((r >> 2) & 1) + 4 h2.  The 16 residual-gradient loads were
+    //      issued in the last chunk, behind its (c) ----
     {
       UIR_DWLN_COORDS;
       const int nn = li < C ? li : 0;
       const float invc = 1.0f / (float)C;
-      float rv[16];
       unsigned mo[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int iy = y0 + 2 * wave + (r >> 3), ix = x0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h2;
         const unsigned m = img + (unsigned)((iy < a.H ? iy : a.H - 1) * a.Wd + (ix < a.Wd ? ix : a.Wd - 1));
         mo[r] = (iy < a.H && ix < a.Wd && li < C) ? m : ~0u;
-        rv[r] = ldg_off(a.dRes, (m * (unsigned)a.ldr + nn) * 4u);
       }
       // Passes - LDS operands, arithmetic (two halves of 8 rows: registers), stores.  As one loop every store sat under its own
       // branch, and since vmcnt retires in issue order and the compiler cannot count a store it may have skipped, each iteration's
@@ -573,6 +584,7 @@ extern "C" int uir_dwln_bwd(const UirDwLnBwdArgs* p, void* stream) {
   UIR_REQUIRE((a.ldg & 3) == 0 && (a.ldx & 3) == 0 && uir_aligned16(a.G) && uir_aligned16(a.X) && (a.ldx >= a.C) && a.ldr >= a.C && a.ldo >= a.C);
   UIR_REQUIRE((reinterpret_cast<uintptr_t>(a.stats) & 7u) == 0);
   const bool split = a.hp > 0;
+  UIR_REQUIRE(a.il == 0 || (a.il == 1 && split));
   const int chreal = split ? 2 * a.h : a.ch;
   if (split) UIR_REQUIRE(a.h > 0 && a.hp >= a.h && (a.hp & 15) == 0 && a.ldg >= 2 * a.hp && a.ldp >= 2 * a.hp);
   else UIR_REQUIRE(a.ch > 0 && (a.ch & 15) == 0 && a.ldg >= a.ch && a.ldp >= a.ch);

@@ -59,9 +59,11 @@ __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }   
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 
-template <int C, int TH, int TW, bool STORE, bool SB>
+template <int C, int TH, int TW, bool STORE, int SBM>
 __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdArgs a) {
   using T = GdfnTile<C, TH, TW>;
+  constexpr bool SB = SBM >= 1;
+  constexpr bool SPREAD = SBM >= 2;      // EXPERIMENT: the t1 / t2 write-out stores issued between the walk's rows / the (c) units
   extern __shared__ float smem[];
   float* T1s = smem;
   float* Gs = smem + T::NRT1 * 32 * T::S1;
@@ -201,7 +203,8 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
       const int py = p / TW, px = p - py * TW;
       const int iy = y0 + py, ix = x0 + px;
       const bool ok = p < T::NI && iy < a.H && ix < a.Wd;
-      st_off[it] = ok ? (unsigned)(((img + (long)iy * a.Wd + ix) * a.ldt + (j < 4 ? 4 * j : hp + 4 * (j - 4))) * 4) : ~0u;
+      // a.il: the chunk's 16 x1 + 16 x2 values are 32 CONSECUTIVE columns (one 128-byte line per pixel and chunk)
+      st_off[it] = ok ? (unsigned)(((img + (long)iy * a.Wd + ix) * a.ldt + (a.il ? 4 * j : (j < 4 ? 4 * j : hp + 4 * (j - 4)))) * 4) : ~0u;
       st_lds[it] = ((py + 1) * T::RW + px + 1) * T::S1 + 4 * j;
     }
   }
@@ -298,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
       load_small(c0 + 16 < hp ? c0 + 16 : c0, wo_n, w1_n, w2_n);
     }
 
+    UIR_ST(9);
     // ---- (a) t1 chunk on tile + ring ----
     if constexpr (SB) {
       // the chunk's W_in fragment is split once per 16-deep k step and meets every row tile of the wave
@@ -316,6 +320,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         for (int q = 0; q < T::RTW; ++q)
           if (wave + 4 * q < T::NRT1) d[q] = uir_mfma_split(Ap[q][s], wp, d[q]);
       }
+      UIR_ST(10);
 #pragma unroll
       for (int q = 0; q < T::RTW; ++q) {
         const int r = wave + 4 * q;
@@ -376,13 +381,23 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     }
 
     // ---- T1 write-out (training): interior rows of the LDS chunk as 16-byte stores, 8 lanes per pixel ----
-    if (STORE) {
+    const unsigned cbytes = a.il ? 8u : 4u;      // bytes per hidden channel of the chunk offset (interleaved: 2 columns per channel)
+    auto t1_store = [&](int it) {
+      if (st_off[it] != ~0u) {
+        const float4 v = *reinterpret_cast<const float4*>(T1s + st_lds[it]);
+        st4(reinterpret_cast<char*>(a.T1) + (st_off[it] + (unsigned)c0 * cbytes), v);
+      }
+    };
+    auto t2_store = [&](int it) {
+      if (st_off[it] != ~0u) {
+        const int e = tid + 256 * it;
+        const float4 v = *reinterpret_cast<const float4*>(Gs + (e >> 3) * T::SG + 4 * (e & 7));
+        st4(reinterpret_cast<char*>(a.T2) + (st_off[it] + (unsigned)c0 * cbytes), v);
+      }
+    };
+    if (STORE && !SPREAD) {
 #pragma unroll
-      for (int it = 0; it < T::NST; ++it)
-        if (st_off[it] != ~0u) {
-          const float4 v = *reinterpret_cast<const float4*>(T1s + st_lds[it]);
-          st4(reinterpret_cast<char*>(a.T1) + (st_off[it] + (unsigned)c0 * 4u), v);
-        }
+      for (int it = 0; it < T::NST; ++it) t1_store(it);
     }
 
     UIR_ST(3);
@@ -417,11 +432,27 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         gdst[16] = t.y;
         gdst += TW * T::SG;
       };
+      if constexpr (SPREAD && STORE) {
+        // the write-out stores ride between the rows of the walk: a burst of NST 1-KB stores per wave stalls at issue behind the
+        // memory pipe (tools/probes/stamps: 10 % of the kernel per write-out), spread out they drain under the VALU work
+        constexpr int NIT = (T::ROWS + 2) / 3, SPI = (T::NST + NIT - 1) / NIT;
+#pragma unroll
+        for (int yi = 0; yi < NIT; ++yi) {
+          const int yb = 3 * yi;
+#pragma unroll
+          for (int q = 0; q < SPI; ++q)
+            if (yi * SPI + q < T::NST) t1_store(yi * SPI + q);
+          step(rw[0], rw[1], rw[2]);
+          if (yb + 1 < T::ROWS) step(rw[1], rw[2], rw[0]);
+          if (yb + 2 < T::ROWS) step(rw[2], rw[0], rw[1]);
+        }
+      } else {
 #pragma unroll 1
       for (int yb = 0; yb < T::ROWS; yb += 3) {
         step(rw[0], rw[1], rw[2]);
         if (yb + 1 < T::ROWS) step(rw[1], rw[2], rw[0]);
         if (yb + 2 < T::ROWS) step(rw[2], rw[0], rw[1]);
+      }
       }
     }
     UIR_ST(4);
@@ -429,14 +460,9 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     UIR_ST(5);
 
     // ---- T2 write-out (training) ----
-    if (STORE) {
+    if (STORE && !SPREAD) {
 #pragma unroll
-      for (int it = 0; it < T::NST; ++it)
-        if (st_off[it] != ~0u) {
-          const int e = tid + 256 * it;
-          const float4 v = *reinterpret_cast<const float4*>(Gs + (e >> 3) * T::SG + 4 * (e & 7));
-          st4(reinterpret_cast<char*>(a.T2) + (st_off[it] + (unsigned)c0 * 4u), v);
-        }
+      for (int it = 0; it < T::NST; ++it) t2_store(it);
     }
 
     UIR_ST(6);
@@ -445,6 +471,12 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     if constexpr (SB) wop = uir_split8(wo);
 #pragma unroll
     for (int j = 0; j < T::UPW; ++j) {
+      if constexpr (SPREAD && STORE) {
+        constexpr int SPU = (T::NST + T::UPW - 1) / T::UPW;
+#pragma unroll
+        for (int q = 0; q < SPU; ++q)
+          if (j * SPU + q < T::NST) t2_store(j * SPU + q);
+      }
       const int u = wave + 4 * j;
       if (u < T::UNITS) {
         const int rt = u / T::NT;
@@ -1053,11 +1085,12 @@ int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
   const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
   const size_t lds = ((size_t)T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : 0)) * 4;   // + two staged W_in chunks
-  const bool sb = uir_fused_split() != 0;
-  if (a.T1) { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, true>), dim3(tiles), dim3(256), lds, st, a);
-              else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, false>), dim3(tiles), dim3(256), lds, st, a); }
-  else { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, true>), dim3(tiles), dim3(256), lds, st, a);
-         else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, false>), dim3(tiles), dim3(256), lds, st, a); }
+  const int sb = uir_fused_split();
+  if (a.T1) { if (sb == 2) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, 2>), dim3(tiles), dim3(256), lds, st, a);
+              else if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, 1>), dim3(tiles), dim3(256), lds, st, a);
+              else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, 0>), dim3(tiles), dim3(256), lds, st, a); }
+  else { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, 1>), dim3(tiles), dim3(256), lds, st, a);
+         else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, 0>), dim3(tiles), dim3(256), lds, st, a); }
   return uir_launch_status();
 }
 
@@ -1067,7 +1100,7 @@ UIR_ST_EXPORT
 extern "C" int uir_gdfn_fwd(const UirGdfnFwdArgs* p, void* stream) {
   const UirGdfnFwdArgs& a = *p;
   UIR_REQUIRE(a.X && a.ln_g && a.ln_b && a.Win && a.Wdw && a.Wout && a.Y);
-  UIR_REQUIRE((a.T1 == nullptr) == (a.T2 == nullptr));
+  UIR_REQUIRE((a.T1 == nullptr) == (a.T2 == nullptr) && (a.il == 0 || a.il == 1));
   UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0 && a.h > 0 && a.hp >= a.h && (a.hp & 15) == 0);
   UIR_REQUIRE(a.ldx >= a.C && (a.ldx & 3) == 0 && a.ldy >= a.C && uir_aligned16(a.X));
   UIR_REQUIRE(uir_aligned16(a.ln_g) && uir_aligned16(a.ln_b) && uir_aligned16(a.Win));

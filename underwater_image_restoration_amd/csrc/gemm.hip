@@ -23,6 +23,9 @@ int uir_conv3x3_small(const UirGemmArgs& a, void* stream);     // csrc/conv3s.hi
 
 namespace {
 
+// UirGemmArgs.il16: column of hidden channel n of the GDFN tensors in the chunk-interleaved layout (x2 partner 16 columns on)
+__device__ __forceinline__ int uir_il16(int n, int il16) { return il16 ? (((n >> 4) << 5) | (n & 15)) : n; }
+
 template <int NT>
 __device__ __forceinline__ void uir_gemm_epilogue(const UirGemmArgs& a, const f32x16 (&acc)[NT], int z, int m0, int n0, int r, int h2) {
   // lane = output channel, 16 accumulator registers = 16 pixels
@@ -48,12 +51,13 @@ __device__ __forceinline__ void uir_gemm_epilogue(const UirGemmArgs& a, const f3
         if (a.R) v += a.R[(long)z * a.r_bs + (long)mm * a.ldr + n];
         Y[(long)mm * a.ldy + n] = v;
       } else if (a.epi == UIR_EPI_GATE_BWD) {
-        const float* gp = a.G + (long)z * a.g_bs + (long)mm * a.ldg + n;
+        const int nc = uir_il16(n, a.il16);
+        const float* gp = a.G + (long)z * a.g_bs + (long)mm * a.ldg + nc;
         const float g1 = gp[0], g2 = gp[a.g_off];
         float ge, dge;
         uir_gelu_pair(g1, ge, dge);
-        Y[(long)mm * a.ldy + n] = v * g2 * dge;
-        Y[(long)mm * a.ldy + a.g_off + n] = v * ge;
+        Y[(long)mm * a.ldy + nc] = v * g2 * dge;
+        Y[(long)mm * a.ldy + a.g_off + nc] = v * ge;
       } else {  // UIR_EPI_LEAKY_BWD: G holds the forward LeakyReLU output
         const float o = a.G[(long)z * a.g_bs + (long)mm * a.ldg + n];
         Y[(long)mm * a.ldy + n] = o > 0.f ? v : v * a.slope;
@@ -258,8 +262,9 @@ __device__ __forceinline__ void uir_gemm1x1_store(const UirGemmArgs& a, const f3
     if (n >= a.N) continue;
     const float bias = biasv[nt];
     const long row0 = (long)m0 + 4 * h2;
-    float* yp = Y + row0 * a.ldy + n;
-    const float* gp = (EPI != UIR_EPI_PLAIN) ? a.G + (long)z * a.g_bs + row0 * a.ldg + n : nullptr;
+    const int nc = (EPI == UIR_EPI_GATE_BWD) ? uir_il16(n, a.il16) : n;      // column of hidden channel n in the GDFN tensors
+    float* yp = Y + row0 * a.ldy + nc;
+    const float* gp = (EPI != UIR_EPI_PLAIN) ? a.G + (long)z * a.g_bs + row0 * a.ldg + nc : nullptr;
     float* pp = (EPI == UIR_EPI_PLAIN && gelu && a.pre_out) ? a.pre_out + row0 * a.ldpre + n : nullptr;
     auto put = [&](int reg) {
       const int dr = (reg & 3) + 8 * (reg >> 2);   // row offset inside the tile (compile-time)
@@ -381,7 +386,7 @@ __device__ __forceinline__ void uir_gemm1x1_store_gate_dw(const UirGemmArgs& a, 
   for (int nt = 0; nt < NT; ++nt) {
     const int n = n0 + 32 * nt + r;
     const bool nok = n < a.N;
-    const int nn = nok ? n : a.N - 1;                    // clamped: no lane-divergent control flow around the MFMAs
+    const int nn = uir_il16(nok ? n : a.N - 1, a.il16);  // clamped: no lane-divergent control flow around the MFMAs
     const long row0 = (long)m0 + 4 * h2;
     float* yp = a.Y + row0 * a.ldy + nn;
     const float* gp = a.G + row0 * a.ldg + nn;
@@ -739,7 +744,9 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   UIR_REQUIRE(a.ldy >= a.N);
   if (a.pro == UIR_PRO_LN) UIR_REQUIRE((a.K & 3) == 0 && a.ln_g && a.ln_b && a.taps == 1 && uir_aligned16(a.ln_g) && uir_aligned16(a.ln_b));
   if (a.pro == UIR_PRO_GATE) UIR_REQUIRE((a.gate_off & 3) == 0 && a.ldx >= a.gate_off + ((a.K + 3) & ~3));
-  if (a.epi == UIR_EPI_GATE_BWD) UIR_REQUIRE(a.G && a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N && !a.R);
+  UIR_REQUIRE(a.il16 == 0 || (a.il16 == 1 && (a.epi == UIR_EPI_GATE_BWD || a.epi == UIR_EPI_GATE_BWD_DW) && a.g_off == 16 &&
+                              (a.N & 15) == 0 && a.ldg >= 2 * a.N && a.ldy >= 2 * a.N));
+  if (a.epi == UIR_EPI_GATE_BWD) UIR_REQUIRE(a.G && (a.il16 || (a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N)) && !a.R);
   if (a.epi == UIR_EPI_LEAKY_BWD) UIR_REQUIRE(a.G && a.ldg >= a.N && !a.R);
   UIR_REQUIRE(a.epi >= UIR_EPI_PLAIN && a.epi <= UIR_EPI_GELU_BWD);
   if (a.epi == UIR_EPI_GELU_BWD) {
@@ -749,7 +756,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   }
   if (a.epi == UIR_EPI_GATE_BWD_DW) {
     // fused dW_out: one column group (N <= 96), K <= 32 channels, whole 128-row tiles, pads only at the tail (N = hp)
-    UIR_REQUIRE(a.G && a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N && !a.R && !a.bias && a.act == UIR_ACT_NONE);
+    UIR_REQUIRE(a.G && (a.il16 || (a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N)) && !a.R && !a.bias && a.act == UIR_ACT_NONE);
     UIR_REQUIRE(a.dw_slab && a.dw_stride >= (long)a.K * (a.n_grp_pad > 0 ? a.n_grp_real : a.N) && a.K <= 32 && a.N <= 96 &&
                 a.taps == 1 && a.batches == 1);
     UIR_REQUIRE((a.M & 127) == 0 && a.pro == UIR_PRO_NONE && (a.n_grp_pad <= 0 || a.n_grp_pad == a.N));

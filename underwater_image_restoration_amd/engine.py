@@ -490,7 +490,8 @@ class Recorder:
     # ---------------------------------------------------------------- kernels
     def gemm(self, name, X, W, Y, *, N, K, w_sn, w_sk, w_st=0, w_bs=0, batches=1, bias=None, R=None,
              taps=1, flip=0, hw=None, n_grp=(0, 0), k_grp=(0, 0), pro=L.PRO_NONE, gate_off=0, ln=None, stats=None,
-             epi=L.EPI_PLAIN, G=None, g_off=0, act=L.ACT_NONE, dw_slab=None, pre_out=None, slope=0.1, out_scale=None, scale_rows=0):
+             epi=L.EPI_PLAIN, G=None, g_off=0, act=L.ACT_NONE, dw_slab=None, pre_out=None, slope=0.1, out_scale=None, scale_rows=0,
+             il16=0):
         M_total = X.shape[0]
         assert M_total % batches == 0 and Y.shape[0] == M_total
         M = M_total // batches
@@ -515,6 +516,7 @@ class Recorder:
             a.ln_g, a.ln_b = _ptr(ln[0]), _ptr(ln[1])
             a.stats = _ptr(stats)
         a.epi, a.g_off, a.act = epi, g_off, act
+        a.il16 = il16
         if G is not None:
             a.G, a.ldg = _ptr(G), _ld(G)
             a.g_bs = M * a.ldg
@@ -683,7 +685,7 @@ class Recorder:
         rows = dims[0] * dims[1] * dims[2]
         self._op(name, lib.uir_dwconv, C.byref(a), nbytes=(8 + (4 if G is not None else 0)) * rows * C_, flops=18 * rows * C_)
 
-    def gdfn_fwd(self, name, X, ln, Win, Wdw, Wout, Y, *, C_, h, hp, dims, T1=None, T2=None, stats=None, eps=1e-5):
+    def gdfn_fwd(self, name, X, ln, Win, Wdw, Wout, Y, *, C_, h, hp, dims, T1=None, T2=None, stats=None, eps=1e-5, il=0):
         """Tile-fused GDFN forward (csrc/gdfn.hip): Y = X + W_out.(gelu(dw(W_in.LN(X))[:h]) * dw(...)[h:])."""
         self._hold(X, ln[0], ln[1], Win, Wdw, Wout, Y, T1, T2, stats)
         a = L.GdfnFwdArgs()
@@ -697,6 +699,7 @@ class Recorder:
         a.B, a.H, a.Wd = dims
         a.C, a.h, a.hp = C_, h, hp
         a.ln_eps = eps
+        a.il = il
         rows = dims[0] * dims[1] * dims[2]
         assert X.shape[0] == rows and C_ in (16, 32, 64, 128) and hp % 16 == 0 and hp >= h
         assert (T1 is None) == (T2 is None) and (T1 is None or (_ld(T1) == _ld(T2) and _ld(T1) >= 2 * hp))
@@ -735,7 +738,7 @@ class Recorder:
         self._op(name, lib.uir_attnv_fwd, C.byref(a), nbytes=rows * 4 * 5 * C_, flops=rows * (4 * C_ * C_ + 18 * C_))
 
     def dwln_bwd(self, name, G, XP, Wdw, W1, X, stats, gamma, beta, dRes, dX, dWdw, dW1, dgamma, dbeta, *, C_, dims, h=0, hp=0, ch=0,
-                 nblocks=512):
+                 nblocks=512, il=0):
         """Backward of LayerNorm -> 1x1 conv -> depthwise 3x3 in one pass (csrc/dwln.hip): dX = dRes + LN'(dw^T(G) . W1) and the four
         parameter gradients (per-workgroup slab rows, summed on the bulk lane).  hp > 0: GDFN column layout (x1 half at [0, h), x2
         half at [hp, hp + h)); hp == 0: `ch` consecutive channels."""
@@ -747,6 +750,7 @@ class Recorder:
         a.gamma, a.beta, a.dRes, a.dX = _ptr(gamma), _ptr(beta), _ptr(dRes), _ptr(dX)
         a.ldg, a.ldp, a.ldx, a.ldr, a.ldo = _ld(G), _ld(XP), _ld(X), _ld(dRes), _ld(dX)
         a.B, a.H, a.Wd, a.C, a.h, a.hp, a.ch = B, H, W, C_, h, hp, ch
+        a.il = il
         tiles = B * ((H + 7) // 8) * ((W + 15) // 16)
         a.nblocks = max(1, min(nblocks, tiles))
         stride = chreal * 9 + chreal * C_ + 2 * C_
@@ -958,6 +962,11 @@ class Plan(Recorder):
         g2, b2 = P(f"{pfx}.norm2.weight"), P(f"{pfx}.norm2.bias")
         Win, Wffdw, Wout = P(f"{pfx}.ffn.project_in.weight"), P(f"{pfx}.ffn.conv.weight"), P(f"{pfx}.ffn.project_out.weight")
 
+        # C <= 32 (full resolution, level 1): the GDFN tensors t1 / t2 / dg are kept in the chunk-interleaved column layout
+        # (UirGdfnFwdArgs.il): their three kernels - uir_gdfn_fwd, the gate-backward GEMM, uir_dwln_bwd - walk them one
+        # 16 + 16 channel chunk at a time, and interleaved that is one 128-byte line per pixel instead of two 64-byte halves
+        # (tools/probes/vmem/halfline: 3.5 vs 5-6.5 TB/s).  The deep levels' separate kernels keep the split layout.
+        il = 1 if (C_ <= 32 and hp <= 96 and M % 128 == 0) else 0
         stats1, stats2 = self.alloc(M, 2), self.alloc(M, 2)
         qkv_pre, qkv = self.alloc(M, 3 * C_), self.alloc(M, 3 * C_)
         gbuf = self.alloc(B * C_ * C_ + 2 * B * C_)
@@ -994,7 +1003,7 @@ class Plan(Recorder):
         # ---- GDFN (:127-130) ----
         # one pass over the pixels; t1/t2 written once for the backward kernels, never re-read in the forward
         self.gdfn_fwd(n + ".gdfn", x1, (g2, b2), Win, Wffdw, Wout, y, C_=C_, h=h, hp=hp, dims=dims,
-                      T1=gpre, T2=g, stats=stats2)
+                      T1=gpre, T2=g, stats=stats2, il=il)
 
         def backward(dy: torch.Tensor) -> torch.Tensor:
             # C <= 32 (full resolution and level 1, ~85 % of the step's bytes): depthwise-transpose -> 1x1-transpose -> LayerNorm
@@ -1015,6 +1024,7 @@ class Plan(Recorder):
             # GDFN
             # LayerNorm backward as the epilogue of the GEMM that produces its output gradient (one 32-column tile)
             fuse_dwout = C_ <= 32 and hp <= 96 and M % 128 == 0
+            assert bool(il) == bool(fuse_dwln and fuse_dwout)
             if not fuse_dwout:
                 with self.bulk():
                     self.gram(n + ".dWout", dy, g, Gr(f"{pfx}.ffn.project_out.weight"), N=C_, K=h, o_sn=h, o_sk=1,
@@ -1025,7 +1035,7 @@ class Plan(Recorder):
                 # Rows beyond the launch's gridDim.x are never written: the slab is zero-filled once, here.
                 dws = torch.zeros(GEMM_SLAB_ROWS, C_ * h, device=self.dev, dtype=torch.float32)
                 self.gemm(n + ".dgate+dWout", dy, Wout, dg, N=hp, K=C_, w_sn=1, w_sk=h, n_grp=(h, hp),
-                          epi=L.EPI_GATE_BWD_DW, G=g, g_off=hp, dw_slab=dws)
+                          epi=L.EPI_GATE_BWD_DW, G=g, g_off=16 if il else hp, dw_slab=dws, il16=il)
                 with self.bulk():
                     self._reduce(n + ".dWout.red", _ptr(dws), GEMM_SLAB_ROWS, C_ * h,
                              _ptr(Gr(f"{pfx}.ffn.project_out.weight")), C_ * h)
@@ -1035,7 +1045,7 @@ class Plan(Recorder):
             if fuse_dwln:
                 self.dwln_bwd(n + ".ffn_dwln_bwd", dg, gpre, Wffdw, Win, x1, stats2, g2, b2, dy, dx1, Gr(f"{pfx}.ffn.conv.weight"),
                               Gr(f"{pfx}.ffn.project_in.weight"), Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"),
-                              C_=C_, dims=dims, h=h, hp=hp)
+                              C_=C_, dims=dims, h=h, hp=hp, il=il)
             else:
                 self.dwconv_bwd(n + ".dgpre+dWffdw", dg, gpre, Wffdw, dgpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
                                 dims=dims, grp=(h, hp))
