@@ -47,7 +47,7 @@ for S, Cc in ((256, 32), (256, 16), (128, 32), (64, 64), (32, 128)):
     r = Recorder(dev, scratch_floats=1 << 20)
     y, st = r.alloc(M, Cc), r.alloc(M, 2)
     T1, T2 = r.alloc(M, ldg)[:, :2 * hp], r.alloc(M, ldg)[:, :2 * hp]
-    r.gdfn_fwd("g", x, (g1, b1), rnd(2 * h, Cc) * .2, rnd(2 * h, 9) * .3, rnd(Cc, h) * .1, y, C_=Cc, h=h, hp=hp, dims=dims, T1=T1, T2=T2, stats=st)
+    r.gdfn_fwd("g", x, (g1, b1), rnd(2 * h, Cc) * .2, rnd(2 * h, 9) * .3, rnd(Cc, h) * .1, y, C_=Cc, h=h, hp=hp, dims=dims, T1=T1, T2=T2, stats=st, il=1 if Cc <= 32 else 0)
     timeit(r, f"{tag} gdfn_fwd")
     del r, T1, T2
     r = Recorder(dev, scratch_floats=1 << 20)
@@ -72,6 +72,6 @@ for S, Cc in ((256, 32), (256, 16), (128, 32), (64, 64), (32, 128)):
         dRes, stats = rnd(M, Cc), torch.stack([rnd(M) * 0.1, 1 + 0.1 * rnd(M)], 1).contiguous()
         dX, dWdw, dW1, dgb = r.alloc(M, Cc), r.alloc(chreal, 9), r.alloc(chreal, Cc), r.alloc(2 * Cc)
         r.dwln_bwd("k", G, XP, rnd(chreal, 9), rnd(chreal, Cc), x, stats, g1, b1, dRes, dX, dWdw, dW1, dgb[:Cc], dgb[Cc:], C_=Cc, dims=dims,
-                   h=hh, hp=hpp, ch=ch)
+                   h=hh, hp=hpp, ch=ch, il=1 if split else 0)     # interleaved GDFN columns, as the step runs them
         timeit(r, f"{tag} dwln_bwd {'gdfn' if split else 'qkv'}")
         del r, G, XP
