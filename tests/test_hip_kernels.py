@@ -1016,3 +1016,72 @@ def test_fused_kernels_agree_between_split_bf16_and_f32_mfma():
     for mode in ("0", "1"):
         o = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UIR_FUSED_SPLIT=mode), capture_output=True, text=True, timeout=300)
         assert o.returncode == 0 and o.stdout.count("ERR") == 2, (mode, o.stdout + o.stderr)
+
+
+# ------------------------------------------------- csrc/tsgemm.hip: the deep levels' contractions on split-bf16 tiles
+@pytest.mark.parametrize("case", ["kc", "ic", "kgrp", "batched", "residual", "ragged", "n64"])
+def test_gemm_tall_skinny_split(case):
+    """uir_gemm sends the plain contractions of the deep U-Net levels (4 096 .. 65 536 rows, K, N >= 64; SpectralTransformer.py:81-83,
+    86,90,122,125 at C = 64 / 128) to uir_ts_gemm: 64- / 128-row tiles, both operands split into three bf16 planes, six products.
+    Against fp64 at the f32-MFMA error level, for k-contiguous and transposed weights, the padded K groups of the GDFN tensors
+    (dt2), per-sample weights (dqk / WA / WB / dv / dvf), a residual and ragged edges."""
+    g = torch.Generator().manual_seed(7)
+    rn = lambda *s: torch.rand(*s, generator=g, dtype=torch.float64) * 2 - 1
+    r = rec()
+    kw, B = {}, 1
+    if case == "kc":
+        M, K, N = 16384, 384, 128
+        x, w = rn(M, K), rn(N, K) * K ** -0.5
+        ref = x @ w.T
+        args = dict(N=N, K=K, w_sn=K, w_sk=1)
+        Wd = dev(w)
+    elif case == "ic":
+        M, K, N = 16384, 384, 128
+        x, w = rn(M, K), rn(K, N) * K ** -0.5
+        ref = x @ w
+        args = dict(N=N, K=K, w_sn=1, w_sk=N)
+        Wd = dev(w)
+    elif case == "kgrp":                 # dt2 at level 2: K = 2 hp columns, h real per half, weights [2 h][C]
+        M, h, hp, N = 8192, 170, 176, 64
+        K = 2 * hp
+        x = rn(M, K)
+        x[:, h:hp] = 0
+        x[:, hp + h:] = 0
+        w = rn(2 * h, N) * (2 * h) ** -0.5
+        ref = x[:, :h] @ w[:h] + x[:, hp:hp + h] @ w[h:]
+        args = dict(N=N, K=K, w_sn=1, w_sk=N, k_grp=(h, hp))
+        Wd = dev(w)
+    elif case == "batched":              # dqk at level 3: per-sample [2C][2C] matrices
+        B, Mb, K, N = 8, 1024, 256, 256
+        M = B * Mb
+        x, w = rn(M, K), rn(B, N, K) * K ** -0.5
+        ref = torch.einsum("bmk,bnk->bmn", x.reshape(B, Mb, K), w).reshape(M, N)
+        args = dict(N=N, K=K, w_sn=K, w_sk=1, w_bs=N * K, batches=B)
+        Wd = dev(w.reshape(B, N * K))
+    elif case == "residual":
+        M, K, N = 8200, 128, 128          # M not a multiple of the tile
+        x, w, res = rn(M, K), rn(N, K) * K ** -0.5, rn(M, N)
+        ref = x @ w.T + res
+        args = dict(N=N, K=K, w_sn=K, w_sk=1, R=dev(res))
+        Wd = dev(w)
+    elif case == "ragged":
+        M, K, N = 5000, 68, 84            # K, N multiples of 4 only
+        x, w = rn(M, 72)[:, :K], rn(K, N) * K ** -0.5
+        ref = x @ w
+        args = dict(N=N, K=K, w_sn=1, w_sk=N)
+        Wd = dev(w)
+    else:                                 # "n64": level-2 dt1, 64 output channels
+        M, K, N = 65536, 192, 64
+        x, w = rn(M, K), rn(K, N) * K ** -0.5
+        ref = x @ w
+        args = dict(N=N, K=K, w_sn=1, w_sk=N)
+        Wd = dev(w)
+    Xd = dev(x) if case != "ragged" else dev(rn(M, 72))
+    if case == "ragged":
+        ref = Xd.double().cpu()[:, :K] @ w
+    Y = r.alloc(M, N)
+    r.gemm("ts", Xd[:, :K] if case == "ragged" else Xd, Wd, Y, **args)
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    e = float((Y.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert e < 3e-6, e

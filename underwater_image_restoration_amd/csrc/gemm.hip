@@ -20,6 +20,7 @@
 #include <cstdlib>
 
 int uir_conv3x3_small(const UirGemmArgs& a, void* stream);     // csrc/conv3s.hip; -1 = not its shape
+int uir_ts_gemm(const UirGemmArgs& a, void* stream);           // csrc/tsgemm.hip; -1 = not its shape
 
 namespace {
 
@@ -771,6 +772,12 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // 3 x 3 convolutions with <= 32 channels on both sides (outputl / output / down1 / down2 and their input gradients): the direct
     // VALU kernel of csrc/conv3s.hip (an MFMA tile is 3/4 ... 7/8 empty for 8 or 4 output channels)
     const int rc = uir_conv3x3_small(a, stream);
+    if (rc >= 0) return rc;
+  }
+  {
+    // the deep levels' plain contractions (16 k - 64 k rows; per-sample weights, padded K groups and a residual included): split-bf16
+    // on 64- / 128-row tiles (csrc/tsgemm.hip)
+    const int rc = uir_ts_gemm(a, stream);
     if (rc >= 0) return rc;
   }
   const int tiles = (a.N + 31) / 32;

@@ -1,0 +1,290 @@
+// uir_ts_gemm: the "tall-skinny" channel contractions of the SpectralTransformer's deep levels (SpectralTransformer.py:81-83,86,90,
+// 122,125 at C = 64 / 128: 16 384 - 65 536 pixel rows, 64 - 256 output channels, 64 - 704 input channels) on split-bf16 MFMA.
+//
+//     D[z][i][j] (+ R) = sum_k A[z][i][k] * B[z](j, k)         rows k-contiguous; B k-contiguous ([N][K]) or n-contiguous ([K][N])
+//
+// These launches are neither byte- nor f32-MFMA-bound on the panel kernel of csrc/gemm.hip (25 - 65 TFLOP/s on 128 - 512 workgroups,
+// one dependent f32 MFMA chain per wave): they are short latency chains.  Here a workgroup owns a TMW x TNW tile (64 or 128 each, so
+// that 16 384 rows x 128 columns are 256 workgroups), both operand chunks (32 k) are split into three bf16 planes when they are staged
+// into LDS (csrc/tiled.hip's construction: 6 products reproduce the f32 product to 3 * 2^-24) and a chunk's 12 - 48 MFMAs run at 16x
+// the f32 rate while the next chunk's loads are in flight.  Also covered, which csrc/tiled.hip's 128 x 128 kernel is not: per-sample
+// weights (blockIdx.z: dqk / WA / WB / dv / dvf), the padded K groups of the GDFN tensors (dt2: pad columns of A are exact zeros, the
+// weight row of a pad k is never real) and a residual.
+#include "uir_common.h"
+#include "../../include/uir_kernels.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int SROW = 32;                   // bf16 per LDS row (64 bytes = four 16-byte chunks), XOR-swizzled as in csrc/tiled.hip
+__device__ __forceinline__ int swz(int row, int chunk) { return (row ^ ((row >> 2) & 1)) * SROW + ((chunk ^ ((row >> 1) & 3)) << 3); }
+
+__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __float_as_uint(x) & 0xffff0000u;
+  const float r1 = x - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xffff0000u;
+  l = __float_as_uint(r1 - __uint_as_float(m));
+}
+// four consecutive k of one row -> 8 bytes in each of the three planes (plane stride PL bf16)
+template <int PL>
+__device__ __forceinline__ void store_row4(unsigned short* s, int row, int k, const float (&x)[4]) {
+  uint32_t h[4], m[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) split3(x[e], h[e], m[e], l[e]);
+  unsigned short* d = s + swz(row, k >> 3) + (k & 7);
+  *reinterpret_cast<uint2*>(d) = make_uint2(uir_pack_hi16(h[0], h[1]), uir_pack_hi16(h[2], h[3]));
+  *reinterpret_cast<uint2*>(d + PL) = make_uint2(uir_pack_hi16(m[0], m[1]), uir_pack_hi16(m[2], m[3]));
+  *reinterpret_cast<uint2*>(d + 2 * PL) = make_uint2(uir_pack_hi16(l[0], l[1]), uir_pack_hi16(l[2], l[3]));
+}
+
+struct TsArgs {
+  const float* A; const float* B; float* D; const float* R;
+  long sa_i, sb_j, sb_k, sd_i, ldr;
+  long a_bs, b_bs, d_bs, r_bs;
+  int MM, NN, KK;
+  int kg_real, kg_pad;       // B rows exist for k % kg_pad < kg_real (kg_pad = 0: every k)
+};
+
+// row of B's k axis that holds contraction index k (A's pad columns are exact zeros: a pad k may read any finite row)
+__device__ __forceinline__ int kmap(int k, int real, int pad) {
+  if (pad <= 0) return k;
+  const int g = k / pad, r = k - g * pad;
+  return g * real + (r < real ? r : real - 1);
+}
+
+// ROWS x 32 chunk of a k-contiguous operand: ROWS / 32 float4 per thread, raw loads from clamped addresses
+template <int ROWS>
+struct KcLoader {
+  static constexpr int NQ = ROWS / 32;
+  const float* p[NQ];
+  __device__ __forceinline__ void init(const float* base, long s_idx, int idx0, int n_idx, int tid) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      int r = idx0 + ((tid + 256 * q) >> 3);
+      r = r < n_idx ? r : n_idx - 1;
+      p[q] = base + (long)r * s_idx + 4 * (tid & 7);
+    }
+  }
+  __device__ __forceinline__ void load(uint4 (&v)[NQ], int k0, int ke) const {
+    const int k = k0 + 4 * ((int)threadIdx.x & 7);
+    const int kc = (k < ke ? k : ke - 4) - 4 * ((int)threadIdx.x & 7);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) v[q] = *reinterpret_cast<const uint4*>(p[q] + kc);
+  }
+  template <int PL>
+  __device__ __forceinline__ void store(unsigned short* s, const uint4 (&v)[NQ], int tid, int k0, int ke) const {
+    const uint32_t mk = k0 + 4 * (tid & 7) < ke ? 0xffffffffu : 0u;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float x[4] = {__uint_as_float(v[q].x & mk), __uint_as_float(v[q].y & mk), __uint_as_float(v[q].z & mk), __uint_as_float(v[q].w & mk)};
+      store_row4<PL>(s, (tid + 256 * q) >> 3, 4 * (tid & 7), x);
+    }
+  }
+};
+
+// ROWS x 32 chunk of an index-contiguous operand (element (j, k) at base[j + kmap(k) * s_k]): the ROWS / 4 index quads x 8 blocks of 4 k
+// are dealt to the first ROWS * 2 threads, each loading 4 float4 (4 consecutive k of one index quad) and transposing in registers
+template <int ROWS>
+struct IcLoader {
+  const float* p;
+  int row0, kb;
+  bool on;
+  __device__ __forceinline__ void init(const float* base, int idx0, int n_idx, int tid) {
+    on = tid < ROWS * 2;
+    const int quad = tid >> 3;
+    kb = 4 * (tid & 7);
+    row0 = 4 * (on ? quad : 0);
+    int i = idx0 + row0;
+    i = i + 4 <= n_idx ? i : n_idx - 4;
+    p = base + i;
+  }
+  __device__ __forceinline__ void load(uint4 (&v)[4], int k0, int ke, long s_k, int real, int pad) const {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = k0 + kb + q;
+      v[q] = *reinterpret_cast<const uint4*>(p + (long)kmap(k < ke ? k : ke - 1, real, pad) * s_k);
+    }
+  }
+  template <int PL>
+  __device__ __forceinline__ void store(unsigned short* s, const uint4 (&v)[4], int k0, int ke) const {
+    if (!on) return;
+    uint32_t mk[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) mk[q] = k0 + kb + q < ke ? 0xffffffffu : 0u;
+    const float r0[4] = {__uint_as_float(v[0].x & mk[0]), __uint_as_float(v[1].x & mk[1]), __uint_as_float(v[2].x & mk[2]), __uint_as_float(v[3].x & mk[3])};
+    const float r1[4] = {__uint_as_float(v[0].y & mk[0]), __uint_as_float(v[1].y & mk[1]), __uint_as_float(v[2].y & mk[2]), __uint_as_float(v[3].y & mk[3])};
+    const float r2[4] = {__uint_as_float(v[0].z & mk[0]), __uint_as_float(v[1].z & mk[1]), __uint_as_float(v[2].z & mk[2]), __uint_as_float(v[3].z & mk[3])};
+    const float r3[4] = {__uint_as_float(v[0].w & mk[0]), __uint_as_float(v[1].w & mk[1]), __uint_as_float(v[2].w & mk[2]), __uint_as_float(v[3].w & mk[3])};
+    store_row4<PL>(s, row0, kb, r0);
+    store_row4<PL>(s, row0 + 1, kb, r1);
+    store_row4<PL>(s, row0 + 2, kb, r2);
+    store_row4<PL>(s, row0 + 3, kb, r3);
+  }
+};
+
+template <bool BKC, int TMW, int TNW>
+__global__ __launch_bounds__(256, 3) void uir_ts_split_kernel(const TsArgs t) {
+  constexpr int RT = TMW / 64, CT = TNW / 64;              // 32-row / 32-column tiles per wave (2 x 2 waves)
+  constexpr int PA = TMW * SROW, PB = TNW * SROW;          // bf16 per plane
+  constexpr int EW = 32 * CT + 4;                          // epilogue LDS row (floats)
+  extern __shared__ float smem[];
+  unsigned short* As = reinterpret_cast<unsigned short*>(smem);
+  unsigned short* Bs = As + 3 * PA;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int tiles_j = (t.NN + TNW - 1) / TNW;
+  const int i0 = ((int)blockIdx.x / tiles_j) * TMW, j0 = ((int)blockIdx.x % tiles_j) * TNW;
+  const int z = blockIdx.z;
+  const float* A = t.A + (long)z * t.a_bs;
+  const float* B = t.B + (long)z * t.b_bs;
+  const int ke = t.KK;
+
+  KcLoader<TMW> la;
+  la.init(A, t.sa_i, i0, t.MM, tid);
+  KcLoader<TNW> lbk;
+  IcLoader<TNW> lbi;
+  if constexpr (BKC) lbk.init(B, t.sb_j, j0, t.NN, tid);
+  else lbi.init(B, j0, t.NN, tid);
+
+  f32x16 acc[RT][CT];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int b = 0; b < CT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  uint4 va[TMW / 32], vb[BKC ? TNW / 32 : 4];
+  auto load_b = [&](int k0) {
+    if constexpr (BKC) lbk.load(vb, k0, ke);
+    else lbi.load(vb, k0, ke, t.sb_k, t.kg_real, t.kg_pad);
+  };
+  auto store_b = [&](int k0) {
+    if constexpr (BKC) lbk.template store<PB>(Bs, vb, tid, k0, ke);
+    else lbi.template store<PB>(Bs, vb, k0, ke);
+  };
+  la.load(va, 0, ke);
+  load_b(0);
+  la.template store<PA>(As, va, tid, 0, ke);
+  store_b(0);
+  __syncthreads();
+  for (int k0 = 0; k0 < ke; k0 += 32) {
+    const bool more = k0 + 32 < ke;
+    la.load(va, k0 + 32, ke);                       // unconditional, clamped: never under a branch (csrc/tiled.hip)
+    load_b(k0 + 32);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kq = 0; kq < 2; ++kq) {
+      bf16x8 fa[RT][3], fb[CT][3];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+        for (int x = 0; x < RT; ++x)
+          fa[x][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(As + pl * PA + swz(32 * RT * wr + 32 * x + li, 2 * kq + h2)));
+#pragma unroll
+        for (int x = 0; x < CT; ++x)
+          fb[x][pl] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(Bs + pl * PB + swz(32 * CT * wc + 32 * x + li, 2 * kq + h2)));
+      }
+#pragma unroll
+      for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b) {
+          f32x16 c = acc[a][b];
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][1], c, 0, 0, 0);     // small terms first
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][2], fb[b][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][2], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][1], fb[b][0], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][1], c, 0, 0, 0);
+          c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[a][0], fb[b][0], c, 0, 0, 0);
+          acc[a][b] = c;
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();                 // every wave has read this chunk
+    if (more) {
+      la.template store<PA>(As, va, tid, k0 + 32, ke);
+      store_b(k0 + 32);
+    }
+    __syncthreads();
+  }
+
+  // row-major epilogue through the wave's own LDS slice (the operand planes are dead behind the loop's last barrier): float4 stores
+  float* D = t.D + (long)z * t.d_bs;
+  const float* R = t.R ? t.R + (long)z * t.r_bs : nullptr;
+  float* ws = smem + wave * (32 * EW);
+  constexpr int LPR = 8 * CT, RPI = 64 / LPR, NI = 32 / RPI;
+  const int c4 = 4 * (lane % LPR), rl = lane / LPR;
+  const int col = j0 + 32 * CT * wc + c4;
+  const bool cok = col < t.NN;                               // NN is a multiple of 4
+#pragma unroll
+  for (int a = 0; a < RT; ++a) {
+#pragma unroll
+    for (int b = 0; b < CT; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ws[uir_mfma_row(r, h2) * EW + 32 * b + li] = acc[a][b][r];
+    __builtin_amdgcn_wave_barrier();
+    const int rb = i0 + 32 * RT * wr + 32 * a;
+    float4 rv[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int row = rb + rl + RPI * i;
+      rv[i] = (R && cok && row < t.MM) ? *reinterpret_cast<const float4*>(R + (long)row * t.ldr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int rr = rl + RPI * i, row = rb + rr;
+      float4 v = *reinterpret_cast<const float4*>(ws + rr * EW + c4);
+      if (cok && row < t.MM) {
+        v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+        *reinterpret_cast<float4*>(D + (long)row * t.sd_i + col) = v;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <bool BKC, int TMW, int TNW>
+int ts_launch(const TsArgs& t, int batches, hipStream_t st) {
+  const dim3 grid(((t.MM + TMW - 1) / TMW) * ((t.NN + TNW - 1) / TNW), 1, batches);
+  const size_t lds_op = (size_t)3 * (TMW + TNW) * SROW * sizeof(unsigned short);
+  const size_t lds_ep = (size_t)4 * 32 * (32 * (TNW / 64) + 4) * sizeof(float);
+  hipLaunchKernelGGL((uir_ts_split_kernel<BKC, TMW, TNW>), grid, dim3(256), lds_op > lds_ep ? lds_op : lds_ep, st, t);
+  return uir_launch_status();
+}
+
+}  // namespace
+
+// -1: not this kernel's shape (the caller continues on the panel kernel).  Plain epilogue only: no bias / activation / prologue.
+int uir_ts_gemm(const UirGemmArgs& a, void* stream) {
+  if (!uir_fused_split()) return -1;
+  if (a.taps != 1 || a.pro != UIR_PRO_NONE || a.epi != UIR_EPI_PLAIN || a.act != UIR_ACT_NONE || a.bias || a.out_scale || a.pre_out) return -1;
+  if (a.n_grp_pad > 0) return -1;
+  const long rows = (long)a.M * a.batches;
+  // the deep levels: few rows (an under-filled chip on the panel kernel), contractions long enough to pay for the operand splits
+  if (rows < 4096 || rows > 65536 || a.M < 256 || a.K < 64 || a.N < 64 || (a.N & 3) || (a.K & 3)) return -1;
+  const bool bkc = a.w_sk == 1 && (a.w_sn & 3) == 0, bic = a.w_sn == 1 && (a.w_sk & 3) == 0;
+  if (!bkc && !bic) return -1;
+  if (a.k_grp_pad > 0 && (!bic || (a.K % a.k_grp_pad) != 0)) return -1;
+  if ((a.ldx & 3) || (a.ldy & 3) || !uir_aligned16(a.X) || !uir_aligned16(a.W) || !uir_aligned16(a.Y) || (a.x_bs & 3) || (a.y_bs & 3) || (a.w_bs & 3)) return -1;
+  if (a.R && ((a.ldr & 3) || !uir_aligned16(a.R) || (a.r_bs & 3))) return -1;
+  TsArgs t{};
+  t.A = a.X; t.B = a.W; t.D = a.Y; t.R = a.R;
+  t.sa_i = a.ldx; t.sb_j = a.w_sn; t.sb_k = a.w_sk; t.sd_i = a.ldy; t.ldr = a.ldr;
+  t.a_bs = a.x_bs; t.b_bs = a.w_bs; t.d_bs = a.y_bs; t.r_bs = a.r_bs;
+  t.MM = a.M; t.NN = a.N; t.KK = a.K;
+  t.kg_real = a.k_grp_real; t.kg_pad = a.k_grp_pad;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  // tile: 64 output columns where N <= 64 (or 65 .. 127: half of a 128-wide tile would idle), 64 rows where 128-row tiles would leave
+  // fewer than ~2 workgroups per CU
+  const bool n64 = a.N < 128 || ((a.N % 128) != 0 && (a.N % 128) <= 64);
+  const long wg128 = (long)((a.M + 127) / 128) * ((a.N + (n64 ? 63 : 127)) / (n64 ? 64 : 128)) * a.batches;
+  const bool m64 = wg128 < 512;
+#define UIR_TS(BK) do { \
+    if (m64 && n64) return ts_launch<BK, 64, 64>(t, a.batches, st); \
+    if (m64) return ts_launch<BK, 64, 128>(t, a.batches, st); \
+    if (n64) return ts_launch<BK, 128, 64>(t, a.batches, st); \
+    return ts_launch<BK, 128, 128>(t, a.batches, st); } while (0)
+  if (bkc) UIR_TS(true);
+  UIR_TS(false);
+#undef UIR_TS
+}
