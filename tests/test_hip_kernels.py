@@ -1019,6 +1019,48 @@ def test_fused_kernels_agree_between_split_bf16_and_f32_mfma():
 
 
 # ------------------------------------------------- csrc/tsgemm.hip: the deep levels' contractions on split-bf16 tiles
+@pytest.mark.parametrize("C,rows", [(64, 8192), (128, 4096)])
+def test_gemm_tall_skinny_gate_and_leaky_epilogues(C, rows):
+    """The same kernel's other epilogues: the GDFN gate backward (split column layout with h of hp real hidden channels - at C = 64 the
+    last real quad of W_out^T's rows straddles h = 170), bias + LeakyReLU and the LeakyReLU backward (UpSample's 1x1 MLPs,
+    SpectralTransformer.py:165-168), against fp64 autograd."""
+    g_ = torch.Generator().manual_seed(9)
+    rn = lambda *s: torch.rand(*s, generator=g_, dtype=torch.float64) * 2 - 1
+    M, h = rows, int(C * 2.66)
+    hp = (h + 15) & ~15
+    r = rec()
+    # gate backward
+    g = rn(M, 2 * hp) * 2
+    g[:, h:hp] = 0
+    g[:, hp + h:] = 0
+    w, dy = rn(C, h) * h ** -0.5, rn(M, C)
+    g1 = g[:, :h].clone().requires_grad_(True)
+    g2 = g[:, hp:hp + h].clone().requires_grad_(True)
+    d1, d2 = torch.autograd.grad((((F.gelu(g1) * g2) @ w.T) * dy).sum(), (g1, g2))
+    dG = r.alloc(M, 2 * hp)
+    dG.fill_(7.0)
+    r.gemm("dgate", dev(dy), dev(w), dG, N=hp, K=C, w_sn=1, w_sk=h, n_grp=(h, hp), epi=L.EPI_GATE_BWD, G=dev(g), g_off=hp)
+    # bias + LeakyReLU forward, its backward
+    x, w0, b0 = rn(M, C), rn(C, C) * C ** -0.5, rn(C)
+    xg = x.clone().requires_grad_(True)
+    hmid = F.leaky_relu(xg @ w0.T + b0, 0.1)
+    dh = rn(M, C)
+    (dpre,) = torch.autograd.grad((hmid * dh).sum(), (xg,))
+    H1, dX = r.alloc(M, C), r.alloc(M, C)
+    r.gemm("l0", dev(x), dev(w0), H1, N=C, K=C, w_sn=C, w_sk=1, bias=dev(b0), act=L.ACT_LEAKY)
+    w2 = rn(C, C) * C ** -0.5
+    dmid = r.alloc(M, C)
+    r.gemm("l2dx", dev(dh), dev(w2), dmid, N=C, K=C, w_sn=1, w_sk=C, epi=L.EPI_LEAKY_BWD, G=H1)
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    e = lambda got, ref: float((got.double().cpu() - ref).abs().max() / ref.abs().max())
+    assert e(dG[:, :h], d1) < 3e-6 and e(dG[:, hp:hp + h], d2) < 3e-6
+    assert float(dG[:, h:hp].abs().max()) == 0 and float(dG[:, hp + h:].abs().max()) == 0
+    assert e(H1, hmid.detach()) < 3e-6
+    want = (dh @ w2) * torch.where(hmid.detach() > 0, 1.0, 0.1)
+    assert e(dmid, want) < 3e-6
+
+
 @pytest.mark.parametrize("case", ["kc", "ic", "kgrp", "batched", "residual", "ragged", "n64"])
 def test_gemm_tall_skinny_split(case):
     """uir_gemm sends the plain contractions of the deep U-Net levels (4 096 .. 65 536 rows, K, N >= 64; SpectralTransformer.py:81-83,

@@ -77,6 +77,15 @@ for lvl, (S, Cc, heads) in (("L2", (64, 64, 4)), ("L3", (32, 128, 8))):
     timeit(r, f"{lvl} bwd dqk (per-sample 2C x 2C)", 2 * M * 4 * Cc * Cc)
     r.gemm("WA", qkv[:, 2 * Cc:], WA, y, N=Cc, K=Cc, w_sn=Cc, w_sk=1, w_bs=Cc * Cc, batches=B)
     timeit(r, f"{lvl} per-sample C x C GEMM (WA / WB / dv / dvf)", 2 * M * Cc * Cc)
+    # UpSample's 1x1 MLPs (amp_fuse / pha_fuse, SpectralTransformer.py:165-168) run on the level's pixels too
+    Wf, bf = rnd(Cc, Cc) * .1, rnd(Cc)
+    hm = r.alloc(M, Cc)
+    r.gemm("f0", x, Wf, hm, N=Cc, K=Cc, w_sn=Cc, w_sk=1, bias=bf, act=L.ACT_LEAKY)
+    timeit(r, f"{lvl} ups 1x1 + bias + LeakyReLU (C x C)", 2 * M * Cc * Cc)
+    r.gemm("f2dx", x, Wf, y, N=Cc, K=Cc, w_sn=1, w_sk=Cc, epi=L.EPI_LEAKY_BWD, G=hm)
+    timeit(r, f"{lvl} ups 1x1 input gradient + LeakyReLU bwd", 2 * M * Cc * Cc)
+    r.gemm("f0dx", x, Wf, y, N=Cc, K=Cc, w_sn=1, w_sk=Cc)
+    timeit(r, f"{lvl} ups 1x1 input gradient (plain, C x C)", 2 * M * Cc * Cc)
     dW = r.alloc(2 * h, Cc)
     r.gram("dWin", gp, x, dW, N=2 * hp, K=Cc, o_sn=Cc, o_sk=1, n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g1, b1), stats=st)
     r.flush_reductions("t")

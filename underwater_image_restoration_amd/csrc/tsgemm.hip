@@ -43,6 +43,10 @@ struct TsArgs {
   long a_bs, b_bs, d_bs, r_bs;
   int MM, NN, KK;
   int kg_real, kg_pad;       // B rows exist for k % kg_pad < kg_real (kg_pad = 0: every k)
+  int n_real;                // index-contiguous B: its rows hold n_real <= NN columns (GATE_BWD: the h real hidden channels of hp)
+  const float* bias;         // [NN] or null (EPI 0)
+  float slope;               // EPI 0: LeakyReLU slope applied to acc + bias (1 = none); EPI 1: the backward's slope
+  const float* G; long ldg, g_bs; int g_off;   // EPI 1: forward LeakyReLU output; EPI 2: the GDFN tensor t2 (x1 half | x2 half at g_off)
 };
 
 // row of B's k axis that holds contraction index k (A's pad columns are exact zeros: a pad k may read any finite row)
@@ -87,16 +91,19 @@ struct KcLoader {
 template <int ROWS>
 struct IcLoader {
   const float* p;
-  int row0, kb;
+  int row0, kb, shift;
   bool on;
+  // n_idx: columns that exist in memory.  A quad that reaches past them is loaded from the last whole quad and its elements are
+  // shifted into place when they are stored (columns past n_idx become zeros): no read past the operand, no wrong column
   __device__ __forceinline__ void init(const float* base, int idx0, int n_idx, int tid) {
     on = tid < ROWS * 2;
     const int quad = tid >> 3;
     kb = 4 * (tid & 7);
     row0 = 4 * (on ? quad : 0);
-    int i = idx0 + row0;
-    i = i + 4 <= n_idx ? i : n_idx - 4;
-    p = base + i;
+    const int i = idx0 + row0;
+    const int ic = i + 4 <= n_idx ? i : n_idx - 4;
+    shift = i - ic;                                        // 0 .. 3 inside the operand, >= 4: the whole quad is past it
+    p = base + ic;
   }
   __device__ __forceinline__ void load(uint4 (&v)[4], int k0, int ke, long s_k, int real, int pad) const {
 #pragma unroll
@@ -111,10 +118,16 @@ struct IcLoader {
     uint32_t mk[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) mk[q] = k0 + kb + q < ke ? 0xffffffffu : 0u;
-    const float r0[4] = {__uint_as_float(v[0].x & mk[0]), __uint_as_float(v[1].x & mk[1]), __uint_as_float(v[2].x & mk[2]), __uint_as_float(v[3].x & mk[3])};
-    const float r1[4] = {__uint_as_float(v[0].y & mk[0]), __uint_as_float(v[1].y & mk[1]), __uint_as_float(v[2].y & mk[2]), __uint_as_float(v[3].y & mk[3])};
-    const float r2[4] = {__uint_as_float(v[0].z & mk[0]), __uint_as_float(v[1].z & mk[1]), __uint_as_float(v[2].z & mk[2]), __uint_as_float(v[3].z & mk[3])};
-    const float r3[4] = {__uint_as_float(v[0].w & mk[0]), __uint_as_float(v[1].w & mk[1]), __uint_as_float(v[2].w & mk[2]), __uint_as_float(v[3].w & mk[3])};
+    float r0[4], r1[4], r2[4], r3[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const uint32_t c0 = v[q].x & mk[q], c1 = v[q].y & mk[q], c2 = v[q].z & mk[q], c3 = v[q].w & mk[q];
+      // element e of the quad is loaded element e + shift
+      r0[q] = __uint_as_float(shift == 0 ? c0 : shift == 1 ? c1 : shift == 2 ? c2 : shift == 3 ? c3 : 0u);
+      r1[q] = __uint_as_float(shift == 0 ? c1 : shift == 1 ? c2 : shift == 2 ? c3 : 0u);
+      r2[q] = __uint_as_float(shift == 0 ? c2 : shift == 1 ? c3 : 0u);
+      r3[q] = __uint_as_float(shift == 0 ? c3 : 0u);
+    }
     store_row4<PL>(s, row0, kb, r0);
     store_row4<PL>(s, row0 + 1, kb, r1);
     store_row4<PL>(s, row0 + 2, kb, r2);
@@ -122,7 +135,8 @@ struct IcLoader {
   }
 };
 
-template <bool BKC, int TMW, int TNW>
+// EPI 0: D = leaky(acc + bias) + R;  1: LeakyReLU backward (D = G > 0 ? acc : slope acc);  2: GDFN gate backward (two outputs)
+template <bool BKC, int TMW, int TNW, int EPI>
 __global__ __launch_bounds__(256, 3) void uir_ts_split_kernel(const TsArgs t) {
   constexpr int RT = TMW / 64, CT = TNW / 64;              // 32-row / 32-column tiles per wave (2 x 2 waves)
   constexpr int PA = TMW * SROW, PB = TNW * SROW;          // bf16 per plane
@@ -144,7 +158,7 @@ __global__ __launch_bounds__(256, 3) void uir_ts_split_kernel(const TsArgs t) {
   KcLoader<TNW> lbk;
   IcLoader<TNW> lbi;
   if constexpr (BKC) lbk.init(B, t.sb_j, j0, t.NN, tid);
-  else lbi.init(B, j0, t.NN, tid);
+  else lbi.init(B, j0, t.n_real, tid);
 
   f32x16 acc[RT][CT];
 #pragma unroll
@@ -224,31 +238,61 @@ __global__ __launch_bounds__(256, 3) void uir_ts_split_kernel(const TsArgs t) {
       for (int r = 0; r < 16; ++r) ws[uir_mfma_row(r, h2) * EW + 32 * b + li] = acc[a][b][r];
     __builtin_amdgcn_wave_barrier();
     const int rb = i0 + 32 * RT * wr + 32 * a;
-    float4 rv[NI];
+    // the band's extra operands (residual / forward output / gate tensor) in flight together, before the first store (they may alias D)
+    float4 rv[NI], gv[EPI == 2 ? NI : 1];
+    const float* G = (EPI != 0) ? t.G + (long)z * t.g_bs : nullptr;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int row = rb + rl + RPI * i;
-      rv[i] = (R && cok && row < t.MM) ? *reinterpret_cast<const float4*>(R + (long)row * t.ldr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = cok && row < t.MM;
+      if (EPI == 0) rv[i] = (R && ok) ? *reinterpret_cast<const float4*>(R + (long)row * t.ldr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      else rv[i] = ok ? *reinterpret_cast<const float4*>(G + (long)row * t.ldg + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (EPI == 2) gv[i] = ok ? *reinterpret_cast<const float4*>(G + (long)row * t.ldg + t.g_off + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    float4 bj = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (EPI == 0 && t.bias && cok) bj = *reinterpret_cast<const float4*>(t.bias + col);
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
       const int rr = rl + RPI * i, row = rb + rr;
       float4 v = *reinterpret_cast<const float4*>(ws + rr * EW + c4);
       if (cok && row < t.MM) {
-        v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
-        *reinterpret_cast<float4*>(D + (long)row * t.sd_i + col) = v;
+        if (EPI == 0) {
+          v.x += bj.x; v.y += bj.y; v.z += bj.z; v.w += bj.w;
+          v.x = v.x > 0.f ? v.x : v.x * t.slope; v.y = v.y > 0.f ? v.y : v.y * t.slope;
+          v.z = v.z > 0.f ? v.z : v.z * t.slope; v.w = v.w > 0.f ? v.w : v.w * t.slope;
+          v.x += rv[i].x; v.y += rv[i].y; v.z += rv[i].z; v.w += rv[i].w;
+          *reinterpret_cast<float4*>(D + (long)row * t.sd_i + col) = v;
+        } else if (EPI == 1) {
+          v.x = rv[i].x > 0.f ? v.x : v.x * t.slope; v.y = rv[i].y > 0.f ? v.y : v.y * t.slope;
+          v.z = rv[i].z > 0.f ? v.z : v.z * t.slope; v.w = rv[i].w > 0.f ? v.w : v.w * t.slope;
+          *reinterpret_cast<float4*>(D + (long)row * t.sd_i + col) = v;
+        } else {
+          // hidden channels col .. col + 3 of the x1 half; pad channels (>= n_real) give exact zeros in both halves
+          const float a4[4] = {v.x, v.y, v.z, v.w}, g1[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w}, g2[4] = {gv[i].x, gv[i].y, gv[i].z, gv[i].w};
+          float o1[4], o2[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float ge, dge;
+            uir_gelu_pair(g1[e], ge, dge);
+            const float av = col + e < t.n_real ? a4[e] : 0.f;
+            o1[e] = av * g2[e] * dge;
+            o2[e] = av * ge;
+          }
+          *reinterpret_cast<float4*>(D + (long)row * t.sd_i + col) = make_float4(o1[0], o1[1], o1[2], o1[3]);
+          *reinterpret_cast<float4*>(D + (long)row * t.sd_i + t.g_off + col) = make_float4(o2[0], o2[1], o2[2], o2[3]);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-template <bool BKC, int TMW, int TNW>
+template <bool BKC, int TMW, int TNW, int EPI>
 int ts_launch(const TsArgs& t, int batches, hipStream_t st) {
   const dim3 grid(((t.MM + TMW - 1) / TMW) * ((t.NN + TNW - 1) / TNW), 1, batches);
   const size_t lds_op = (size_t)3 * (TMW + TNW) * SROW * sizeof(unsigned short);
   const size_t lds_ep = (size_t)4 * 32 * (32 * (TNW / 64) + 4) * sizeof(float);
-  hipLaunchKernelGGL((uir_ts_split_kernel<BKC, TMW, TNW>), grid, dim3(256), lds_op > lds_ep ? lds_op : lds_ep, st, t);
+  hipLaunchKernelGGL((uir_ts_split_kernel<BKC, TMW, TNW, EPI>), grid, dim3(256), lds_op > lds_ep ? lds_op : lds_ep, st, t);
   return uir_launch_status();
 }
 
@@ -257,8 +301,14 @@ int ts_launch(const TsArgs& t, int batches, hipStream_t st) {
 // -1: not this kernel's shape (the caller continues on the panel kernel).  Plain epilogue only: no bias / activation / prologue.
 int uir_ts_gemm(const UirGemmArgs& a, void* stream) {
   if (!uir_fused_split()) return -1;
-  if (a.taps != 1 || a.pro != UIR_PRO_NONE || a.epi != UIR_EPI_PLAIN || a.act != UIR_ACT_NONE || a.bias || a.out_scale || a.pre_out) return -1;
-  if (a.n_grp_pad > 0) return -1;
+  if (a.taps != 1 || a.pro != UIR_PRO_NONE || a.out_scale || a.pre_out || a.il16) return -1;
+  const int epi = a.epi == UIR_EPI_PLAIN ? 0 : a.epi == UIR_EPI_LEAKY_BWD ? 1 : a.epi == UIR_EPI_GATE_BWD ? 2 : -1;
+  if (epi < 0 || (a.act != UIR_ACT_NONE && (a.act != UIR_ACT_LEAKY || epi != 0)) || (epi != 0 && (a.bias || a.R || !a.G || a.batches != 1))) return -1;
+  // column groups only as the gate backward has them: one group, N = hp columns of which the first h are real
+  if (a.n_grp_pad > 0 && !(epi == 2 && a.n_grp_pad == a.N && a.w_sn == 1)) return -1;
+  if (epi == 2 && ((a.g_off & 3) || (a.ldg & 3) || !uir_aligned16(a.G) || a.ldg < a.g_off + a.N || a.ldy < a.g_off + a.N)) return -1;
+  if (epi == 1 && ((a.ldg & 3) || !uir_aligned16(a.G) || a.ldg < a.N)) return -1;
+  if (a.bias && !uir_aligned16(a.bias)) return -1;
   const long rows = (long)a.M * a.batches;
   // the deep levels: few rows (an under-filled chip on the panel kernel), contractions long enough to pay for the operand splits
   if (rows < 4096 || rows > 65536 || a.M < 256 || a.K < 64 || a.N < 64 || (a.N & 3) || (a.K & 3)) return -1;
@@ -273,18 +323,31 @@ int uir_ts_gemm(const UirGemmArgs& a, void* stream) {
   t.a_bs = a.x_bs; t.b_bs = a.w_bs; t.d_bs = a.y_bs; t.r_bs = a.r_bs;
   t.MM = a.M; t.NN = a.N; t.KK = a.K;
   t.kg_real = a.k_grp_real; t.kg_pad = a.k_grp_pad;
+  t.n_real = a.n_grp_pad > 0 ? a.n_grp_real : a.N;
+  if (t.n_real < 4) return -1;
+  t.bias = a.bias;
+  t.slope = (epi == 0 && a.act != UIR_ACT_LEAKY) ? 1.0f : a.slope;
+  t.G = a.G; t.ldg = a.ldg; t.g_bs = a.g_bs; t.g_off = a.g_off;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  // tile: 64 output columns where N <= 64 (or 65 .. 127: half of a 128-wide tile would idle), 64 rows where 128-row tiles would leave
-  // fewer than ~2 workgroups per CU
-  const bool n64 = a.N < 128 || ((a.N % 128) != 0 && (a.N % 128) <= 64);
-  const long wg128 = (long)((a.M + 127) / 128) * ((a.N + (n64 ? 63 : 127)) / (n64 ? 64 : 128)) * a.batches;
-  const bool m64 = wg128 < 512;
-#define UIR_TS(BK) do { \
-    if (m64 && n64) return ts_launch<BK, 64, 64>(t, a.batches, st); \
-    if (m64) return ts_launch<BK, 64, 128>(t, a.batches, st); \
-    if (n64) return ts_launch<BK, 128, 64>(t, a.batches, st); \
-    return ts_launch<BK, 128, 128>(t, a.batches, st); } while (0)
-  if (bkc) UIR_TS(true);
-  UIR_TS(false);
+  // tile: the largest of 128 x 128, 64 x 128 / 128 x 64, 64 x 64 that still gives the chip two workgroups per CU (512): these launches
+  // are latency chains of K / 32 chunks, and a second workgroup on the CU runs under the first one's barriers and load waits
+  // (level 3's dt1, 16 384 x 384 -> 128: 256 workgroups of 64 x 128 lost to the f32 kernel of csrc/tiled.hip, 512 of 64 x 64 do not).
+  // 64-wide column tiles also where a 128-wide one would be at least half empty.
+  auto wgs = [&](int tm, int tn) { return (long)((a.M + tm - 1) / tm) * ((a.N + tn - 1) / tn) * a.batches; };
+  const bool nfit128 = a.N >= 128 && !((a.N % 128) != 0 && (a.N % 128) <= 64);
+  bool m64, n64;
+  if (nfit128 && wgs(128, 128) >= 512) { m64 = false; n64 = false; }
+  else if (nfit128 && wgs(64, 128) >= 512) { m64 = true; n64 = false; }
+  else if (wgs(128, 64) >= 512) { m64 = false; n64 = true; }
+  else { m64 = true; n64 = true; }
+#define UIR_TS(BK, EP) do { \
+    if (m64 && n64) return ts_launch<BK, 64, 64, EP>(t, a.batches, st); \
+    if (m64) return ts_launch<BK, 64, 128, EP>(t, a.batches, st); \
+    if (n64) return ts_launch<BK, 128, 64, EP>(t, a.batches, st); \
+    return ts_launch<BK, 128, 128, EP>(t, a.batches, st); } while (0)
+  if (epi == 2) { if (bkc) return -1; UIR_TS(false, 2); }        // the gate backward contracts against W_out^T: n-contiguous
+  if (epi == 1) { if (bkc) UIR_TS(true, 1); UIR_TS(false, 1); }
+  if (bkc) UIR_TS(true, 0);
+  UIR_TS(false, 0);
 #undef UIR_TS
 }
