@@ -1127,3 +1127,8 @@ def test_gemm_tall_skinny_split(case):
     torch.cuda.synchronize()
     e = float((Y.double().cpu() - ref).abs().max() / ref.abs().max())
     assert e < 3e-6, e
+    first = Y.clone()
+    Y.zero_()
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    assert torch.equal(first, Y)                       # bitwise run-to-run

@@ -72,3 +72,44 @@ def test_module_step_refuses_what_cannot_fit_with_the_numbers():
     assert 1 <= mb < 8 and 8 % mb == 0
     with pytest.raises(RuntimeError, match="GiB"):
         step.check_memory(1, 4096, 4096)
+
+
+def test_new_shapes_are_sized_against_free_memory_not_against_plans_that_stay_alive(monkeypatch):
+    """the modules keep the plans of other shapes alive, so a validation tail batch sized against "free + existing plans"
+    ran out of memory while recording its plans beside training plans that fill the HBM.  With the device's free memory pinned to a
+    budget just above one training micro-batch: (1) validation of the training shape reuses the training micro-batch (no second set
+    of plans), (2) a tail batch that cannot get its own plans beside the training plans makes the step drop them FIRST and is then
+    sized against what is really free - and both still evaluate correctly."""
+    from underwater_image_restoration_amd import engine
+    m, step = _fresh("NewBigFRFNModel")
+    S, B = 128, 4
+    x = torch.rand(B, 3, S, S, device="cuda")
+    y = torch.rand(B, 3, S, S, device="cuda")
+    need2 = step.plan_bytes_estimate(2, S, S)
+    budget = int(need2 / 0.92 * 1.2)                       # room for plans of micro-batch 2 (not 4), once
+
+    def fake_free(dev):
+        return max(0, budget - step.plan_bytes())
+    monkeypatch.setattr(engine, "device_bytes_available", fake_free)
+    assert step.micro_batch_for(B, S, S) == 2
+    step(x, y)
+    torch.cuda.synchronize()
+    held = step.plan_bytes()
+    assert held > 0
+    # (1) same shape, validation: the training micro-batch and its plans
+    with torch.no_grad():
+        l_a, p_a = step.evaluate(x, y)
+    assert step.micro_batch_for(B, S, S, train=False) == 2 and step.plan_bytes() == held
+    # (2) a tail batch of 3 images (micro-batch 3 or 1): its forward-only plans do not fit beside the training plans
+    with torch.no_grad():
+        l_t, p_t = step.evaluate(x[:3], y[:3])
+        torch.cuda.synchronize()
+    assert np_isfinite(float(l_t)) and np_isfinite(float(p_t))
+    # the training shape comes back afterwards and trains on
+    l2, n2 = step(x, y)
+    assert np_isfinite(float(l2)) and np_isfinite(float(n2))
+
+
+def np_isfinite(v):
+    import math
+    return math.isfinite(v)

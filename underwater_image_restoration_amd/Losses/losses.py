@@ -25,8 +25,8 @@ truth)`` (src/Losses/losses.py:30-160), for the loss names on the SpectralTransf
                 backward to the image run on the HIP kernels (Losses/perceptual.py), composed with the terms above and TVLoss (:11-28).
                 They need the USER's torchvision VGG16 weight file (a download in the reference) and refuse without it.
 
-Forward and backward are HIP reductions (uir_loss_*).  Other reference loss names need
-third-party packages / pretrained VGG weights that are outside this build's scope.
+Forward and backward are HIP reductions (uir_loss_*).  The one reference name without an implementation is "ffl": the
+reference itself raises AttributeError for it (losses.py:30-48 never builds self.ffl for that name).
 """
 from __future__ import annotations
 
@@ -35,10 +35,8 @@ import torch
 from .. import _lib as L
 from .. import ops
 
-# names the reference defines on top of torchvision's pretrained VGG16 (a weight download, losses.py:219-222: "perceptual" and every
-# mix; "ffl" alone raises AttributeError in the reference, :30-48 never builds self.ffl for it).  pytorch_msssim.MS_SSIM and
-# focal_frequency_loss.FocalFrequencyLoss are un-vendored, unpinned pip packages (requirements.txt:14-15) restated above.  "fflMix" (:108-117) needs all three: its Charbonnier, Gradient_Loss and (restated,
-# unpinned) FocalFrequencyLoss terms exist above; the VGG16 and MS-SSIM terms cannot be built here.
+# "ffl" alone is an AttributeError in the reference (losses.py:30-48 never builds self.ffl for it): refused here with that explanation.
+# Every other name of the reference's LossFunction is implemented above / in Losses/perceptual.py.
 _REFERENCE_OTHER = ("ffl",)
 
 

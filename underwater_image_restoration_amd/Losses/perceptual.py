@@ -52,7 +52,7 @@ def _find_weights():
     cand.append(os.path.join(home, "hub", "checkpoints", "vgg16-397923af.pth"))
     for f in cand:
         if os.path.isfile(f):
-            set_vgg16_weights(torch.load(f, map_location="cpu"))
+            set_vgg16_weights(torch.load(f, map_location="cpu", weights_only=True))     # a state_dict of tensors: nothing else is unpickled
             return _weights_sd
     raise NotImplementedError(
         "the perceptual loss needs torchvision's pretrained VGG16 weights, which the reference downloads and this build can neither "

@@ -300,7 +300,7 @@ int ts_launch(const TsArgs& t, int batches, hipStream_t st) {
 
 // -1: not this kernel's shape (the caller continues on the panel kernel).  Plain epilogue only: no bias / activation / prologue.
 int uir_ts_gemm(const UirGemmArgs& a, void* stream) {
-  if (!uir_fused_split()) return -1;
+  if (!uir_fused_split() || uir_mixed_mode() != 0) return -1;      // UIR_MIXED: the 16-bit kernel of csrc/tiled.hip takes these calls
   if (a.taps != 1 || a.pro != UIR_PRO_NONE || a.out_scale || a.pre_out || a.il16) return -1;
   const int epi = a.epi == UIR_EPI_PLAIN ? 0 : a.epi == UIR_EPI_LEAKY_BWD ? 1 : a.epi == UIR_EPI_GATE_BWD ? 2 : -1;
   if (epi < 0 || (a.act != UIR_ACT_NONE && (a.act != UIR_ACT_LEAKY || epi != 0)) || (epi != 0 && (a.bias || a.R || !a.G || a.batches != 1))) return -1;

@@ -21,8 +21,9 @@ KNOBS = {
                         "uir_attnv_fwd) run their channel contractions on split-bf16 MFMA in registers (3 bf16 planes per f32 operand, 6 products, "
                         "f32-accurate: csrc/uir_common.h uir_mfma_split); 0 = on the f32 MFMA (the arithmetic of rounds 1-3)",
                         "tests/test_hip_kernels.py::test_fused_kernels_agree_between_split_bf16_and_f32_mfma"),
-    "UIR_MIXED": ("0", "read by libuir_hip.so: bf16 | fp16 = MIXED precision - every wide contraction of csrc/tiled.hip (the Linear layers of "
-                  "AST / NewBigFRFNModel with >= 256 input channels and their input / weight gradients) takes its operands rounded to that "
+    "UIR_MIXED": ("0", "read by libuir_hip.so: bf16 | fp16 = MIXED precision - every plain Linear contraction with >= 64 input channels, >= 64 outputs and "
+                  ">= 256 rows (csrc/gemm.hip routes them all to csrc/tiled.hip in this mode: the Linear layers of AST / NewBigFRFNModel "
+                  "from 64 -> 256 upwards, their input and weight gradients) takes its operands rounded to that "
                   "16-bit type on the bf16 / f16 matrix pipe, f32 accumulation, f32 master weights, everything else f32 (BASELINE "
                   "configs[4]'s 'mixed fp16'); results are NOT f32-accurate and no f32 number is measured with it; any other value is refused",
                   "tests/test_tiled.py::test_mixed_mode_equals_the_rounded_operand_products"),

@@ -237,6 +237,8 @@ class ModuleTrainStep:
         for m in self.mods:
             m._ensure_flat(dev)
             m._flat_grads_only = True
+            # from here on a module's output IS its plan's output buffer (a second call overwrites the first result): the contract
+            # of a network driven by this step object, and it stays set for the modules' lifetime - clone an output to keep it
             m._alias_io = True
         self.flats = [m._flat for m in self.mods]
         # ONE gradient bucket for the whole network: every module's flat gradient buffer becomes a view of it, so data parallelism
@@ -285,15 +287,44 @@ class ModuleTrainStep:
         key = (B, H, W, train)
         if key in self._mb_cache:                 # decided once per shape (the plans exist from then on)
             return self._mb_cache[key]
-        from .engine import device_bytes_available
+        if not train:
+            # validation: a training plan of the same micro-batch shape serves a forward too (TokenModule._plan_for), so prefer a
+            # micro-batch the training step already runs - no second set of plans beside plans that fill the HBM
+            for (b2, h2, w2, t2), mb2 in self._mb_cache.items():
+                if t2 and (h2, w2) == (H, W) and B % mb2 == 0:
+                    self._mb_cache[key] = mb2
+                    return mb2
+        from . import engine
         dev = self.bucket.device
-        have = device_bytes_available(dev) + self.plan_bytes()
-        for mb in sorted((d for d in range(1, B + 1) if B % d == 0), reverse=True):
-            if self.plan_bytes_estimate(mb, H, W, train) <= 0.92 * have:
-                self._mb_cache[key] = mb
-                return mb
-        raise RuntimeError(f"{type(self.model).__name__}(HIP): even one {H}x{W} image needs ~{self.plan_bytes_estimate(1, H, W, train) / 2**30:.1f} GiB "
-                           f"of HBM for its launch plans ({have / 2**30:.1f} GiB available)")
+
+        def pick(have):
+            for mb in sorted((d for d in range(1, B + 1) if B % d == 0), reverse=True):
+                if self.plan_bytes_estimate(mb, H, W, train) <= 0.92 * have:
+                    return mb
+            return None
+        # Only memory that is FREE counts: the modules keep the plans of other shapes alive (TokenModule._plan_for evicts by count,
+        # never for memory), so a new shape sized against "free + existing plans" ran out of memory while recording its plans
+        # (e.g. a validation tail batch beside training plans at 92 % of the HBM).  If the existing plans are in the way - the new
+        # shape would get a smaller micro-batch than an empty device allows, or none - they are dropped first (rebuilt on demand,
+        # their cached decisions with them) and the shape is sized against what is then really free.
+        free = engine.device_bytes_available(dev)
+        mb, best = pick(free), pick(free + self.plan_bytes())
+        if best is not None and (mb is None or mb < best):
+            self.drop_plans()
+            free = engine.device_bytes_available(dev)
+            mb = pick(free)
+        if mb is None:
+            raise RuntimeError(f"{type(self.model).__name__}(HIP): even one {H}x{W} image needs ~{self.plan_bytes_estimate(1, H, W, train) / 2**30:.1f} GiB "
+                               f"of HBM for its launch plans ({free / 2**30:.1f} GiB available)")
+        self._mb_cache[key] = mb
+        return mb
+
+    def drop_plans(self) -> None:
+        """Free every module's launch plans (activation buffers) and what torch's allocator caches; they are rebuilt on demand."""
+        for m in self.mods:
+            m._plans.clear()
+        self._mb_cache.clear()
+        torch.cuda.empty_cache()
 
     def check_memory(self, B: int, H: int, W: int) -> int:
         """Fail before the first batch, with the numbers, if the configuration cannot run; returns the micro-batch."""
