@@ -40,7 +40,7 @@ ALG_FLOPS_PER_IMAGE_256 = 90.14e9
 HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(image_size: int, budget_s: float = 25.0):
+def cpu_baseline(image_size: int, budget_s: float = 45.0):
     """The oracle's train step (fwd + L1 + bwd + clip + Adam) on the host cores: bounded sample."""
     from oracle import cpu_ref as O
     cores = os.cpu_count() or 1
@@ -70,7 +70,9 @@ def cpu_baseline(image_size: int, budget_s: float = 25.0):
     one()                                   # warm-up (also sizes the sample)
     warm = time.time() - t0
     print(f"[bench] cpu_baseline: warm-up step {warm:.1f} s", file=sys.stderr, flush=True)
-    n = 3 if warm <= budget_s else 1                  # BASELINE.md section 4 asks for 3; a box slower than 25 s/step gets 1 (stated)
+    # BASELINE.md section 4 asks for 3 timed steps: a B = 16 step takes ~30 s on a 16-thread share (BENCH_r03: 30.3 s), so 1 + 3 steps
+    # are ~2 minutes of CPU work; only a box slower than 45 s/step falls back to 1 timed step (stated in `sample`)
+    n = 3 if warm <= budget_s else 1
     t0 = time.time()
     for _ in range(n):
         one()

@@ -79,8 +79,9 @@ struct DwLn {
   static constexpr int OFF_XH = OFF_GS + NI * SG;
   static constexpr int OFF_RS = OFF_XH + NI * SX;
   static constexpr int OFF_WR = OFF_RS + NI;
-  static constexpr int OFF_DWA = OFF_WR + 4 * 16 * 18;
-  static constexpr int LDS_FLOATS = OFF_DWA + NCH * 16 * 18;
+  static constexpr int SW = C + 4;                         // row stride of the staged W1 chunk [32 rows][C] (16-byte rows)
+  static constexpr int OFF_W1 = OFF_WR + 4 * 16 * 18;
+  static constexpr int LDS_FLOATS = OFF_W1 + 32 * SW;
   static_assert(C == 16 || C == 32, "channel count");
 };
 
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
   float* XH = smem + T::OFF_XH;
   float* RS = smem + T::OFF_RS;
   float* WR = smem + T::OFF_WR;
-  float* DWA = smem + T::OFF_DWA;
+  float* W1s = smem + T::OFF_W1;
   const int tiles_x = (a.Wd + T::TW - 1) / T::TW, tiles_y = (a.H + T::TH - 1) / T::TH;
   const int ntiles = a.B * tiles_x * tiles_y;
   const int h = a.h, hp = a.hp, ch = a.ch;
@@ -134,7 +135,6 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     gam16 = a.gamma[n16];
     bet16 = a.beta[n16];
     gam_n = li < C ? a.gamma[li] : 0.f;
-    for (int e = t_; e < NCH * 16 * 18; e += 256) DWA[e] = 0.f;
   }
   // dW1 granule accumulators, one per chunk, live across all tiles.  Named registers selected by a uniform branch: the chunk loop
   // stays ROLLED (unrolled, hipcc hoisted every chunk's weight / address work and spilled 339 VGPRs).
@@ -144,6 +144,13 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
 #define DW_GET(ci, v) do { if (ci == 0) v = dw0; else if (ci == 1) v = dw1; else if (ci == 2) v = dw2; else if (ci == 3) v = dw3; else if (ci == 4) v = dw4; else v = dw5; } while (0)
 #define DW_PUT(ci, v) do { if (ci == 0) dw0 = v; else if (ci == 1) dw1 = v; else if (ci == 2) dw2 = v; else if (ci == 3) dw3 = v; else if (ci == 4) dw4 = v; else dw5 = v; } while (0)
   float dgam = 0.f, dbet = 0.f;
+  // depthwise weight-gradient sums of the workgroup: entry e (< 288 = 16 channels x 18) of chunk ci lives in thread e (da*) resp.
+  // thread e - 256 (db*, threads 0..31) - in registers, not in LDS (the 6.9 KB they took hold the staged W1 chunk now)
+  float da0 = 0.f, da1 = 0.f, da2 = 0.f, da3 = 0.f, da4 = 0.f, da5 = 0.f, db0 = 0.f, db1 = 0.f, db2 = 0.f, db3 = 0.f, db4 = 0.f, db5 = 0.f;
+#define DA_ADD(ci, va, vb) do { if (ci == 0) { da0 += va; db0 += vb; } else if (ci == 1) { da1 += va; db1 += vb; } else if (ci == 2) { da2 += va; db2 += vb; } \
+                                else if (ci == 3) { da3 += va; db3 += vb; } else if (ci == 4) { da4 += va; db4 += vb; } else { da5 += va; db5 += vb; } } while (0)
+#define DA_GET(ci, va, vb) do { if (ci == 0) { va = da0; vb = db0; } else if (ci == 1) { va = da1; vb = db1; } else if (ci == 2) { va = da2; vb = db2; } \
+                                else if (ci == 3) { va = da3; vb = db3; } else if (ci == 4) { va = da4; vb = db4; } else { va = da5; vb = db5; } } while (0)
 
   // tile coordinates: first row / column, first pixel row of the image, rows of the tile inside the image (>= 1)
   struct Tc { int y0, x0; unsigned img; int nrows; };
@@ -203,12 +210,25 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
 #pragma unroll
     for (int t = 0; t < 9; ++t) wf_n[t] = f32x2{ldg_off(a.Wdw + (8 - t), pa), ldg_off(a.Wdw + (8 - t), pb)};
   };
+  // the chunk's 32 rows of W1 (16 of group A, 16 of group B): ONE float4 per thread, a chunk ahead, staged through LDS with the G rows;
+  // every lane then reads its 16 B-operand values with LDS loads - they were 16 global dword loads per lane and chunk, a third of
+  // the small loads whose issue stalls (behind the G stream in the memory pipe) cost the kernel ~20 % (tools/probes/stamps)
+  float4 w1pre;
+  auto load_w1 = [&](int ci, int t) {
+    const int r_ = t / (C / 4), q_ = t - r_ * (C / 4), r = r_ < 32 ? r_ : 31;        // C = 16: threads 128.. repeat row 31 (not stored)
+    const int i = r & 15;
+    const int base = r < 16 ? (SPLIT ? 16 * ci : 32 * ci) : (SPLIT ? h + 16 * ci : 32 * ci + 16);
+    const int limA = SPLIT ? h - 16 * ci : ch - 32 * ci;
+    const bool ok = i < (r < 16 || SPLIT ? limA : limA - 16);
+    w1pre = *reinterpret_cast<const float4*>(a.W1 + (unsigned)((ok ? base + i : 0) * C + 4 * q_));
+  };
   {
     UIR_DWLN_COORDS;
     const Tc c0 = coords(blockIdx.x);
 #pragma unroll
     for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it, c0);
     load_wf(0, cp);
+    load_w1(0, t_);
     load_g(0, t_);
     load_xp(0, cp, sx, c0);
   }
@@ -254,7 +274,6 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float rv[16];                                            // the epilogue's residual-gradient values: in flight from the last chunk's (c) on
 
 #pragma unroll 1
     for (int ci = 0; ci < NCH; ++ci) {
@@ -286,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
 #pragma unroll
         for (int t = 0; t < 9; ++t) wf[t] = wf_n[t] * wm;
       }
+      if (t_ / (C / 4) < 32) *reinterpret_cast<float4*>(W1s + (t_ / (C / 4)) * T::SW + 4 * (t_ % (C / 4))) = w1pre;
       lds_barrier2();
       UIR_ST(1);
       // issue order = need order (vmcnt retires in order): this chunk's 1x1 weights now (used after the walk); the next chunk's
@@ -295,22 +315,9 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       // real channel count (last chunk only) are re-pointed at row 0: their dP is exactly zero (masked taps), any finite weight does.
       float w1v[16];
       {
-        const int baseA = SPLIT ? 16 * ci : 32 * ci, baseB = SPLIT ? h + 16 * ci : 32 * ci + 16;
-        const int limA = SPLIT ? h - 16 * ci : ch - 32 * ci, limB = SPLIT ? limA : limA - 16;       // valid channels i < lim
-        const float* wA = a.W1 + (size_t)(unsigned)(baseA * C);                                       // uniform: scalar bases
-        const float* wB = a.W1 + (size_t)(unsigned)(baseB * C);
-        const unsigned lo = (unsigned)(4 * h2 * C + (li < C ? li : C - 1)) * 4u;
-        if (limA >= 16 && limB >= 16) {
+        const float* wp = W1s + 4 * h2 * T::SW + (li < C ? li : C - 1);
 #pragma unroll
-          for (int s = 0; s < 16; ++s) w1v[s] = ldg_off(s < 8 ? wA : wB, lo + (unsigned)((8 * ((s >> 2) & 1) + (s & 3)) * C) * 4u);
-        } else {
-#pragma unroll
-          for (int s = 0; s < 16; ++s) {
-            const int i = 8 * ((s >> 2) & 1) + 4 * h2 + (s & 3);
-            const bool ok = i < (s < 8 ? limA : limB);
-            w1v[s] = ldg_off(ok ? (s < 8 ? wA : wB) : a.W1, ok ? lo + (unsigned)((8 * ((s >> 2) & 1) + (s & 3)) * C) * 4u : 0u);
-          }
-        }
+        for (int s = 0; s < 16; ++s) w1v[s] = wp[((s < 8 ? 0 : 16) + 8 * ((s >> 2) & 1) + (s & 3)) * T::SW];
       }
       const f32x2 xm = f32x2{colok && colA(ci) + cp < chcols ? 1.f : 0.f, colok && colB(ci) + cp < chcols ? 1.f : 0.f};
       // the next unit's G rows (24 of the ~40 KB a chunk moves per workgroup) leave NOW, behind w1v in issue order: their registers
@@ -320,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
 #pragma unroll
         for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it, tn);
       }
+      load_w1(cn, t_);
       load_g(cn, t_);
       UIR_ST(2);
 
@@ -390,8 +398,12 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       UIR_ST(10);
       lds_barrier2();
       UIR_ST(4);
-      for (int e = t_; e < 16 * 18; e += 256)
-        DWA[ci * 288 + e] += (WR[e] + WR[288 + e]) + (WR[576 + e] + WR[864 + e]);
+      {
+        const int e2 = t_ < 32 ? t_ + 256 : t_;             // (threads >= 32 read a valid slot again; their second sum is unused)
+        const float va = (WR[t_] + WR[288 + t_]) + (WR[576 + t_] + WR[864 + t_]);
+        const float vb = (WR[e2] + WR[288 + e2]) + (WR[576 + e2] + WR[864 + e2]);
+        DA_ADD(ci, va, vb);
+      }
       UIR_ST(5);
 
       // ---- (c) dT += dP chunk . W1 chunk (row tile = wave) ----
@@ -402,15 +414,6 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
           const f32x4v v = *reinterpret_cast<const f32x4v*>(gr + 8 * jj);
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc = uir_mfma(v[e], w1v[4 * jj + e], acc);
-        }
-      }
-      if (last) {                                            // uniform; the 16 loads land under (d) instead of stalling the epilogue
-        const int nn = li < C ? li : 0;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int iy = y0 + 2 * wave + (r >> 3), ix = x0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h2;
-          const unsigned m = img + (unsigned)((iy < a.H ? iy : a.H - 1) * a.Wd + (ix < a.Wd ? ix : a.Wd - 1));
-          rv[r] = ldg_off(a.dRes, (m * (unsigned)a.ldr + nn) * 4u);
         }
       }
       UIR_ST(6);
@@ -453,18 +456,20 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     }
 
     // ---- tile epilogue: LayerNorm backward on the dT accumulators (lane = channel, registers = pixels of row tile `wave`).
-    //      Register r is tile row 2 wave + (r >> 3), column (r & 3) + 8 ((r >> 2) & 1) + 4 h2.  The 16 residual-gradient loads were
-    //      issued in the last chunk, behind its (c) ----
+    //      Register r is tile row 2 wave + (r >> 3), column (r & 3) + 8 ((r >> 2) & 1) + 4 h2.  All 16 residual-gradient loads are
+    //      issued first ----
     {
       UIR_DWLN_COORDS;
       const int nn = li < C ? li : 0;
       const float invc = 1.0f / (float)C;
       unsigned mo[16];
+      float rv[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int iy = y0 + 2 * wave + (r >> 3), ix = x0 + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h2;
         const unsigned m = img + (unsigned)((iy < a.H ? iy : a.H - 1) * a.Wd + (ix < a.Wd ? ix : a.Wd - 1));
         mo[r] = (iy < a.H && ix < a.Wd && li < C) ? m : ~0u;
+        rv[r] = ldg_off(a.dRes, (m * (unsigned)a.ldr + nn) * 4u);
       }
       // Passes - LDS operands, arithmetic (two halves of 8 rows: registers), stores.  As one loop every store sat under its own
       // branch, and since vmcnt retires in issue order and the compiler cannot count a store it may have skipped, each iteration's
@@ -541,13 +546,24 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
   }
 #undef DW_GET
 #undef DW_PUT
-  for (int e = t_; e < NCH * 288; e += 256) {
-    const int ci = e / 288, rem = e - ci * 288, c = rem / 18, q = rem - c * 18;
-    const int grp = q / 9, t = q - grp * 9;
-    const bool ok = grp == 0 ? okA(ci, c) : okB(ci, c);
-    const long row = grp == 0 ? rowA(ci, c) : rowB(ci, c);
-    if (ok) slab[row * 9 + (8 - t)] = DWA[e];
+#pragma unroll 1
+  for (int ci = 0; ci < NCH; ++ci) {
+    float va, vb;
+    DA_GET(ci, va, vb);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int rem = t_ + 256 * half;
+      if (rem < 288) {
+        const int c = rem / 18, q = rem - c * 18;
+        const int grp = q / 9, t = q - grp * 9;
+        const bool ok = grp == 0 ? okA(ci, c) : okB(ci, c);
+        const long row = grp == 0 ? rowA(ci, c) : rowB(ci, c);
+        if (ok) slab[row * 9 + (8 - t)] = half == 0 ? va : vb;
+      }
+    }
   }
+#undef DA_ADD
+#undef DA_GET
   {
     const float g = dgam + __shfl_xor(dgam, 32), bsum = dbet + __shfl_xor(dbet, 32);
     lds_barrier2();

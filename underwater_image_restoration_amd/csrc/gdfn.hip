@@ -56,14 +56,20 @@ __device__ __forceinline__ void st4(char* p, const float4& v) {
   __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
 }
 __device__ __forceinline__ void pin(float& x) { asm volatile("" : "+v"(x)); }   // value must be in its VGPR here
+// `ok ? load : 0` written as a select lets hipcc put the load under an exec branch (a conditional VMEM instruction and its wait);
+// loaded from a clamped address and masked by an AND the load is unconditional
+__device__ __forceinline__ float4 keep4(const float4& t, bool ok) {
+  const unsigned m = ok ? 0xffffffffu : 0u;
+  return make_float4(__uint_as_float(__float_as_uint(t.x) & m), __uint_as_float(__float_as_uint(t.y) & m),
+                     __uint_as_float(__float_as_uint(t.z) & m), __uint_as_float(__float_as_uint(t.w) & m));
+}
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));      // four consecutive floats at a 4-byte aligned address
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 
-template <int C, int TH, int TW, bool STORE, int SBM>
+template <int C, int TH, int TW, bool STORE, bool SB>
 __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdArgs a) {
   using T = GdfnTile<C, TH, TW>;
-  constexpr bool SB = SBM >= 1;
-  constexpr bool SPREAD = SBM >= 2;      // EXPERIMENT: the t1 / t2 write-out stores issued between the walk's rows / the (c) units
   extern __shared__ float smem[];
   float* T1s = smem;
   float* Gs = smem + T::NRT1 * 32 * T::S1;
@@ -225,8 +231,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
       const int e = tid + 256 * it, r = e / (C / 4), q = e - r * (C / 4);
       const int cc = c0 + (r & 15);
       const bool ok = cc < h;
-      const float4 t = *reinterpret_cast<const float4*>(a.Win + (long)(ok ? (r < 16 ? cc : h + cc) : 0) * C + 4 * q);
-      stg[it] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+      stg[it] = keep4(*reinterpret_cast<const float4*>(a.Win + (long)(ok ? (r < 16 ? cc : h + cc) : 0) * C + 4 * q), ok);
     }
   };
   auto stage_store = [&](int buf) {               // registers -> LDS
@@ -237,12 +242,26 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     }
   };
   auto load_small = [&](int c0, float (&wo_)[8], float (&w1_)[9], float (&w2_)[9]) {
+    // W_out[my_n][k] for the lane's two groups of four consecutive k: ONE 16-byte load per group (4-byte aligned: a row is h floats)
+    // wherever the whole group is real - every group but the last chunk's; 8 dword loads with 64-bit address arithmetic cost the
+    // chunk ~10 % of its time in issue stalls behind the write-out stores (tools/probes/stamps)
+    const unsigned wrow = (unsigned)(my_n < C ? my_n : 0) * (unsigned)h;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int kk = c0 + 8 * (s >> 2) + 4 * h2 + (s & 3);
-      const bool ok = my_n < C && kk < h;
-      const float t = a.Wout[ok ? (long)my_n * h + kk : 0];
-      wo_[s] = ok ? t : 0.f;
+    for (int g = 0; g < 2; ++g) {
+      const int k0 = c0 + 8 * g + 4 * h2;
+      if (k0 + 4 <= h) {
+        const f32x4u t = *reinterpret_cast<const f32x4u*>(a.Wout + (wrow + (unsigned)k0));
+        const unsigned m = my_n < C ? 0xffffffffu : 0u;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) wo_[4 * g + e] = __uint_as_float(__float_as_uint(t[e]) & m);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = my_n < C && k0 + e < h;
+          const float t = a.Wout[ok ? wrow + (unsigned)(k0 + e) : 0u];
+          wo_[4 * g + e] = ok ? t : 0.f;
+        }
+      }
     }
     const int cc = c0 + cp;
     const bool ok = cc < h;
@@ -260,10 +279,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     const bool ok = cc < h;
     const float* wr = a.Win + (long)(ok ? (li < 16 ? cc : h + cc) : 0) * C + 4 * h2;
 #pragma unroll
-    for (int jj = 0; jj < NPF; ++jj) {
-      const float4 t = *reinterpret_cast<const float4*>(wr + 8 * jj);
-      win_[jj] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int jj = 0; jj < NPF; ++jj) win_[jj] = keep4(*reinterpret_cast<const float4*>(wr + 8 * jj), ok);
   };
   // SB: only W_in is fetched a chunk ahead (it is needed first, at the top of (a)); W_out and the depthwise taps of the CURRENT chunk
   // are loaded at its top and land under (a) - the bf16 planes of the A operand take the registers of the second small-weight set
@@ -395,7 +411,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         st4(reinterpret_cast<char*>(a.T2) + (st_off[it] + (unsigned)c0 * cbytes), v);
       }
     };
-    if (STORE && !SPREAD) {
+    if (STORE) {
 #pragma unroll
       for (int it = 0; it < T::NST; ++it) t1_store(it);
     }
@@ -432,27 +448,11 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         gdst[16] = t.y;
         gdst += TW * T::SG;
       };
-      if constexpr (SPREAD && STORE) {
-        // the write-out stores ride between the rows of the walk: a burst of NST 1-KB stores per wave stalls at issue behind the
-        // memory pipe (tools/probes/stamps: 10 % of the kernel per write-out), spread out they drain under the VALU work
-        constexpr int NIT = (T::ROWS + 2) / 3, SPI = (T::NST + NIT - 1) / NIT;
-#pragma unroll
-        for (int yi = 0; yi < NIT; ++yi) {
-          const int yb = 3 * yi;
-#pragma unroll
-          for (int q = 0; q < SPI; ++q)
-            if (yi * SPI + q < T::NST) t1_store(yi * SPI + q);
-          step(rw[0], rw[1], rw[2]);
-          if (yb + 1 < T::ROWS) step(rw[1], rw[2], rw[0]);
-          if (yb + 2 < T::ROWS) step(rw[2], rw[0], rw[1]);
-        }
-      } else {
 #pragma unroll 1
       for (int yb = 0; yb < T::ROWS; yb += 3) {
         step(rw[0], rw[1], rw[2]);
         if (yb + 1 < T::ROWS) step(rw[1], rw[2], rw[0]);
         if (yb + 2 < T::ROWS) step(rw[2], rw[0], rw[1]);
-      }
       }
     }
     UIR_ST(4);
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     UIR_ST(5);
 
     // ---- T2 write-out (training) ----
-    if (STORE && !SPREAD) {
+    if (STORE) {
 #pragma unroll
       for (int it = 0; it < T::NST; ++it) t2_store(it);
     }
@@ -471,12 +471,6 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     if constexpr (SB) wop = uir_split8(wo);
 #pragma unroll
     for (int j = 0; j < T::UPW; ++j) {
-      if constexpr (SPREAD && STORE) {
-        constexpr int SPU = (T::NST + T::UPW - 1) / T::UPW;
-#pragma unroll
-        for (int q = 0; q < SPU; ++q)
-          if (j * SPU + q < T::NST) t2_store(j * SPU + q);
-      }
       const int u = wave + 4 * j;
       if (u < T::UNITS) {
         const int rt = u / T::NT;
@@ -652,10 +646,7 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
       const bool ok = cc < HD;
       const float* wr = a.Wqkv + (long)(ok ? cc : 0) * C + 4 * h2;
 #pragma unroll
-      for (int jj = 0; jj < T::KJ; ++jj) {
-        const float4 t = *reinterpret_cast<const float4*>(wr + 8 * jj);
-        win[jj] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int jj = 0; jj < T::KJ; ++jj) win[jj] = keep4(*reinterpret_cast<const float4*>(wr + 8 * jj), ok);
     }
     {
       const int c1 = c0 + cp, c2 = c0 + 16 + cp;
@@ -894,10 +885,7 @@ __global__ __launch_bounds__(256, 2) void uir_attnv_fwd_kernel(const UirAttnvFwd
       const bool ok = cc < C;
       const float* wr = WA + (long)(ok ? cc : 0) * C + 4 * h2;
 #pragma unroll
-      for (int jj = 0; jj < T::KJ; ++jj) {
-        const float4 t = *reinterpret_cast<const float4*>(wr + 8 * jj);
-        wa[jj] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
+      for (int jj = 0; jj < T::KJ; ++jj) wa[jj] = keep4(*reinterpret_cast<const float4*>(wr + 8 * jj), ok);
     }
     float4 wb[4];   // (c) B operand: WB[my_n][c0 + 8 jj + 4 h2 + e]
     {
@@ -906,8 +894,7 @@ __global__ __launch_bounds__(256, 2) void uir_attnv_fwd_kernel(const UirAttnvFwd
 #pragma unroll
       for (int jj = 0; jj < 4; ++jj) {
         const bool ok = nok && (c0 + 8 * jj + 4 * h2) < C;
-        const float4 t = *reinterpret_cast<const float4*>(wr + (ok ? 8 * jj : 0));
-        wb[jj] = ok ? t : make_float4(0.f, 0.f, 0.f, 0.f);
+        wb[jj] = keep4(*reinterpret_cast<const float4*>(wr + (ok ? 8 * jj : 0)), ok);
       }
     }
     f32x2 wv[9];
@@ -1085,12 +1072,11 @@ int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
   const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
   const size_t lds = ((size_t)T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : 0)) * 4;   // + two staged W_in chunks
-  const int sb = uir_fused_split();
-  if (a.T1) { if (sb == 2) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, 2>), dim3(tiles), dim3(256), lds, st, a);
-              else if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, 1>), dim3(tiles), dim3(256), lds, st, a);
-              else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, 0>), dim3(tiles), dim3(256), lds, st, a); }
-  else { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, 1>), dim3(tiles), dim3(256), lds, st, a);
-         else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, 0>), dim3(tiles), dim3(256), lds, st, a); }
+  const bool sb = uir_fused_split() != 0;
+  if (a.T1) { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, true>), dim3(tiles), dim3(256), lds, st, a);
+              else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, false>), dim3(tiles), dim3(256), lds, st, a); }
+  else { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, true>), dim3(tiles), dim3(256), lds, st, a);
+         else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, false>), dim3(tiles), dim3(256), lds, st, a); }
   return uir_launch_status();
 }
 

@@ -817,7 +817,6 @@ int uir_mixed_mode() {
 int uir_fused_split() {
   static const int mode = [] {
     const char* v = getenv("UIR_FUSED_SPLIT");
-    if (v && v[0] == '2' && !v[1]) return 2;     // EXPERIMENT (round 4): spread write-out stores in uir_gdfn_fwd
     return (v && v[0] == '0' && !v[1]) ? 0 : 1;
   }();
   return mode;
