@@ -361,12 +361,33 @@ int uir_dft_axis(const UirDftArgs* args, void* stream);
  * matrix cores (4x fewer MFMAs at N = 128).  ta / tb are host-built (fp64) MFMA operand tables for this
  * (N, sign): ta[16][64] = stage-A operand per (k-step, lane); tb[8][2*N2][64] = stage-B block-diagonal operand
  * per (k1 pair, k-step, lane) with the inter-stage twiddle folded in (layout: csrc/spectral.hip, engine.dft2_tables). */
+/* Round 4: the element-wise neighbours of UpSample's transforms (SpectralTransformer.py:176-186 and their adjoints) ride on the
+ * transform that produces / consumes their operand, so the complex planes between them never reach HBM:
+ *   pro  UIR_DFT_PRO_POLAR       input z = in_re * exp(i in_im)                       (torch.complex(Mag cos, Mag sin), :183-185)
+ *        UIR_DFT_PRO_CABS_BWD    input z = in_re / aux2 * (aux0 + i aux1), 0 where aux2 == 0     (adjoint of |z|: in_re = g_t,
+ *                                aux0 / aux1 / aux2 = Re z, Im z, |z| saved by the forward)
+ *        UIR_DFT_PRO_MAGPHA_BWD  input (g_re, g_im) of uir_magpha_bwd from in_re = g_mag, in_im = g_pha, aux0 = mag, aux1 = pha
+ *   epi  UIR_DFT_EPI_MAGPHA      out_re = |F|, out_im = atan2(Im, Re), Im := +0 at the self-conjugate bins (uir_magpha_fwd; the
+ *                                transform must be the H axis of a [B][H][W][C] tensor: O = B, N = H, I = W)
+ *        UIR_DFT_EPI_CABS        out_re / out_im as usual and aux_out = |out|                                    (:186)
+ *        UIR_DFT_EPI_POLAR_BWD   out_re = g_mag, out_im = g_pha of uir_polar_bwd with aux0 = mag, aux1 = pha at the output element */
+#define UIR_DFT_PRO_NONE 0
+#define UIR_DFT_PRO_POLAR 1
+#define UIR_DFT_PRO_CABS_BWD 2
+#define UIR_DFT_PRO_MAGPHA_BWD 3
+#define UIR_DFT_EPI_NONE 0
+#define UIR_DFT_EPI_MAGPHA 1
+#define UIR_DFT_EPI_CABS 2
+#define UIR_DFT_EPI_POLAR_BWD 3
 typedef struct UirDft2Args {
   const float* in_re; const float* in_im;   /* in_im may be NULL (real input)                    */
   float* out_re; float* out_im;             /* out_im may be NULL (only the real part wanted)    */
   const float* ta; const float* tb;
   int O, N, I, C;                            /* tensor viewed as [O][N][I][C], transform along N  */
   float scale;
+  int pro, epi;                              /* UIR_DFT_PRO_* / UIR_DFT_EPI_* (at most one of them non-zero)          */
+  const float* aux0; const float* aux1; const float* aux2;   /* element-wise operands, same [O][N][I][C] layout       */
+  float* aux_out;                            /* UIR_DFT_EPI_CABS: |out|                                               */
 } UirDft2Args;
 int uir_dft_axis2(const UirDft2Args* args, void* stream);
 

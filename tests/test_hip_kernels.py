@@ -722,6 +722,56 @@ def test_dft_matches_fft2_and_adjoint(B, H, W, C):
     assert rel(chw(dxr, B, H, W), dx) < TOL
 
 
+@pytest.mark.parametrize("S,C", [(32, 128), (64, 64), (128, 32), (32, 40)])
+def test_dft_with_fused_elementwise_neighbours(S, C):
+    """UirDft2Args.pro / .epi (round 4): mag / pha, the polar form, |.| and their adjoints applied inside the transform that produces /
+    consumes them, against fp64 torch on the same operands - the whole FFT branch of UpSample (SpectralTransformer.py:176-186) forward
+    and its hand-written backward, at the three sizes the two-stage DFT kernel runs (a partial channel tile included)."""
+    B, H, W = 2, S, S
+    M = B * H * W
+    x = rnd(B, C, H, W, seed=1)
+    f = torch.fft.fft2(x)
+    mag_ref, pha_ref = f.abs(), torch.angle(f)
+    r = rec()
+    ar, ai, mag, pha = (r.alloc(M, C) for _ in range(4))
+    r.dft("w", dev(hwc(x)), None, ar, ai, O=B * H, N=W, I=1, C_=C, sign=-1.0, scale=1.0)
+    r.dft("h+magpha", ar, ai, mag, pha, O=B, N=H, I=W, C_=C, sign=-1.0, scale=1.0, epi=L.DFT_EPI_MAGPHA)
+    # polar -> ifft2 -> abs from arbitrary (Mag, Pha)
+    Mg = (rnd(B, C, H, W, seed=2) + 1.5).requires_grad_(True)
+    Ph = (3 * rnd(B, C, H, W, seed=3)).requires_grad_(True)
+    z = torch.complex(Mg * torch.cos(Ph), Mg * torch.sin(Ph))
+    t_ref = torch.fft.ifft2(z).abs()
+    gt = rnd(B, C, H, W, seed=4)
+    gM_ref, gP_ref = torch.autograd.grad((t_ref * gt).sum(), (Mg, Ph))
+    Md, Pd = dev(hwc(Mg.detach())), dev(hwc(Ph.detach()))
+    cr, ci, tr, ti, t = (r.alloc(M, C) for _ in range(5))
+    r.dft("polar+ih", Md, Pd, cr, ci, O=B, N=H, I=W, C_=C, sign=1.0, scale=1.0, pro=L.DFT_PRO_POLAR)
+    r.dft("iw+cabs", cr, ci, tr, ti, O=B * H, N=W, I=1, C_=C, sign=1.0, scale=1.0 / (H * W), epi=L.DFT_EPI_CABS, aux_out=t)
+    gcr, gci, gM, gP = (r.alloc(M, C) for _ in range(4))
+    r.dft("cabs_bwd+iw_bwd", dev(hwc(gt)), None, gcr, gci, O=B * H, N=W, I=1, C_=C, sign=-1.0, scale=1.0 / (H * W),
+          pro=L.DFT_PRO_CABS_BWD, aux=(tr, ti, t))
+    r.dft("ih_bwd+polar_bwd", gcr, gci, gM, gP, O=B, N=H, I=W, C_=C, sign=-1.0, scale=1.0, epi=L.DFT_EPI_POLAR_BWD, aux=(Md, Pd))
+    # (g_mag, g_pha) -> gradient of the real input through magpha_bwd + the adjoint transforms
+    xx = x.clone().requires_grad_(True)
+    ff = torch.fft.fft2(xx)
+    gm, gp = rnd(B, C, H, W, seed=5), rnd(B, C, H, W, seed=6)
+    (dx_ref,) = torch.autograd.grad((ff.abs() * gm).sum() + (torch.angle(ff) * gp).sum(), (xx,))
+    gar, gai, dx = (r.alloc(M, C) for _ in range(3))
+    r.dft("magpha_bwd+h_bwd", dev(hwc(gm)), dev(hwc(gp)), gar, gai, O=B, N=H, I=W, C_=C, sign=1.0, scale=1.0,
+          pro=L.DFT_PRO_MAGPHA_BWD, aux=(mag, pha))
+    r.dft("w_bwd", gar, gai, dx, None, O=B * H, N=W, I=1, C_=C, sign=1.0, scale=1.0)
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    assert rel(chw(mag, B, H, W), mag_ref) < TOL
+    # phase: compare as unit phasors where the magnitude is not tiny (the angle of a ~0 bin is ill-conditioned; +-pi are one point)
+    pc = chw(pha, B, H, W).double().cpu()
+    ok = mag_ref > 1e-3 * mag_ref.max()
+    assert float((torch.cos(pc) - torch.cos(pha_ref)).abs()[ok].max()) < 1e-4 and float((torch.sin(pc) - torch.sin(pha_ref)).abs()[ok].max()) < 1e-4
+    assert rel(chw(t, B, H, W), t_ref.detach()) < TOL
+    assert rel(chw(gM, B, H, W), gM_ref) < 5 * TOL and rel(chw(gP, B, H, W), gP_ref) < 5 * TOL
+    assert rel(chw(dx, B, H, W), dx_ref) < 5 * TOL
+
+
 def test_spectral_elementwise_and_adjoints():
     B, H, W, C = 2, 8, 8, 32
     x = rnd(B, C, H, W, seed=1)

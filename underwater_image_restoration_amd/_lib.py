@@ -138,9 +138,12 @@ class DftArgs(C.Structure):
 
 class Dft2Args(C.Structure):
     _fields_ = [("in_re", fp), ("in_im", fp), ("out_re", fp), ("out_im", fp), ("ta", fp), ("tb", fp),
-                ("O", C.c_int), ("N", C.c_int), ("I", C.c_int), ("C", C.c_int), ("scale", C.c_float)]
+                ("O", C.c_int), ("N", C.c_int), ("I", C.c_int), ("C", C.c_int), ("scale", C.c_float),
+                ("pro", C.c_int), ("epi", C.c_int), ("aux0", fp), ("aux1", fp), ("aux2", fp), ("aux_out", fp)]
 
 
+DFT_PRO_POLAR, DFT_PRO_CABS_BWD, DFT_PRO_MAGPHA_BWD = 1, 2, 3
+DFT_EPI_MAGPHA, DFT_EPI_CABS, DFT_EPI_POLAR_BWD = 1, 2, 3
 RESIZE_SRC_SLACK = 16
 
 

@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256) void uir_dft_kernel(const UirDftArgs a, int ct
 // k1 in {0-3, 8-11}, half 1 owns k1 + 4.  Stage B therefore transforms the PAIR (k1, k1 + 4) per MFMA tile with a
 // block-diagonal operand (rows (which k1, Re|Im, k2), contraction (n2, Re|Im) x lane half): its B operand is simply
 // accumulator register j (+8 for Im) of stage A - no shuffles, no LDS.  Operand tables are built on the host in fp64.
-template <int N2>
+// PRO / EPI (UirDft2Args.pro / .epi): the element-wise op in front of / behind the transform is applied where its operand sits in
+// registers - on the loaded line resp. on the (Re, Im) register pair of an output element - with the arithmetic of the stand-alone
+// kernels below (uir_polar_fwd, uir_cabs_bwd, uir_magpha_bwd / uir_magpha_fwd, uir_cabs_fwd, uir_polar_bwd).
+template <int N2, int PRO, int EPI>
 __global__ __launch_bounds__(256) void uir_dft2_kernel(const UirDft2Args a, int ctiles, long items) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 31, h2 = lane >> 5;
@@ -122,26 +125,65 @@ __global__ __launch_bounds__(256) void uir_dft2_kernel(const UirDft2Args a, int 
   for (int s = 0; s < 16; ++s) ta[s] = a.ta[s * 64 + lane];
 
   f32x16 D[N2];
+  // fused-path trigonometry: hardware sine / cosine behind a fract range reduction (__sincosf, ~1e-6 absolute); the library sincosf's
+  // large-argument path needs a scratch table, which costs this register-full kernel its occupancy
+  auto conv = [&](float& re, float& im, float x0, float x1, float x2) {
+    if (PRO == UIR_DFT_PRO_POLAR) {
+      float sn, cs;
+      __sincosf(im, &sn, &cs);
+      const float m = re;
+      re = m * cs;
+      im = m * sn;
+    } else if (PRO == UIR_DFT_PRO_CABS_BWD) {
+      const float q = x2 > 0.f ? re / x2 : 0.f;
+      re = q * x0;
+      im = q * x1;
+    } else if (PRO == UIR_DFT_PRO_MAGPHA_BWD) {
+      float sn, cs;
+      __sincosf(x1, &sn, &cs);
+      float ga = 0.f, gb = 0.f;
+      if (x0 > 0.f) {
+        const float q = im / x0;
+        ga = re * cs - q * sn;
+        gb = re * sn + q * cs;
+      }
+      re = ga;
+      im = gb;
+    }
+  };
 #pragma unroll
   for (int n2 = 0; n2 < N2; ++n2) {
-    float br[8], bi[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const long off = line + (long)(N2 * (2 * s + h2) + n2) * nstride + cc;
-      br[s] = a.in_re[off];
-      bi[s] = imp[off];
-    }
-    // all 16 loads of this n2 in flight before its MFMAs: hipcc sinks each imaginary-part load next to the MFMA that consumes it
-    // (`global_load_dword; s_waitcnt vmcnt(0); v_mfma`, eight serialised round trips per n2) when left to schedule freely
-    __builtin_amdgcn_sched_barrier(0);
     f32x16 d;
 #pragma unroll
     for (int q = 0; q < 16; ++q) d[q] = 0.f;
+    // PRO: two half batches of 4 k-steps (their extra operands would not fit beside the N2 accumulators otherwise)
+    constexpr int NB = PRO == UIR_DFT_PRO_NONE ? 1 : 2, SB = 8 / NB;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) d = uir_mfma(ta[s], cok ? br[s] : 0.f, d);
-    if (has_im) {
+    for (int hb = 0; hb < NB; ++hb) {
+      float br[SB], bi[SB], x0[SB], x1[SB], x2[SB];
 #pragma unroll
-      for (int s = 0; s < 8; ++s) d = uir_mfma(ta[8 + s], cok ? bi[s] : 0.f, d);
+      for (int t = 0; t < SB; ++t) {
+        const int s = SB * hb + t;
+        const long off = line + (long)(N2 * (2 * s + h2) + n2) * nstride + cc;
+        br[t] = a.in_re[off];
+        bi[t] = imp[off];
+        x0[t] = x1[t] = x2[t] = 0.f;
+        if (PRO == UIR_DFT_PRO_CABS_BWD) { x0[t] = a.aux0[off]; x1[t] = a.aux1[off]; x2[t] = a.aux2[off]; }
+        if (PRO == UIR_DFT_PRO_MAGPHA_BWD) { x0[t] = a.aux0[off]; x1[t] = a.aux1[off]; }
+      }
+      // all loads of the batch in flight before its MFMAs: hipcc sinks each imaginary-part load next to the MFMA that consumes it
+      // (`global_load_dword; s_waitcnt vmcnt(0); v_mfma`, eight serialised round trips per n2) when left to schedule freely
+      __builtin_amdgcn_sched_barrier(0);
+      if (PRO != UIR_DFT_PRO_NONE) {
+#pragma unroll
+        for (int t = 0; t < SB; ++t) conv(br[t], bi[t], x0[t], x1[t], x2[t]);
+      }
+#pragma unroll
+      for (int t = 0; t < SB; ++t) d = uir_mfma(ta[SB * hb + t], cok ? br[t] : 0.f, d);
+      if (has_im || PRO != UIR_DFT_PRO_NONE) {
+#pragma unroll
+        for (int t = 0; t < SB; ++t) d = uir_mfma(ta[8 + SB * hb + t], cok ? bi[t] : 0.f, d);
+      }
     }
     D[n2] = d;
   }
@@ -156,7 +198,7 @@ __global__ __launch_bounds__(256) void uir_dft2_kernel(const UirDft2Args a, int 
 #pragma unroll
     for (int s = 0; s < 2 * N2; ++s) e = uir_mfma(tb[s], D[s >> 1][j + 8 * (s & 1)], e);
     const int aj = (j & 3) + 8 * (j >> 2);          // k1 of lane half 0; half 1 holds k1 + 4 ... as ROW blocks w = 0 / 1
-    if (cok) {
+    if (cok && EPI == UIR_DFT_EPI_NONE) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int k2 = (q & 3) + 4 * h2, p = (q >> 2) & 1, w = q >> 3;
@@ -164,6 +206,38 @@ __global__ __launch_bounds__(256) void uir_dft2_kernel(const UirDft2Args a, int 
           const int k = aj + 4 * w + 16 * k2;
           float* dst = p ? a.out_im : a.out_re;
           dst[line + (long)k * nstride + c] = e[q] * a.scale;
+        }
+      }
+    }
+    if (cok && EPI != UIR_DFT_EPI_NONE) {
+      // output element k: Re in register q (p = 0), Im in register q + 4
+#pragma unroll
+      for (int qq = 0; qq < 8; ++qq) {
+        const int q = (qq & 3) + 8 * (qq >> 2);
+        const int k2 = (q & 3) + 4 * h2, w = q >> 3;
+        if (k2 < N2) {
+          const int k = aj + 4 * w + 16 * k2;
+          const long dst = line + (long)k * nstride + c;
+          const float re = e[q] * a.scale;
+          float im = e[q + 4] * a.scale;
+          if (EPI == UIR_DFT_EPI_MAGPHA) {
+            // H-axis transform of [B][H][W][C]: h = k, w = i; Im is exactly +0 at the self-conjugate bins of a real signal
+            const bool hs = (k == 0) || (((N & 1) == 0) && k == N / 2);
+            const bool ws = (i == 0) || (((a.I & 1) == 0) && i == a.I / 2);
+            if (hs && ws) im = 0.0f;
+            a.out_re[dst] = sqrtf(re * re + im * im);
+            a.out_im[dst] = atan2f(im, re);
+          } else if (EPI == UIR_DFT_EPI_CABS) {
+            a.out_re[dst] = re;
+            a.out_im[dst] = im;
+            a.aux_out[dst] = sqrtf(re * re + im * im);
+          } else {
+            float sn, cs;
+            __sincosf(a.aux1[dst], &sn, &cs);
+            const float m = a.aux0[dst];
+            a.out_re[dst] = re * cs + im * sn;
+            a.out_im[dst] = m * (im * cs - re * sn);
+          }
         }
       }
     }
@@ -304,10 +378,24 @@ extern "C" int uir_dft_axis2(const UirDft2Args* p, void* stream) {
   const long blocks = (items + 3) / 4;
   UIR_REQUIRE(blocks < (1L << 31));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  switch (a.N) {
-    case 32: hipLaunchKernelGGL(uir_dft2_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, st, a, ctiles, items); break;
-    case 64: hipLaunchKernelGGL(uir_dft2_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, st, a, ctiles, items); break;
-    default: hipLaunchKernelGGL(uir_dft2_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, st, a, ctiles, items); break;
-  }
+  UIR_REQUIRE(a.pro >= 0 && a.pro <= 3 && a.epi >= 0 && a.epi <= 3 && (a.pro == 0 || a.epi == 0));
+  if (a.pro == UIR_DFT_PRO_POLAR) UIR_REQUIRE(a.in_im);
+  if (a.pro == UIR_DFT_PRO_CABS_BWD) UIR_REQUIRE(a.aux0 && a.aux1 && a.aux2);
+  if (a.pro == UIR_DFT_PRO_MAGPHA_BWD) UIR_REQUIRE(a.in_im && a.aux0 && a.aux1);
+  if (a.epi != UIR_DFT_EPI_NONE) UIR_REQUIRE(a.out_im);
+  if (a.epi == UIR_DFT_EPI_CABS) UIR_REQUIRE(a.aux_out);
+  if (a.epi == UIR_DFT_EPI_POLAR_BWD) UIR_REQUIRE(a.aux0 && a.aux1);
+  const dim3 g((unsigned)blocks), b(256);
+#define UIR_D2(N2V, PV, EV) hipLaunchKernelGGL((uir_dft2_kernel<N2V, PV, EV>), g, b, 0, st, a, ctiles, items)
+#define UIR_D2N(PV, EV) do { if (a.N == 32) UIR_D2(2, PV, EV); else if (a.N == 64) UIR_D2(4, PV, EV); else UIR_D2(8, PV, EV); } while (0)
+  if (a.pro == UIR_DFT_PRO_POLAR) UIR_D2N(UIR_DFT_PRO_POLAR, 0);
+  else if (a.pro == UIR_DFT_PRO_CABS_BWD) UIR_D2N(UIR_DFT_PRO_CABS_BWD, 0);
+  else if (a.pro == UIR_DFT_PRO_MAGPHA_BWD) UIR_D2N(UIR_DFT_PRO_MAGPHA_BWD, 0);
+  else if (a.epi == UIR_DFT_EPI_MAGPHA) UIR_D2N(0, UIR_DFT_EPI_MAGPHA);
+  else if (a.epi == UIR_DFT_EPI_CABS) UIR_D2N(0, UIR_DFT_EPI_CABS);
+  else if (a.epi == UIR_DFT_EPI_POLAR_BWD) UIR_D2N(0, UIR_DFT_EPI_POLAR_BWD);
+  else UIR_D2N(0, 0);
+#undef UIR_D2N
+#undef UIR_D2
   return uir_launch_status();
 }

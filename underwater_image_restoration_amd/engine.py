@@ -39,6 +39,7 @@ EXPANSION = 2.66
 LN_EPS = 1e-5
 # Which tile-fused kernels each level uses is fixed here (measured choices, profiles/r01/d_ab_notes.md), not read from the
 # environment: the only environment variables the product reads are listed in knobs.py.
+FUSED_DFT_SIZES = (32, 64, 128)   # axis lengths of the two-stage DFT kernel, which carries UpSample's element-wise ops (UirDft2Args.pro / .epi)
 _ATTNV_FUSED = (32, 64)        # MDTA tail as uir_attnv_fwd; C = 16 / 128: half-empty tiles / one workgroup per CU, three kernels are as fast
 SCRATCH_FLOATS = 96 * 1024 * 1024  # 384 MB of slab scratch shared by every reduction
 
@@ -890,13 +891,19 @@ class Recorder:
         self._op(name, lib.uir_copy_cols, _ptr(src), _ld(src), scol, _ptr(dst), _ld(dst), dcol, src.shape[0], C_, accumulate,
                  nbytes=4 * src.shape[0] * C_ * (3 if accumulate else 2))
 
-    def dft(self, name, in_re, in_im, out_re, out_im, *, O, N, I, C_, sign, scale):
-        self._hold(in_re, in_im, out_re, out_im)
+    def dft(self, name, in_re, in_im, out_re, out_im, *, O, N, I, C_, sign, scale, pro=0, epi=0, aux=(), aux_out=None):
+        """pro / epi (L.DFT_PRO_* / L.DFT_EPI_*, two-stage kernel only): the element-wise op in front of / behind the transform rides on it
+        (include/uir_kernels.h UirDft2Args); aux = its extra operands, aux_out = |out| of DFT_EPI_CABS."""
+        self._hold(in_re, in_im, out_re, out_im, aux_out, *aux)
         elems = O * N * I * C_
-        planes = (1 if in_im is None else 2) + (1 if out_im is None else 2)
+        planes = (1 if in_im is None else 2) + (1 if out_im is None else 2) + len(aux) + (1 if aux_out is not None else 0)
+        assert (pro == 0 and epi == 0) or N in (32, 64, 128), "fused element-wise forms exist on the two-stage DFT kernel only"
         if N in (32, 64, 128):
             a = L.Dft2Args()
             a.in_re, a.in_im, a.out_re, a.out_im = _ptr(in_re), _ptr(in_im), _ptr(out_re), _ptr(out_im)
+            a.pro, a.epi = pro, epi
+            ax = list(aux) + [None] * (3 - len(aux))
+            a.aux0, a.aux1, a.aux2, a.aux_out = _ptr(ax[0]), _ptr(ax[1]), _ptr(ax[2]), _ptr(aux_out)
             ta, tb = dft2_tables(N, sign, self.dev)
             self.keep += [ta, tb]
             a.ta, a.tb = _ptr(ta), _ptr(tb)
@@ -1185,19 +1192,32 @@ class Plan(Recorder):
         M = B * H * W
         Ch = C_ // 2
         f = f"{pfx}.Fups"
-        ar, ai, fr, fi = (self.alloc(M, C_) for _ in range(4))
+        ar, ai = self.alloc(M, C_), self.alloc(M, C_)
         mag, pha = self.alloc(M, C_), self.alloc(M, C_)
+        # the spectrum's element-wise neighbours ride on the transforms where the two-stage DFT kernel runs them (H, W in {32, 64,
+        # 128}: every level of a 256 x 256 input): mag / pha, the polar form, |.| and their adjoints never make a round trip
+        # through HBM as separate launches (round 4)
+        fuse_ew = H in FUSED_DFT_SIZES and W in FUSED_DFT_SIZES
         self.dft(f + ".dftW", x, None, ar, ai, O=B * H, N=W, I=1, C_=C_, sign=-1.0, scale=1.0)
-        self.dft(f + ".dftH", ar, ai, fr, fi, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0)
-        self._op(f + ".magpha", lib.uir_magpha_fwd, _ptr(fr), _ptr(fi), _ptr(mag), _ptr(pha), B, H, W, C_)
+        if fuse_ew:
+            self.dft(f + ".dftH+magpha", ar, ai, mag, pha, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0, epi=L.DFT_EPI_MAGPHA)
+        else:
+            fr, fi = self.alloc(M, C_), self.alloc(M, C_)
+            self.dft(f + ".dftH", ar, ai, fr, fi, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0)
+            self._op(f + ".magpha", lib.uir_magpha_fwd, _ptr(fr), _ptr(fi), _ptr(mag), _ptr(pha), B, H, W, C_)
         Mag, amp_bw = self._fuse(f + ".amp_fuse", mag, C_)
         Pha, pha_bw = self._fuse(f + ".pha_fuse", pha, C_)
-        zr, zi, cr, ci, tr, ti = (self.alloc(M, C_) for _ in range(6))
+        cr, ci, tr, ti = (self.alloc(M, C_) for _ in range(4))
         t = self.alloc(M, C_)
-        self._op(f + ".polar", lib.uir_polar_fwd, _ptr(Mag), _ptr(Pha), _ptr(zr), _ptr(zi), M * C_)
-        self.dft(f + ".idftH", zr, zi, cr, ci, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0)
-        self.dft(f + ".idftW", cr, ci, tr, ti, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0 / (H * W))
-        self._op(f + ".cabs", lib.uir_cabs_fwd, _ptr(tr), _ptr(ti), _ptr(t), M * C_)
+        if fuse_ew:
+            self.dft(f + ".polar+idftH", Mag, Pha, cr, ci, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0, pro=L.DFT_PRO_POLAR)
+            self.dft(f + ".idftW+cabs", cr, ci, tr, ti, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0 / (H * W), epi=L.DFT_EPI_CABS, aux_out=t)
+        else:
+            zr, zi = self.alloc(M, C_), self.alloc(M, C_)
+            self._op(f + ".polar", lib.uir_polar_fwd, _ptr(Mag), _ptr(Pha), _ptr(zr), _ptr(zi), M * C_)
+            self.dft(f + ".idftH", zr, zi, cr, ci, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0)
+            self.dft(f + ".idftW", cr, ci, tr, ti, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0 / (H * W))
+            self._op(f + ".cabs", lib.uir_cabs_fwd, _ptr(tr), _ptr(ti), _ptr(t), M * C_)
         Wpost, bpost = self.P(f + ".post.weight"), self.P(f + ".post.bias")
         po = self.alloc(M, Ch)
         self.gemm(f + ".post", t, Wpost, po, N=Ch, K=C_, w_sn=C_, w_sk=1, bias=bpost)
@@ -1230,17 +1250,29 @@ class Plan(Recorder):
                 self.gram(f + ".post.dW", dpo, t, self.Gr(f + ".post.weight"), N=Ch, K=C_, o_sn=C_, o_sk=1)
             dtt = self.alloc(M, C_)
             self.gemm(f + ".post.dX", dpo, Wpost, dtt, N=C_, K=Ch, w_sn=1, w_sk=C_)
-            gtr, gti, gcr, gci, gzr, gzi = (self.alloc(M, C_) for _ in range(6))
-            self._op(f + ".cabs_bwd", lib.uir_cabs_bwd, _ptr(tr), _ptr(ti), _ptr(t), _ptr(dtt), _ptr(gtr), _ptr(gti), M * C_)
-            self.dft(f + ".idftW_bwd", gtr, gti, gcr, gci, O=B * H, N=W, I=1, C_=C_, sign=-1.0, scale=1.0 / (H * W))
-            self.dft(f + ".idftH_bwd", gcr, gci, gzr, gzi, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0)
+            gcr, gci = self.alloc(M, C_), self.alloc(M, C_)
             gMag, gPha = self.alloc(M, C_), self.alloc(M, C_)
-            self._op(f + ".polar_bwd", lib.uir_polar_bwd, _ptr(Mag), _ptr(Pha), _ptr(gzr), _ptr(gzi), _ptr(gMag), _ptr(gPha), M * C_)
+            if fuse_ew:
+                self.dft(f + ".cabs_bwd+idftW_bwd", dtt, None, gcr, gci, O=B * H, N=W, I=1, C_=C_, sign=-1.0, scale=1.0 / (H * W),
+                         pro=L.DFT_PRO_CABS_BWD, aux=(tr, ti, t))
+                self.dft(f + ".idftH_bwd+polar_bwd", gcr, gci, gMag, gPha, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0,
+                         epi=L.DFT_EPI_POLAR_BWD, aux=(Mag, Pha))
+            else:
+                gtr, gti, gzr, gzi = (self.alloc(M, C_) for _ in range(4))
+                self._op(f + ".cabs_bwd", lib.uir_cabs_bwd, _ptr(tr), _ptr(ti), _ptr(t), _ptr(dtt), _ptr(gtr), _ptr(gti), M * C_)
+                self.dft(f + ".idftW_bwd", gtr, gti, gcr, gci, O=B * H, N=W, I=1, C_=C_, sign=-1.0, scale=1.0 / (H * W))
+                self.dft(f + ".idftH_bwd", gcr, gci, gzr, gzi, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0)
+                self._op(f + ".polar_bwd", lib.uir_polar_bwd, _ptr(Mag), _ptr(Pha), _ptr(gzr), _ptr(gzi), _ptr(gMag), _ptr(gPha), M * C_)
             gmag = amp_bw(gMag)
             gpha = pha_bw(gPha)
-            gfr, gfi, gar, gai = (self.alloc(M, C_) for _ in range(4))
-            self._op(f + ".magpha_bwd", lib.uir_magpha_bwd, _ptr(mag), _ptr(pha), _ptr(gmag), _ptr(gpha), _ptr(gfr), _ptr(gfi), M * C_)
-            self.dft(f + ".dftH_bwd", gfr, gfi, gar, gai, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0)
+            gar, gai = self.alloc(M, C_), self.alloc(M, C_)
+            if fuse_ew:
+                self.dft(f + ".magpha_bwd+dftH_bwd", gmag, gpha, gar, gai, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0,
+                         pro=L.DFT_PRO_MAGPHA_BWD, aux=(mag, pha))
+            else:
+                gfr, gfi = self.alloc(M, C_), self.alloc(M, C_)
+                self._op(f + ".magpha_bwd", lib.uir_magpha_bwd, _ptr(mag), _ptr(pha), _ptr(gmag), _ptr(gpha), _ptr(gfr), _ptr(gfi), M * C_)
+                self.dft(f + ".dftH_bwd", gfr, gfi, gar, gai, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0)
             dxf = self.alloc(M, C_)
             self.dft(f + ".dftW_bwd", gar, gai, dxf, None, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0)
             self.join(pfx + ".join_bwd")
