@@ -23,7 +23,11 @@ extern "C" {
 /* ---------------------------------------------------------------- uir_gemm */
 enum { UIR_PRO_NONE = 0, UIR_PRO_LN = 1, UIR_PRO_GATE = 2 };
 #define UIR_GEMM_SLAB_ROWS 512   /* max workgroups (= slab rows) of the GEMM variants with fused reductions */
-enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2, UIR_EPI_GATE_BWD_DW = 3, UIR_EPI_GELU_BWD = 4 };
+enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2, UIR_EPI_GATE_BWD_DW = 3, UIR_EPI_GELU_BWD = 4, UIR_EPI_PLAIN_DW = 5 };
+/* UIR_EPI_PLAIN_DW (round 4): Y = X . W^T as PLAIN (no bias / activation / residual) and, from the same pass over X, the per-batch Gram
+ *   dW[z][k][j] = sum_m X[z][m][k] * G[z][m][j]   (K <= 32 channels of X, j < dw_cols <= 32 columns of a second tensor G [batches][M][ldg])
+ * as per-workgroup partials dw_slab[blockIdx.x][z * K * dw_cols + k * dw_cols + j] (summed by uir_reduce_slab).  MDTA's value path: dvf = dx1 . WB
+ * with dW_B = dx1^T vf, and dv = du . WA with dW_A = du^T v (SpectralTransformer.py:100,113 backward) - X is read once instead of twice. */
 enum { UIR_ACT_NONE = 0, UIR_ACT_LEAKY = 1, UIR_ACT_GELU = 2 };   /* GELU: exact-erf form; plain epilogue only */
 
 /* Dense channel contraction over HWC rows, 1 or 9 (3x3, pad 1) taps:
@@ -56,7 +60,7 @@ typedef struct UirGemmArgs {
   int act;             /* applied before epi                                                     */
   float slope;         /* LeakyReLU negative slope                                               */
   float ln_eps;
-  float* dw_slab;      /* GATE_BWD_DW: per-workgroup partials [gridDim.x][dw_stride] of the project_out     */
+  float* dw_slab;      /* GATE_BWD_DW / PLAIN_DW: per-workgroup partials [gridDim.x][dw_stride] of the project_out     */
   long dw_stride;      /* weight gradient dW[k][n] = sum_m X[m][k] * gate(G)[m][n], summed by uir_reduce_slab;*/
                        /* gridDim.x = min(M/128, UIR_GEMM_SLAB_ROWS).  Requires K <= 32, N <= 96, M % 128 == 0 */
                        /* GELU_BWD: Y = (X.W^T) * gelu'(G + bias) (bias = the bias INSIDE the GELU, not added to the  */
@@ -71,6 +75,8 @@ typedef struct UirGemmArgs {
   const float* out_scale; /* optional (with R; PLAIN epilogue, taps 1, batches 1): Y = R + out_scale[row / scale_rows] * act(X.W^T + bias) -  */
   int scale_rows;      /* (>= 32) the per-sample DropPath factor of a residual branch (timm drop_path: src/Models/AST.py:617,620,        */
                        /* src/model/model.py:91) folded into the branch's last Linear; scale_rows = token rows per sample        */
+  int dw_cols;         /* EPI_PLAIN_DW: columns of G that enter the fused Gram (<= 32)                                                   */
+  int dw_rows;         /* EPI_PLAIN_DW: workgroups per batch = slab rows written (1 .. M / 128); the caller reduces exactly these        */
   int il16;            /* EPI_GATE_BWD / EPI_GATE_BWD_DW only: 1 = G and Y hold the GDFN tensors in the chunk-interleaved layout of      */
                        /* UirGdfnFwdArgs.il (hidden channel n at column 32 (n / 16) + n % 16, its x2 partner g_off = 16 columns on)      */
 } UirGemmArgs;
@@ -732,6 +738,8 @@ int uir_stream_destroy(void* stream);
 
 /* library self-description (used by the loader test) */
 const char* uir_version(void);
+/* hipGetErrorString of the HIP error behind this thread's most recent UIR_ELAUNCH ("no error" if there was none) */
+const char* uir_last_launch_error(void);
 /* Layout of an argument struct as the compiler built it: out[0] = sizeof, out[1 + i] = offsetof(field i) in declaration
  * order; returns 1 + number of fields, -1 for an unknown name / too small a buffer.  A host binding (ctypes, cgo, JNI)
  * checks its mirror of each struct against this at load time (csrc/abi_layout.hip is generated from this header). */

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 29
     for name in declared:
         assert hasattr(L.lib, name), f"{name} declared in include/uir_kernels.h but not exported by libuir_hip.so"
-    assert declared - {"uir_version"} == set(L.SIGNATURES), "ctypes signature table out of sync with the header"
+    assert declared - {"uir_version", "uir_last_launch_error"} == set(L.SIGNATURES), "ctypes signature table out of sync with the header"
     assert L.lib.uir_version().decode().startswith("uir_hip")
 
 
@@ -339,3 +339,18 @@ def test_trainer_calls_set_epoch(monkeypatch):
     args = types.SimpleNamespace(train_batch_size=2, lossf="L1", lr=3e-4, arch="SpectralTransformer", use_dwt="Fourier", optim="adam")
     MT.ModelTrainer("a", "b", "c", "d").train(args, "SpectralTransformer", 3, 3e-4, "cuda")
     assert calls == [0, 1, 2]
+
+
+def test_package_import_binds_the_library_to_the_hip_runtime_torch_uses():
+    """`import underwater_image_restoration_amd` as the FIRST import of a process: exactly one libamdhip64 may end up mapped (torch's).
+    With the library loaded ahead of torch, /opt/rocm's runtime came in beside torch's and every launch failed with hipErrorNoDevice."""
+    import subprocess
+    import sys
+    code = ("import underwater_image_restoration_amd\n"
+            "libs = sorted(set(l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l))\n"
+            "print(len(libs), libs)\n")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = [ln for ln in out.stdout.splitlines() if ln and ln[0].isdigit()][-1]
+    assert last.startswith("1 "), last

@@ -997,6 +997,43 @@ def test_gemm_gate_bwd_in_the_interleaved_layout(M, C, fused_dw):
         assert rel(dws.sum(0).reshape(C, h), dy.T @ gate.detach()) < TOL
 
 
+@pytest.mark.parametrize("B,HW,C,rows,ldz,zoff", [(2, 384, 32, 3, 32, 0), (3, 256, 16, 1, 48, 32), (1, 1024, 32, 5, 96, 64), (2, 512, 16, 4, 16, 0),
+                                                   (1, 128, 24, 1, 24, 0)])
+def test_gemm_with_the_per_sample_gram_in_its_epilogue(B, HW, C, rows, ldz, zoff):
+    """EPI_PLAIN_DW (MDTA value path backward, SpectralTransformer.py:100,113): Y[b] = X[b] . W[b] stored as the plain GEMM stores it, and
+    dW[b] = X[b]^T Z[b] as `rows` partial slab rows per sample from the same pass over X; Z is a column window of a wider tensor."""
+    X, Wm = rnd(B * HW, C, seed=3), rnd(B, C, C, seed=5)
+    Zf = rnd(B * HW, ldz, seed=7)
+    Z = Zf[:, zoff:zoff + C]
+    r = rec()
+    Y, Yp = r.alloc(B * HW, C), r.alloc(B * HW, C)
+    slab = r.alloc(rows, 2 * B * C * C)
+    slab.fill_(3.0)
+    Zd = dev(Zf)[:, zoff:zoff + C]
+    r.gemm("dv+dW", dev(X), dev(Wm), Y, N=C, K=C, w_sn=1, w_sk=C, w_bs=C * C, batches=B, epi=L.EPI_PLAIN_DW, G=Zd, dw_slab=slab[:, B * C * C:],
+           dw_cols=C, dw_rows=rows)
+    r.gemm("dv", dev(X), dev(Wm), Yp, N=C, K=C, w_sn=1, w_sk=C, w_bs=C * C, batches=B)
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    want = torch.einsum("bmk,bkn->bmn", X.view(B, HW, C).double(), Wm.double()).reshape(B * HW, C)
+    assert rel(Y, want) < TOL
+    assert torch.equal(Y, Yp)                       # the same contraction order as the plain epilogue
+    assert float((slab[:, :B * C * C] - 3.0).abs().max()) == 0          # the neighbour's columns of a shared slab stay untouched
+    dW = slab[:, B * C * C:].sum(0).reshape(B, C, C)
+    assert rel(dW, torch.einsum("bmk,bmj->bkj", X.view(B, HW, C).double(), Z.reshape(B, HW, C).double())) < TOL
+    # refused: partial row tiles, more slab rows than row tiles, a residual
+    bad = rec()
+    with pytest.raises(RuntimeError):
+        bad.gemm("x", dev(X)[:B * 100], dev(Wm), Y[:B * 100], N=C, K=C, w_sn=1, w_sk=C, w_bs=C * C, batches=B, epi=L.EPI_PLAIN_DW,
+                 G=Zd[:B * 100], dw_slab=slab, dw_cols=C, dw_rows=1)
+        bad.run(bad.fwd)
+    bad = rec()
+    with pytest.raises(RuntimeError):
+        bad.gemm("x", dev(X), dev(Wm), Y, N=C, K=C, w_sn=1, w_sk=C, w_bs=C * C, batches=B, epi=L.EPI_PLAIN_DW, G=Zd, dw_slab=slab, dw_cols=C,
+                 dw_rows=HW // 128 + 1)
+        bad.run(bad.fwd)
+
+
 @pytest.mark.parametrize("B,H,W,C,split", [(2, 16, 32, 32, True), (1, 24, 16, 32, False), (2, 8, 16, 16, True), (1, 16, 16, 16, False),
                                            (1, 20, 24, 32, True), (3, 12, 40, 16, False), (1, 40, 72, 32, False),
                                            (2, 16, 32, 32, "il"), (1, 20, 24, 16, "il"), (1, 40, 72, 32, "il")])

@@ -8,6 +8,11 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# torch FIRST: it brings its own HIP runtime (torch/lib/libamdhip64.so, soname libamdhip64.so.7) and libuir_hip.so must bind to THAT one -
+# the streams and device pointers it is handed belong to it.  Loaded before torch, the library would pull in /opt/rocm's runtime instead,
+# torch would then load its own beside it, and every launch would fail ("no ROCm-capable device is detected").
+import torch  # noqa: F401
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libuir_hip.so")
 
@@ -15,7 +20,7 @@ fp = C.c_void_p  # device pointers travel as integers
 
 # enums (mirror include/uir_kernels.h)
 PRO_NONE, PRO_LN, PRO_GATE = 0, 1, 2
-EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW, EPI_GELU_BWD = 0, 1, 2, 3, 4
+EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW, EPI_GELU_BWD, EPI_PLAIN_DW = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_LEAKY, ACT_GELU = 0, 1, 2
 # L1ColorLum has the same formula as L1withColor in the reference (src/Losses/losses.py:59-66 vs :67-75)
 LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4, "LuminanceCharbonnier": 5,
@@ -46,7 +51,7 @@ class GemmArgs(C.Structure):
                 ("pro", C.c_int), ("gate_off", C.c_int), ("epi", C.c_int), ("g_off", C.c_int), ("act", C.c_int),
                 ("slope", C.c_float), ("ln_eps", C.c_float), ("dw_slab", fp), ("dw_stride", C.c_long),
                 ("tap0", C.c_int), ("ntap", C.c_int), ("pre_out", fp), ("ldpre", C.c_long),
-                ("out_scale", fp), ("scale_rows", C.c_int), ("il16", C.c_int)]
+                ("out_scale", fp), ("scale_rows", C.c_int), ("dw_cols", C.c_int), ("dw_rows", C.c_int), ("il16", C.c_int)]
 
 
 class GramArgs(C.Structure):
@@ -343,6 +348,8 @@ def _load() -> C.CDLL:
     _verify_structs(lib)
     lib.uir_version.restype = C.c_char_p
     lib.uir_version.argtypes = []
+    lib.uir_last_launch_error.restype = C.c_char_p
+    lib.uir_last_launch_error.argtypes = []
     return lib
 
 
@@ -358,4 +365,6 @@ class UirError(RuntimeError):
 def check(status: int, what: str) -> None:
     if status != 0:
         kind = {1: "argument check failed (UIR_EINVAL)", 2: "HIP launch error (UIR_ELAUNCH)"}.get(status, str(status))
+        if status == 2:
+            kind += ": " + lib.uir_last_launch_error().decode()
         raise UirError(f"{what}: {kind}")

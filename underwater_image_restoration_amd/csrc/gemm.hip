@@ -415,6 +415,39 @@ __device__ __forceinline__ void uir_gemm1x1_store_gate_dw(const UirGemmArgs& a, 
   }
 }
 
+// Plain store + fused per-batch Gram (EPI_PLAIN_DW, K <= 32, one column group, full tiles): dW[k][j] += sum_px X[px][k] * Z[px][j] over the
+// tile's pixels.  A operand X^T (lane = channel k) as in uir_gemm1x1_store_gate_dw; B operand Z = a.G (lane = column j, register = pixel):
+// 16 dword loads of whole rows.  One 32 x 32 dW tile (Z has <= 32 columns), accumulated across the workgroup's row tiles.
+template <int NT>
+__device__ __forceinline__ void uir_gemm1x1_store_plain_dw(const UirGemmArgs& a, const f32x16 (&acc)[NT], f32x16& gacc, int z, int m0, int n0,
+                                                            int r, int h2) {
+  const long row0 = (long)m0 + 4 * h2;
+  const bool kok = r < a.K, jok = r < a.dw_cols;
+  float ap[16], zv[16];
+  {
+    const float* xp = a.X + (long)z * a.x_bs + row0 * a.ldx + (kok ? r : 0);
+    const float* zp = a.G + (long)z * a.g_bs + row0 * a.ldg + (jok ? r : 0);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+      const long o = (long)((s & 3) + 8 * (s >> 2));
+      ap[s] = xp[o * a.ldx];
+      zv[s] = zp[o * a.ldg];
+    }
+  }
+  float* Y = a.Y + (long)z * a.y_bs;
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int n = n0 + 32 * nt + r;
+    if (n < a.N) {
+      float* yp = Y + row0 * a.ldy + n;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) yp[(long)((reg & 3) + 8 * (reg >> 2)) * a.ldy] = acc[nt][reg];
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < 16; ++s) gacc = uir_mfma(kok ? ap[s] : 0.f, jok ? zv[s] : 0.f, gacc);
+}
+
 template <int NT, int PRO, int EPI, bool HAS_R>
 __global__ __launch_bounds__(256, EPI == UIR_EPI_GATE_BWD_DW ? 2 : 3) void uir_gemm1x1_kernel(const UirGemmArgs a, const int Kp, const int tiles) {
   extern __shared__ __attribute__((aligned(16))) float wl[];
@@ -582,6 +615,10 @@ __global__ __launch_bounds__(256, EPI == UIR_EPI_GATE_BWD_DW ? 2 : 3) void uir_g
 #pragma unroll
       for (int q = 0; q < 16; ++q) gacc[nt][q] = 0.f;
   }
+  if constexpr (EPI == UIR_EPI_PLAIN_DW) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) gacc[0][q] = 0.f;
+  }
 
   auto step = [&](float4 (&an)[4], float4 (&un)[NU], const bool anok, float4 (&nx)[4], float4 (&nu)[NU], bool& nxok) -> bool {
     const int m0 = tile * 128 + wave * 32;
@@ -674,6 +711,7 @@ __global__ __launch_bounds__(256, EPI == UIR_EPI_GATE_BWD_DW ? 2 : 3) void uir_g
     }
     if (last && m0 < a.M) {
       if constexpr (EPI == UIR_EPI_GATE_BWD_DW) uir_gemm1x1_store_gate_dw<NT>(a, acc, gacc, m0, n0, r, h2);
+      else if constexpr (EPI == UIR_EPI_PLAIN_DW) uir_gemm1x1_store_plain_dw<NT>(a, acc, gacc[0], z, m0, n0, r, h2);
       else if constexpr (EPI == UIR_EPI_GELU_BWD) uir_gemm1x1_store_gelu_bwd<NT>(a, acc, bias, dbacc, z, m0, n0, r, h2);
       else uir_gemm1x1_store<NT, EPI, HAS_R>(a, acc, bias, rv, z, m0, n0, r, h2);
     }
@@ -702,6 +740,27 @@ __global__ __launch_bounds__(256, EPI == UIR_EPI_GATE_BWD_DW ? 2 : 3) void uir_g
     for (int e = threadIdx.x; e < NT * 32; e += 256) {
       const int n = n0 + e;
       if (n < a.N) slab[n] = (red[e] + red[NT * 32 + e]) + (red[2 * NT * 32 + e] + red[3 * NT * 32 + e]);
+    }
+  }
+  if constexpr (EPI == UIR_EPI_PLAIN_DW) {
+    // the 4 waves' partial dW tiles meet in LDS in a fixed order (the weight panel is dead); one slab row per workgroup, batch z's columns
+    __syncthreads();
+    float* red = wl;
+    for (int w = 0; w < 4; ++w) {
+      if (wave == w) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          float* p = &red[q * 64 + lane];
+          *p = (w == 0) ? gacc[0][q] : (*p + gacc[0][q]);
+        }
+      }
+      __syncthreads();
+    }
+    float* slab = a.dw_slab + (long)blockIdx.x * a.dw_stride + (long)z * a.K * a.dw_cols;
+    for (int e = threadIdx.x; e < 1024; e += 256) {
+      const int ln = e & 63, q = e >> 6;
+      const int cch = uir_mfma_row(q, ln >> 5), j = ln & 31;
+      if (cch < a.K && j < a.dw_cols) slab[(long)cch * a.dw_cols + j] = red[e];
     }
   }
   if constexpr (EPI == UIR_EPI_GATE_BWD_DW) {
@@ -749,7 +808,13 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
                               (a.N & 15) == 0 && a.ldg >= 2 * a.N && a.ldy >= 2 * a.N));
   if (a.epi == UIR_EPI_GATE_BWD) UIR_REQUIRE(a.G && (a.il16 || (a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N)) && !a.R);
   if (a.epi == UIR_EPI_LEAKY_BWD) UIR_REQUIRE(a.G && a.ldg >= a.N && !a.R);
-  UIR_REQUIRE(a.epi >= UIR_EPI_PLAIN && a.epi <= UIR_EPI_GELU_BWD);
+  UIR_REQUIRE(a.epi >= UIR_EPI_PLAIN && a.epi <= UIR_EPI_PLAIN_DW);
+  if (a.epi == UIR_EPI_PLAIN_DW) {
+    // plain store + fused per-batch Gram against G: K <= 32, one column group, whole 128-row tiles, no bias / activation / residual
+    UIR_REQUIRE(a.G && a.dw_slab && a.dw_cols > 0 && a.dw_cols <= 32 && a.ldg >= a.dw_cols && a.K <= 32 && a.N <= 96 && !a.R && !a.bias &&
+                a.act == UIR_ACT_NONE && a.taps == 1 && a.pro == UIR_PRO_NONE && (a.M & 127) == 0 && a.n_grp_pad <= 0 && a.k_grp_pad <= 0 &&
+                a.dw_stride >= (long)a.batches * a.K * a.dw_cols && a.dw_rows >= 1 && a.dw_rows <= a.M / 128);
+  }
   if (a.epi == UIR_EPI_GELU_BWD) {
     // out = acc * gelu'(G + bias), per-workgroup column sums of out to dw_slab rows [gridDim.x][dw_stride]
     UIR_REQUIRE(a.G && a.ldg >= a.N && a.bias && a.dw_slab && a.dw_stride >= a.N && !a.R && a.act == UIR_ACT_NONE);
@@ -856,11 +921,13 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // small problems (deep U-Net levels): favour many narrow column groups over A re-use - the
     // row panel is L2-resident there and parallelism is what is missing
     if ((long)((a.M + 127) / 128) * groups1 * a.batches < 1024) nt1 = 1;
+    if (a.epi == UIR_EPI_PLAIN_DW) nt1 = tiles;                 // the fused Gram belongs to ONE column group
     while (nt1 > 1 && (size_t)nt1 * 32 * Kp * 4 > 60 * 1024) { --nt1; }
     groups1 = (tiles + nt1 - 1) / nt1;
     // (a float4 epilogue through a per-wave LDS transpose was tried and measured slower: profiles/r01/d_ab_notes.md)
     size_t lds = (size_t)nt1 * 32 * Kp * 4 + (size_t)2 * K8 * 4 + (size_t)(nt1 * 32 + K8) * 4;
     if (a.epi == UIR_EPI_GATE_BWD_DW && lds < (size_t)nt1 * 1024 * 4) lds = (size_t)nt1 * 1024 * 4;   // 4-wave dW sum
+    if (a.epi == UIR_EPI_PLAIN_DW && lds < (size_t)1024 * 4) lds = (size_t)1024 * 4;
     if (a.epi == UIR_EPI_GELU_BWD && lds < (size_t)4 * nt1 * 32 * 4) lds = (size_t)4 * nt1 * 32 * 4;      // 4-wave bias-gradient sum
     const bool combo_ok = (a.pro == UIR_PRO_NONE) || (a.epi == UIR_EPI_PLAIN && !(a.pro == UIR_PRO_LN && a.R));
     if (lds <= 100 * 1024 && combo_ok) {
@@ -873,6 +940,10 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
       constexpr int slab_rows = UIR_GEMM_SLAB_ROWS;
       if ((a.epi == UIR_EPI_GATE_BWD_DW || a.epi == UIR_EPI_GELU_BWD) && gx > slab_rows) gx = slab_rows;
       if (gx > rtiles) gx = rtiles;
+      if (a.epi == UIR_EPI_PLAIN_DW) {
+        UIR_REQUIRE(groups1 == 1);
+        gx = a.dw_rows;
+      }
       dim3 grid1(gx, groups1, a.batches);
 #define UIR_L1(NTV, PROV, EPIV, RV) \
   hipLaunchKernelGGL((uir_gemm1x1_kernel<NTV, PROV, EPIV, RV>), grid1, dim3(256), lds, st, a, Kp, rtiles)
@@ -882,6 +953,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     else if (a.epi == UIR_EPI_GATE_BWD_DW) UIR_L1(NTV, PROV, UIR_EPI_GATE_BWD_DW, false); \
     else if (a.epi == UIR_EPI_LEAKY_BWD) UIR_L1(NTV, PROV, UIR_EPI_LEAKY_BWD, false); \
     else if (a.epi == UIR_EPI_GELU_BWD) UIR_L1(NTV, PROV, UIR_EPI_GELU_BWD, false);   \
+    else if (a.epi == UIR_EPI_PLAIN_DW) UIR_L1(NTV, PROV, UIR_EPI_PLAIN_DW, false);   \
     else if (a.R) UIR_L1(NTV, PROV, UIR_EPI_PLAIN, true);                           \
     else UIR_L1(NTV, PROV, UIR_EPI_PLAIN, false);                                   \
   } while (0)
@@ -903,7 +975,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     }
   }
   UIR_REQUIRE(a.ntap <= 0);          // tap ranges exist only on the LDS-panel path above
-  UIR_REQUIRE(a.epi != UIR_EPI_GELU_BWD);   // ... and so does the GELU-backward epilogue (the caller keeps K <= 128)
+  UIR_REQUIRE(a.epi != UIR_EPI_GELU_BWD && a.epi != UIR_EPI_PLAIN_DW);   // ... and so does the GELU-backward epilogue (the caller keeps K <= 128)
   const int groups = (tiles + 3) / 4;
   const int nt = (tiles + groups - 1) / groups;
   dim3 grid((a.M + 127) / 128, groups, a.batches), block(256);

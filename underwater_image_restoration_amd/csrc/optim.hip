@@ -103,3 +103,4 @@ extern "C" int uir_stream_destroy(void* stream) {
 }
 
 extern "C" const char* uir_version(void) { return "uir_hip 0.1 gfx950"; }
+extern "C" const char* uir_last_launch_error(void) { return hipGetErrorString(uir_last_hip_error); }

@@ -14,9 +14,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 #define UIR_REQUIRE(cond) do { if (!(cond)) return UIR_EINVAL; } while (0)
 
+// Status of the launch just made.  hipGetLastError is sticky since ROCm 7 (it reports the last ERROR of any HIP call on this thread, e.g. one the
+// host framework provoked and handled before this entry point ran - seen as a spurious UIR_ELAUNCH on the first launch of a plan);
+// hipExtGetLastError is the status of the most recent HIP call, i.e. of this entry point's own launch.
+inline thread_local hipError_t uir_last_hip_error = hipSuccess;   // read by uir_last_launch_error()
 static inline int uir_launch_status() {
-  hipError_t e = hipGetLastError();
-  return e == hipSuccess ? UIR_OK : UIR_ELAUNCH;
+  hipError_t e = hipExtGetLastError();
+  if (e == hipSuccess) return UIR_OK;
+  (void)hipGetLastError();             // our own failure: consumed here, reported through the return code
+  uir_last_hip_error = e;
+  return UIR_ELAUNCH;
 }
 
 static inline bool uir_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -147,6 +147,8 @@ def twiddles(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 _GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per Gram launch
+FUSE_VALUE_GRAMS = True        # MDTA backward at C <= 32: dW_B / dW_A inside the dvf / dv GEMMs (EPI_PLAIN_DW); False = separate Gram launches
+_PLAIN_DW_WGS = 768            # workgroups of a GEMM with the fused per-sample Gram (EPI_PLAIN_DW): the resident set at 3 per CU
 GEMM_SLAB_ROWS = 512           # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
 FUSED_DW_MINROWS = 16 * 128 * 128   # depthwise backward as ONE pass (dX + dW) from this many pixels on; below, two kernels on two lanes
 _DFT2_CACHE: dict = {}
@@ -492,7 +494,7 @@ class Recorder:
     def gemm(self, name, X, W, Y, *, N, K, w_sn, w_sk, w_st=0, w_bs=0, batches=1, bias=None, R=None,
              taps=1, flip=0, hw=None, n_grp=(0, 0), k_grp=(0, 0), pro=L.PRO_NONE, gate_off=0, ln=None, stats=None,
              epi=L.EPI_PLAIN, G=None, g_off=0, act=L.ACT_NONE, dw_slab=None, pre_out=None, slope=0.1, out_scale=None, scale_rows=0,
-             il16=0):
+             il16=0, dw_cols=0, dw_rows=0):
         M_total = X.shape[0]
         assert M_total % batches == 0 and Y.shape[0] == M_total
         M = M_total // batches
@@ -518,6 +520,7 @@ class Recorder:
             a.stats = _ptr(stats)
         a.epi, a.g_off, a.act = epi, g_off, act
         a.il16 = il16
+        a.dw_cols, a.dw_rows = dw_cols, dw_rows
         if G is not None:
             a.G, a.ldg = _ptr(G), _ld(G)
             a.g_bs = M * a.ldg
@@ -540,8 +543,9 @@ class Recorder:
         rows = M * batches
         kreal = k_grp[0] * (K // k_grp[1]) if k_grp[1] else K
         nreal = n_grp[0] * (N // n_grp[1]) if n_grp[1] else N
+        gcols = dw_cols if epi == L.EPI_PLAIN_DW else N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1)
         nb = 4 * rows * (K * (2 if pro == L.PRO_GATE else 1) + N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1)
-                         + (N if R is not None else 0) + (N * (2 if epi in (L.EPI_GATE_BWD, L.EPI_GATE_BWD_DW) else 1) if G is not None else 0)
+                         + (N if R is not None else 0) + (gcols if G is not None else 0)
                          + (N if pre_out is not None else 0))
         self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps,
                  variant=f"uir_gemm1x1_kernel<*,{pro},{epi},*>")     # the rocprofv3 symbol family (NT and HAS_R vary per call)
@@ -1066,20 +1070,34 @@ class Plan(Recorder):
             # dWB | dWA partials side by side in one slab: a single reduction launch (before uir_attn_bwd) instead of two
             nab = B * C_ * C_
             tn_ = (C_ + 31) // 32
-            nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B)
-            slab_ab = self.alloc(nch_ab * 2 * nab)
             assert dWA.data_ptr() == dWB.data_ptr() + 4 * nab
-            got = self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
-                            shared_slab=(slab_ab, 0, 2 * nab))
-            assert got == nch_ab
-            self.gemm(n + ".dvf", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
+            # C <= 32: each per-sample Gram rides in the epilogue of the GEMM that reads the same gradient rows (EPI_PLAIN_DW): dx1 and du are
+            # read once instead of twice
+            fuse_ab = FUSE_VALUE_GRAMS and C_ <= 32 and HW % 128 == 0
+            if fuse_ab:
+                nch_ab = max(1, min(_PLAIN_DW_WGS // B, HW // 128))
+                slab_ab = self.alloc(nch_ab, 2 * nab)
+                self.gemm(n + ".dvf+dWB", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B, epi=L.EPI_PLAIN_DW, G=vf,
+                          dw_slab=slab_ab, dw_cols=C_, dw_rows=nch_ab)
+            else:
+                nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B)
+                slab_ab = self.alloc(nch_ab * 2 * nab)
+                got = self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
+                                shared_slab=(slab_ab, 0, 2 * nab))
+                assert got == nch_ab
+                self.gemm(n + ".dvf", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
             self.dwconv_bwd(n + ".du+dWkvdw", dvf, u, Wkvdw_f, du, Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, creal=C_,
                             dims=dims)
-            got = self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
-                            shared_slab=(slab_ab, nab, 2 * nab))
-            assert got == nch_ab
+            if fuse_ab:
+                self.gemm(n + ".dv+dWA", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B, epi=L.EPI_PLAIN_DW,
+                          G=v_, dw_slab=slab_ab[:, nab:], dw_cols=C_, dw_rows=nch_ab)
+            else:
+                got = self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
+                                shared_slab=(slab_ab, nab, 2 * nab))
+                assert got == nch_ab
             self._reduce(n + ".dWAB.red", _ptr(slab_ab), nch_ab, 2 * nab, _ptr(dWB), 2 * nab)
-            self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
+            if not fuse_ab:
+                self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
             ba = L.AttnBwdArgs()
             ba.dWA, ba.dWB, ba.G, ba.sq_q, ba.sq_k, ba.temperature = _ptr(dWA), _ptr(dWB), _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp)
             ba.attn, ba.P, ba.Wof = _ptr(attn), _ptr(Pm), _ptr(Wof)
