@@ -219,8 +219,9 @@ def test_gemm_conv3x3_fwd_and_input_grad(B, H, W, Cin, Cout):
 
 @pytest.mark.parametrize("Cin,Cout", [(32, 8), (8, 3), (16, 8), (32, 16)])
 def test_gemm_conv3x3_small_channels(Cin, Cout):
-    """the direct small-channel kernel behind uir_gemm (conv3s.hip): outputl / output / down1 / down2 shapes and their input
-    gradients, ragged 16 x 16 tiles, residual, padded 3-of-4 channel groups"""
+    """the small-channel kernels behind uir_gemm (conv3m.hip: 8 .. 32 channels on both sides, conv3s.hip: output 8 -> 3 and its
+    transpose): outputl / output / down1 / down2 shapes and their input gradients, ragged 16 x 16 tiles, residual, padded 3-of-4
+    channel groups"""
     B, H, W = 2, 19, 35
     x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
     w = rnd(Cout, Cin, 3, 3, seed=2)
@@ -240,10 +241,14 @@ def test_gemm_conv3x3_small_channels(Cin, Cout):
     dyp[:, :Cout] = hwc(dy)
     kgrp = dict(k_grp=(Cout, Np)) if Np != Cout else {}
     r.gemm("c.dx", dev(dyp), Wd, dX, N=Cin, K=Np, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=(H, W), **kgrp)
+    resx = rnd(B * H * W, Cin, seed=6)               # the skip path's share added to the input gradient (engine._conv3 backward, R=)
+    dXr = r.alloc(B * H * W, Cin)
+    r.gemm("c.dx.r", dev(dyp), Wd, dXr, N=Cin, K=Np, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=(H, W), R=dev(resx), **kgrp)
     r.run(r.fwd)
     assert rel(chw(Y[:, :Cout], B, H, W), y) < TOL
     assert rel(chw(Yr[:, :Cout], B, H, W), y + chw(res[:, :Cout], B, H, W)) < TOL
     assert rel(chw(dX, B, H, W), dx) < TOL
+    assert rel(chw(dXr, B, H, W), dx + chw(resx, B, H, W)) < TOL
     if Np != Cout:
         assert float(Y[:, Cout:].abs().max()) == 0
 

@@ -1,6 +1,7 @@
-// uir_conv3x3_small: dense 3x3 convolutions (pad 1, no bias) with at most EIGHT output channels - the network's ends and its first
-// down-sampler: outputl 32 -> 8 and output 8 -> 3 (SpectralTransformer.py:247,252,269-270), down1 16 -> 8 (:154), and output's input
-// gradient 3 -> 8 (the same contraction with the weight's channel axes swapped and the taps mirrored).
+// uir_conv3x3_small: dense 3x3 convolutions (pad 1, no bias) with at most EIGHT channels on both sides - the network's last layer
+// output 8 -> 3 (SpectralTransformer.py:252,270) and its input gradient 3 -> 8 (the same contraction with the weight's channel axes
+// swapped and the taps mirrored).  (Rounds 2-3 also served outputl 32 -> 8 and down1 16 -> 8 here; since round 4 every shape with
+// 8 .. 32 channels on both sides runs on the 16x16x4 MFMA kernel of csrc/conv3m.hip.)
 // On the MFMA path of uir_gemm a 32-column tile is 3/4 ... 7/8 empty for 8 or 4 output channels and the nine-tap panel walk costs
 // 9 x K/32 chunk trips per row tile: 220 us for outputl at 16 x 256 x 256, 0.7 TB/s.  Here: one thread per pixel, its <= 8 outputs in
 // registers, the 18 x 18 x K input tile of a 16 x 16 pixel workgroup tile in LDS, the weights as SCALAR operands (uniform
@@ -142,7 +143,8 @@ int uir_conv3x3_small(const UirGemmArgs& a, void* stream) {
   // measured against the MFMA path at 16 x 256 x 256 (16 x 128 x 128 for down2): outputl 179 vs 220 us, output 32 vs 108, down1 89 vs 148,
   // output's input gradient 33 vs 109.  With 16 or 32 outputs (two or four passes, each waiting on its own scalar loads) the MFMA
   // path wins (outputl.dX 253 vs 111 us, down2 125 vs 68): those shapes are not served here.
-  UIR_C3(32, 8, false); UIR_C3(8, 4, false); UIR_C3(16, 8, false); UIR_C3(4, 8, true);
+  // (round 4: outputl 32 -> 8 and down1 16 -> 8 moved to csrc/conv3m.hip, which uir_gemm asks first: 110 vs 179 us, 54 vs 83 us)
+  UIR_C3(8, 4, false); UIR_C3(4, 8, true);
 #undef UIR_C3
   return -1;
 }

@@ -19,6 +19,7 @@
 #include "../../include/uir_kernels.h"
 #include <cstdlib>
 
+int uir_conv3x3_mfma(const UirGemmArgs& a, void* stream);      // csrc/conv3m.hip; -1 = not its shape
 int uir_conv3x3_small(const UirGemmArgs& a, void* stream);     // csrc/conv3s.hip; -1 = not its shape
 int uir_ts_gemm(const UirGemmArgs& a, void* stream);           // csrc/tsgemm.hip; -1 = not its shape
 
@@ -836,6 +837,9 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
   {
     // 3 x 3 convolutions with <= 32 channels on both sides (outputl / output / down1 / down2 and their input gradients): the direct
     // VALU kernel of csrc/conv3s.hip (an MFMA tile is 3/4 ... 7/8 empty for 8 or 4 output channels)
+    // 8 .. 32 channels on both sides: the LDS-staged 16x16x4 MFMA kernel of csrc/conv3m.hip
+    const int rm = uir_conv3x3_mfma(a, stream);
+    if (rm >= 0) return rm;
     const int rc = uir_conv3x3_small(a, stream);
     if (rc >= 0) return rc;
   }
