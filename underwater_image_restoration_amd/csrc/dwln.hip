@@ -81,7 +81,9 @@ struct DwLn {
   static constexpr int OFF_WR = OFF_RS + NI;
   static constexpr int SW = C + 4;                         // row stride of the staged W1 chunk [32 rows][C] (16-byte rows)
   static constexpr int OFF_W1 = OFF_WR + 4 * 16 * 18;
-  static constexpr int LDS_FLOATS = OFF_W1 + 32 * SW;
+  static constexpr int SWF = 20;                           // row stride of the staged depthwise taps [16 channel pairs][9 A | 9 B] (16-byte rows)
+  static constexpr int OFF_WF = OFF_W1 + 32 * SW;
+  static constexpr int LDS_FLOATS = OFF_WF + 16 * SWF;
   static_assert(C == 16 || C == 32, "channel count");
 };
 
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
   float* RS = smem + T::OFF_RS;
   float* WR = smem + T::OFF_WR;
   float* W1s = smem + T::OFF_W1;
+  float* WFs = smem + T::OFF_WF;
   const int tiles_x = (a.Wd + T::TW - 1) / T::TW, tiles_y = (a.H + T::TH - 1) / T::TH;
   const int ntiles = a.B * tiles_x * tiles_y;
   const int h = a.h, hp = a.hp, ch = a.ch;
@@ -203,12 +206,34 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       xpv[y] = f32x2{ldg_off(rowp, oa), ldg_off(rowp, ob)};
     }
   };
-  // depthwise taps of the thread's channel pair, window order (window position t meets tap 8 - t): raw rows, masked at use
-  f32x2 wf[9], wf_n[9];
-  auto load_wf = [&](int ci, int cp_) {
-    const unsigned pa = (unsigned)(okA(ci, cp_) ? rowA(ci, cp_) : 0) * 36u, pb = (unsigned)(okB(ci, cp_) ? rowB(ci, cp_) : 0) * 36u;
-#pragma unroll
-    for (int t = 0; t < 9; ++t) wf_n[t] = f32x2{ldg_off(a.Wdw + (8 - t), pa), ldg_off(a.Wdw + (8 - t), pb)};
+  // depthwise taps of the chunk's 32 channels (288 floats): element t of the chunk by thread t (and 256 + t by threads 0..31), a chunk
+  // ahead, staged through LDS with the G rows like the W1 chunk - they were 18 global dword loads per lane and chunk (a channel
+  // pair's 2 x 9 taps, replicated over the pair's 4 strips), the other half of the small loads behind the `xp/wf-issue` stamp.
+  // LDS row of channel pair cp: window order (position t meets tap 8 - t), 9 of group A then 9 of group B; missing channels hold 0
+  f32x2 wf[9];
+  float wfpre0, wfpre1;
+  auto wf_src = [&](int ci, int e, bool& ok) -> unsigned {
+    const int r = e / 9, tap = e - 9 * r, i = r & 15;
+    ok = r < 16 ? okA(ci, i) : okB(ci, i);
+    return (unsigned)((ok ? (r < 16 ? rowA(ci, i) : rowB(ci, i)) : 0) * 9 + tap);
+  };
+  auto load_wf = [&](int ci, int t) {
+    bool ok;
+    wfpre0 = a.Wdw[wf_src(ci, t, ok)];
+    wfpre1 = a.Wdw[wf_src(ci, 256 + (t & 31), ok)];
+  };
+  auto store_wf = [&](int ci, int t) {
+    bool ok0, ok1;
+    (void)wf_src(ci, t, ok0);
+    (void)wf_src(ci, 256 + (t & 31), ok1);
+    {
+      const int r = t / 9, tap = t - 9 * r;
+      WFs[(r & 15) * T::SWF + (r >> 4) * 9 + (8 - tap)] = ok0 ? wfpre0 : 0.f;
+    }
+    if (t < 32) {
+      const int e = 256 + t, r = e / 9, tap = e - 9 * r;
+      WFs[(r & 15) * T::SWF + (r >> 4) * 9 + (8 - tap)] = ok1 ? wfpre1 : 0.f;
+    }
   };
   // the chunk's 32 rows of W1 (16 of group A, 16 of group B): ONE float4 per thread, a chunk ahead, staged through LDS with the G rows;
   // every lane then reads its 16 B-operand values with LDS loads - they were 16 global dword loads per lane and chunk, a third of
@@ -227,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     const Tc c0 = coords(blockIdx.x);
 #pragma unroll
     for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it, c0);
-    load_wf(0, cp);
+    load_wf(0, t_);
     load_w1(0, t_);
     load_g(0, t_);
     load_xp(0, cp, sx, c0);
@@ -292,8 +317,6 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
           const int e = t_ + 256 * it;
           *reinterpret_cast<float4*>(GS1 + (e >> 3) * T::S1 + 4 * (e & 7)) = gv[it];       // (rows >= NPX1: unused filler)
         }
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wf[t] = wf_n[t];
       } else {
 #pragma unroll
         for (int it = 0; it < T::NLD; ++it) {
@@ -301,10 +324,8 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
           const float k = (goff[it] != ~0u && g_col(ci, e) + 4 <= chcols) ? 1.f : 0.f;
           *reinterpret_cast<float4*>(GS1 + (e >> 3) * T::S1 + 4 * (e & 7)) = make_float4(gv[it].x * k, gv[it].y * k, gv[it].z * k, gv[it].w * k);
         }
-        const f32x2 wm = f32x2{okA(ci, cp) ? 1.f : 0.f, okB(ci, cp) ? 1.f : 0.f};
-#pragma unroll
-        for (int t = 0; t < 9; ++t) wf[t] = wf_n[t] * wm;
       }
+      store_wf(ci, t_);
       if (t_ / (C / 4) < 32) *reinterpret_cast<float4*>(W1s + (t_ / (C / 4)) * T::SW + 4 * (t_ % (C / 4))) = w1pre;
       lds_barrier2();
       UIR_ST(1);
@@ -328,7 +349,18 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         for (int it = 0; it < T::NLD; ++it) goff[it] = g_off(t_ + 256 * it, tn);
       }
       load_w1(cn, t_);
+      load_wf(cn, t_);
       load_g(cn, t_);
+      {
+        // this chunk's taps: 18 consecutive floats of the pair's LDS row (4 x b128 + b64)
+        const float* wr = WFs + cp * T::SWF;
+        const float4 q0 = *reinterpret_cast<const float4*>(wr), q1 = *reinterpret_cast<const float4*>(wr + 4),
+                     q2 = *reinterpret_cast<const float4*>(wr + 8), q3 = *reinterpret_cast<const float4*>(wr + 12);
+        const float2 q4 = *reinterpret_cast<const float2*>(wr + 16);
+        const float w18[18] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wf[t] = f32x2{w18[t], w18[9 + t]};
+      }
       UIR_ST(2);
 
       // ---- (b) transposed depthwise 3x3 + depthwise weight-gradient terms ----
@@ -382,7 +414,6 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       else walk(std::false_type{});
       UIR_ST(3);
       load_xp(cn, cp, sx, last ? tn : tc);
-      load_wf(cn, cp);
       UIR_ST(9);
       // sum over the wave's four strips = the four lanes of a quad: two DPP adds per value (quad_perm [1,0,3,2], [2,3,0,1]); the strips
       // on lanes 16 apart needed a v_permlane16_swap + v_permlane32_swap pair with its register copies (~110 VALU per chunk instead
