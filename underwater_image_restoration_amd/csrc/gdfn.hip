@@ -74,6 +74,12 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
   float* T1s = smem;
   float* Gs = smem + T::NRT1 * 32 * T::S1;
   float* Ws = smem + T::LDS_FLOATS;       // wide levels: two staged W_in chunks [32 rows][C + 4]
+  // C <= 32, split-bf16 form: ALL depthwise taps of the launch staged once per workgroup, row of hidden channel cc = 9 taps of x1's
+  // channel | 9 of x2's (stride 20 floats: 16-byte rows); they were 18 dword loads per lane and chunk (tools/probes/stamps: the
+  // weight loads' issue stalls behind the write-out stores were 11.6 % of the kernel)
+  constexpr bool TAPS_LDS = SB && C <= 32;
+  constexpr int SWT = 20;
+  float* WT = smem + T::LDS_FLOATS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
   const int tiles_x = (a.Wd + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   int bid = blockIdx.x;
@@ -86,6 +92,16 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
   const int h = a.h, hp = a.hp;
 
   UIR_ST_DECL;
+  constexpr int NTAP = TAPS_LDS ? 7 : 1;      // hp <= 96: 96 * 18 = 1728 tap slots = 6.75 per thread
+  float tapv[NTAP];
+  if constexpr (TAPS_LDS) {
+#pragma unroll
+    for (int it = 0; it < NTAP; ++it) {
+      const int e = tid + 256 * it, cc = e / 18, q = e - 18 * cc;
+      const bool ok = cc < h;
+      tapv[it] = a.Wdw[ok ? (q < 9 ? cc * 9 + q : (h + cc) * 9 + (q - 9)) : 0];
+    }
+  }
   // ---- phase 0: x on tile + ring -> LayerNorm -> A-operand registers (k = 8jj + 4h2 + e) ----
   float A[T::RTW][C / 2];
   {
@@ -137,6 +153,13 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     }
   }
 
+  if constexpr (TAPS_LDS) {                 // visible after chunk 0's first barrier, read first in its (b)
+#pragma unroll
+    for (int it = 0; it < NTAP; ++it) {
+      const int e = tid + 256 * it, cc = e / 18, q = e - 18 * cc;
+      if (cc < hp) WT[cc * SWT + q] = cc < h ? tapv[it] : 0.f;
+    }
+  }
   // SB: the A operand as three bf16 planes per 16-deep k step, split ONCE per tile (it is the same for every chunk)
   UirBf3 Ap[SB ? T::RTW : 1][SB ? C / 16 : 1];
   if constexpr (SB) {
@@ -263,15 +286,17 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         }
       }
     }
-    const int cc = c0 + cp;
-    const bool ok = cc < h;
-    const float* p1 = a.Wdw + (long)(ok ? cc : 0) * 9;
-    const float* p2 = a.Wdw + (long)(ok ? h + cc : 0) * 9;
+    if constexpr (!TAPS_LDS) {
+      const int cc = c0 + cp;
+      const bool ok = cc < h;
+      const float* p1 = a.Wdw + (long)(ok ? cc : 0) * 9;
+      const float* p2 = a.Wdw + (long)(ok ? h + cc : 0) * 9;
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-      const float u1 = p1[t], u2 = p2[t];
-      w1_[t] = ok ? u1 : 0.f;
-      w2_[t] = ok ? u2 : 0.f;
+      for (int t = 0; t < 9; ++t) {
+        const float u1 = p1[t], u2 = p2[t];
+        w1_[t] = ok ? u1 : 0.f;
+        w2_[t] = ok ? u2 : 0.f;
+      }
     }
   };
   auto load_win = [&](int c0, float4 (&win_)[NPF]) {   // the W_in fragment alone (SB, C <= 32)
@@ -387,8 +412,10 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     if constexpr (SB) {
 #pragma unroll
       for (int t = 0; t < 8; ++t) pin(wo[t]);
+      if constexpr (!TAPS_LDS) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) { pin(w1[t]); pin(w2[t]); }
+        for (int t = 0; t < 9; ++t) { pin(w1[t]); pin(w2[t]); }
+      }
     } else {
 #pragma unroll
     for (int t = 0; t < 8; ++t) pin(wo_n[t]);
@@ -422,8 +449,18 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     {
       const float* rp = T1s + (ys * T::RW + sx) * T::S1 + cp;
       f32x2 rw[3][3], wv[9];
+      if constexpr (TAPS_LDS) {
+        const float* wr = WT + (c0 + cp) * SWT;
+        const float4 q0 = *reinterpret_cast<const float4*>(wr), q1 = *reinterpret_cast<const float4*>(wr + 4),
+                     q2 = *reinterpret_cast<const float4*>(wr + 8), q3 = *reinterpret_cast<const float4*>(wr + 12);
+        const float2 q4 = *reinterpret_cast<const float2*>(wr + 16);
+        const float w18[18] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
 #pragma unroll
-      for (int t = 0; t < 9; ++t) wv[t] = f32x2{w1[t], w2[t]};
+        for (int t = 0; t < 9; ++t) wv[t] = f32x2{w18[t], w18[9 + t]};
+      } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = f32x2{w1[t], w2[t]};
+      }
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
@@ -559,6 +596,20 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
   const int y0 = ty * TH, x0 = tx * TW;
   const long img = (long)b * a.H * a.Wd;
   constexpr int HD = 3 * C;
+  // C <= 32, split-bf16 form: the depthwise taps of all 3C channels staged once per workgroup (see uir_gdfn_fwd_kernel); row of
+  // pair (chunk, cp) = 9 taps of channel 32 chunk + cp | 9 of channel 32 chunk + 16 + cp, zeros past 3C
+  constexpr bool TAPS_LDS = SB && C <= 32;
+  constexpr int SWT = 20, NPR = ((HD + 31) / 32) * 16, NTAP = TAPS_LDS ? (NPR * 18 + 255) / 256 : 1;
+  float* WT = smem + T::LDS_FLOATS;
+  float tapv[NTAP];
+  if constexpr (TAPS_LDS) {
+#pragma unroll
+    for (int it = 0; it < NTAP; ++it) {
+      const int e = tid + 256 * it, pr = e / 18, q = e - 18 * pr;
+      const int ch = 32 * (pr >> 4) + (pr & 15) + (q < 9 ? 0 : 16);
+      tapv[it] = a.Wdw[(pr < NPR && ch < HD) ? ch * 9 + (q < 9 ? q : q - 9) : 0];
+    }
+  }
 
   // ---- phase 0: x on tile + ring -> LayerNorm -> A-operand registers ----
   float A[T::RTW][C / 2];
@@ -611,6 +662,14 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
     }
   }
 
+  if constexpr (TAPS_LDS) {                 // visible after chunk 0's first barrier
+#pragma unroll
+    for (int it = 0; it < NTAP; ++it) {
+      const int e = tid + 256 * it, pr = e / 18, q = e - 18 * pr;
+      const int ch = 32 * (pr >> 4) + (pr & 15) + (q < 9 ? 0 : 16);
+      if (pr < NPR) WT[pr * SWT + q] = ch < HD ? tapv[it] : 0.f;
+    }
+  }
   UirBf3 Ap[SB ? T::RTW : 1][SB ? C / 16 : 1];       // SB: A operand as bf16 planes, split once per tile (uir_gdfn_fwd_kernel)
   if constexpr (SB) {
 #pragma unroll
@@ -648,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
 #pragma unroll
       for (int jj = 0; jj < T::KJ; ++jj) win[jj] = keep4(*reinterpret_cast<const float4*>(wr + 8 * jj), ok);
     }
-    {
+    if constexpr (!TAPS_LDS) {
       const int c1 = c0 + cp, c2 = c0 + 16 + cp;
       const bool ok1 = c1 < HD, ok2 = c2 < HD;
       const float* p1 = a.Wdw + (long)(ok1 ? c1 : 0) * 9;
@@ -721,8 +780,10 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
     if constexpr (PF) {   // see uir_gdfn_fwd_kernel: the prefetched weights must be complete before this chunk's stores
 #pragma unroll
       for (int jj = 0; jj < T::KJ; ++jj) { pin(win_n[jj].x); pin(win_n[jj].y); pin(win_n[jj].z); pin(win_n[jj].w); }
+      if constexpr (!TAPS_LDS) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) { pin(w1_n[t]); pin(w2_n[t]); }
+        for (int t = 0; t < 9; ++t) { pin(w1_n[t]); pin(w2_n[t]); }
+      }
     }
     // ---- pre-depthwise write-out (read again only by the backward: streaming stores) ----
 #pragma unroll
@@ -735,8 +796,18 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
     {
       const float* rp = T1s + (ys * T::RW + sx) * T::S1 + cp;
       f32x2 rw[3][3], wv[9];
+      if constexpr (TAPS_LDS) {
+        const float* wr = WT + ((c0 >> 5) * 16 + cp) * SWT;
+        const float4 q0 = *reinterpret_cast<const float4*>(wr), q1 = *reinterpret_cast<const float4*>(wr + 4),
+                     q2 = *reinterpret_cast<const float4*>(wr + 8), q3 = *reinterpret_cast<const float4*>(wr + 12);
+        const float2 q4 = *reinterpret_cast<const float2*>(wr + 16);
+        const float w18[18] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
 #pragma unroll
-      for (int t = 0; t < 9; ++t) wv[t] = f32x2{w1[t], w2[t]};
+        for (int t = 0; t < 9; ++t) wv[t] = f32x2{w18[t], w18[9 + t]};
+      } else {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = f32x2{w1[t], w2[t]};
+      }
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr)
 #pragma unroll
@@ -779,8 +850,10 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
     if constexpr (PF) {
 #pragma unroll
       for (int jj = 0; jj < T::KJ; ++jj) win[jj] = win_n[jj];
+      if constexpr (!TAPS_LDS) {
 #pragma unroll
-      for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
+        for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
+      }
     }
     // the next (a) writes T1s (all reads done before the barrier above); Gs is rewritten after the next barrier,
     // which every wave reaches only after its qkv write-out
@@ -791,7 +864,10 @@ template <int C, int TH, int TW>
 int qkv_fwd_launch(const UirQkvFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
   const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
-  if (uir_fused_split()) hipLaunchKernelGGL((uir_qkv_fwd_kernel<C, TH, TW, true>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
+  // + the staged depthwise taps (C <= 32, split-bf16 form): 16 rows of 20 floats per 32-channel chunk
+  if (uir_fused_split())
+    hipLaunchKernelGGL((uir_qkv_fwd_kernel<C, TH, TW, true>), dim3(tiles), dim3(256),
+                       ((size_t)T::LDS_FLOATS + (C <= 32 ? ((3 * C + 31) / 32) * 16 * 20 : 0)) * 4, st, a);
   else hipLaunchKernelGGL((uir_qkv_fwd_kernel<C, TH, TW, false>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
   return uir_launch_status();
 }
@@ -1071,8 +1147,10 @@ template <int C, int TH, int TW>
 int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
   const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
-  const size_t lds = ((size_t)T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : 0)) * 4;   // + two staged W_in chunks
   const bool sb = uir_fused_split() != 0;
+  if (C <= 32 && sb && a.hp > 96) return UIR_EINVAL;                                     // the staged taps' 7 slots per thread
+  // + two staged W_in chunks (wide levels) / the staged depthwise taps (C <= 32, split-bf16 form)
+  const size_t lds = ((size_t)T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : (sb ? a.hp * 20 : 0))) * 4;
   if (a.T1) { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, true>), dim3(tiles), dim3(256), lds, st, a);
               else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, false>), dim3(tiles), dim3(256), lds, st, a); }
   else { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, true>), dim3(tiles), dim3(256), lds, st, a);
