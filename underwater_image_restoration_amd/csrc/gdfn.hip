@@ -74,12 +74,13 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
   float* T1s = smem;
   float* Gs = smem + T::NRT1 * 32 * T::S1;
   float* Ws = smem + T::LDS_FLOATS;       // wide levels: two staged W_in chunks [32 rows][C + 4]
-  // C <= 32, split-bf16 form: ALL depthwise taps of the launch staged once per workgroup, row of hidden channel cc = 9 taps of x1's
-  // channel | 9 of x2's (stride 20 floats: 16-byte rows); they were 18 dword loads per lane and chunk (tools/probes/stamps: the
-  // weight loads' issue stalls behind the write-out stores were 11.6 % of the kernel)
-  constexpr bool TAPS_LDS = SB && C <= 32;
-  constexpr int SWT = 20;
-  float* WT = smem + T::LDS_FLOATS;
+  // split-bf16 form: ALL depthwise taps of the launch staged once per workgroup, row of hidden channel cc = 9 taps of x1's channel |
+  // 9 of x2's; they were 18 dword loads per lane and chunk (tools/probes/stamps: the weight loads' issue stalls behind the write-out
+  // stores were 11.6 % of the kernel at C = 32; at C >= 64, with one or two workgroups per CU, each chunk waited out their latency).
+  // Row stride 20 floats (16-byte rows, b128 reads) where LDS allows it (C <= 32), 18 (b64 reads) beside the staged W_in chunks
+  constexpr bool TAPS_LDS = SB;
+  constexpr int SWT = C <= 32 ? 20 : 18;
+  float* WT = smem + T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
   const int tiles_x = (a.Wd + TW - 1) / TW, tiles_y = (a.H + TH - 1) / TH;
   int bid = blockIdx.x;
@@ -92,14 +93,33 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
   const int h = a.h, hp = a.hp;
 
   UIR_ST_DECL;
-  constexpr int NTAP = TAPS_LDS ? 7 : 1;      // hp <= 96: 96 * 18 = 1728 tap slots = 6.75 per thread
+  // hp * 18 tap slots: <= 6.75 per thread at hp <= 96 (C <= 32: registers across phase 0); C >= 64 (hp <= 352: 24.75 per thread)
+  // copies them in groups of four before phase 0
+  constexpr int NTAP = !TAPS_LDS ? 1 : C <= 32 ? 7 : 4;
   float tapv[NTAP];
-  if constexpr (TAPS_LDS) {
+  auto tap_load = [&](int it0) {
 #pragma unroll
     for (int it = 0; it < NTAP; ++it) {
-      const int e = tid + 256 * it, cc = e / 18, q = e - 18 * cc;
+      const int e = tid + 256 * (it0 + it), cc = e / 18, q = e - 18 * cc;
       const bool ok = cc < h;
       tapv[it] = a.Wdw[ok ? (q < 9 ? cc * 9 + q : (h + cc) * 9 + (q - 9)) : 0];
+    }
+  };
+  auto tap_store = [&](int it0) {
+#pragma unroll
+    for (int it = 0; it < NTAP; ++it) {
+      const int e = tid + 256 * (it0 + it), cc = e / 18, q = e - 18 * cc;
+      if (cc < hp) WT[cc * SWT + q] = cc < h ? tapv[it] : 0.f;
+    }
+  };
+  if constexpr (TAPS_LDS) {
+    if constexpr (C <= 32) {
+      tap_load(0);
+    } else {
+      for (int it0 = 0; it0 * 256 < hp * 18; it0 += NTAP) {
+        tap_load(it0);
+        tap_store(it0);
+      }
     }
   }
   // ---- phase 0: x on tile + ring -> LayerNorm -> A-operand registers (k = 8jj + 4h2 + e) ----
@@ -153,13 +173,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     }
   }
 
-  if constexpr (TAPS_LDS) {                 // visible after chunk 0's first barrier, read first in its (b)
-#pragma unroll
-    for (int it = 0; it < NTAP; ++it) {
-      const int e = tid + 256 * it, cc = e / 18, q = e - 18 * cc;
-      if (cc < hp) WT[cc * SWT + q] = cc < h ? tapv[it] : 0.f;
-    }
-  }
+  if constexpr (TAPS_LDS && C <= 32) tap_store(0);   // visible after chunk 0's first barrier, read first in its (b)
   // SB: the A operand as three bf16 planes per 16-deep k step, split ONCE per tile (it is the same for every chunk)
   UirBf3 Ap[SB ? T::RTW : 1][SB ? C / 16 : 1];
   if constexpr (SB) {
@@ -315,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
       for (int jj = 0; jj < NPF; ++jj) win[jj] = win_n[jj];
     } else {
       stage_load(0);
+      load_small(0, wo, w1, w2);
       stage_store(0);
       lds_barrier();
     }
@@ -331,9 +346,15 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
   UIR_ST(0);
   for (int c0 = 0; c0 < hp; c0 += 16) {
     if constexpr (SB) {
-      if constexpr (PF) load_win(c0 + 16 < hp ? c0 + 16 : c0, win_n);
-      else stage_load(c0 + 16 < hp ? c0 + 16 : c0);
-      load_small(c0, wo, w1, w2);
+      if constexpr (PF) {
+        load_win(c0 + 16 < hp ? c0 + 16 : c0, win_n);
+        load_small(c0, wo, w1, w2);
+      } else {
+        // wide levels (one or two workgroups per CU): nothing hides a load issued and consumed inside one chunk - W_out's fragment
+        // is fetched a chunk ahead too (the taps live in LDS)
+        stage_load(c0 + 16 < hp ? c0 + 16 : c0);
+        load_small(c0 + 16 < hp ? c0 + 16 : c0, wo_n, w1_n, w2_n);
+      }
     } else if constexpr (PF) {
       // in flight across (a) and (b): the LDS-only barriers do not wait for them
       load_w(c0 + 16 < hp ? c0 + 16 : c0, win_n, wo_n, w1_n, w2_n);
@@ -411,7 +432,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
     }
     if constexpr (SB) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) pin(wo[t]);
+      for (int t = 0; t < 8; ++t) pin(PF ? wo[t] : wo_n[t]);
       if constexpr (!TAPS_LDS) {
 #pragma unroll
         for (int t = 0; t < 9; ++t) { pin(w1[t]); pin(w2[t]); }
@@ -451,10 +472,22 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
       f32x2 rw[3][3], wv[9];
       if constexpr (TAPS_LDS) {
         const float* wr = WT + (c0 + cp) * SWT;
-        const float4 q0 = *reinterpret_cast<const float4*>(wr), q1 = *reinterpret_cast<const float4*>(wr + 4),
-                     q2 = *reinterpret_cast<const float4*>(wr + 8), q3 = *reinterpret_cast<const float4*>(wr + 12);
-        const float2 q4 = *reinterpret_cast<const float2*>(wr + 16);
-        const float w18[18] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
+        float w18[18];
+        if constexpr (SWT == 20) {
+          const float4 q0 = *reinterpret_cast<const float4*>(wr), q1 = *reinterpret_cast<const float4*>(wr + 4),
+                       q2 = *reinterpret_cast<const float4*>(wr + 8), q3 = *reinterpret_cast<const float4*>(wr + 12);
+          const float2 q4 = *reinterpret_cast<const float2*>(wr + 16);
+          const float t18[18] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w, q4.x, q4.y};
+#pragma unroll
+          for (int t = 0; t < 18; ++t) w18[t] = t18[t];
+        } else {
+#pragma unroll
+          for (int t = 0; t < 9; ++t) {
+            const float2 q = *reinterpret_cast<const float2*>(wr + 2 * t);
+            w18[2 * t] = q.x;
+            w18[2 * t + 1] = q.y;
+          }
+        }
 #pragma unroll
         for (int t = 0; t < 9; ++t) wv[t] = f32x2{w18[t], w18[9 + t]};
       } else {
@@ -536,11 +569,13 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
 #pragma unroll
       for (int jj = 0; jj < T::KJ; ++jj) win[jj] = win_n[jj];
     }
+    if constexpr (!SB || !PF) {
+#pragma unroll
+      for (int t = 0; t < 8; ++t) wo[t] = wo_n[t];
+    }
     if constexpr (!SB) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t) wo[t] = wo_n[t];
-#pragma unroll
-    for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
+      for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
     }
     wbuf ^= 1;
     UIR_ST(7);
@@ -1147,10 +1182,12 @@ template <int C, int TH, int TW>
 int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
   const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
-  const bool sb = uir_fused_split() != 0;
-  if (C <= 32 && sb && a.hp > 96) return UIR_EINVAL;                                     // the staged taps' 7 slots per thread
-  // + two staged W_in chunks (wide levels) / the staged depthwise taps (C <= 32, split-bf16 form)
-  const size_t lds = ((size_t)T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : (sb ? a.hp * 20 : 0))) * 4;
+  // + two staged W_in chunks (wide levels) + the staged depthwise taps (split-bf16 form).  A hidden width whose taps do not fit
+  // beside two workgroups' tile buffers (or the C <= 32 form's 7 tap slots per thread) runs the f32-MFMA form, which reads them from global
+  bool sb = uir_fused_split() != 0;
+  const size_t lds0 = ((size_t)T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : 0)) * 4;
+  if (sb && (lds0 + (size_t)a.hp * (C <= 32 ? 20 : 18) * 4 > 80 * 1024 || (C <= 32 && a.hp > 96))) sb = false;
+  const size_t lds = lds0 + (sb ? (size_t)a.hp * (C <= 32 ? 20 : 18) * 4 : 0);
   if (a.T1) { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, true>), dim3(tiles), dim3(256), lds, st, a);
               else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, false>), dim3(tiles), dim3(256), lds, st, a); }
   else { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, true>), dim3(tiles), dim3(256), lds, st, a);
@@ -1176,7 +1213,7 @@ extern "C" int uir_gdfn_fwd(const UirGdfnFwdArgs* p, void* stream) {
     case 16: return gdfn_fwd_launch<16, 12, 16>(a, st);
     case 32: return gdfn_fwd_launch<32, 12, 16>(a, st);
     case 64: return gdfn_fwd_launch<64, 8, 16>(a, st);
-    case 128: return gdfn_fwd_launch<128, 8, 8>(a, st);
+    case 128: return gdfn_fwd_launch<128, 4, 8>(a, st);
     default: return UIR_EINVAL;
   }
 }
@@ -1194,7 +1231,7 @@ extern "C" int uir_qkv_fwd(const UirQkvFwdArgs* p, void* stream) {
     case 16: return qkv_fwd_launch<16, 12, 16>(a, st);
     case 32: return qkv_fwd_launch<32, 12, 16>(a, st);
     case 64: return qkv_fwd_launch<64, 8, 16>(a, st);
-    case 128: return qkv_fwd_launch<128, 8, 8>(a, st);
+    case 128: return qkv_fwd_launch<128, 4, 8>(a, st);
     default: return UIR_EINVAL;
   }
 }
@@ -1212,7 +1249,7 @@ extern "C" int uir_attnv_fwd(const UirAttnvFwdArgs* p, void* stream) {
     case 16: return attnv_fwd_launch<16, 12, 16>(a, st);
     case 32: return attnv_fwd_launch<32, 12, 16>(a, st);
     case 64: return attnv_fwd_launch<64, 8, 16>(a, st);
-    case 128: return attnv_fwd_launch<128, 8, 8>(a, st);
+    case 128: return attnv_fwd_launch<128, 4, 8>(a, st);
     default: return UIR_EINVAL;
   }
 }
