@@ -1,17 +1,14 @@
 #!/bin/bash
-O=gpurun_out/r04t; mkdir -p $O
-python -m pytest tests/test_hip_kernels.py -x -q -k "gdfn or qkv or attnv or fused" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
-L=underwater_image_restoration_amd/libuir_hip.so
+O=$GRAFT_REPO_ROOT/gpurun_out/r04x; mkdir -p $O; R=$GRAFT_REPO_ROOT
+python -m pytest tests/test_hip_model.py tests/test_hip_kernels.py -x -q > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.txt
+run() { PYTHONPATH=. python3 tools/xp/ab_engine_flag.py "$@" 2>$O/err.txt | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a $O/ab.txt; }
 for i in 1 2; do
-for v in old new; do
-  cp tools/xp/libs/$v.so $L
-  echo "== $v" | tee -a $O/fused.txt
-  python tools/bench_fused.py 2>&1 | grep -i "C=128\|C= 64" | tee -a $O/fused.txt
+  run BULK_DEFER=0
+  run BULK_DEFER=30
+  run BULK_DEFER=30 SIDE_LOW_PRIORITY=False
 done
-done
-for i in 1 2 3; do
-for v in old new; do
-  cp tools/xp/libs/$v.so $L
-  python bench.py --no-cpu-baseline --no-kernel-breakdown --steps 10 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a $O/ab.txt
-done
-done
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-breakdown > $O/trace.log 2>&1 && echo trace-ok
+cd $R
+f=$(find $O/trace -name "*kernel_trace.csv" | head -1)
+python3 tools/trace_gaps.py $f 3 | tee $O/gaps.txt

@@ -144,10 +144,10 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         float4 v[T::KJ];
         float s = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < T::KJ; ++jj) {
-          v[jj] = *reinterpret_cast<const float4*>(xr + 8 * jj);
-          s += (v[jj].x + v[jj].y) + (v[jj].z + v[jj].w);
-        }
+        for (int jj = 0; jj < T::KJ; ++jj) v[jj] = *reinterpret_cast<const float4*>(xr + 8 * jj);
+        __builtin_amdgcn_sched_barrier(0);          // all of the row's loads in flight before the first is summed (one variant waited for each)
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) s += (v[jj].x + v[jj].y) + (v[jj].z + v[jj].w);
         s += __shfl_xor(s, 32);
         const float mean = s / (float)C;
         float qq = 0.f;
@@ -668,10 +668,10 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
         float4 v[T::KJ];
         float s = 0.f;
 #pragma unroll
-        for (int jj = 0; jj < T::KJ; ++jj) {
-          v[jj] = *reinterpret_cast<const float4*>(xr + 8 * jj);
-          s += (v[jj].x + v[jj].y) + (v[jj].z + v[jj].w);
-        }
+        for (int jj = 0; jj < T::KJ; ++jj) v[jj] = *reinterpret_cast<const float4*>(xr + 8 * jj);
+        __builtin_amdgcn_sched_barrier(0);          // all of the row's loads in flight before the first is summed (one variant waited for each)
+#pragma unroll
+        for (int jj = 0; jj < T::KJ; ++jj) s += (v[jj].x + v[jj].y) + (v[jj].z + v[jj].w);
         s += __shfl_xor(s, 32);
         const float mean = s / (float)C;
         float qq = 0.f;

@@ -147,6 +147,13 @@ def twiddles(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
 
 
 _GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per Gram launch
+# Cross-lane ordering costs the CHAIN: every event recorded on (or waited for by) the main stream is a barrier packet between two of
+# its kernels - 6-7 us of idle queue each (rocprofv3 kernel trace, tools/trace_gaps.py: 162 such gaps = 1.05 ms of a 36.4 ms step).
+# BULK_DEFER: weight-gradient (bulk lane) launches are held back on the host until this many chain launches have passed since the
+# first held one, then released behind ONE event (their inputs are never overwritten inside a step and nothing but the step's final
+# join reads their results, so a later release is only more of the lag the lane already has).  0 = release at once.
+BULK_DEFER = 30
+SIDE_LOW_PRIORITY = True       # side lane on a lowest-priority stream (it fills what the chain leaves idle)
 FUSE_VALUE_GRAMS = True        # MDTA backward at C <= 32: dW_B / dW_A inside the dvf / dv GEMMs (EPI_PLAIN_DW); False = separate Gram launches
 _PLAIN_DW_WGS = 768            # workgroups of a GEMM with the fused per-sample Gram (EPI_PLAIN_DW): the resident set at 3 per CU
 GEMM_SLAB_ROWS = 512           # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
@@ -216,15 +223,18 @@ class Recorder:
         self.cur = self.fwd
         self.keep: List[object] = []  # ctypes structs / tensors referenced by raw pointer
         self.bytes = 0
-        self.meta: Dict[int, list] = {id(self.fwd): [], id(self.bwd): []}
+        # launches that depend on the weights alone (MDTA's P = W_kv[vf] W_o): recorded apart and spliced into the forward list early
+        # (Plan._build), all on the side lane behind one event and one join - per block they cost the chain two barrier packets
+        self.pro: List[tuple] = []
+        self.meta: Dict[int, list] = {id(self.fwd): [], id(self.bwd): [], id(self.pro): []}
         # per launch: the device kernel its arguments select ("uir_gemm<taps=1,pro=1,epi=0>" ...), for per-kernel reports
-        self.variants: Dict[int, list] = {id(self.fwd): [], id(self.bwd): []}
+        self.variants: Dict[int, list] = {id(self.fwd): [], id(self.bwd): [], id(self.pro): []}
         self.scratch = self.alloc(scratch_floats)
         # lane 0 = the critical dX chain (current stream); lane 1 = weight-gradient work that nothing
         # on the chain waits for, run on a second HIP stream with its own slab scratch
         self.lane = 0
         self.scratch_side = self.alloc(scratch_floats)
-        self.lanes: Dict[int, list] = {id(self.fwd): [], id(self.bwd): []}
+        self.lanes: Dict[int, list] = {id(self.fwd): [], id(self.bwd): [], id(self.pro): []}
         self._side_stream = None
         self._bulk_stream = None
         self._events: List[object] = []
@@ -297,6 +307,28 @@ class Recorder:
 
         def __exit__(self, *a):
             self.rec.lane = self.prev
+
+    class _Prologue:
+        def __init__(self, rec):
+            self.rec = rec
+
+        def __enter__(self):
+            self.prev = (self.rec.lane, self.rec.cur)
+            self.rec.lane, self.rec.cur = 1, self.rec.pro
+
+        def __exit__(self, *a):
+            self.rec.lane, self.rec.cur = self.prev
+
+    def prologue(self):
+        return Recorder._Prologue(self)
+
+    def splice_prologue(self, at: int) -> None:
+        """Move the weight-only launches to position `at` of the forward list (once, at the end of the forward's construction)."""
+        for d in (self.meta, self.lanes, self.variants):
+            d[id(self.fwd)][at:at] = d[id(self.pro)]
+            del d[id(self.pro)][:]
+        self.fwd[at:at] = self.pro
+        del self.pro[:]
 
     class _Bulk(_Side):
         def __enter__(self):
@@ -379,7 +411,7 @@ class Recorder:
         if self._side_stream is None:
             # lowest priority: the side lane fills bandwidth the critical dX chain leaves idle
             lo = max(torch.cuda.Stream.priority_range()) if hasattr(torch.cuda.Stream, "priority_range") else 0
-            self._side_stream = torch.cuda.Stream(device=self.dev, priority=lo)
+            self._side_stream = torch.cuda.Stream(device=self.dev, priority=lo if SIDE_LOW_PRIORITY else 0)
         side = self._side_stream
         st1 = C.c_void_p(side.cuda_stream)
         if self._bulk_stream is None:
@@ -390,6 +422,40 @@ class Recorder:
         main_dirty = True           # main has launched work the side stream has not been ordered after
         bulk_dirty = True           # ... the bulk stream has not been ordered after
         side_dirty = False          # side has launched work the bulk stream has not been ordered after
+        held: list = []             # bulk launches not yet released (BULK_DEFER)
+        held_age = 0                # chain launches since the first of them
+
+        def release_bulk():
+            nonlocal nev, bulk_dirty, side_dirty, held_age
+            if bulk_dirty:
+                if nev == len(self._events):
+                    self._events.append(torch.cuda.Event())
+                ev = self._events[nev]
+                nev += 1
+                ev.record(main)
+                bulk.wait_event(ev)
+                bulk_dirty = False
+            if side_dirty:      # bulk work may consume side-lane results (e.g. the Sups weight gradient reads `ds`)
+                if nev == len(self._events):
+                    self._events.append(torch.cuda.Event())
+                ev = self._events[nev]
+                nev += 1
+                ev.record(side)
+                bulk.wait_event(ev)
+                side_dirty = False
+            for hopi, hfn, hargs, hname in held:
+                if timed is not None:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(bulk)
+                rc = hfn(*hargs, st4)
+                if timed is not None:
+                    e1.record(bulk)
+                    timed.append((hopi, e0, e1))
+                if rc:
+                    L.check(rc, hname)
+            held.clear()
+            held_age = 0
+
         for opi, ((fn, args, name), lane) in enumerate(zip(ops, lanes)):
             if lane == 3:                       # stage marker
                 if marks is not None:
@@ -406,32 +472,15 @@ class Recorder:
                 main.wait_event(ev)
                 continue
             if lane == 4:
-                if bulk_dirty:
-                    if nev == len(self._events):
-                        self._events.append(torch.cuda.Event())
-                    ev = self._events[nev]
-                    nev += 1
-                    ev.record(main)
-                    bulk.wait_event(ev)
-                    bulk_dirty = False
-                if side_dirty:      # bulk work may consume side-lane results (e.g. the Sups weight gradient reads `ds`)
-                    if nev == len(self._events):
-                        self._events.append(torch.cuda.Event())
-                    ev = self._events[nev]
-                    nev += 1
-                    ev.record(side)
-                    bulk.wait_event(ev)
-                    side_dirty = False
-                if timed is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(bulk)
-                rc = fn(*args, st4)
-                if timed is not None:
-                    e1.record(bulk)
-                    timed.append((opi, e0, e1))
-                if rc:
-                    L.check(rc, name)
+                held.append((opi, fn, args, name))
+                if BULK_DEFER <= 0:
+                    release_bulk()
                 continue
+            if held:
+                if held_age >= BULK_DEFER:
+                    release_bulk()
+                else:
+                    held_age += 1
             if lane == 1:
                 if main_dirty:
                     if nev == len(self._events):
@@ -461,6 +510,8 @@ class Recorder:
                 bulk_dirty = True
             if rc:
                 L.check(rc, name)
+        if held:
+            release_bulk()
         if nev == len(self._events):
             self._events.append(torch.cuda.Event())
         ev = self._events[nev]
@@ -943,6 +994,7 @@ class Plan(Recorder):
         super().__init__(fp.device, fp)
         self.B, self.H, self.W = B, H, W
         self.want_backward = want_backward
+        self._p_state, self._p_splice_at = 1, 0
         self._build()
 
     @classmethod
@@ -951,6 +1003,8 @@ class Plan(Recorder):
         self = cls.__new__(cls)
         Recorder.__init__(self, fp.device, fp, scratch_floats)
         return self
+
+    _p_state = 0          # 0: _block records its own P launch + join; 1 / 2 / 3: first / second / later block of a full plan (see _block)
 
     # ------------------------------------------------------------ sub-graphs
     def _block(self, pfx: str, x: torch.Tensor, C_: int, heads: int, dims, y_out: "torch.Tensor | None" = None) -> Tuple[torch.Tensor, Callable]:
@@ -993,13 +1047,22 @@ class Plan(Recorder):
         n = pfx
         # ---- MDTA (live path of :93-100,107,110,113) ----
         self.qkv_fwd(n + ".qkv+conv", x, (g1, b1), Wqkv, Wdw, qkv_pre, qkv, C_=C_, dims=dims, stats=stats1)
-        # P = W_kv[vf] @ W_o depends on weights only: side lane, joined right before its first use
-        with self.side():
+        # P = W_kv[vf] @ W_o depends on weights only: side lane.  A full plan (Plan._build, _p_state >= 1) computes the first block's in
+        # place, joined right before its first use, and ALL the others right behind that join (Recorder.prologue: the side lane has the
+        # first block's GDFN to finish them), joined once before the second block's attention.  At the very start of the step they
+        # left the GPU idle while the host enqueued them (~300 us).  A block recorded by itself (unit tests) keeps its own launch + join
+        hoist = self._p_state >= 2
+        with (self.prologue() if hoist else self.side()):
             self.gemm(n + ".P", Wkvf, Wo, Pm, N=C_, K=C_, w_sn=1, w_sk=C_)
         fa = L.AttnFwdArgs()
         self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
                   out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, fused_out=gbuf)
-        self.join(n + ".P.join")
+        if self._p_state <= 2:
+            self.join(n + ".P.join")
+        if self._p_state == 1:
+            self._p_splice_at = len(self.fwd)
+        if self._p_state in (1, 2):
+            self._p_state += 1
         fa.G, fa.sq_q, fa.sq_k, fa.temperature, fa.P, fa.Wof = _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp), _ptr(Pm), _ptr(Wof)
         fa.attn, fa.WA, fa.WB = _ptr(attn), _ptr(WA), _ptr(WB)
         fa.B, fa.C, fa.heads = B, C_, heads
@@ -1216,6 +1279,13 @@ class Plan(Recorder):
         # 128}: every level of a 256 x 256 input): mag / pha, the polar form, |.| and their adjoints never make a round trip
         # through HBM as separate launches (round 4)
         fuse_ew = H in FUSED_DFT_SIZES and W in FUSED_DFT_SIZES
+        cat = self.alloc(4 * M, C_)
+        # the 3x3 shuffle branch is independent of the long spectral chain: side lane, joined before `reduce`.  Recorded FIRST: a side
+        # launch is ordered after everything the chain has launched when it is recorded - behind the spectral chain it started only when
+        # that had finished and the chain then idled for the whole branch (190-235 us per level, tools/trace_gaps.py)
+        with self.side():
+            s, sups_bw = self._conv3(pfx + ".Sups", x, f"{pfx}.Sups.body.0.weight", C_, 2 * C_, dims)
+            self._op(pfx + ".Sups.shuffle", lib.uir_pixel_shuffle, _ptr(s), _ld(s), _ptr(cat), _ld(cat), Ch, B, H, W, Ch)
         self.dft(f + ".dftW", x, None, ar, ai, O=B * H, N=W, I=1, C_=C_, sign=-1.0, scale=1.0)
         if fuse_ew:
             self.dft(f + ".dftH+magpha", ar, ai, mag, pha, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0, epi=L.DFT_EPI_MAGPHA)
@@ -1239,12 +1309,7 @@ class Plan(Recorder):
         Wpost, bpost = self.P(f + ".post.weight"), self.P(f + ".post.bias")
         po = self.alloc(M, Ch)
         self.gemm(f + ".post", t, Wpost, po, N=Ch, K=C_, w_sn=C_, w_sk=1, bias=bpost)
-        cat = self.alloc(4 * M, C_)
         self._op(f + ".scatter", lib.uir_scatter_even, _ptr(po), _ld(po), _ptr(bpost), _ptr(cat), _ld(cat), 0, B, H, W, Ch)
-        # the 3x3 shuffle branch is independent of the long spectral chain: side lane, joined before `reduce`
-        with self.side():
-            s, sups_bw = self._conv3(pfx + ".Sups", x, f"{pfx}.Sups.body.0.weight", C_, 2 * C_, dims)
-            self._op(pfx + ".Sups.shuffle", lib.uir_pixel_shuffle, _ptr(s), _ld(s), _ptr(cat), _ld(cat), Ch, B, H, W, Ch)
         self.join(pfx + ".join")
         Wred = self.P(f"{pfx}.reduce.weight")
         self.gemm(pfx + ".reduce", cat, Wred, y_out, N=Ch, K=C_, w_sn=C_, w_sk=1)
@@ -1357,6 +1422,7 @@ class Plan(Recorder):
         y4, out_bw = self._conv3("output", y8, "output.weight", 8, 3, d0, n_grp=(3, 4), Np=4)
         self._op("out.to_nchw", lib.uir_hwc4_to_nchw3, _ptr(y4), _ptr(self.out_nchw), B, H, W)
         self.mark("fwd.output")
+        self.splice_prologue(self._p_splice_at)
         if not self.want_backward:
             return
         # ------------------------------ backward ------------------------------
