@@ -15,3 +15,9 @@ python tools/probes/stamps/run.py > $O/phase_stamps.txt 2>&1 && echo stamps-ok
 python tools/bench_frfn.py --what net --no-cpu > $O/frfnnet_bench.json 2> $O/frfnnet.err && echo frfnnet-ok
 python tools/bench_frfn.py --what ast --no-cpu > $O/ast_bench.json 2> $O/ast.err && echo ast-ok
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete
+python tools/bench_conv3.py > $O/bench_conv3.txt 2>&1 && echo conv3-ok
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-breakdown > $O/trace.log 2>&1 && echo trace-ok
+cd $R
+python3 tools/trace_gaps.py $(find $O/trace -name "*kernel_trace.csv" | head -1) 3 > $O/chain_gaps.txt 2>&1
+find $O -name "*kernel_trace.csv" -delete

@@ -1,14 +1,13 @@
 #!/bin/bash
-O=$GRAFT_REPO_ROOT/gpurun_out/r04x; mkdir -p $O; R=$GRAFT_REPO_ROOT
-python -m pytest tests/test_hip_model.py tests/test_hip_kernels.py -x -q > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.txt
-run() { PYTHONPATH=. python3 tools/xp/ab_engine_flag.py "$@" 2>$O/err.txt | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('$*', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a $O/ab.txt; }
+O=gpurun_out/r04y2; mkdir -p $O
+run() { PYTHONPATH=. python3 tools/xp/ab_frfn.py "$@" 2>$O/err.txt | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a $O/ab.txt; }
+runh() { PYTHONPATH=. python3 tools/xp/ab_engine_flag.py "$@" 2>$O/err.txt | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('headline $*', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a $O/ab.txt; }
 for i in 1 2; do
-  run BULK_DEFER=0
-  run BULK_DEFER=30
-  run BULK_DEFER=30 SIDE_LOW_PRIORITY=False
+  run net BULK_DEFER=0
+  run net BULK_DEFER=30
+  run ast BULK_DEFER=0
+  run ast BULK_DEFER=30
+  runh BULK_DEFER=0
+  runh BULK_DEFER=30
 done
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-breakdown > $O/trace.log 2>&1 && echo trace-ok
-cd $R
-f=$(find $O/trace -name "*kernel_trace.csv" | head -1)
-python3 tools/trace_gaps.py $f 3 | tee $O/gaps.txt
+python -m pytest tests/test_hip_model.py -x -q 2>&1 | tail -2

@@ -151,7 +151,9 @@ _GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per
 # its kernels - 6-7 us of idle queue each (rocprofv3 kernel trace, tools/trace_gaps.py: 162 such gaps = 1.05 ms of a 36.4 ms step).
 # BULK_DEFER: weight-gradient (bulk lane) launches are held back on the host until this many chain launches have passed since the
 # first held one, then released behind ONE event (their inputs are never overwritten inside a step and nothing but the step's final
-# join reads their results, so a later release is only more of the lag the lane already has).  0 = release at once.
+# join reads their results, so a later release is only more of the lag the lane already has).  0 = release at once.  Only where the
+# chain still has 2 x BULK_DEFER launches to go: held work released near the end of a list is a tail behind its last chain kernel (the
+# short per-module lists of NewBigFRFNModel / AST lost 2-5 % with an unconditional hold).
 BULK_DEFER = 30
 SIDE_LOW_PRIORITY = True       # side lane on a lowest-priority stream (it fills what the chain leaves idle)
 FUSE_VALUE_GRAMS = True        # MDTA backward at C <= 32: dW_B / dW_A inside the dvf / dv GEMMs (EPI_PLAIN_DW); False = separate Gram launches
@@ -424,6 +426,7 @@ class Recorder:
         side_dirty = False          # side has launched work the bulk stream has not been ordered after
         held: list = []             # bulk launches not yet released (BULK_DEFER)
         held_age = 0                # chain launches since the first of them
+        chain_left = sum(1 for ln in lanes if ln in (0, 1))      # chain / side launches still to come
 
         def release_bulk():
             nonlocal nev, bulk_dirty, side_dirty, held_age
@@ -473,11 +476,12 @@ class Recorder:
                 continue
             if lane == 4:
                 held.append((opi, fn, args, name))
-                if BULK_DEFER <= 0:
+                if BULK_DEFER <= 0 or chain_left < 2 * BULK_DEFER:
                     release_bulk()
                 continue
+            chain_left -= 1
             if held:
-                if held_age >= BULK_DEFER:
+                if held_age >= BULK_DEFER or chain_left < 2 * BULK_DEFER:
                     release_bulk()
                 else:
                     held_age += 1
