@@ -235,6 +235,12 @@ typedef struct UirQkvFwdArgs {
   int B, H, Wd;
   int C;               /* in {16,32,64,128}                                                       */
   float ln_eps;
+  /* optional (C <= 32), round 4: the per-sample Gram of MDTA's attention logits from the tile that is on chip anyway
+   * (SpectralTransformer.py:96-98: q k^T and the norms F.normalize divides by).  Row `tile` of gram_slab (tile = (b * tiles_y + ty) *
+   * tiles_x + tx, 12 x 16 pixel tiles) receives  G[C][C] = sum_px q[px][m] k[px][n]  |  sum_px q[px][m]^2 [C]  |  sum_px k[px][n]^2 [C];
+   * the caller sums a sample's rows (uir_reduce_slab / _batch).  NULL: not computed. */
+  float* gram_slab;
+  long gram_stride;    /* floats between rows, >= C * C + 2 * C                                    */
 } UirQkvFwdArgs;
 int uir_qkv_fwd(const UirQkvFwdArgs* args, void* stream);
 

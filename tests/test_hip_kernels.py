@@ -1002,6 +1002,36 @@ def test_gemm_gate_bwd_in_the_interleaved_layout(M, C, fused_dw):
         assert rel(dws.sum(0).reshape(C, h), dy.T @ gate.detach()) < TOL
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 24, 32, 32), (1, 19, 35, 32), (2, 12, 16, 16), (3, 29, 21, 16)])
+def test_qkv_fwd_with_the_logits_gram_inside(B, H, W, C):
+    """UirQkvFwdArgs.gram_slab (MDTA forward at C <= 32, SpectralTransformer.py:93-98): q k^T per sample and the sums of squares that
+    F.normalize divides by, as per-tile partials of the launch that produces q and k, summed by one batched reduction - against the
+    same launch's own q / k output in fp64 (ragged 12 x 16 tiles: pixels outside the image must not count), bitwise run to run,
+    and q | k | v unchanged by the option."""
+    M = B * H * W
+    x, g1, b1 = rnd(M, C, seed=1), rnd(C, seed=2) + 1.0, rnd(C, seed=3)
+    Wqkv, Wdw = rnd(3 * C, C, seed=4) * 0.3, rnd(3 * C, 9, seed=5) * 0.3
+    outs = []
+    for rep_ in range(2):
+        r = rec()
+        pre, qkv, qkv0 = r.alloc(M, 3 * C), r.alloc(M, 3 * C), r.alloc(M, 3 * C)
+        gbuf = r.alloc(B * C * C + 2 * B * C)
+        gbuf.fill_(5.0)
+        G, sq, sk = gbuf[:B * C * C], gbuf[B * C * C:B * C * C + B * C], gbuf[B * C * C + B * C:]
+        r.qkv_fwd("qkv", dev(x), (dev(g1), dev(b1)), dev(Wqkv), dev(Wdw), pre, qkv, C_=C, dims=(B, H, W), gram_out=(G, sq, sk))
+        r.qkv_fwd("qkv0", dev(x), (dev(g1), dev(b1)), dev(Wqkv), dev(Wdw), pre, qkv0, C_=C, dims=(B, H, W))
+        r.run(r.fwd)
+        torch.cuda.synchronize()
+        outs.append(gbuf.clone())
+        assert torch.equal(qkv, qkv0)
+    assert torch.equal(outs[0], outs[1])
+    q = qkv[:, :C].double().cpu().reshape(B, H * W, C)
+    k = qkv[:, C:2 * C].double().cpu().reshape(B, H * W, C)
+    assert rel(G.reshape(B, C, C), torch.einsum("bpm,bpn->bmn", q, k)) < TOL
+    assert rel(sq.reshape(B, C), (q * q).sum(1)) < TOL
+    assert rel(sk.reshape(B, C), (k * k).sum(1)) < TOL
+
+
 @pytest.mark.parametrize("B,HW,C,rows,ldz,zoff", [(2, 384, 32, 3, 32, 0), (3, 256, 16, 1, 48, 32), (1, 1024, 32, 5, 96, 64), (2, 512, 16, 4, 16, 0),
                                                    (1, 128, 24, 1, 24, 0)])
 def test_gemm_with_the_per_sample_gram_in_its_epilogue(B, HW, C, rows, ldz, zoff):

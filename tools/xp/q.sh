@@ -1,13 +1,9 @@
 #!/bin/bash
-O=gpurun_out/r04y2; mkdir -p $O
-run() { PYTHONPATH=. python3 tools/xp/ab_frfn.py "$@" 2>$O/err.txt | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a $O/ab.txt; }
+O=gpurun_out/r04aa; mkdir -p $O
+python -m pytest tests/test_hip_kernels.py -x -q -k "qkv or gdfn or fused" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
+python -m pytest tests/test_hip_model.py -x -q > $O/pytest_model.txt 2>&1; echo "pytest model rc=$?"; tail -2 $O/pytest_model.txt
 runh() { PYTHONPATH=. python3 tools/xp/ab_engine_flag.py "$@" 2>$O/err.txt | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('headline $*', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a $O/ab.txt; }
-for i in 1 2; do
-  run net BULK_DEFER=0
-  run net BULK_DEFER=30
-  run ast BULK_DEFER=0
-  run ast BULK_DEFER=30
-  runh BULK_DEFER=0
-  runh BULK_DEFER=30
+for i in 1 2 3; do
+  runh FUSE_QK_GRAM=False
+  runh FUSE_QK_GRAM=True
 done
-python -m pytest tests/test_hip_model.py -x -q 2>&1 | tail -2

@@ -99,7 +99,8 @@ class GdfnFwdArgs(C.Structure):
 class QkvFwdArgs(C.Structure):
     _fields_ = [("X", fp), ("ln_g", fp), ("ln_b", fp), ("Wqkv", fp), ("Wdw", fp), ("Ypre", fp), ("Y", fp), ("stats", fp),
                 ("ldx", C.c_int), ("ldp", C.c_int), ("ldq", C.c_int),
-                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int), ("ln_eps", C.c_float)]
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int), ("ln_eps", C.c_float),
+                ("gram_slab", fp), ("gram_stride", C.c_long)]
 
 
 class AttnvFwdArgs(C.Structure):

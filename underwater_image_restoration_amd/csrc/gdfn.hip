@@ -761,6 +761,28 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
   float w1[9], w2[9], w1_n[9], w2_n[9];
   if (PF) load_w(0, win, w1, w2);
 
+  // ---- optional Gram of the attention logits (C <= 32, a.gram_slab): the q and k tiles pass through Gs anyway.  Each wave contracts its
+  // quarter of the tile's pixels on the f32 MFMA (A = q^T: lane = q channel, B = k: lane = k channel, k-slot h2 = pixel 2 s + h2); at
+  // C = 16 q and k share chunk 0 (columns 0..15 | 16..31) and the chunk's self-product holds q k^T off its diagonal blocks and both
+  // norms on its diagonal.  Pixels outside the image (ragged last tile row / column) do not count.
+  constexpr bool GRAM_OK = C <= 32;
+  constexpr int GSTEPS = GRAM_OK ? T::NI / 8 : 1;            // 2 pixels per step, a quarter of the tile per wave
+  const bool gram = GRAM_OK && a.gram_slab != nullptr;
+  float qa[GSTEPS];
+  f32x16 gd;
+  float sq_q = 0.f, sq_k = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) gd[i] = 0.f;
+  auto gram_frag = [&](float (&o)[GSTEPS]) {
+#pragma unroll
+    for (int s = 0; s < GSTEPS; ++s) {
+      const int p = (T::NI / 4) * wave + 2 * s + h2;
+      const int py = p / TW, px = p - py * TW;
+      const float v = Gs[p * T::SG + li];
+      o[s] = (y0 + py < a.H && x0 + px < a.Wd) ? v : 0.f;
+    }
+  };
+
   for (int c0 = 0; c0 < HD; c0 += 32) {
     if constexpr (PF) {
       load_w(c0 + 32 < HD ? c0 + 32 : c0, win_n, w1_n, w2_n);
@@ -882,6 +904,28 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
         const float4 v = *reinterpret_cast<const float4*>(Gs + (e >> 3) * T::SG + 4 * (e & 7));
         *reinterpret_cast<float4*>(reinterpret_cast<char*>(a.Y) + (st_out[it] + (unsigned)c0 * 4u)) = v;
       }
+    if constexpr (GRAM_OK) {
+      // Gs still holds this chunk's tile: it is rewritten only behind the next chunk's first barrier, which this wave has not reached
+      if (gram) {
+        if (C == 16 && c0 == 0) {
+          gram_frag(qa);
+#pragma unroll
+          for (int s = 0; s < GSTEPS; ++s) gd = uir_mfma(qa[s], qa[s], gd);
+        } else if (C == 32 && c0 == 0) {
+          gram_frag(qa);
+#pragma unroll
+          for (int s = 0; s < GSTEPS; ++s) sq_q = fmaf(qa[s], qa[s], sq_q);
+        } else if (C == 32 && c0 == 32) {
+          float kb[GSTEPS];
+          gram_frag(kb);
+#pragma unroll
+          for (int s = 0; s < GSTEPS; ++s) {
+            gd = uir_mfma(qa[s], kb[s], gd);
+            sq_k = fmaf(kb[s], kb[s], sq_k);
+          }
+        }
+      }
+    }
     if constexpr (PF) {
 #pragma unroll
       for (int jj = 0; jj < T::KJ; ++jj) win[jj] = win_n[jj];
@@ -892,6 +936,39 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
     }
     // the next (a) writes T1s (all reads done before the barrier above); Gs is rewritten after the next barrier,
     // which every wave reaches only after its qkv write-out
+  }
+  if constexpr (GRAM_OK) {
+    if (gram) {
+      // the four waves' partials meet in T1s (dead now) in a fixed order; one slab row per tile: G [C][C] | sum q^2 [C] | sum k^2 [C]
+      constexpr int RS = 1024 + 64;
+      sq_q += __shfl_xor(sq_q, 32);
+      sq_k += __shfl_xor(sq_k, 32);
+      lds_barrier();
+      float* red = T1s;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) red[wave * RS + i * 64 + lane] = gd[i];
+      if (h2 == 0) {
+        red[wave * RS + 1024 + li] = sq_q;
+        red[wave * RS + 1056 + li] = sq_k;
+      }
+      lds_barrier();
+      float* row = a.gram_slab + (long)blockIdx.x * a.gram_stride;
+      for (int e = tid; e < 1024; e += 256) {
+        const float v = (red[e] + red[RS + e]) + (red[2 * RS + e] + red[3 * RS + e]);
+        const int i = e >> 6, ln = e & 63;
+        const int m = uir_mfma_row(i, ln >> 5), n = ln & 31;
+        if (C == 32) {
+          row[m * 32 + n] = v;
+        } else {
+          if (m < 16 && n >= 16) row[m * 16 + (n - 16)] = v;
+          if (m == n) row[256 + m] = v;                     // sum q^2 at 256 + m (m < 16), sum k^2 at 272 + (m - 16)
+        }
+      }
+      if (C == 32 && tid < 64) {
+        const int e = 1024 + tid;
+        row[e] = (red[e] + red[RS + e]) + (red[2 * RS + e] + red[3 * RS + e]);
+      }
+    }
   }
 }
 
@@ -1221,6 +1298,7 @@ extern "C" int uir_gdfn_fwd(const UirGdfnFwdArgs* p, void* stream) {
 extern "C" int uir_qkv_fwd(const UirQkvFwdArgs* p, void* stream) {
   const UirQkvFwdArgs& a = *p;
   UIR_REQUIRE(a.X && a.ln_g && a.ln_b && a.Wqkv && a.Wdw && a.Ypre && a.Y);
+  UIR_REQUIRE(!a.gram_slab || (a.C <= 32 && a.gram_stride >= (long)a.C * a.C + 2 * a.C));
   UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0);
   UIR_REQUIRE(a.ldx >= a.C && (a.ldx & 3) == 0 && uir_aligned16(a.X) && uir_aligned16(a.ln_g) && uir_aligned16(a.ln_b) &&
               uir_aligned16(a.Wqkv));

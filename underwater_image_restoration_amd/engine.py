@@ -156,6 +156,7 @@ _GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per
 # short per-module lists of NewBigFRFNModel / AST lost 2-5 % with an unconditional hold).
 BULK_DEFER = 30
 SIDE_LOW_PRIORITY = True       # side lane on a lowest-priority stream (it fills what the chain leaves idle)
+FUSE_QK_GRAM = True            # MDTA forward at C <= 32: q k^T and the norms inside uir_qkv_fwd (UirQkvFwdArgs.gram_slab); False = uir_gram launch
 FUSE_VALUE_GRAMS = True        # MDTA backward at C <= 32: dW_B / dW_A inside the dvf / dv GEMMs (EPI_PLAIN_DW); False = separate Gram launches
 _PLAIN_DW_WGS = 768            # workgroups of a GEMM with the fused per-sample Gram (EPI_PLAIN_DW): the resident set at 3 per CU
 GEMM_SLAB_ROWS = 512           # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
@@ -285,17 +286,21 @@ class Recorder:
         if not self._pending:
             return
         pend, self._pending = self._pending, []
+        self._reduce_batch(tag + ".red_batch", pend, 4)
+
+    def _reduce_batch(self, name: str, pend: "List[tuple]", lane: int) -> None:
+        """ONE uir_reduce_slab_batch launch for a list of (name, slab ptr, rows, row stride, out ptr, n) reductions."""
         descs = (L.ReduceDesc * len(pend))()
         first, tot = [], 0
-        for d, (name, src, rows, stride, dst, n) in zip(descs, pend):
+        for d, (_nm, src, rows, stride, dst, n) in zip(descs, pend):
             d.slab, d.out, d.stride, d.n, d.nchunks, d.accumulate, d.scale = src, dst, stride, n, rows, 0, 1.0
             first.append(tot)
             tot += (n + 63) // 64
         dt = torch.frombuffer(bytearray(bytes(descs)), dtype=torch.uint8).to(self.dev)
         ft = torch.tensor(first, dtype=torch.int32).to(self.dev)
         self.keep += [dt, ft]
-        prev, self.lane = self.lane, 4
-        self._op(tag + ".red_batch", lib.uir_reduce_slab_batch, dt.data_ptr(), ft.data_ptr(), len(pend), tot,
+        prev, self.lane = self.lane, lane
+        self._op(name, lib.uir_reduce_slab_batch, dt.data_ptr(), ft.data_ptr(), len(pend), tot,
                  variant=f"uir_reduce_slab_batch")
         self.lane = prev
 
@@ -768,8 +773,15 @@ class Recorder:
         self._op(name, lib.uir_gdfn_fwd, C.byref(a), nbytes=rows * (12 * C_ + stored),
                  flops=rows * (2 * C_ * 2 * hp + 18 * 2 * hp + 2 * hp * C_))
 
-    def qkv_fwd(self, name, X, ln, Wqkv, Wdw, Ypre, Y, *, C_, dims, stats=None, eps=1e-5):
-        """Tile-fused norm1 -> qkv 1x1 -> depthwise 3x3 (csrc/gdfn.hip uir_qkv_fwd)."""
+    @staticmethod
+    def qkv_tiles(dims) -> int:
+        """Tiles per image of uir_qkv_fwd at C <= 32 (12 x 16 pixels): rows per sample of its Gram slab."""
+        return ((dims[1] + 11) // 12) * ((dims[2] + 15) // 16)
+
+    def qkv_fwd(self, name, X, ln, Wqkv, Wdw, Ypre, Y, *, C_, dims, stats=None, eps=1e-5, gram_out=None):
+        """Tile-fused norm1 -> qkv 1x1 -> depthwise 3x3 (csrc/gdfn.hip uir_qkv_fwd).
+        gram_out = (G [B][C*C], sum q^2 [B][C], sum k^2 [B][C]) (C <= 32): the attention logits' Gram and norms come out of the same
+        launch as per-tile partials and are summed per sample by ONE batched reduction right behind it."""
         self._hold(X, ln[0], ln[1], Wqkv, Wdw, Ypre, Y, stats)
         a = L.QkvFwdArgs()
         a.X, a.ln_g, a.ln_b, a.Wqkv, a.Wdw, a.Ypre, a.Y = (_ptr(X), _ptr(ln[0]), _ptr(ln[1]), _ptr(Wqkv), _ptr(Wdw),
@@ -781,8 +793,22 @@ class Recorder:
         a.ln_eps = eps
         rows = dims[0] * dims[1] * dims[2]
         assert X.shape[0] == rows and C_ in (16, 32, 64, 128)
+        pend = []
+        if gram_out is not None:
+            assert C_ <= 32
+            tpi, stride = self.qkv_tiles(dims), C_ * C_ + 2 * C_
+            slab = self._slab()
+            assert dims[0] * tpi * stride <= slab.numel()
+            a.gram_slab, a.gram_stride = _ptr(slab), stride
+            self._hold(*gram_out)
+            for b in range(dims[0]):
+                base = _ptr(slab) + 4 * b * tpi * stride
+                for off, t, n in ((0, gram_out[0], C_ * C_), (C_ * C_, gram_out[1], C_), (C_ * C_ + C_, gram_out[2], C_)):
+                    pend.append((name, base + 4 * off, tpi, stride, _ptr(t) + 4 * b * n, n))
         self.keep.append(a)
         self._op(name, lib.uir_qkv_fwd, C.byref(a), nbytes=rows * 4 * (C_ + 6 * C_), flops=rows * (2 * C_ * 3 * C_ + 18 * 3 * C_))
+        if pend:
+            self._reduce_batch(name + ".gram.red", pend, self.lane)
 
     def attnv_fwd(self, name, V, WA, WB, Wdw, R, U, VF, Y, *, C_, dims):
         """Tile-fused MDTA tail (csrc/gdfn.hip uir_attnv_fwd): U = V.WA[b]^T, VF = dw3x3(U), Y = VF.WB[b]^T + R."""
@@ -1050,7 +1076,10 @@ class Plan(Recorder):
 
         n = pfx
         # ---- MDTA (live path of :93-100,107,110,113) ----
-        self.qkv_fwd(n + ".qkv+conv", x, (g1, b1), Wqkv, Wdw, qkv_pre, qkv, C_=C_, dims=dims, stats=stats1)
+        # C <= 32: q k^T and the two norms come out of the qkv launch (the q and k tiles are on chip there); wider levels: a Gram launch
+        fuse_qk = FUSE_QK_GRAM and C_ <= 32
+        self.qkv_fwd(n + ".qkv+conv", x, (g1, b1), Wqkv, Wdw, qkv_pre, qkv, C_=C_, dims=dims, stats=stats1,
+                     gram_out=(Gm, sqq, sqk) if fuse_qk else None)
         # P = W_kv[vf] @ W_o depends on weights only: side lane.  A full plan (Plan._build, _p_state >= 1) computes the first block's in
         # place, joined right before its first use, and ALL the others right behind that join (Recorder.prologue: the side lane has the
         # first block's GDFN to finish them), joined once before the second block's attention.  At the very start of the step they
@@ -1059,8 +1088,9 @@ class Plan(Recorder):
         with (self.prologue() if hoist else self.side()):
             self.gemm(n + ".P", Wkvf, Wo, Pm, N=C_, K=C_, w_sn=1, w_sk=C_)
         fa = L.AttnFwdArgs()
-        self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
-                  out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, fused_out=gbuf)
+        if not fuse_qk:
+            self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
+                      out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, fused_out=gbuf)
         if self._p_state <= 2:
             self.join(n + ".P.join")
         if self._p_state == 1:
