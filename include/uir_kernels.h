@@ -741,6 +741,13 @@ int uir_uiqm(const UirUiqmArgs* args, void* stream);
  * bits over the 8 XCDs), for the weight-gradient lane of the train step.  The caller owns the stream. */
 int uir_stream_create_cu_masked(int n_enabled, void** out_stream);
 int uir_stream_destroy(void* stream);
+/* Ordering events between the streams of ONE device (the step's chain / side / bulk lanes): no timing, no system-scope fence at the record
+ * (hipEventDisableTiming | hipEventDisableSystemFence) - a default event's record writes the caches back for the host and other devices,
+ * which nothing here reads, and stalls the recording queue for it.  Not for host synchronisation. */
+int uir_event_create(void** out_event);
+int uir_event_destroy(void* event);
+int uir_event_record(void* event, void* stream);
+int uir_stream_wait_event(void* stream, void* event);
 
 /* library self-description (used by the loader test) */
 const char* uir_version(void);

@@ -300,6 +300,10 @@ SIGNATURES = {
     "uir_uiqm": [C.POINTER(UiqmArgs), fp],
     "uir_stream_create_cu_masked": [i32, C.POINTER(C.c_void_p)],
     "uir_stream_destroy": [fp],
+    "uir_event_create": [C.POINTER(fp)],
+    "uir_event_destroy": [fp],
+    "uir_event_record": [fp, fp],
+    "uir_stream_wait_event": [fp, fp],
     "uir_abi_layout": [C.c_char_p, C.POINTER(C.c_long), i32],   # host helper: returns a count (c_long)
 }
 

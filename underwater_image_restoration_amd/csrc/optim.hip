@@ -97,6 +97,25 @@ extern "C" int uir_stream_create_cu_masked(int n_enabled, void** out) {
   return UIR_OK;
 }
 
+extern "C" int uir_event_create(void** out) {
+  UIR_REQUIRE(out);
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) return UIR_ELAUNCH;
+  *out = ev;
+  return UIR_OK;
+}
+extern "C" int uir_event_destroy(void* ev) {
+  UIR_REQUIRE(ev);
+  return hipEventDestroy(static_cast<hipEvent_t>(ev)) == hipSuccess ? UIR_OK : UIR_ELAUNCH;
+}
+extern "C" int uir_event_record(void* ev, void* stream) {
+  UIR_REQUIRE(ev);
+  return hipEventRecord(static_cast<hipEvent_t>(ev), static_cast<hipStream_t>(stream)) == hipSuccess ? UIR_OK : UIR_ELAUNCH;
+}
+extern "C" int uir_stream_wait_event(void* stream, void* ev) {
+  UIR_REQUIRE(ev);
+  return hipStreamWaitEvent(static_cast<hipStream_t>(stream), static_cast<hipEvent_t>(ev), 0) == hipSuccess ? UIR_OK : UIR_ELAUNCH;
+}
 extern "C" int uir_stream_destroy(void* stream) {
   UIR_REQUIRE(stream);
   return hipStreamDestroy(static_cast<hipStream_t>(stream)) == hipSuccess ? UIR_OK : UIR_ELAUNCH;

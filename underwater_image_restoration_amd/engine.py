@@ -155,6 +155,7 @@ _GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per
 # chain still has 2 x BULK_DEFER launches to go: held work released near the end of a list is a tail behind its last chain kernel (the
 # short per-module lists of NewBigFRFNModel / AST lost 2-5 % with an unconditional hold).
 BULK_DEFER = 30
+FAST_LANE_EVENTS = True        # lane-ordering events without the system-scope fence (see _LaneEvent)
 SIDE_LOW_PRIORITY = True       # side lane on a lowest-priority stream (it fills what the chain leaves idle)
 FUSE_QK_GRAM = True            # MDTA forward at C <= 32: q k^T and the norms inside uir_qkv_fwd (UirQkvFwdArgs.gram_slab); False = uir_gram launch
 FUSE_VALUE_GRAMS = True        # MDTA backward at C <= 32: dW_B / dW_A inside the dvf / dv GEMMs (EPI_PLAIN_DW); False = separate Gram launches
@@ -213,6 +214,41 @@ def _ld(t: torch.Tensor) -> int:
     return t.stride(0)
 
 
+class _LaneEvent:
+    """Orders one lane's stream after another's inside a launch list.  FAST_LANE_EVENTS: an event without the system-scope fence of a
+    default event's record (include/uir_kernels.h uir_event_create) - every record / wait on the main stream is a barrier packet between
+    two chain kernels (tools/trace_gaps.py), and a default record also writes the caches back for readers that do not exist here."""
+
+    def __init__(self):
+        self.h = None
+        self.t = None
+        if FAST_LANE_EVENTS:
+            h = C.c_void_p()
+            L.check(lib.uir_event_create(C.byref(h)), "uir_event_create")
+            self.h = h
+        else:
+            self.t = torch.cuda.Event()
+
+    def record_on(self, stream) -> None:
+        if self.h is not None:
+            L.check(lib.uir_event_record(self.h, C.c_void_p(stream.cuda_stream)), "uir_event_record")
+        else:
+            self.t.record(stream)
+
+    def make_wait(self, stream) -> None:
+        if self.h is not None:
+            L.check(lib.uir_stream_wait_event(C.c_void_p(stream.cuda_stream), self.h), "uir_stream_wait_event")
+        else:
+            stream.wait_event(self.t)
+
+    def __del__(self):
+        if self.h is not None and lib is not None:
+            try:
+                lib.uir_event_destroy(self.h)
+            except Exception:
+                pass
+
+
 class Recorder:
     """Kernel-level recorder: buffers + an ordered list of C-ABI launches with pre-built
     argument structs.  `Plan` (below) records the whole network with it; the GPU unit tests
@@ -240,7 +276,8 @@ class Recorder:
         self.lanes: Dict[int, list] = {id(self.fwd): [], id(self.bwd): [], id(self.pro): []}
         self._side_stream = None
         self._bulk_stream = None
-        self._events: List[object] = []
+        self._events: List[object] = []        # lane-ordering events inside a list (_LaneEvent)
+        self._join_events: List[object] = []   # the two joins at the end of a list: torch events (default fences)
         self._pending: List[tuple] = []        # bulk-lane slab reductions waiting for the stage's batched launch
 
     # ------------------------------------------------------------------ memory
@@ -437,19 +474,19 @@ class Recorder:
             nonlocal nev, bulk_dirty, side_dirty, held_age
             if bulk_dirty:
                 if nev == len(self._events):
-                    self._events.append(torch.cuda.Event())
+                    self._events.append(_LaneEvent())
                 ev = self._events[nev]
                 nev += 1
-                ev.record(main)
-                bulk.wait_event(ev)
+                ev.record_on(main)
+                ev.make_wait(bulk)
                 bulk_dirty = False
             if side_dirty:      # bulk work may consume side-lane results (e.g. the Sups weight gradient reads `ds`)
                 if nev == len(self._events):
-                    self._events.append(torch.cuda.Event())
+                    self._events.append(_LaneEvent())
                 ev = self._events[nev]
                 nev += 1
-                ev.record(side)
-                bulk.wait_event(ev)
+                ev.record_on(side)
+                ev.make_wait(bulk)
                 side_dirty = False
             for hopi, hfn, hargs, hname in held:
                 if timed is not None:
@@ -473,11 +510,11 @@ class Recorder:
                 continue
             if lane == 2:                       # join marker
                 if nev == len(self._events):
-                    self._events.append(torch.cuda.Event())
+                    self._events.append(_LaneEvent())
                 ev = self._events[nev]
                 nev += 1
-                ev.record(side)
-                main.wait_event(ev)
+                ev.record_on(side)
+                ev.make_wait(main)
                 continue
             if lane == 4:
                 held.append((opi, fn, args, name))
@@ -493,11 +530,11 @@ class Recorder:
             if lane == 1:
                 if main_dirty:
                     if nev == len(self._events):
-                        self._events.append(torch.cuda.Event())
+                        self._events.append(_LaneEvent())
                     ev = self._events[nev]
                     nev += 1
-                    ev.record(main)
-                    side.wait_event(ev)
+                    ev.record_on(main)
+                    ev.make_wait(side)
                     main_dirty = False
                 if timed is not None:
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -521,15 +558,13 @@ class Recorder:
                 L.check(rc, name)
         if held:
             release_bulk()
-        if nev == len(self._events):
-            self._events.append(torch.cuda.Event())
-        ev = self._events[nev]
+        while len(self._join_events) < 2:
+            self._join_events.append(torch.cuda.Event())
+        ev = self._join_events[0]
         ev.record(side)
         main.wait_event(ev)         # join: everything after this list sees the side lane's results
         if 4 in lanes:
-            if nev + 1 >= len(self._events):
-                self._events.append(torch.cuda.Event())
-            ev2 = self._events[nev + 1]
+            ev2 = self._join_events[1]
             ev2.record(bulk)
             main.wait_event(ev2)
 
