@@ -23,6 +23,8 @@ def main():
         r.gemm(name, x, w, y, N=Cout, K=Cin, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=(S, S), **ng)
         r.gemm(name + ".dX", dy, w, dx, N=Cin, K=Cout, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=(S, S), **kg)
         r.gemm(name + ".dX+R", dy, w, dx, N=Cin, K=Cout, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=(S, S), R=res, **kg)
+        dw = r.alloc(w.shape[0], Cin, 3, 3)
+        r.gram(name + ".dW", dy, x, dw, N=Cout, K=Cin, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=(S, S), **ng)
         sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for i, (fn, args, label) in enumerate(r.fwd):
             for _ in range(3):
@@ -35,6 +37,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1000 / 20
+            if fn is None:
+                continue
             nb = 4 * M * (Cin + Cout + (Cin if i == 2 else 0))
             print(f"{label:14s} {us:8.1f} us  {nb / us / 1e3:7.0f} GB/s", flush=True)
 

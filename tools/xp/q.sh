@@ -1,13 +1,17 @@
 #!/bin/bash
-O=$GRAFT_REPO_ROOT/gpurun_out/r04ab; mkdir -p $O; R=$GRAFT_REPO_ROOT
-python -m pytest tests/test_hip_model.py -x -q > $O/pytest_model.txt 2>&1; echo "pytest model rc=$?"; tail -2 $O/pytest_model.txt
-runh() { PYTHONPATH=. python3 tools/xp/ab_engine_flag.py "$@" 2>$O/err.txt | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print('headline $*', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a $O/ab.txt; }
-for i in 1 2 3; do
-  runh FAST_LANE_EVENTS=False
-  runh FAST_LANE_EVENTS=True
+O=gpurun_out/r04ac; mkdir -p $O
+python -m pytest tests/test_hip_kernels.py -x -q -k "gram or conv3x3" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
+L=underwater_image_restoration_amd/libuir_hip.so
+for v in old new; do
+  cp tools/xp/libs/$v.so $L
+  echo "== $v" | tee -a $O/conv3.txt
+  python tools/bench_conv3.py 2>&1 | grep "dW\|red" | tee -a $O/conv3.txt
 done
-cd /tmp && export TMPDIR=/tmp
-timeout -k 10 400 rocprofv3 --kernel-trace --output-format csv -d $O/trace -- python3 $R/bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-breakdown > $O/trace.log 2>&1 && echo trace-ok
-cd $R
-python3 tools/trace_gaps.py $(find $O/trace -name "*kernel_trace.csv" | head -1) 3 | tee $O/gaps.txt | head -12
-find $O -name "*kernel_trace.csv" -delete
+for i in 1 2 3; do
+for v in old new; do
+  cp tools/xp/libs/$v.so $L
+  python bench.py --no-cpu-baseline --no-kernel-breakdown --steps 10 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a $O/ab.txt
+done
+done
+cp tools/xp/libs/new.so $L
+python -m pytest tests/test_hip_model.py -x -q 2>&1 | tail -2

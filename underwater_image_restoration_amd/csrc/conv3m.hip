@@ -190,7 +190,168 @@ int conv3m_launch(const UirGemmArgs& a, hipStream_t st) {
   return uir_launch_status();
 }
 
+// ---- the weight gradient of the same convolutions: dW[n][k][tap] = sum_px dY[px][n] * X[px + off(tap)][k] (uir_gram, taps = 9) ----
+// N <= 16 outputs, K <= 32 inputs (outputl, output, down1, down2): the nine-tap column kernel of csrc/gram.hip gathers nine shifted copies of
+// dY per pixel pair from global memory and ran these four launches at 0.03-0.04 of the HBM peak (0.27 ms each on the bulk lane).  Here the
+// X tile with its ring and the dY tile go through LDS once per 16 x 16 pixel tile; v_mfma_f32_16x16x4_f32 contracts over PIXELS:
+// A = dY^T (row = output channel, k-slot j16 = pixel x + 4 j16 of an image row), B = X shifted by the tap (column = input channel of a
+// 16-channel block), one 16 x 16 accumulator per (tap, channel block) held across all the workgroup's tiles - 18 of them for outputl.
+// The two pixels a 32-lane half reads sit 4 apart: 4 * 36 floats = 16 banks.  Rows / columns past N / K multiply padding and are never stored.
+template <int KC, int NQ>
+__global__ __launch_bounds__(256, 2) void uir_conv3x3_wgrad_kernel(const UirGramArgs a, const int ntiles) {
+  using T = Conv3m<KC>;
+  constexpr int NCB = KC >= 32 ? 2 : 1;
+  constexpr int NS = 20;                                    // dY tile row stride (floats): 4 * 20 = 16 banks between the two pixels of a half
+  constexpr int NEY = 256 * NQ, NLY = (NEY + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float tile[];       // X: [RH * RW][KS] | dY: [256][NS]
+  float* ys = tile + T::RH * T::RW * T::KS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l16 = lane & 15, j16 = lane >> 4;
+  const int tiles_x = (a.Wd + 15) / 16, tiles_y = (a.H + 15) / 16;
+  struct Tc { int y0, x0; long img; };
+  auto coords = [&](int tl) {
+    int bid = tl < ntiles ? tl : ntiles - 1;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y;
+    Tc c;
+    c.y0 = ty * 16; c.x0 = tx * 16; c.img = (long)(bid / tiles_y) * a.H * a.Wd;
+    return c;
+  };
+  float4 sx[T::NLD], sy[NLY];
+  auto load_tile = [&](const Tc& c) {
+#pragma unroll
+    for (int t = 0; t < T::NLD; ++t) {
+      const int e = min(tid + 256 * t, T::NE - 1);
+      const int p = e / T::KQ, q = e - p * T::KQ;
+      const int ry = p / T::RW, rx = p - ry * T::RW;
+      const int iy = min(max(c.y0 + ry - 1, 0), a.H - 1), ix = min(max(c.x0 + rx - 1, 0), a.Wd - 1);
+      sx[t] = *reinterpret_cast<const float4*>(a.B + (c.img + (long)iy * a.Wd + ix) * a.ldb + 4 * q);
+    }
+#pragma unroll
+    for (int t = 0; t < NLY; ++t) {
+      const int e = tid + 256 * t, p = e / NQ, q = e - p * NQ;
+      const int iy = min(c.y0 + (p >> 4), a.H - 1), ix = min(c.x0 + (p & 15), a.Wd - 1);
+      sy[t] = *reinterpret_cast<const float4*>(a.A + (c.img + (long)iy * a.Wd + ix) * a.lda + 4 * q);
+    }
+  };
+  f32x4m acc[9][NCB];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int cb = 0; cb < NCB; ++cb) acc[t][cb] = f32x4m{0.f, 0.f, 0.f, 0.f};
+  load_tile(coords(blockIdx.x));
+
+  for (int tl = blockIdx.x; tl < ntiles; tl += gridDim.x) {
+    const Tc c = coords(tl);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < T::NLD; ++t) {
+      const int e = tid + 256 * t;
+      const int p = e / T::KQ, q = e - p * T::KQ;
+      const int ry = p / T::RW, rx = p - ry * T::RW;
+      const int iy = c.y0 + ry - 1, ix = c.x0 + rx - 1;
+      const float z = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd) ? 1.f : 0.f;
+      if (e < T::NE) *reinterpret_cast<float4*>(tile + p * T::KS + 4 * q) = make_float4(sx[t].x * z, sx[t].y * z, sx[t].z * z, sx[t].w * z);
+    }
+#pragma unroll
+    for (int t = 0; t < NLY; ++t) {
+      const int e = tid + 256 * t, p = e / NQ, q = e - p * NQ;
+      const float z = (c.y0 + (p >> 4) < a.H && c.x0 + (p & 15) < a.Wd) ? 1.f : 0.f;     // pixels outside the image add nothing
+      if (e < NEY) *reinterpret_cast<float4*>(ys + p * NS + 4 * q) = make_float4(sy[t].x * z, sy[t].y * z, sy[t].z * z, sy[t].w * z);
+    }
+    __syncthreads();
+    load_tile(coords(tl + gridDim.x));
+
+    // this wave: image rows 4 wave .. 4 wave + 3 of the tile, 4 k-steps (16 pixels) per row; step (r, q): pixel x = q + 4 j16
+    const float* ap0 = ys + ((4 * wave) * 16 + 4 * j16) * NS + l16;
+    const float* bp0 = tile + ((4 * wave) * T::RW + 4 * j16) * T::KS + l16;
+    float av[2], bv[2][9][NCB];
+    auto fetch = [&](const int st, float& ao, float (&bo)[9][NCB]) {
+      const int r = st >> 2, q = st & 3;
+      ao = ap0[(r * 16 + q) * NS];
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb) bo[t][cb] = bp0[((r + t / 3) * T::RW + q + t % 3) * T::KS + 16 * cb];
+    };
+    // operands of step st + 1 are read while step st's MFMAs issue; the widest variant (K = 32, N = 16) has no registers for the second
+    // set (it spilled 60 bytes): its reads precede their own MFMAs
+    constexpr bool PIPE = !(KC == 32 && NQ == 4);
+    if (PIPE) fetch(0, av[0], bv[0]);
+#pragma unroll
+    for (int st = 0; st < 16; ++st) {
+      const int cur = PIPE ? (st & 1) : 0;
+      if (PIPE) {
+        if (st + 1 < 16) fetch(st + 1, av[(st + 1) & 1], bv[(st + 1) & 1]);
+      } else {
+        fetch(st, av[0], bv[0]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+          acc[t][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur], bv[cur][t][cb], acc[t][cb], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  // the four waves' partials meet in LDS in a fixed order; one slab row per workgroup
+  __syncthreads();
+  float* red = tile;
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            float* p = &red[((t * NCB + cb) * 4 + i) * 64 + lane];
+            *p = (w == 0) ? acc[t][cb][i] : (*p + acc[t][cb][i]);
+          }
+    }
+    __syncthreads();
+  }
+  float* slab = a.slab + (long)blockIdx.x * a.slab_stride;
+  for (int idx = tid; idx < 9 * NCB * 256; idx += 256) {
+    const int ln = idx & 63, i = (idx >> 6) & 3, tc = idx >> 8;
+    const int t = tc / NCB, cb = tc - t * NCB;
+    const int n = 4 * (ln >> 4) + i, k = 16 * cb + (ln & 15);
+    if (n < a.N && k < a.K) {
+      const int nr = uir_colmap(n, a.n_grp_real, a.n_grp_pad);
+      const int kr = uir_colmap(k, a.k_grp_real, a.k_grp_pad);
+      if (nr >= 0 && kr >= 0) slab[(long)nr * a.o_sn + (long)kr * a.o_sk + (long)t * a.o_st] = red[idx];
+    }
+  }
+}
+
+template <int KC, int NQ>
+int conv3m_wgrad_launch(const UirGramArgs& a, hipStream_t st) {
+  using T = Conv3m<KC>;
+  const int tiles = (a.M / (a.H * a.Wd)) * ((a.H + 15) / 16) * ((a.Wd + 15) / 16);
+  const size_t lds = (size_t)T::LDS_BYTES + 256 * 20 * sizeof(float);
+  hipLaunchKernelGGL((uir_conv3x3_wgrad_kernel<KC, NQ>), dim3(a.nchunks), dim3(256), lds, st, a, tiles);
+  return uir_launch_status();
+}
+
 }  // namespace
+
+// Weight gradient of a 3 x 3 convolution with N <= 16 outputs and K <= 32 inputs; -1: not a shape this kernel serves (uir_gram continues).
+// One slab row per workgroup, a.nchunks workgroups (any count >= 1: workgroup w takes tiles w, w + nchunks, ...).
+int uir_conv3x3_wgrad(const UirGramArgs& a, void* stream) {
+  if (a.taps != 9 || a.batches != 1 || a.pro_b != 0 || a.sq_a_off >= 0 || a.sq_b_off >= 0 || a.cs_a_off >= 0) return -1;
+  if (a.N > 16 || a.N < 4 || (a.N & 3) || a.K > 32 || a.K < 8 || (a.K & 3) || (a.lda & 3) || (a.ldb & 3) || !uir_aligned16(a.A) ||
+      !uir_aligned16(a.B))
+    return -1;
+  const int Kc = a.K <= 8 ? 8 : a.K <= 16 ? 16 : 32;
+  if (a.ldb < Kc || a.K != Kc) return -1;          // X rows are read in float4 groups up to the template width
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int nq = a.N / 4;
+#define UIR_C3W(KV, QV) if (Kc == KV && nq == QV) return conv3m_wgrad_launch<KV, QV>(a, st)
+  UIR_C3W(32, 2); UIR_C3W(32, 4); UIR_C3W(16, 2); UIR_C3W(8, 1);
+#undef UIR_C3W
+  return -1;
+}
 
 // -1: not a shape this kernel serves (the caller continues with csrc/conv3s.hip / the MFMA panel paths)
 int uir_conv3x3_mfma(const UirGemmArgs& a, void* stream) {

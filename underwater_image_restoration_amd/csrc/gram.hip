@@ -13,6 +13,8 @@
 #define UIR_GRAM_U3 3   // row pairs per trip of the 3-tile variants: 3 keeps them at 3 waves/SIMD (4: 174 registers -> 2 waves)
 #endif
 
+int uir_conv3x3_wgrad(const UirGramArgs& a, void* stream);     // csrc/conv3m.hip; -1 = not its shape
+
 namespace {
 
 // EXTRAS: also the column sums of squares / column sums (only the q.k^T Gram and the bias gradients ask for them: the
@@ -497,6 +499,11 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
       t.allow_split = a.N >= 256 || a.K >= 256;
       return uir_tiled_gemm(t, st);
     }
+  }
+  {
+    // 3 x 3 weight gradients with <= 16 outputs and 8 / 16 / 32 inputs: the LDS-staged pixel contraction of csrc/conv3m.hip
+    const int rw = uir_conv3x3_wgrad(a, stream);
+    if (rw >= 0) return rw;
   }
   const int tn_tiles = (a.N + 31) / 32, tk_tiles = (a.K + 31) / 32;
   constexpr bool cols9 = true;

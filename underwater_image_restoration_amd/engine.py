@@ -159,6 +159,7 @@ FAST_LANE_EVENTS = True        # lane-ordering events without the system-scope f
 SIDE_LOW_PRIORITY = True       # side lane on a lowest-priority stream (it fills what the chain leaves idle)
 FUSE_QK_GRAM = True            # MDTA forward at C <= 32: q k^T and the norms inside uir_qkv_fwd (UirQkvFwdArgs.gram_slab); False = uir_gram launch
 FUSE_VALUE_GRAMS = True        # MDTA backward at C <= 32: dW_B / dW_A inside the dvf / dv GEMMs (EPI_PLAIN_DW); False = separate Gram launches
+_WGRAD3_WGS = 512              # workgroups of the LDS-staged 3 x 3 weight-gradient kernel (two per CU)
 _PLAIN_DW_WGS = 768            # workgroups of a GEMM with the fused per-sample Gram (EPI_PLAIN_DW): the resident set at 3 per CU
 GEMM_SLAB_ROWS = 512           # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
 FUSED_DW_MINROWS = 16 * 128 * 128   # depthwise backward as ONE pass (dX + dW) from this many pixels on; below, two kernels on two lanes
@@ -669,7 +670,11 @@ class Recorder:
             groups = (tk + 3) // 4
         else:
             groups = ((tn + 1) // 2) * ((tk + 1) // 2)
-        if taps == 9 and tn == 1 and tk == 1 and not extras and pro_b == 0:
+        if (taps == 9 and batches == 1 and not extras and pro_b == 0 and N in (4, 8, 16) and K in (8, 16, 32)):
+            # csrc/conv3m.hip uir_conv3x3_wgrad: persistent workgroups over 16 x 16 pixel tiles, one slab row each
+            nch = max(1, min(batches * ((hw[0] + 15) // 16) * ((hw[1] + 15) // 16) * (M // (hw[0] * hw[1])), _WGRAD3_WGS))
+            rpc = ((M + nch - 1) // nch + 7) & ~7
+        elif taps == 9 and tn == 1 and tk == 1 and not extras and pro_b == 0:
             nch, rpc = self._chunks(M, 1, batches)          # all 9 taps handled inside one workgroup
         elif (taps == 1 and batches == 1 and pro_b == 0 and not extras and min(N, K) >= 128 and not (n_grp[1] or k_grp[1])
               and shared_slab is None and fused_out is None):
