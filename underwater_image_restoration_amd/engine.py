@@ -156,7 +156,8 @@ _GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per
 # short per-module lists of NewBigFRFNModel / AST lost 2-5 % with an unconditional hold).
 BULK_DEFER = 30
 FAST_LANE_EVENTS = True        # lane-ordering events without the system-scope fence (see _LaneEvent)
-SIDE_LOW_PRIORITY = True       # side lane on a lowest-priority stream (it fills what the chain leaves idle)
+SIDE_LOW_PRIORITY = True       # side lane on the least-priority stream torch offers (on this ROCm build priority_range() is (0, -1): the
+                               # default priority - no difference was ever measured, nor with the chain on a priority -1 stream)
 FUSE_QK_GRAM = True            # MDTA forward at C <= 32: q k^T and the norms inside uir_qkv_fwd (UirQkvFwdArgs.gram_slab); False = uir_gram launch
 FUSE_VALUE_GRAMS = True        # MDTA backward at C <= 32: dW_B / dW_A inside the dvf / dv GEMMs (EPI_PLAIN_DW); False = separate Gram launches
 _WGRAD3_WGS = 512              # workgroups of the LDS-staged 3 x 3 weight-gradient kernel (two per CU)
