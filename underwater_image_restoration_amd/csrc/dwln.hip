@@ -69,7 +69,9 @@ struct DwLn {
   static constexpr int NPX1 = RW * RH;                    // 180 tile + ring pixels
   static constexpr int NI = TH * TW;                      // 128 interior pixels = 4 MFMA row tiles, one per wave
   static constexpr int NLD = (NPX1 * 8 + 255) / 256;      // float4 loads per thread and G chunk (6)
-  static constexpr int S1 = 40, SG = 36, SX = 36;         // LDS row strides (floats): G chunk / dP chunk / xhat
+  static constexpr int S1 = 40, SG = 36;                  // LDS row strides (floats): G chunk / dP chunk
+  static constexpr int SXT = NI + 4;                      // xhat is kept TRANSPOSED, [channel][pixel]: (d) reads four consecutive pixels of one
+                                                          // channel with one ds_read_b128 (four MFMA steps), the epilogue four of its 16 rows
   static constexpr int GS1_ROWS = NLD * 32;               // 192 (rows >= NPX1 hold zeros)
   static constexpr int NXL = (NI * (C / 4)) / 256;        // float4 loads per thread of the x tile (4 at C = 32, 2 at C = 16)
   static constexpr int NG = 2 * (C / 16);                 // 16 x 16 granules of a chunk's dW1 tile (4 at C = 32, 2 at C = 16)
@@ -77,7 +79,8 @@ struct DwLn {
   static constexpr int STEPS = NI / 4 / PARTS;            // 16x16x4 MFMA steps per wave and chunk
   static constexpr int OFF_GS = GS1_ROWS * S1;
   static constexpr int OFF_XH = OFF_GS + NI * SG;
-  static constexpr int OFF_RS = OFF_XH + NI * SX;
+  static constexpr int OFF_RS = OFF_XH + NI * SG;          // (the [32][NI + 4] transposed xhat fits the [NI][36] it replaced)
+  static_assert(32 * SXT <= NI * SG, "xhat buffer");
   static constexpr int OFF_WR = OFF_RS + NI;
   static constexpr int SW = C + 4;                         // row stride of the staged W1 chunk [32 rows][C] (16-byte rows)
   static constexpr int OFF_W1 = OFF_WR + 4 * 16 * 18;
@@ -289,8 +292,11 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         const float4 v = xv[it];
         const float2 st = sv[it];
         const float rs = okv[it] ? st.y : 0.f;
-        *reinterpret_cast<float4*>(XH + p * T::SX + 4 * q) =
-            make_float4((v.x - st.x) * rs, (v.y - st.x) * rs, (v.z - st.x) * rs, (v.w - st.x) * rs);
+        float* xd = XH + 4 * q * T::SXT + p;
+        xd[0] = (v.x - st.x) * rs;
+        xd[T::SXT] = (v.y - st.x) * rs;
+        xd[2 * T::SXT] = (v.z - st.x) * rs;
+        xd[3 * T::SXT] = (v.w - st.x) * rs;
         if (q == 0) RS[p] = rs;
       }
     }
@@ -449,34 +455,35 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       }
       UIR_ST(6);
       // ---- (d) dW1 chunk granule += dP^T . (xhat gamma + beta) over this wave's pixels.  k-slot j of step s is pixel
-      //      8 (s >> 1) + 2 (s & 1) + (j >> 1) + 4 (j & 1): the two rows a 32-lane half reads sit 4 * 36 floats = 16 banks apart ----
+      //      16 (s >> 2) + 4 j + (s & 3): a lane's four steps of a group read four CONSECUTIVE pixels - one ds_read_b128 of the transposed
+      //      xhat for the B operand; the two A rows a 32-lane half reads sit 4 * 36 floats = 16 banks apart ----
       {
-        const float* ga = Gs + 16 * gr_k + l16 + ((j16 >> 1) + 4 * (j16 & 1) + 8 * (part * (T::STEPS / 2))) * T::SG;
-        const float* xb = XH + n16 + ((j16 >> 1) + 4 * (j16 & 1) + 8 * (part * (T::STEPS / 2))) * T::SX;
+        const int p0 = 4 * j16 + 64 * part * (T::STEPS / 16);
+        const float* ga = Gs + 16 * gr_k + l16 + p0 * T::SG;
+        const float* xb = XH + n16 * T::SXT + p0;
         f32x4v d, d1 = f32x4v{0.f, 0.f, 0.f, 0.f};             // two chains: a dependent v_mfma_f32_16x16x4_f32 issues every 40 cycles, not 32
         DW_GET(ci, d);
         constexpr int NGR = T::STEPS / 8;                      // groups of 8 steps = 32 pixels; operands of group g + 1 are read
-        float av[2][8], bv[2][8];                              // from LDS before the MFMAs of group g are issued
-        auto fetch = [&](int g, float (&ao)[8], float (&bo)[8]) {
+        float av[2][8];                                        // from LDS before the MFMAs of group g are issued
+        f32x4v bq[2][2];
+        auto fetch = [&](int g, float (&ao)[8], f32x4v (&bo)[2]) {
 #pragma unroll
-          for (int s = 0; s < 8; ++s) {
-            const int p = 32 * g + 8 * (s >> 1) + 2 * (s & 1);   // compile-time LDS offsets
-            ao[s] = ga[p * T::SG];
-            bo[s] = xb[p * T::SX];
-          }
+          for (int s = 0; s < 8; ++s) ao[s] = ga[(32 * g + 16 * (s >> 2) + (s & 3)) * T::SG];   // compile-time LDS offsets
+          bo[0] = *reinterpret_cast<const f32x4v*>(xb + 32 * g);
+          bo[1] = *reinterpret_cast<const f32x4v*>(xb + 32 * g + 16);
         };
         // sched_barriers: as plain code hipcc sank every ds_read next to the MFMA that consumes it - one exposed LDS round trip per
-        // MFMA pair, 26 % of the kernel (tools/probes/stamps, tools/scan_isa_chains.py); pinned, a group's 16 reads land under the
+        // MFMA pair, 26 % of the kernel (tools/probes/stamps, tools/scan_isa_chains.py); pinned, a group's reads land under the
         // previous group's 8 MFMAs
-        fetch(0, av[0], bv[0]);
+        fetch(0, av[0], bq[0]);
 #pragma unroll
         for (int g = 0; g < NGR; ++g) {
-          if (g + 1 < NGR) fetch(g + 1, av[(g + 1) & 1], bv[(g + 1) & 1]);
+          if (g + 1 < NGR) fetch(g + 1, av[(g + 1) & 1], bq[(g + 1) & 1]);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int s = 0; s < 8; s += 2) {
-            d = mfma16(av[g & 1][s], fmaf(bv[g & 1][s], gam16, bet16), d);
-            d1 = mfma16(av[g & 1][s + 1], fmaf(bv[g & 1][s + 1], gam16, bet16), d1);
+            d = mfma16(av[g & 1][s], fmaf(bq[g & 1][s >> 2][s & 3], gam16, bet16), d);
+            d1 = mfma16(av[g & 1][s + 1], fmaf(bq[g & 1][(s + 1) >> 2][(s + 1) & 3], gam16, bet16), d1);
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -511,11 +518,15 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       for (int hf = 0; hf < 2; ++hf) {
         float xqv[8], rsv[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const int r = 8 * hf + q;
-          const int p = (2 * wave + (r >> 3)) * T::TW + (r & 3) + 8 * ((r >> 2) & 1) + 4 * h2;
-          xqv[q] = XH[p * T::SX + nn];
-          rsv[q] = RS[p];
+        for (int q4 = 0; q4 < 2; ++q4) {                     // registers 8 hf + 4 q4 .. + 3: four consecutive pixels of tile row 2 wave + hf
+          const int p = (2 * wave + hf) * T::TW + 8 * q4 + 4 * h2;
+          const f32x4v xv4 = *reinterpret_cast<const f32x4v*>(XH + nn * T::SXT + p);
+          const f32x4v rs4 = *reinterpret_cast<const f32x4v*>(RS + p);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            xqv[4 * q4 + e] = xv4[e];
+            rsv[4 * q4 + e] = rs4[e];
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
