@@ -39,8 +39,8 @@ def test_factory_builds_the_references_ast():
     assert [str(tuple(v.shape)) for v in sd.values()] == list(MAN["shapes"])
     assert sum(p.numel() for p in m.parameters()) == int(MAN["n_params"]) == 19919507
     for (k, v), s, a in zip(sd.items(), MAN["sums"], MAN["abs_sums"]):      # same registration order and initialisers: same RNG stream
-        assert abs(float(v.double().sum()) - s) <= 1e-9 * max(1.0, abs(s)), k
-        assert abs(float(v.double().abs().sum()) - a) <= 1e-9 * max(1.0, a), k
+        assert abs(float(v.double().sum()) - s) <= 1e-7 * max(1.0, abs(s)), k
+        assert abs(float(v.double().abs().sum()) - a) <= 1e-7 * max(1.0, a), k
     blocks = [b for l in O.LAYERS for b in m.get_submodule(l).blocks]
     assert np.allclose([b.drop_prob for b in blocks], MAN["drop_probs"], atol=1e-7)
     assert [b.shift_size for b in blocks] == [0, 4] * 9 and [b.att for b in blocks] == [False] * 8 + [True] * 10

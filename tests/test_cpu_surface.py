@@ -159,7 +159,7 @@ def test_default_init_matches_reference_rng_stream(golden_dir):
     m = Models.init_model("SpectralTransformer")
     got = {k: float(v.double().sum()) for k, v in m.state_dict().items()}
     for k, s in zip(g["names"], g["sums"]):
-        assert abs(got[k] - s) <= 1e-9 * max(1.0, abs(s)), k
+        assert abs(got[k] - s) <= 1e-7 * max(1.0, abs(s)), k
 
 
 def test_dataloader_contract(tmp_path):

@@ -24,7 +24,8 @@ def test_factory_builds_the_references_network():
     assert [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
     assert sum(p.numel() for p in m.parameters()) == int(g["n_params"]) == 35949007
     for (k, v), s in zip(sd.items(), g["sums"]):                       # same registration order and initialisers: same RNG stream
-        assert abs(float(v.double().sum()) - s) <= 1e-9 * max(1.0, abs(s)), k
+        # (1e-7: trunc_normal_'s erfinv differs in the last bits between host CPUs of the pool - 2.3e-9 on one box)
+        assert abs(float(v.double().sum()) - s) <= 1e-7 * max(1.0, abs(s)), k
     with pytest.raises(ValueError):
         m(torch.zeros(1, 3, 100, 100))
     # stochastic depth as the reference assigns it: linspace(0, 0.1, 4) to encoder_k, enc_dpr[0] = 0 to every encoder_k_1

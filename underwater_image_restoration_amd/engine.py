@@ -423,7 +423,7 @@ class Recorder:
                 self.keep.append(t)
 
     def run(self, ops: Sequence[tuple], marks: "list | None" = None, serial: bool = False,
-            timed: "list | None" = None) -> None:
+            timed: "list | None" = None, join_bulk: bool = True) -> None:
         """Execute a launch list.  serial=True ignores the lanes (everything on the current stream, in list
         order): the reference schedule the overlapped execution must reproduce bit for bit.
         timed=[]: a HIP event pair is recorded around every launch ON THE STREAM IT IS LAUNCHED ON, in the real
@@ -566,9 +566,26 @@ class Recorder:
         ev.record(side)
         main.wait_event(ev)         # join: everything after this list sees the side lane's results
         if 4 in lanes:
+            if join_bulk:
+                ev2 = self._join_events[1]
+                ev2.record(bulk)
+                main.wait_event(ev2)
+                self._bulk_unjoined = False
+            else:
+                # the weight-gradient lane runs on past the end of this list: the caller joins it (join_bulk()) before anything reads a
+                # gradient or overwrites an activation - a network of many short lists (one per module) otherwise waits out the lane's
+                # tail at every module boundary (NewBigFRFNModel: 27 gaps of 60-270 us per step, rocprofv3 trace)
+                self._bulk_unjoined = True
+
+    def join_bulk(self) -> None:
+        """Order the current stream after everything this recorder's bulk lane has been given (see run(join_bulk=False))."""
+        if getattr(self, "_bulk_unjoined", False) and self._bulk_stream is not None:
+            while len(self._join_events) < 2:
+                self._join_events.append(torch.cuda.Event())
             ev2 = self._join_events[1]
-            ev2.record(bulk)
-            main.wait_event(ev2)
+            ev2.record(self._bulk_stream)
+            torch.cuda.current_stream().wait_event(ev2)
+        self._bulk_unjoined = False
 
     def run_timed(self, ops: Sequence[tuple]) -> "List[Tuple[str, str, int, int, float]]":
         """Run a launch list with a HIP event pair around EVERY launch (on the stream the kernels

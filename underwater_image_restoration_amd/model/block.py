@@ -530,14 +530,19 @@ class TokenPlan(Recorder):
     def _record(self, x):
         raise NotImplementedError
 
+    # True (set per call by _TokenFunction.backward when a fused optimizer owns the gradients, trainer.ModuleTrainStep): the backward
+    # list does not wait for its weight-gradient lane; the train step joins every plan's lane once, before it touches the gradients
+    defer_bulk_join = False
+
     def forward(self, x_rows: torch.Tensor) -> torch.Tensor:
+        self.join_bulk()                # (no-op unless a backward left its lane running and nobody joined it: activations are reused)
         self.x_in.copy_(x_rows.reshape(self.x_in.shape))
         self.run(self.fwd)
         return self.y_out
 
     def backward(self, dy_rows: torch.Tensor) -> torch.Tensor:
         self.dy_in.copy_(dy_rows.reshape(self.dy_in.shape))
-        self.run(self.bwd)
+        self.run(self.bwd, join_bulk=not self.defer_bulk_join)
         return self.dx_out
 
     # algorithmic work of one forward + backward (for the bench tools): every launch's operands once
@@ -697,6 +702,9 @@ class FdfpPlan(TokenPlan):
         return record_fdfp(self, "", x, self.dim, self.hidden, (self.B, self.H, self.W))
 
 
+DEFER_BULK_JOIN = True     # see TokenPlan.defer_bulk_join (False: every backward list waits for its own weight-gradient lane)
+
+
 class _TokenFunction(torch.autograd.Function):
     """One autograd node for a whole plan-backed module: forward and backward are launch lists."""
 
@@ -718,6 +726,7 @@ class _TokenFunction(torch.autograd.Function):
         if ctx.serial != m._serial:
             raise RuntimeError(f"{type(m).__name__}(HIP): a later forward overwrote the saved activations; call backward before "
                                "the next forward")
+        ctx.plan.defer_bulk_join = bool(m._flat_grads_only) and DEFER_BULK_JOIN
         dx = ctx.plan.backward(dy.contiguous())
         dx = None if dx is None else (dx if m._alias_io else dx.clone()).view(ctx.shape)
         fp = m._flat

@@ -340,6 +340,13 @@ class ModuleTrainStep:
         f = mb / B                                # see TrainStep._weights (losses the reference also divides by the batch size)
         return f * f if self.kind in (0, 1, 4) else f
 
+    def _join_bulk_lanes(self) -> None:
+        """The modules' backward lists leave their weight-gradient lanes running (TokenPlan.defer_bulk_join): ONE join per plan here,
+        after the whole backward, instead of a wait for the lane's tail at each of the ~27 module boundaries."""
+        for m in self.mods:
+            for plan in m._plans.values():
+                plan.join_bulk()
+
     def __call__(self, raw: torch.Tensor, ref: torch.Tensor, lr: "float | None" = None):
         for m in self.mods:                       # a module whose parameters moved (e.g. .to()) re-flattens: keep the optimizer's view
             if m._flat is not self.flats[self.mods.index(m)]:
@@ -351,6 +358,7 @@ class ModuleTrainStep:
             res = ops.loss_sums(out.detach(), ref, self.kind)
             dout = ops.loss_grad(out.detach(), ref, self._one, self.kind, aux=res)
             out.backward(dout)
+            self._join_bulk_lanes()
             loss = res[0]
         else:
             if self._acc is None:
@@ -365,6 +373,7 @@ class ModuleTrainStep:
                 res = ops.loss_sums(out.detach(), ref[o:o + mb], self.kind)
                 dout = ops.loss_grad(out.detach(), ref[o:o + mb], self._wdev, self.kind, aux=res)
                 out.backward(dout)
+                self._join_bulk_lanes()
                 ops.flat_accumulate(self.bucket, self._acc, n, accumulate=i > 0)
                 ops.axpy_scalar(self._loss_acc, res[0], w, first=i == 0)
             ops.flat_accumulate(self._acc, self.bucket, n, accumulate=False)
