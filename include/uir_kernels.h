@@ -445,6 +445,8 @@ int uir_patch3x3_bwd(const float* dP, int ldp, float* dx, int ldx, int B, int H,
 int uir_gather_sum(const float* src, const int* idx, float* dst, long n, int group, void* stream);
 /* dst[m][dcol + c] = src[m][scol + c] (+ dst if accumulate), c < C: torch.cat joins (:209,264-267) */
 int uir_copy_cols(const float* src, int lds, int scol, float* dst, int ldd, int dcol, long M, int C, int accumulate, void* stream);
+/* dst[0 .. n) = src[0 .. n): n % 4 == 0, both 16-byte aligned; an ordinary kernel in stream order (no blit / barrier packets around it) */
+int uir_copy_flat(const float* src, float* dst, long n, void* stream);
 /* slab[block][c] = sum over that block's rows of src[m][col + c]: bias gradients of the 1x1
  * convs with bias (SpectralTransformer.py:165-172) */
 int uir_colsum_partials(const float* src, int ld, int col, long M, int C, float* slab, int nblocks, void* stream);

@@ -245,6 +245,7 @@ SIGNATURES = {
     "uir_patch4s2_bwd": [fp, i32, fp, i32, i32, i32, i32, i32, fp],
     "uir_gather_sum": [fp, fp, fp, i64, i32, fp],
     "uir_copy_cols": [fp, i32, i32, fp, i32, i32, i64, i32, i32, fp],
+    "uir_copy_flat": [fp, fp, i64, fp],
     "uir_colsum_partials": [fp, i32, i32, i64, i32, fp, i32, fp],
     "uir_nchw3_to_hwc4": [fp, fp, i32, i32, i32, fp],
     "uir_im2col3x3_c3": [fp, fp, i32, i32, i32, fp],

@@ -186,6 +186,12 @@ __global__ void copy_cols_kernel(const float* __restrict__ src, int lds, int sco
   }
 }
 
+// flat device-to-device copy as an ordinary kernel (float4 per thread): the module networks copy each module's input / output gradient into
+// its plan's buffer - as hipMemcpyAsync (torch's copy_) each of those ~54 copies per step left the queue idle for 30-60 us around the blit
+__global__ void copy_flat4_kernel(const float4* __restrict__ src, float4* __restrict__ dst, long n4) {
+  GRID_STRIDE(idx, n4) dst[idx] = src[idx];
+}
+
 __global__ void nchw3_to_hwc4_kernel(const float* __restrict__ src, float* __restrict__ dst, long HW, long n) {
   GRID_STRIDE(idx, n) {  // idx over [B][HW]
     const long b = idx / HW, p = idx - b * HW;
@@ -299,6 +305,12 @@ extern "C" int uir_copy_cols(const float* src, int lds, int scol, float* dst, in
   UIR_REQUIRE(src && dst && M > 0 && C > 0 && lds >= scol + C && ldd >= dcol + C);
   const long n = M * C;
   hipLaunchKernelGGL(copy_cols_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, scol, dst, ldd, dcol, C, accumulate, n);
+  return uir_launch_status();
+}
+extern "C" int uir_copy_flat(const float* src, float* dst, long n, void* stream) {
+  UIR_REQUIRE(src && dst && n > 0 && (n & 3) == 0 && uir_aligned16(src) && uir_aligned16(dst));
+  hipLaunchKernelGGL(copy_flat4_kernel, ew_grid(n / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                     reinterpret_cast<const float4*>(src), reinterpret_cast<float4*>(dst), n / 4);
   return uir_launch_status();
 }
 extern "C" int uir_nchw3_to_hwc4(const float* src, float* dst, int B, int H, int Wd, void* stream) {

@@ -534,14 +534,26 @@ class TokenPlan(Recorder):
     # list does not wait for its weight-gradient lane; the train step joins every plan's lane once, before it touches the gradients
     defer_bulk_join = False
 
+    @staticmethod
+    def _copy_in(dst: torch.Tensor, src: torch.Tensor) -> None:
+        """dst <- src (same element count).  Contiguous f32 on the device: the library's copy kernel, in stream order - torch's copy_
+        is a hipMemcpyAsync there, which left the queue idle for 30-60 us around each of the ~54 module-boundary copies of a step."""
+        src = src.reshape(dst.shape)
+        n = dst.numel()
+        if (src.is_contiguous() and dst.is_contiguous() and src.dtype == torch.float32 and src.device == dst.device and dst.is_cuda
+                and n % 4 == 0 and src.data_ptr() % 16 == 0 and dst.data_ptr() % 16 == 0):
+            L.check(lib.uir_copy_flat(src.data_ptr(), dst.data_ptr(), n, C.c_void_p(torch.cuda.current_stream().cuda_stream)), "uir_copy_flat")
+        else:
+            dst.copy_(src)
+
     def forward(self, x_rows: torch.Tensor) -> torch.Tensor:
         self.join_bulk()                # (no-op unless a backward left its lane running and nobody joined it: activations are reused)
-        self.x_in.copy_(x_rows.reshape(self.x_in.shape))
+        self._copy_in(self.x_in, x_rows)
         self.run(self.fwd)
         return self.y_out
 
     def backward(self, dy_rows: torch.Tensor) -> torch.Tensor:
-        self.dy_in.copy_(dy_rows.reshape(self.dy_in.shape))
+        self._copy_in(self.dy_in, dy_rows)
         self.run(self.bwd, join_bulk=not self.defer_bulk_join)
         return self.dx_out
 
