@@ -1,8 +1,12 @@
 #!/bin/bash
-O=gpurun_out/r04aj; mkdir -p $O
-python -m pytest tests/test_frfn_net.py tests/test_ast.py tests/test_module_fullsize.py tests/test_decoder_block.py tests/test_encoder_block.py tests/test_frfn.py -q -x > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
-run() { PYTHONPATH=. python3 tools/xp/ab_frfn.py "$@" 2>$O/err.txt | grep '^{' | python3 -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$*', round(d['ms_per_step'],3), round(d['value'],1))" | tee -a $O/ab.txt; }
+O=gpurun_out/r04ak; mkdir -p $O
+python -m pytest tests/test_hip_kernels.py -x -q -k "gdfn or fused" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
+L=underwater_image_restoration_amd/libuir_hip.so
 for i in 1 2; do
-  run net
-  run ast
+for v in old new; do
+  cp tools/xp/libs/$v.so $L
+  echo "== $v" | tee -a $O/fused.txt
+  python tools/bench_fused.py 2>&1 | grep -i "C=128\|C= 64" | grep gdfn | tee -a $O/fused.txt
 done
+done
+cp tools/xp/libs/new.so $L

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
   // 9 of x2's; they were 18 dword loads per lane and chunk (tools/probes/stamps: the weight loads' issue stalls behind the write-out
   // stores were 11.6 % of the kernel at C = 32; at C >= 64, with one or two workgroups per CU, each chunk waited out their latency).
   // Row stride 20 floats (16-byte rows, b128 reads) where LDS allows it (C <= 32), 18 (b64 reads) beside the staged W_in chunks
-  constexpr bool TAPS_LDS = SB;
+  // C = 64 keeps them too (row stride 18, b64 reads, behind the two staged f32 W_in chunks): no faster, but the kernel spills without;
+  // C = 128 has no LDS for them beside its bf16 weight planes
+  constexpr bool TAPS_LDS = SB && C <= 64;
   constexpr int SWT = C <= 32 ? 20 : 18;
   float* WT = smem + T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : 0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
@@ -271,11 +273,28 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
       stg[it] = keep4(*reinterpret_cast<const float4*>(a.Win + (long)(ok ? (r < 16 ? cc : h + cc) : 0) * C + 4 * q), ok);
     }
   };
+  // SB, wide levels: the staging threads split the chunk into its three bf16 planes ONCE (each of the four waves splitting the rows it
+  // reads was 640 VALU instructions per wave and chunk at C = 128, ~45 % of a chunk).  Plane p of buffer b: [32 rows][C + 8] bf16, a
+  // lane's eight values of k step s - k = 16 s + 4 h2 + e and 16 s + 8 + 4 h2 + e, the order the A planes use - contiguous: the
+  // float4 at k = 16 s + 8 g + 4 h goes to slot 16 s + 8 h + 4 g
+  constexpr bool WPRE = SB && C >= 128;              // (C = 64: four k steps per chunk - the split is a small part there, and LDS is full)
+  constexpr int RSB = C + 8;                       // plane row stride (bf16 units): 16-byte rows, (C + 8) / 2 = 4 mod 32 dwords
+  constexpr int PLSZ = 32 * RSB;                   // one plane (bf16 units)
+  __bf16* Wp = reinterpret_cast<__bf16*>(Ws);
   auto stage_store = [&](int buf) {               // registers -> LDS
 #pragma unroll
     for (int it = 0; it < NSTG; ++it) {
       const int e = tid + 256 * it, r = e / (C / 4), q = e - r * (C / 4);
-      *reinterpret_cast<float4*>(Ws + buf * 32 * WS + r * WS + 4 * q) = stg[it];
+      if constexpr (WPRE) {
+        const UirBf3x4 pl = uir_split4(stg[it]);
+        const int slot = 16 * (q >> 2) + 8 * (q & 1) + 4 * ((q >> 1) & 1);
+        __bf16* d = Wp + buf * 3 * PLSZ + r * RSB + slot;
+        *reinterpret_cast<uint2*>(d) = pl.h;
+        *reinterpret_cast<uint2*>(d + PLSZ) = pl.m;
+        *reinterpret_cast<uint2*>(d + 2 * PLSZ) = pl.l;
+      } else {
+        *reinterpret_cast<float4*>(Ws + buf * 32 * WS + r * WS + 4 * q) = stg[it];
+      }
     }
   };
   auto load_small = [&](int c0, float (&wo_)[8], float (&w1_)[9], float (&w2_)[9]) {
@@ -375,9 +394,17 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
 #pragma unroll
       for (int s = 0; s < C / 16; ++s) {
         UirBf3 wp;
-        if constexpr (PF) wp = uir_split8(win[2 * s], win[2 * s + 1]);
-        else wp = uir_split8(*reinterpret_cast<const float4*>(Ws + wbuf * 32 * WS + li * WS + 16 * s + 4 * h2),
-                             *reinterpret_cast<const float4*>(Ws + wbuf * 32 * WS + li * WS + 16 * s + 8 + 4 * h2));
+        if constexpr (PF) {
+          wp = uir_split8(win[2 * s], win[2 * s + 1]);
+        } else if constexpr (!WPRE) {
+          wp = uir_split8(*reinterpret_cast<const float4*>(Ws + wbuf * 32 * WS + li * WS + 16 * s + 4 * h2),
+                          *reinterpret_cast<const float4*>(Ws + wbuf * 32 * WS + li * WS + 16 * s + 8 + 4 * h2));
+        } else {
+          const __bf16* src = Wp + wbuf * 3 * PLSZ + li * RSB + 16 * s + 8 * h2;
+          wp.h = *reinterpret_cast<const uir_bf16x8*>(src);
+          wp.m = *reinterpret_cast<const uir_bf16x8*>(src + PLSZ);
+          wp.l = *reinterpret_cast<const uir_bf16x8*>(src + 2 * PLSZ);
+        }
 #pragma unroll
         for (int q = 0; q < T::RTW; ++q)
           if (wave + 4 * q < T::NRT1) d[q] = uir_mfma_split(Ap[q][s], wp, d[q]);
@@ -435,7 +462,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
       for (int t = 0; t < 8; ++t) pin(PF ? wo[t] : wo_n[t]);
       if constexpr (!TAPS_LDS) {
 #pragma unroll
-        for (int t = 0; t < 9; ++t) { pin(w1[t]); pin(w2[t]); }
+        for (int t = 0; t < 9; ++t) { pin(PF ? w1[t] : w1_n[t]); pin(PF ? w2[t] : w2_n[t]); }
       }
     } else {
 #pragma unroll
@@ -573,7 +600,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
 #pragma unroll
       for (int t = 0; t < 8; ++t) wo[t] = wo_n[t];
     }
-    if constexpr (!SB) {
+    if constexpr (!TAPS_LDS && (!SB || !PF)) {        // (SB at C = 128: taps in registers, fetched a chunk ahead with W_out's fragment)
 #pragma unroll
       for (int t = 0; t < 9; ++t) { w1[t] = w1_n[t]; w2[t] = w2_n[t]; }
     }
@@ -1262,9 +1289,20 @@ int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
   // + two staged W_in chunks (wide levels) + the staged depthwise taps (split-bf16 form).  A hidden width whose taps do not fit
   // beside two workgroups' tile buffers (or the C <= 32 form's 7 tap slots per thread) runs the f32-MFMA form, which reads them from global
   bool sb = uir_fused_split() != 0;
-  const size_t lds0 = ((size_t)T::LDS_FLOATS + (C > 32 ? 2 * 32 * (C + 4) : 0)) * 4;
-  if (sb && (lds0 + (size_t)a.hp * (C <= 32 ? 20 : 18) * 4 > 80 * 1024 || (C <= 32 && a.hp > 96))) sb = false;
-  const size_t lds = lds0 + (sb ? (size_t)a.hp * (C <= 32 ? 20 : 18) * 4 : 0);
+  // C <= 32: + the staged depthwise taps (split-bf16 form; hp <= 96: 7 tap slots per thread).  C = 64: + two staged f32 W_in chunks [32][C + 4]
+  // + (split-bf16 form) the taps.  C = 128: + two staged W_in chunks, f32 or (split-bf16 form) three bf16 planes [32][C + 8] each.
+  // A hidden width whose taps do not fit runs the f32-MFMA form, which reads them from global
+  size_t lds = (size_t)T::LDS_FLOATS * 4;
+  if (C <= 32) {
+    if (sb && a.hp > 96) sb = false;
+    if (sb) lds += (size_t)a.hp * 20 * 4;
+  } else if (C == 64) {
+    lds += (size_t)2 * 32 * (C + 4) * 4;
+    if (sb && lds + (size_t)a.hp * 18 * 4 > 80 * 1024) sb = false;
+    if (sb) lds += (size_t)a.hp * 18 * 4;
+  } else {
+    lds += sb ? (size_t)2 * 3 * 32 * (C + 8) * 2 : (size_t)2 * 32 * (C + 4) * 4;
+  }
   if (a.T1) { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, true>), dim3(tiles), dim3(256), lds, st, a);
               else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, false>), dim3(tiles), dim3(256), lds, st, a); }
   else { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, true>), dim3(tiles), dim3(256), lds, st, a);

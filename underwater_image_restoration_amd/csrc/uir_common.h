@@ -106,6 +106,25 @@ __device__ __forceinline__ UirBf3 uir_split8(const float4& a, const float4& b) {
   const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
   return uir_split8(x);
 }
+// four values -> three pairs of bf16 (one dword pair per plane), for staging threads that split a weight chunk ONCE for all the waves of a
+// workgroup (each wave re-splitting the chunk it reads was 45 % of a chunk's time in uir_gdfn_fwd<128>)
+struct UirBf3x4 { uint2 h, m, l; };
+__device__ __forceinline__ UirBf3x4 uir_split4(const float4& v) {
+  const float x[4] = {v.x, v.y, v.z, v.w};
+  uint32_t hh[4], mm[4], ll[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    hh[e] = __float_as_uint(x[e]) & 0xffff0000u;
+    const float r1 = x[e] - __uint_as_float(hh[e]);
+    mm[e] = __float_as_uint(r1) & 0xffff0000u;
+    ll[e] = __float_as_uint(r1 - __uint_as_float(mm[e]));
+  }
+  UirBf3x4 o;
+  o.h = make_uint2(uir_pack_hi16(hh[0], hh[1]), uir_pack_hi16(hh[2], hh[3]));
+  o.m = make_uint2(uir_pack_hi16(mm[0], mm[1]), uir_pack_hi16(mm[2], mm[3]));
+  o.l = make_uint2(uir_pack_hi16(ll[0], ll[1]), uir_pack_hi16(ll[2], ll[3]));
+  return o;
+}
 // c += A . B over one 16-deep k step, f32-accurate; small terms first
 __device__ __forceinline__ f32x16 uir_mfma_split(const UirBf3& a, const UirBf3& b, f32x16 c) {
   c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a.m, b.m, c, 0, 0, 0);
