@@ -40,7 +40,8 @@ LN_EPS = 1e-5
 # Which tile-fused kernels each level uses is fixed here (measured choices, profiles/r01/d_ab_notes.md), not read from the
 # environment: the only environment variables the product reads are listed in knobs.py.
 FUSED_DFT_SIZES = (32, 64, 128)   # axis lengths of the two-stage DFT kernel, which carries UpSample's element-wise ops (UirDft2Args.pro / .epi)
-_ATTNV_FUSED = (32, 64)        # MDTA tail as uir_attnv_fwd; C = 16 / 128: half-empty tiles / one workgroup per CU, three kernels are as fast
+_ATTNV_FUSED = (16, 32, 64, 128)   # MDTA tail as uir_attnv_fwd on every level (round 1 kept C = 16 / 128 on three launches: as fast then; since the
+                                   # fused forwards' round-4 work C = 16 is 100 vs 132 us, C = 128 - 4 x 8 tiles - 24 vs ~25 us and two launches fewer)
 SCRATCH_FLOATS = 96 * 1024 * 1024  # 384 MB of slab scratch shared by every reduction
 
 
