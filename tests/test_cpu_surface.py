@@ -354,3 +354,31 @@ def test_package_import_binds_the_library_to_the_hip_runtime_torch_uses():
     assert out.returncode == 0, out.stderr[-2000:]
     last = [ln for ln in out.stdout.splitlines() if ln and ln[0].isdigit()][-1]
     assert last.startswith("1 "), last
+
+
+def test_launch_order_keeps_the_chain_queue_busy():
+    """The launch-list properties behind DESIGN.md 17.2 (6), checked on a plan built on the CPU (no launches): (a) every block's weight-only
+    P = W_kv W_o GEMM but the first is recorded on the side lane directly behind the first join, with exactly one more join - they cost
+    the chain two barrier packets per block where they sat; (b) in each up-sampler the shuffle branch (Sups, side lane) is recorded BEFORE
+    the spectral chain it overlaps and joined after it - recorded behind it, it started only when the chain had finished; (c) a hold on
+    bulk-lane launches is only taken where the chain has launches left to cover their release."""
+    from underwater_image_restoration_amd import Models, engine as E
+    m = Models.init_model("SpectralTransformer")
+    plan = E.Plan(m._ensure_flat("cpu"), 1, 64, 64)
+    names = [mm[0] for mm in plan.meta[id(plan.fwd)]]
+    lanes = plan.lanes[id(plan.fwd)]
+    assert len(names) == len(lanes) == len(plan.fwd) and not plan.pro
+    p_idx = [i for i, n in enumerate(names) if n.endswith(".P")]
+    assert len(p_idx) == 24 and all(lanes[i] == 1 for i in p_idx)
+    p_joins = [i for i, n in enumerate(names) if n.endswith(".P.join")]
+    assert len(p_joins) == 2 and all(lanes[i] == 2 for i in p_joins)
+    assert p_idx[0] < p_joins[0] and p_idx[1:] == list(range(p_joins[0] + 1, p_joins[0] + 24))      # 23 hoisted launches, contiguous
+    assert p_joins[1] > p_idx[-1] and names.index("encoders.0.1.attn_fwd") > p_joins[1]
+    for k in (1, 2, 3):
+        i_s, i_sh = names.index(f"ups_{k}.Sups"), names.index(f"ups_{k}.Sups.shuffle")
+        i_first, i_last, i_join = names.index(f"ups_{k}.Fups.dftW"), names.index(f"ups_{k}.Fups.scatter"), names.index(f"ups_{k}.join")
+        assert lanes[i_s] == lanes[i_sh] == 1 and i_s < i_sh < i_first < i_last < i_join and lanes[i_join] == 2
+    assert E.BULK_DEFER > 0 and E.FUSE_QK_GRAM and E.FUSE_VALUE_GRAMS
+    # the backward list: weight-gradient work is on the bulk lane, and there is enough chain behind most of it to hold it
+    bl = plan.lanes[id(plan.bwd)]
+    assert sum(1 for x in bl if x == 4) > 100 and sum(1 for x in bl if x in (0, 1)) > 8 * E.BULK_DEFER
