@@ -98,6 +98,12 @@ def main():
     ap.add_argument("--breakdown-file", default="")
     ap.add_argument("--timeline-file", default="")
     args = ap.parse_args()
+    # stdout carries exactly ONE line, the JSON: RCCL prints a version banner to file descriptor 1 when its first communicator is created
+    # (seen with --gpus > 1), and other native libraries may do the like.  Keep a private copy of the real stdout for the final line and
+    # point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -262,7 +268,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(S)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist.is_initialized():
         dist.destroy_process_group()
 
