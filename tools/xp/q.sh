@@ -1,4 +1,13 @@
 #!/bin/bash
-O=gpurun_out/r04an; mkdir -p $O
-UIR_FORCE_ALLREDUCE=1 python bench.py --no-cpu-baseline --no-kernel-breakdown --steps 5 --warmup 2 > $O/bench_allreduce.json 2> $O/err.txt; echo "rc=$? lines=$(wc -l < $O/bench_allreduce.json)"; cut -c1-120 $O/bench_allreduce.json
-python bench.py --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_plain.json 2> $O/err3.txt; echo "rc=$? lines=$(wc -l < $O/bench_plain.json)"; python3 -c "import json; d=json.loads(open('$O/bench_plain.json').read()); print(d['value'], d['roofline']['traffic'])"
+O=gpurun_out/r04ao; mkdir -p $O
+python -m pytest tests/test_hip_kernels.py -x -q -k "qkv or fused" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
+L=underwater_image_restoration_amd/libuir_hip.so
+for i in 1 2; do
+for v in old new; do
+  cp tools/xp/libs/$v.so $L
+  echo "== $v" | tee -a $O/fused.txt
+  python tools/bench_fused.py 2>&1 | grep -i "C=128\|C= 64" | grep qkv | tee -a $O/fused.txt
+done
+done
+cp tools/xp/libs/new.so $L
+python -m pytest tests/test_hip_model.py -x -q 2>&1 | tail -2

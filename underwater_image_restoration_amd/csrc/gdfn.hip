@@ -761,8 +761,36 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
     st_lds[it] = ((py + 1) * T::RW + px + 1) * T::S1 + 4 * j;
   }
 
+  // wide levels, split-bf16 form: the chunk's 32 rows of W_qkv go through LDS as three bf16 planes, split ONCE by the staging threads and
+  // fetched a chunk ahead (uir_gdfn_fwd_kernel's scheme).  Before, every lane loaded its half row (C / 2 floats) at the top of the chunk
+  // and consumed it at once - the load's latency and 80 split instructions per k step and wave, every chunk
+  constexpr bool WPRE = SB && C > 32;
+  constexpr int RSB = C + 8, PLSZ = 32 * RSB;           // plane row stride / plane size (bf16 units)
+  constexpr int NSTG = WPRE ? (32 * (C / 4)) / 256 : 1;
+  __bf16* Wp = reinterpret_cast<__bf16*>(smem + T::LDS_FLOATS);
+  float4 stg[NSTG];
+  auto stage_load = [&](int c0) {
+#pragma unroll
+    for (int it = 0; it < NSTG; ++it) {
+      const int e = tid + 256 * it, r = e / (C / 4), q = e - r * (C / 4);
+      const bool ok = c0 + r < HD;
+      stg[it] = keep4(*reinterpret_cast<const float4*>(a.Wqkv + (long)(ok ? c0 + r : 0) * C + 4 * q), ok);
+    }
+  };
+  auto stage_store = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < NSTG; ++it) {
+      const int e = tid + 256 * it, r = e / (C / 4), q = e - r * (C / 4);
+      const UirBf3x4 pl = uir_split4(stg[it]);
+      const int slot = 16 * (q >> 2) + 8 * (q & 1) + 4 * ((q >> 1) & 1);     // k = 16 s + 8 g + 4 h -> slot 16 s + 8 h + 4 g
+      __bf16* d = Wp + buf * 3 * PLSZ + r * RSB + slot;
+      *reinterpret_cast<uint2*>(d) = pl.h;
+      *reinterpret_cast<uint2*>(d + PLSZ) = pl.m;
+      *reinterpret_cast<uint2*>(d + 2 * PLSZ) = pl.l;
+    }
+  };
   auto load_w = [&](int c0, float4 (&win)[T::KJ], float (&w1)[9], float (&w2)[9]) {
-    {
+    if constexpr (!WPRE) {
       const int cc = c0 + li;
       const bool ok = cc < HD;
       const float* wr = a.Wqkv + (long)(ok ? cc : 0) * C + 4 * h2;
@@ -787,6 +815,12 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
   float4 win[T::KJ], win_n[NPF];
   float w1[9], w2[9], w1_n[9], w2_n[9];
   if (PF) load_w(0, win, w1, w2);
+  int wbuf = 0;
+  if constexpr (WPRE) {
+    stage_load(0);
+    stage_store(0);
+    lds_barrier();
+  }
 
   // ---- optional Gram of the attention logits (C <= 32, a.gram_slab): the q and k tiles pass through Gs anyway.  Each wave contracts its
   // quarter of the tile's pixels on the f32 MFMA (A = q^T: lane = q channel, B = k: lane = k channel, k-slot h2 = pixel 2 s + h2); at
@@ -814,7 +848,8 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
     if constexpr (PF) {
       load_w(c0 + 32 < HD ? c0 + 32 : c0, win_n, w1_n, w2_n);
     } else {
-      load_w(c0, win, w1, w2);
+      if constexpr (WPRE) stage_load(c0 + 32 < HD ? c0 + 32 : c0);     // next chunk's rows: into the other buffer after (a)
+      load_w(c0, win, w1, w2);                                          // (WPRE: the depthwise taps only)
     }
     // ---- (a) 32 output channels of the 1x1 on tile + ring ----
     if constexpr (SB) {
@@ -825,7 +860,15 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
         for (int i = 0; i < 16; ++i) d[q][i] = 0.f;
 #pragma unroll
       for (int s = 0; s < C / 16; ++s) {
-        const UirBf3 wp = uir_split8(win[2 * s], win[2 * s + 1]);
+        UirBf3 wp;
+        if constexpr (WPRE) {
+          const __bf16* src = Wp + wbuf * 3 * PLSZ + li * RSB + 16 * s + 8 * h2;
+          wp.h = *reinterpret_cast<const uir_bf16x8*>(src);
+          wp.m = *reinterpret_cast<const uir_bf16x8*>(src + PLSZ);
+          wp.l = *reinterpret_cast<const uir_bf16x8*>(src + 2 * PLSZ);
+        } else {
+          wp = uir_split8(win[2 * s], win[2 * s + 1]);
+        }
 #pragma unroll
         for (int q = 0; q < T::RTW; ++q)
           if (wave + 4 * q < T::NRT1) d[q] = uir_mfma_split(Ap[q][s], wp, d[q]);
@@ -861,6 +904,10 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
     }
     }
     lds_barrier();
+    if constexpr (WPRE) {
+      stage_store(wbuf ^ 1);     // (a) of the previous chunk was the last reader of that buffer; visible after the next barrier
+      wbuf ^= 1;                 // (this chunk's (a) is done: the next (a) reads what was just stored)
+    }
     if constexpr (PF) {   // see uir_gdfn_fwd_kernel: the prefetched weights must be complete before this chunk's stores
 #pragma unroll
       for (int jj = 0; jj < T::KJ; ++jj) { pin(win_n[jj].x); pin(win_n[jj].y); pin(win_n[jj].z); pin(win_n[jj].w); }
@@ -1004,9 +1051,10 @@ int qkv_fwd_launch(const UirQkvFwdArgs& a, hipStream_t st) {
   using T = GdfnTile<C, TH, TW>;
   const int tiles = a.B * ((a.H + TH - 1) / TH) * ((a.Wd + TW - 1) / TW);
   // + the staged depthwise taps (C <= 32, split-bf16 form): 16 rows of 20 floats per 32-channel chunk
+  // ... / the two staged weight chunks as bf16 planes (wide levels)
   if (uir_fused_split())
     hipLaunchKernelGGL((uir_qkv_fwd_kernel<C, TH, TW, true>), dim3(tiles), dim3(256),
-                       ((size_t)T::LDS_FLOATS + (C <= 32 ? ((3 * C + 31) / 32) * 16 * 20 : 0)) * 4, st, a);
+                       (size_t)T::LDS_FLOATS * 4 + (C <= 32 ? (size_t)((3 * C + 31) / 32) * 16 * 20 * 4 : (size_t)2 * 3 * 32 * (C + 8) * 2), st, a);
   else hipLaunchKernelGGL((uir_qkv_fwd_kernel<C, TH, TW, false>), dim3(tiles), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
   return uir_launch_status();
 }
