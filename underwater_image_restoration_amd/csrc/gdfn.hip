@@ -1412,7 +1412,7 @@ extern "C" int uir_attnv_fwd(const UirAttnvFwdArgs* p, void* stream) {
   switch (a.C) {
     case 16: return attnv_fwd_launch<16, 12, 16>(a, st);
     case 32: return attnv_fwd_launch<32, 12, 16>(a, st);
-    case 64: return attnv_fwd_launch<64, 8, 16>(a, st);
+    case 64: return attnv_fwd_launch<64, 8, 8>(a, st);
     case 128: return attnv_fwd_launch<128, 4, 8>(a, st);
     default: return UIR_EINVAL;
   }
