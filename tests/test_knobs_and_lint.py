@@ -87,3 +87,38 @@ def test_pipelined_kernels_keep_their_loads_in_flight():
                     _nloads, prof = scan.wait_profile(body)
                     assert scan.longest_chain(prof) < 4, (name, prof)
     assert seen >= 10
+
+
+def test_trace_gaps_tool_on_a_synthetic_trace(tmp_path, capsys):
+    """tools/trace_gaps.py (the chain-queue idle analysis of DESIGN.md 17.2 (6)) on a hand-made rocprofv3 kernel-trace CSV: two steps
+    delimited by the optimizer kernel, the busiest queue is the chain, gaps are attributed to the kernel in front of them."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("trace_gaps", os.path.join(ROOT, "tools", "trace_gaps.py"))
+    tg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tg)
+    rows = ['"Kind","Agent_Id","Queue_Id","Stream_Id","Thread_Id","Dispatch_Id","Kernel_Id","Kernel_Name","Correlation_Id","Start_Timestamp","End_Timestamp"']
+    t = 1000
+
+    def k(name, q, dur, gap=0):
+        nonlocal t
+        t += gap
+        rows.append(f'"KERNEL_DISPATCH","Agent 2",{q},0,1,1,1,"{name}",1,{t},{t + dur}')
+        t += dur
+
+    k("clip_adam_kernel", 1, 10)
+    for _ in range(2):
+        k("a_kernel", 1, 100_000)
+        k("b_kernel", 1, 50_000, gap=7_000)            # 7 us behind a_kernel
+        rows.append(f'"KERNEL_DISPATCH","Agent 2",3,0,1,1,1,"bulk_kernel",1,{t - 40_000},{t - 10_000}')
+        k("c_kernel", 1, 20_000, gap=200_000)          # 200 us behind b_kernel
+        k("clip_adam_kernel", 1, 10_000)
+    p = tmp_path / "t_kernel_trace.csv"
+    p.write_text("\n".join(rows) + "\n")
+    sys.argv = ["trace_gaps.py", str(p), "2"]
+    tg.main()
+    out = capsys.readouterr().out
+    assert "chain queue 1" in out and "idle 0.207 ms" in out and "busy 0.180 ms" in out
+    assert "other queues busy 0.030 ms" in out
+    lines = [ln for ln in out.splitlines() if ln.strip().startswith(("a_kernel", "b_kernel"))]
+    assert lines[0].split()[0] == "b_kernel" and abs(float(lines[0].split()[1]) - 0.200) < 1e-9
+    assert lines[1].split()[0] == "a_kernel" and abs(float(lines[1].split()[1]) - 0.007) < 1e-9
