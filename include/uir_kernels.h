@@ -133,6 +133,46 @@ typedef struct UirReduceDesc {
 } UirReduceDesc;
 int uir_reduce_slab_batch(const UirReduceDesc* descs_dev, const int* first_block_dev, int ndesc, int total_blocks, void* stream);
 
+/* ------------------------------------------------------- uir_conv3x3_split */
+/* Dense 3x3 convolution (pad 1, no bias) with >= 32 channels on both sides as an implicit GEMM on split-bf16 MFMA
+ * (csrc/conv3b.hip): UpSample1's Conv2d(C, 2C, 3) forward, its input gradient and its weight gradient
+ * (SpectralTransformer.py:191-198; autograd's convolution_backward for :196).  f32-accurate: every f32 operand is the exact
+ * sum of three bf16 planes and six of the nine plane products are accumulated in f32 (csrc/uir_common.h).
+ *
+ * uir_conv3x3_wsplit  native weight W[Cout][Cin][3][3] -> bf16 planes, once per optimizer step:
+ *     planes_fwd[pl][tap][cout][cin]      = plane pl of W[cout][cin][tap]          (forward:        N = Cout, K = Cin)
+ *     planes_bwd[pl][8 - tap][cin][cout]  = plane pl of W[cout][cin][tap]          (input gradient: N = Cin,  K = Cout)
+ *   each 3 * 9 * Cout * Cin 16-bit values; either pointer may be NULL.
+ * uir_conv3x3_split   Y[p][n] = (R ? R[p][n] : 0) + sum_tap sum_k X[nbr(p, tap)][k] * Wp[tap][n][k]  over HWC pixel rows
+ *   p = (b * H + y) * Wd + x (zero outside the image).  H % 4 == 0, Wd % 16 == 0, N % 32 == 0, K % 32 == 0; rows 16-byte aligned.
+ * uir_conv3x3_split_wgrad  slab[c][(n * K + k) * 9 + tap] = sum over the pixels p of chunk c of dY[p][n] * X[nbr(p, tap)][k]
+ *   (the native weight layout per slab row; uir_reduce_slab sums the rows).  N % 64 == 0, K % 32 == 0, H % 4 == 0,
+ *   Wd % 16 == 0.  `nchunks` (<= B * H/4 * Wd/16) slab rows are written, one per workgroup column. */
+typedef struct UirConv3bArgs {
+  const float* X;            /* [B*H*Wd][ldx]                                                      */
+  const unsigned short* Wp;  /* bf16 planes [3][9][N][K] (uir_conv3x3_wsplit)                      */
+  float* Y;                  /* [B*H*Wd][ldy]                                                      */
+  const float* R;            /* optional residual [B*H*Wd][ldr]; may alias Y                       */
+  int ldx, ldy, ldr;
+  int B, H, Wd;
+  int N, K;
+  int tile;                  /* 0 = chosen by the library; else 1000 * pixels + columns of the workgroup tile (tests, tuning): */
+                             /* 256032 (H % 16), 128032, 128064, 128128 (H % 8), 64064, 64128                                  */
+} UirConv3bArgs;
+typedef struct UirConv3bWgradArgs {
+  const float* dY;           /* [B*H*Wd][ldy], N columns used                                      */
+  const float* X;            /* [B*H*Wd][ldx], K columns used                                      */
+  float* slab;               /* [rows][slab_stride], slab_stride >= N * K * 9                      */
+  long slab_stride;
+  int ldy, ldx;
+  int B, H, Wd;
+  int N, K;
+  int nchunks;
+} UirConv3bWgradArgs;
+int uir_conv3x3_wsplit(const float* W, int Cout, int Cin, unsigned short* planes_fwd, unsigned short* planes_bwd, void* stream);
+int uir_conv3x3_split(const UirConv3bArgs* args, void* stream);
+int uir_conv3x3_split_wgrad(const UirConv3bWgradArgs* args, void* stream);
+
 /* -------------------------------------------------------------- uir_dwconv */
 /* Depthwise 3x3, pad 1, no bias, on HWC rows; C (padded) % 4 == 0.  flip=1 gives the
  * input-gradient.  Replaces nn.Conv2d(groups=C) sites SpectralTransformer.py:82,89,123-124. */

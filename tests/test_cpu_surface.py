@@ -38,7 +38,7 @@ def test_struct_layouts_match_the_compiled_library():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_abi
     structs = gen_abi.parse_structs(open(os.path.join(ROOT, "include", "uir_kernels.h")).read())
-    assert len(structs) == 24 and {n for n, _ in structs} == set(L.STRUCTS)
+    assert len(structs) == 26 and {n for n, _ in structs} == set(L.STRUCTS)
     for cname, fields in structs:
         cls = L.STRUCTS[cname]
         assert [f for f, _, _ in fields] == [f[0] for f in cls._fields_], cname
@@ -382,3 +382,41 @@ def test_launch_order_keeps_the_chain_queue_busy():
     # the backward list: weight-gradient work is on the bulk lane, and there is enough chain behind most of it to hold it
     bl = plan.lanes[id(plan.bwd)]
     assert sum(1 for x in bl if x == 4) > 100 and sum(1 for x in bl if x in (0, 1)) > 8 * E.BULK_DEFER
+
+
+def test_small_conv_wgrad_shape_list_matches_the_kernel_dispatch():
+    """engine.Recorder.gram sizes the chunks of csrc/conv3m.hip's uir_conv3x3_wgrad only for the (K, N) pairs that kernel instantiates
+    (the two conditions were written twice and differed; a rejected shape fell through to the generic nine-tap Gram with
+    chunking computed for the other kernel).  The kernel's list is read from its source."""
+    import re
+    from underwater_image_restoration_amd import engine as E
+    src = open(os.path.join(ROOT, "underwater_image_restoration_amd", "csrc", "conv3m.hip")).read()
+    body = src[src.index("int uir_conv3x3_wgrad("):src.index("int uir_conv3x3_mfma(")]
+    pairs = sorted((int(k), 4 * int(q)) for k, q in re.findall(r"UIR_C3W\((\d+), (\d+)\);", body))
+    assert pairs == sorted(E._WGRAD3_SHAPES) and len(pairs) == 4
+
+
+def test_upsampler_convolutions_take_the_split_bf16_kernels():
+    """UpSample1's 3x3 convolutions (SpectralTransformer.py:196) run on csrc/conv3b.hip in all three directions: the weight planes are split
+    once (side lane, ahead of the convolution), forward and input gradient are uir_conv3x3_split launches and the weight gradient a
+    uir_conv3x3_split_wgrad launch on the bulk lane; UIR_FUSED_SPLIT=0 (engine.CONV3_SPLIT False) records the nine-tap f32 paths."""
+    from underwater_image_restoration_amd import Models, engine as E
+    m = Models.init_model("SpectralTransformer")
+    plan = E.Plan(m._ensure_flat("cpu"), 1, 128, 128)
+    fn = {mm[0]: mm[1] for mm in plan.meta[id(plan.fwd)]}
+    bn = {mm[0]: mm[1] for mm in plan.meta[id(plan.bwd)]}
+    names = [mm[0] for mm in plan.meta[id(plan.fwd)]]
+    for k in (1, 2, 3):
+        assert fn[f"ups_{k}.Sups.wsplit"] == "uir_conv3x3_wsplit" and fn[f"ups_{k}.Sups"] == "uir_conv3x3_split"
+        assert names.index(f"ups_{k}.Sups.wsplit") < names.index(f"ups_{k}.Sups")
+        assert bn[f"ups_{k}.Sups.dX"] == "uir_conv3x3_split" and bn[f"ups_{k}.Sups.dW"] == "uir_conv3x3_split_wgrad"
+    bl = dict(zip([mm[0] for mm in plan.meta[id(plan.bwd)]], plan.lanes[id(plan.bwd)]))
+    assert all(bl[f"ups_{k}.Sups.dW"] == 4 and bl[f"ups_{k}.Sups.dX"] == 1 for k in (1, 2, 3))
+    old = E.CONV3_SPLIT
+    try:
+        E.CONV3_SPLIT = False
+        plan2 = E.Plan(m._ensure_flat("cpu"), 1, 128, 128)
+        f2 = {mm[0]: mm[1] for mm in plan2.meta[id(plan2.fwd)]}
+        assert f2["ups_1.Sups"] == "uir_gemm" and "ups_1.Sups.wsplit" not in f2
+    finally:
+        E.CONV3_SPLIT = old

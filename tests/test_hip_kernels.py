@@ -253,6 +253,68 @@ def test_gemm_conv3x3_small_channels(Cin, Cout):
         assert float(Y[:, Cout:].abs().max()) == 0
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 8, 16, 32, 64), (1, 4, 16, 64, 128), (3, 16, 32, 64, 32), (1, 12, 16, 64, 64), (1, 32, 32, 128, 256),
+                                            (2, 16, 48, 96, 160), (1, 64, 64, 64, 128), (1, 128, 128, 32, 64)])
+def test_conv3x3_split_bf16_fwd_dx_dw(B, H, W, Cin, Cout):
+    """csrc/conv3b.hip through Recorder.conv3_wsplit / conv3_split / conv3_split_wgrad: UpSample1's Conv2d(C, 2C, 3) (SpectralTransformer.py:196)
+    forward, input gradient (+ residual) and weight gradient on split-bf16 MFMA vs torch fp64, held to the f32 tolerance of the f32-MFMA
+    kernels: every tile shape of the dispatcher (4- and 8-row tiles, 32 / 64 / 128 output columns), image borders inside and between tiles,
+    several 32-channel chunks, and the three shapes of the network (at one image)."""
+    x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
+    w = (rnd(Cout, Cin, 3, 3, seed=2) * (Cin * 9) ** -0.5).requires_grad_(True)
+    y = F.conv2d(x, w, padding=1)
+    dy = rnd(*y.shape, seed=3)
+    dx, dw = torch.autograd.grad((y * dy).sum(), (x, w))
+    r = rec()
+    dims = (B, H, W)
+    assert Recorder.conv3_split_ok(Cout, Cin, dims) and Recorder.conv3_split_ok(Cin, Cout, dims)
+    Wd, xd, dyd = dev(w.detach()), dev(hwc(x.detach())), dev(hwc(dy))
+    pf, pb = r.conv3_wsplit("c.wsplit", Wd, Cout, Cin, want_bwd=True)
+    # outputs as column slices of wider buffers (row strides != N), pre-filled: every element must be written
+    Ybig, dXbig = r.alloc(B * H * W, Cout + 8), r.alloc(B * H * W, Cin + 4)
+    Ybig.fill_(7.0); dXbig.fill_(7.0)
+    Y, dX = Ybig[:, 4:4 + Cout], dXbig[:, :Cin]
+    r.conv3_split("c", xd, pf, Y, N=Cout, K=Cin, dims=dims)
+    r.conv3_split("c.dx", dyd, pb, dX, N=Cin, K=Cout, dims=dims)
+    resx = rnd(B * H * W, Cin, seed=6)
+    dXr = r.alloc(B * H * W, Cin)
+    r.conv3_split("c.dx.r", dyd, pb, dXr, N=Cin, K=Cout, dims=dims, R=dev(resx))
+    dW = None
+    if Recorder.conv3_split_wgrad_ok(Cout, Cin, dims):
+        dW = r.alloc(Cout, Cin, 3, 3)
+        r.conv3_split_wgrad("c.dw", dyd, xd, dW, N=Cout, K=Cin, dims=dims)
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    assert rel(chw(Y, B, H, W), y) < TOL
+    assert rel(chw(dX, B, H, W), dx) < TOL
+    assert rel(chw(dXr, B, H, W), dx + chw(resx, B, H, W)) < TOL
+    assert float((Ybig[:, :4] - 7).abs().max()) == 0 and float((Ybig[:, 4 + Cout:] - 7).abs().max()) == 0
+    if dW is not None:
+        assert rel(dW, dw) < TOL
+    else:
+        assert Cout % 64
+
+
+def test_conv3x3_split_planes_are_an_exact_three_way_split():
+    """uir_conv3x3_wsplit: plane h + plane m + plane l == the f32 weight EXACTLY (bit for bit), in both layouts."""
+    Cout, Cin = 64, 32
+    w = (rnd(Cout, Cin, 3, 3, seed=9) * 0.37).float()
+    r = rec()
+    pf, pb = r.conv3_wsplit("w", dev(w), Cout, Cin, want_bwd=True)
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    n = 9 * Cout * Cin
+
+    def planes(t):
+        u = t.view(torch.int16)[:3 * n].to(torch.int32).cpu().reshape(3, n)
+        return (u << 16).view(torch.float32).double()
+    f = planes(pf).sum(0).reshape(9, Cout, Cin)
+    b = planes(pb).sum(0).reshape(9, Cin, Cout)
+    wt = w.double().reshape(Cout, Cin, 9)
+    assert torch.equal(f, wt.permute(2, 0, 1).contiguous())
+    assert torch.equal(b, wt.permute(2, 1, 0).flip(0).contiguous())
+
+
 def test_conv3x3_as_patches_for_wide_layers_on_few_pixels():
     """record_conv3x3's patch path (uir_patch3x3 + one K = 9 Cin GEMM on the native weight; engine.Recorder.conv_as_patches): forward,
     input gradient, weight gradient written in the native [Cout][Cin][3][3] layout, bias gradient - vs torch fp64; the patch kernel is

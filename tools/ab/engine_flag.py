@@ -1,7 +1,9 @@
-"""A/B helper: bench.py's headline run with engine module constants overridden.  usage: ab_engine_flag.py NAME=VALUE [NAME=VALUE ...]"""
+"""A/B helper: bench.py's headline run with engine module constants overridden.  usage: python tools/ab/engine_flag.py NAME=VALUE [NAME=VALUE ...]"""
 import ast
+import os
 import sys
 import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 torch.cuda.set_device(0)
 import bench
 import underwater_image_restoration_amd.engine as e

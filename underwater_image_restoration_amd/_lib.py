@@ -67,6 +67,16 @@ class GramArgs(C.Structure):
                 ("rows_per_chunk", C.c_int), ("nchunks", C.c_int)]
 
 
+class Conv3bArgs(C.Structure):
+    _fields_ = [("X", fp), ("Wp", fp), ("Y", fp), ("R", fp), ("ldx", C.c_int), ("ldy", C.c_int), ("ldr", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("N", C.c_int), ("K", C.c_int), ("tile", C.c_int)]
+
+
+class Conv3bWgradArgs(C.Structure):
+    _fields_ = [("dY", fp), ("X", fp), ("slab", fp), ("slab_stride", C.c_long), ("ldy", C.c_int), ("ldx", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("N", C.c_int), ("K", C.c_int), ("nchunks", C.c_int)]
+
+
 class DwArgs(C.Structure):
     _fields_ = [("X", fp), ("Wt", fp), ("Y", fp), ("ldx", C.c_int), ("ldy", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
@@ -217,6 +227,9 @@ SIGNATURES = {
     "uir_gram": [C.POINTER(GramArgs), fp],
     "uir_reduce_slab": [fp, i32, i64, fp, i64, i32, f32, fp],
     "uir_reduce_slab_batch": [fp, fp, i32, i32, fp],
+    "uir_conv3x3_wsplit": [fp, i32, i32, fp, fp, fp],
+    "uir_conv3x3_split": [C.POINTER(Conv3bArgs), fp],
+    "uir_conv3x3_split_wgrad": [C.POINTER(Conv3bWgradArgs), fp],
     "uir_dwconv": [C.POINTER(DwArgs), fp],
     "uir_dwconv_wgrad": [C.POINTER(DwWgradArgs), fp],
     "uir_dwconv_bwd_fused": [C.POINTER(DwBwdArgs), fp],
@@ -309,7 +322,7 @@ SIGNATURES = {
 }
 
 # C struct name -> ctypes mirror (every argument struct of include/uir_kernels.h)
-STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirDwArgs": DwArgs, "UirDwWgradArgs": DwWgradArgs,
+STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirConv3bArgs": Conv3bArgs, "UirConv3bWgradArgs": Conv3bWgradArgs, "UirDwArgs": DwArgs, "UirDwWgradArgs": DwWgradArgs,
            "UirDwBwdArgs": DwBwdArgs, "UirGdfnFwdArgs": GdfnFwdArgs, "UirQkvFwdArgs": QkvFwdArgs,
            "UirAttnvFwdArgs": AttnvFwdArgs, "UirDwLnBwdArgs": DwLnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
            "UirAttnFwdArgs": AttnFwdArgs, "UirAttnBwdArgs": AttnBwdArgs, "UirDftArgs": DftArgs, "UirDft2Args": Dft2Args,

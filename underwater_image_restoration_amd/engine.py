@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from . import _lib as L
+from . import knobs
 
 lib = L.lib
 
@@ -161,7 +162,12 @@ SIDE_LOW_PRIORITY = True       # side lane on the least-priority stream torch of
                                # default priority - no difference was ever measured, nor with the chain on a priority -1 stream)
 FUSE_QK_GRAM = True            # MDTA forward at C <= 32: q k^T and the norms inside uir_qkv_fwd (UirQkvFwdArgs.gram_slab); False = uir_gram launch
 FUSE_VALUE_GRAMS = True        # MDTA backward at C <= 32: dW_B / dW_A inside the dvf / dv GEMMs (EPI_PLAIN_DW); False = separate Gram launches
+_WGRAD3_SHAPES = ((32, 8), (32, 16), (16, 8), (8, 4))   # (K, N) pairs csrc/conv3m.hip uir_conv3x3_wgrad accepts (with 16-byte rows); any other
+                               # shape runs the generic nine-tap Gram, which needs ITS chunking (tests/test_cpu_surface.py holds the two lists together)
 _WGRAD3_WGS = 512              # workgroups of the LDS-staged 3 x 3 weight-gradient kernel (two per CU)
+CONV3_SPLIT = True             # 3x3 convolutions with >= 32 channels on both sides (UpSample1, down3): forward / input gradient / weight gradient on the
+                               # split-bf16 implicit-GEMM kernels of csrc/conv3b.hip; False = the nine-tap f32 MFMA paths of uir_gemm / uir_gram
+_CONV3B_WGS = 512              # workgroups of a uir_conv3x3_split_wgrad launch (two 6-wave workgroups per CU)
 _PLAIN_DW_WGS = 768            # workgroups of a GEMM with the fused per-sample Gram (EPI_PLAIN_DW): the resident set at 3 per CU
 GEMM_SLAB_ROWS = 512           # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
 FUSED_DW_MINROWS = 16 * 128 * 128   # depthwise backward as ONE pass (dX + dW) from this many pixels on; below, two kernels on two lanes
@@ -689,7 +695,8 @@ class Recorder:
             groups = (tk + 3) // 4
         else:
             groups = ((tn + 1) // 2) * ((tk + 1) // 2)
-        if (taps == 9 and batches == 1 and not extras and pro_b == 0 and N in (4, 8, 16) and K in (8, 16, 32)):
+        if (taps == 9 and batches == 1 and not extras and pro_b == 0 and (K, N) in _WGRAD3_SHAPES and _ld(A) % 4 == 0 and _ld(Bm) % 4 == 0
+                and _ld(Bm) >= K and _ptr(A) % 16 == 0 and _ptr(Bm) % 16 == 0):
             # csrc/conv3m.hip uir_conv3x3_wgrad: persistent workgroups over 16 x 16 pixel tiles, one slab row each
             nch = max(1, min(batches * ((hw[0] + 15) // 16) * ((hw[1] + 15) // 16) * (M // (hw[0] * hw[1])), _WGRAD3_WGS))
             rpc = ((M + nch - 1) // nch + 7) & ~7
@@ -765,6 +772,65 @@ class Recorder:
             if key in extras:
                 t = extras[key]
                 self._reduce(name + ".red." + key, sp + 4 * off, nch, stride, _ptr(t), t.numel())
+
+    # ---- 3 x 3 convolutions with >= 32 channels on both sides on split-bf16 MFMA (csrc/conv3b.hip): weight planes once per step,
+    # the halo'd pixel tile in LDS once per 32-channel chunk, nine taps as row offsets
+    @staticmethod
+    def conv3_split_ok(N: int, K: int, dims) -> bool:
+        """uir_conv3x3_split's contract for N outputs / K inputs on dims = (B, H, W)."""
+        _B, H, W = dims
+        return (CONV3_SPLIT and knobs.flag("UIR_FUSED_SPLIT") and N >= 32 and K >= 32 and N % 32 == 0 and K % 32 == 0 and W % 16 == 0
+                and H % (4 if N % 64 == 0 else 8) == 0)
+
+    @staticmethod
+    def conv3_split_wgrad_ok(N: int, K: int, dims) -> bool:
+        _B, H, W = dims
+        return CONV3_SPLIT and knobs.flag("UIR_FUSED_SPLIT") and N >= 64 and K >= 32 and N % 64 == 0 and K % 32 == 0 and W % 16 == 0 and H % 4 == 0
+
+    def conv3_wsplit(self, name, Wt, Cout, Cin, want_bwd: bool):
+        """bf16 planes of a native [Cout][Cin][3][3] weight: (forward planes, input-gradient planes or None); one launch per step."""
+        n16 = 3 * 9 * Cout * Cin
+        pf = self.alloc((n16 + 1) // 2)
+        pb = self.alloc((n16 + 1) // 2) if want_bwd else None
+        self._hold(Wt)
+        self._op(name, lib.uir_conv3x3_wsplit, _ptr(Wt), Cout, Cin, _ptr(pf), _ptr(pb), nbytes=4 * Cout * Cin * 9 + 2 * n16 * (2 if want_bwd else 1),
+                 variant="uir_conv3b_wsplit")
+        return pf, pb
+
+    def conv3_split(self, name, X, planes, Y, *, N, K, dims, R=None, tile=0):
+        B, H, W = dims
+        assert X.shape[0] == B * H * W and Y.shape[0] == B * H * W and self.conv3_split_ok(N, K, dims)
+        self._hold(X, planes, Y, R)
+        a = L.Conv3bArgs()
+        a.X, a.Wp, a.Y, a.R = _ptr(X), _ptr(planes), _ptr(Y), _ptr(R)
+        a.ldx, a.ldy, a.ldr = _ld(X), _ld(Y), (_ld(R) if R is not None else 0)
+        a.B, a.H, a.Wd, a.N, a.K, a.tile = B, H, W, N, K, tile
+        self.keep.append(a)
+        rows = B * H * W
+        self._op(name, lib.uir_conv3x3_split, C.byref(a), nbytes=4 * rows * (K + N + (N if R is not None else 0)), flops=2 * rows * N * K * 9,
+                 variant="uir_conv3b_kernel<*>")
+
+    def conv3_split_wgrad(self, name, dY, X, out, *, N, K, dims):
+        """out (native [N][K][3][3], contiguous) = the weight gradient; partial slab rows + one reduction like uir_gram."""
+        B, H, W = dims
+        assert dY.shape[0] == B * H * W and X.shape[0] == B * H * W and self.conv3_split_wgrad_ok(N, K, dims) and out.numel() == N * K * 9
+        self._hold(dY, X, out)
+        ntiles = B * (H // 4) * (W // 16)
+        nch = max(1, min(ntiles, _CONV3B_WGS // ((N // 64) * (K // 32))))
+        stride = N * K * 9
+        if self._batching():
+            slab_t = self.alloc(nch * stride)
+        else:
+            slab_t = self._slab()
+            assert nch * stride <= slab_t.numel(), (name, nch, stride)
+        a = L.Conv3bWgradArgs()
+        a.dY, a.X, a.slab, a.slab_stride = _ptr(dY), _ptr(X), _ptr(slab_t), stride
+        a.ldy, a.ldx = _ld(dY), _ld(X)
+        a.B, a.H, a.Wd, a.N, a.K, a.nchunks = B, H, W, N, K, nch
+        self.keep.append(a)
+        rows = B * H * W
+        self._op(name, lib.uir_conv3x3_split_wgrad, C.byref(a), nbytes=4 * rows * (N + K), flops=2 * rows * N * K * 9, variant="uir_conv3b_wgrad_kernel")
+        self._reduce(name + ".red", slab_t.data_ptr(), nch, stride, _ptr(out), stride)
 
     # ---- wide 3 x 3 convolutions on few pixels as ONE plain contraction over patches (uir_patch3x3: k = cin * 9 + tap, the native
     # weight's own order, so weight.view(Cout, 9 Cin) and its gradient are used in place).  The in-place nine-tap kernels tile the
@@ -1305,13 +1371,27 @@ class Plan(Recorder):
         Wt = self.P(Wname)
         if y is None:
             y = self.alloc(M, Np)
-        self.gemm(name, x, Wt, y, N=Np, K=Kp, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=dims[1:], k_grp=k_grp, n_grp=n_grp)
+        plain = Kp == Cin and Np == Cout and not k_grp[1] and not n_grp[1]
+        # >= 32 channels on both sides (UpSample1 at every level, down3): csrc/conv3b.hip, each direction by its own contract
+        split_f = plain and self.conv3_split_ok(Cout, Cin, dims)
+        split_b = plain and self.want_backward_convs() and self.conv3_split_ok(Cin, Cout, dims)
+        split_w = plain and self.want_backward_convs() and self.conv3_split_wgrad_ok(Cout, Cin, dims)
+        pf = pb = None
+        if split_f or split_b:
+            pf, pb = self.conv3_wsplit(name + ".wsplit", Wt, Cout, Cin, want_bwd=split_b)
+        if split_f:
+            self.conv3_split(name, x, pf, y, N=Cout, K=Cin, dims=dims)
+        else:
+            self.gemm(name, x, Wt, y, N=Np, K=Kp, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=dims[1:], k_grp=k_grp, n_grp=n_grp)
 
         def backward(dy, need_dx=True, dw_on_chain=False, R=None):
             """R: a gradient to ADD to the input gradient (the skip path's share: no separate accumulate pass)."""
             def dw():
-                self.gram(name + ".dW", dy, x, self.Gr(Wname), N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:],
-                          n_grp=n_grp, k_grp=k_grp)
+                if split_w:
+                    self.conv3_split_wgrad(name + ".dW", dy, x, self.Gr(Wname), N=Cout, K=Cin, dims=dims)
+                else:
+                    self.gram(name + ".dW", dy, x, self.Gr(Wname), N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:],
+                              n_grp=n_grp, k_grp=k_grp)
             if dw_on_chain:      # last op of the step: the chain has nothing left to do, the bulk lane still has a queue
                 dw()
             else:
@@ -1320,10 +1400,16 @@ class Plan(Recorder):
             if not need_dx:
                 return None
             dx = self.alloc(M, Kp)
-            self.gemm(name + ".dX", dy, Wt, dx, N=Kp, K=Np, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=dims[1:],
-                      n_grp=k_grp, k_grp=n_grp, R=R)
+            if split_b:
+                self.conv3_split(name + ".dX", dy, pb, dx, N=Cin, K=Cout, dims=dims, R=R)
+            else:
+                self.gemm(name + ".dX", dy, Wt, dx, N=Kp, K=Np, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=dims[1:],
+                          n_grp=k_grp, k_grp=n_grp, R=R)
             return dx
         return y, backward
+
+    def want_backward_convs(self) -> bool:
+        return getattr(self, "want_backward", True)
 
     def _down(self, pfx, x, C_, dims):
         """DownSample (:154-158): conv3x3 C->C/2 + PixelUnshuffle(2)."""
