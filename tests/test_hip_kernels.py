@@ -283,12 +283,22 @@ def test_conv3x3_split_bf16_fwd_dx_dw(B, H, W, Cin, Cout):
     if Recorder.conv3_split_wgrad_ok(Cout, Cin, dims):
         dW = r.alloc(Cout, Cin, 3, 3)
         r.conv3_split_wgrad("c.dw", dyd, xd, dW, N=Cout, K=Cin, dims=dims)
+    # every workgroup tile the shape admits, forced (UirConv3bArgs.tile): the library's own choice covers only two of the six
+    forced = []
+    for tm, tn in ((256, 32), (128, 32), (128, 128), (64, 128), (128, 64), (64, 64)):
+        if H % (tm // 16) == 0 and Cout % tn == 0:
+            Yt = r.alloc(B * H * W, Cout)
+            r.conv3_split(f"c.{tm}x{tn}", xd, pf, Yt, N=Cout, K=Cin, dims=dims, tile=1000 * tm + tn)
+            forced.append(((tm, tn), Yt))
     r.run(r.fwd)
     torch.cuda.synchronize()
     assert rel(chw(Y, B, H, W), y) < TOL
     assert rel(chw(dX, B, H, W), dx) < TOL
     assert rel(chw(dXr, B, H, W), dx + chw(resx, B, H, W)) < TOL
     assert float((Ybig[:, :4] - 7).abs().max()) == 0 and float((Ybig[:, 4 + Cout:] - 7).abs().max()) == 0
+    assert len(forced) >= 2
+    for tl, Yt in forced:
+        assert rel(chw(Yt, B, H, W), y) < TOL, tl
     if dW is not None:
         assert rel(dW, dw) < TOL
     else:

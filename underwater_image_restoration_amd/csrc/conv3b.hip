@@ -412,16 +412,11 @@ extern "C" int uir_conv3x3_split(const UirConv3bArgs* p, void* stream) {
   auto wgs = [&](int tm, int tn) { return (long)a.B * (a.H / (tm / TW)) * (a.Wd / TW) * (a.N / tn); };
   int tile = a.tile;
   if (tile == 0) {
-    if (!n64) {
-      // 32-column tiles, 4 waves x 64 or 32 pixels: the taller tile while it still fills the chip twice (one weight fragment then meets two pixel tiles)
-      tile = (h16 && wgs(256, 32) >= 512) ? 256032 : 128032;
-    } else {
-      // the largest tile that still gives the chip two workgroups per CU (csrc/tsgemm.hip's rule)
-      if (n128 && h8 && wgs(128, 128) >= 512) tile = 128128;
-      else if (n128 && wgs(64, 128) >= 512) tile = 64128;
-      else if (h8 && wgs(128, 64) >= 512) tile = 128064;
-      else tile = 64064;
-    }
+    // measured on the network's three layers and down3 (tools/bench_conv3b.py --tiles, profiles/r05): 128-pixel tiles always beat 64-pixel ones
+    // (59-63 us against 102-111: half the MFMAs per weight fragment and a 1.7 x halo), 64 output columns tie with 128 and give twice the
+    // workgroups; with 32 output columns the 256-pixel tile (one weight fragment against two pixel tiles per wave) wins from 256 workgroups on
+    if (!n64) tile = (h16 && wgs(256, 32) >= 256) ? 256032 : 128032;
+    else tile = h8 ? 128064 : 64064;
   }
   switch (tile) {
     case 256032: UIR_REQUIRE(h16); return conv3b_launch<256, 32>(a, st);

@@ -157,6 +157,10 @@ _GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per
 # chain still has 2 x BULK_DEFER launches to go: held work released near the end of a list is a tail behind its last chain kernel (the
 # short per-module lists of NewBigFRFNModel / AST lost 2-5 % with an unconditional hold).
 BULK_DEFER = 30
+# Weight-gradient launches recorded between these two stage marks of the backward list (decoder level 2, ups_1, encoder levels 3 and 2: short,
+# latency-bound chain kernels that a concurrent Gram slows down one for one) are held until the second mark has passed and then run beside the
+# long bandwidth-bound kernels of levels 1 and 0.  None: no stage hold (only BULK_DEFER).
+BULK_HOLD_STAGES = None        # e.g. ("bwd.ups_2", "bwd.enc2(L2)")
 FAST_LANE_EVENTS = True        # lane-ordering events without the system-scope fence (see _LaneEvent)
 SIDE_LOW_PRIORITY = True       # side lane on the least-priority stream torch offers (on this ROCm build priority_range() is (0, -1): the
                                # default priority - no difference was ever measured, nor with the chain on a priority -1 stream)
@@ -477,6 +481,7 @@ class Recorder:
         side_dirty = False          # side has launched work the bulk stream has not been ordered after
         held: list = []             # bulk launches not yet released (BULK_DEFER)
         held_age = 0                # chain launches since the first of them
+        stage_hold = False          # between the two marks of BULK_HOLD_STAGES: bulk launches wait for the second mark
         chain_left = sum(1 for ln in lanes if ln in (0, 1))      # chain / side launches still to come
 
         def release_bulk():
@@ -516,6 +521,13 @@ class Recorder:
                     e = torch.cuda.Event(enable_timing=True)
                     e.record(main)
                     marks.append((name, e))
+                if BULK_HOLD_STAGES is not None:
+                    if name == BULK_HOLD_STAGES[0]:
+                        stage_hold = True
+                    elif name == BULK_HOLD_STAGES[1]:
+                        stage_hold = False
+                        if held:
+                            release_bulk()
                 continue
             if lane == 2:                       # join marker
                 if nev == len(self._events):
@@ -527,11 +539,11 @@ class Recorder:
                 continue
             if lane == 4:
                 held.append((opi, fn, args, name))
-                if BULK_DEFER <= 0 or chain_left < 2 * BULK_DEFER:
+                if not stage_hold and (BULK_DEFER <= 0 or chain_left < 2 * BULK_DEFER):
                     release_bulk()
                 continue
             chain_left -= 1
-            if held:
+            if held and not stage_hold:
                 if held_age >= BULK_DEFER or chain_left < 2 * BULK_DEFER:
                     release_bulk()
                 else:
@@ -1149,7 +1161,7 @@ class Plan(Recorder):
         super().__init__(fp.device, fp)
         self.B, self.H, self.W = B, H, W
         self.want_backward = want_backward
-        self._p_state, self._p_splice_at = 1, 0
+        self._p_state = 1
         self._build()
 
     @classmethod
@@ -1159,7 +1171,7 @@ class Plan(Recorder):
         Recorder.__init__(self, fp.device, fp, scratch_floats)
         return self
 
-    _p_state = 0          # 0: _block records its own P launch + join; 1 / 2 / 3: first / second / later block of a full plan (see _block)
+    _p_state = 0          # 0: _block records its own P launch + join; 1 / 2: first / later block of a full plan (see _block)
 
     # ------------------------------------------------------------ sub-graphs
     def _block(self, pfx: str, x: torch.Tensor, C_: int, heads: int, dims, y_out: "torch.Tensor | None" = None) -> Tuple[torch.Tensor, Callable]:
@@ -1205,23 +1217,23 @@ class Plan(Recorder):
         fuse_qk = FUSE_QK_GRAM and C_ <= 32
         self.qkv_fwd(n + ".qkv+conv", x, (g1, b1), Wqkv, Wdw, qkv_pre, qkv, C_=C_, dims=dims, stats=stats1,
                      gram_out=(Gm, sqq, sqk) if fuse_qk else None)
-        # P = W_kv[vf] @ W_o depends on weights only: side lane.  A full plan (Plan._build, _p_state >= 1) computes the first block's in
-        # place, joined right before its first use, and ALL the others right behind that join (Recorder.prologue: the side lane has the
-        # first block's GDFN to finish them), joined once before the second block's attention.  At the very start of the step they
-        # left the GPU idle while the host enqueued them (~300 us).  A block recorded by itself (unit tests) keeps its own launch + join
-        hoist = self._p_state >= 2
+        # P = W_kv[vf] @ W_o depends on weights only: side lane.  A full plan (Plan._build, _p_state >= 1) records ALL 24 of them at the very
+        # start of the forward list (Recorder.prologue, spliced at index 0): the side lane runs them beside the embedding and the first
+        # block's qkv kernel, and ONE join in front of the first block's attention covers every block.  (Round 4 kept the first block's in
+        # place and the others behind its join: tools/chain_gaps_events.py showed the chain waiting 43 us there for the first two - a side
+        # launch starts only after everything the chain had launched when it was recorded.)  A block recorded by itself (unit tests) keeps
+        # its own launch + join
+        hoist = self._p_state >= 1
         with (self.prologue() if hoist else self.side()):
             self.gemm(n + ".P", Wkvf, Wo, Pm, N=C_, K=C_, w_sn=1, w_sk=C_)
         fa = L.AttnFwdArgs()
         if not fuse_qk:
             self.gram(n + ".qk_gram", q_, k_, Gm, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B,
                       out_elems=B * C_ * C_, extras={"sq_a": sqq, "sq_b": sqk}, fused_out=gbuf)
-        if self._p_state <= 2:
+        if self._p_state <= 1:
             self.join(n + ".P.join")
         if self._p_state == 1:
-            self._p_splice_at = len(self.fwd)
-        if self._p_state in (1, 2):
-            self._p_state += 1
+            self._p_state = 2
         fa.G, fa.sq_q, fa.sq_k, fa.temperature, fa.P, fa.Wof = _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp), _ptr(Pm), _ptr(Wof)
         fa.attn, fa.WA, fa.WB = _ptr(attn), _ptr(WA), _ptr(WB)
         fa.B, fa.C, fa.heads = B, C_, heads
@@ -1601,7 +1613,7 @@ class Plan(Recorder):
         y4, out_bw = self._conv3("output", y8, "output.weight", 8, 3, d0, n_grp=(3, 4), Np=4)
         self._op("out.to_nchw", lib.uir_hwc4_to_nchw3, _ptr(y4), _ptr(self.out_nchw), B, H, W)
         self.mark("fwd.output")
-        self.splice_prologue(self._p_splice_at)
+        self.splice_prologue(0)
         if not self.want_backward:
             return
         # ------------------------------ backward ------------------------------
