@@ -296,7 +296,7 @@ def test_conv3x3_split_bf16_fwd_dx_dw(B, H, W, Cin, Cout):
     assert rel(chw(dX, B, H, W), dx) < TOL
     assert rel(chw(dXr, B, H, W), dx + chw(resx, B, H, W)) < TOL
     assert float((Ybig[:, :4] - 7).abs().max()) == 0 and float((Ybig[:, 4 + Cout:] - 7).abs().max()) == 0
-    assert len(forced) >= 2
+    assert len(forced) >= 1
     for tl, Yt in forced:
         assert rel(chw(Yt, B, H, W), y) < TOL, tl
     if dW is not None:

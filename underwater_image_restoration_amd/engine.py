@@ -157,10 +157,6 @@ _GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per
 # chain still has 2 x BULK_DEFER launches to go: held work released near the end of a list is a tail behind its last chain kernel (the
 # short per-module lists of NewBigFRFNModel / AST lost 2-5 % with an unconditional hold).
 BULK_DEFER = 30
-# Weight-gradient launches recorded between these two stage marks of the backward list (decoder level 2, ups_1, encoder levels 3 and 2: short,
-# latency-bound chain kernels that a concurrent Gram slows down one for one) are held until the second mark has passed and then run beside the
-# long bandwidth-bound kernels of levels 1 and 0.  None: no stage hold (only BULK_DEFER).
-BULK_HOLD_STAGES = None        # e.g. ("bwd.ups_2", "bwd.enc2(L2)")
 FAST_LANE_EVENTS = True        # lane-ordering events without the system-scope fence (see _LaneEvent)
 SIDE_LOW_PRIORITY = True       # side lane on the least-priority stream torch offers (on this ROCm build priority_range() is (0, -1): the
                                # default priority - no difference was ever measured, nor with the chain on a priority -1 stream)
@@ -481,7 +477,6 @@ class Recorder:
         side_dirty = False          # side has launched work the bulk stream has not been ordered after
         held: list = []             # bulk launches not yet released (BULK_DEFER)
         held_age = 0                # chain launches since the first of them
-        stage_hold = False          # between the two marks of BULK_HOLD_STAGES: bulk launches wait for the second mark
         chain_left = sum(1 for ln in lanes if ln in (0, 1))      # chain / side launches still to come
 
         def release_bulk():
@@ -521,13 +516,6 @@ class Recorder:
                     e = torch.cuda.Event(enable_timing=True)
                     e.record(main)
                     marks.append((name, e))
-                if BULK_HOLD_STAGES is not None:
-                    if name == BULK_HOLD_STAGES[0]:
-                        stage_hold = True
-                    elif name == BULK_HOLD_STAGES[1]:
-                        stage_hold = False
-                        if held:
-                            release_bulk()
                 continue
             if lane == 2:                       # join marker
                 if nev == len(self._events):
@@ -539,11 +527,11 @@ class Recorder:
                 continue
             if lane == 4:
                 held.append((opi, fn, args, name))
-                if not stage_hold and (BULK_DEFER <= 0 or chain_left < 2 * BULK_DEFER):
+                if BULK_DEFER <= 0 or chain_left < 2 * BULK_DEFER:
                     release_bulk()
                 continue
             chain_left -= 1
-            if held and not stage_hold:
+            if held:
                 if held_age >= BULK_DEFER or chain_left < 2 * BULK_DEFER:
                     release_bulk()
                 else:
