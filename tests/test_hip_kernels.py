@@ -464,6 +464,59 @@ def test_gram_conv3x3_weight_grad(B, H, W, Cin, Cout):
     assert rel(out, dw) < TOL
 
 
+@pytest.mark.parametrize("M,C", [(4096, 64), (2500, 128), (9000, 64)])
+def test_gram_split_bf16_deep_level_weight_gradients(M, C):
+    """csrc/gramb.hip behind uir_gram (M >= 2048, >= 32 columns on both sides): the deep levels' dW_in (LayerNorm prologue on the narrow operand,
+    padded hidden groups on the wide one), dW_qkv, dW_out (gate prologue on the wide operand, K = h no multiple of 4) and a plain per-sample
+    Gram written through output strides, at the network's channel counts (SpectralTransformer.py:81,122,125 under autograd), ragged row
+    counts (not a multiple of the 64-row stage / of the chunk) included - vs torch fp64 at the f32 kernels' tolerance."""
+    h = int(C * 2.66)
+    hp = (h + 15) // 16 * 16
+    x, g, be = rnd(M, C, seed=1, scale=2), 1 + 0.1 * rnd(C, seed=2), 0.1 * rnd(C, seed=3)
+    dgp = rnd(M, 2 * hp, seed=4)
+    dgp[:, h:hp] = 0
+    dgp[:, hp + h:] = 0
+    st = torch.stack([x.mean(1), 1 / torch.sqrt(x.var(1, unbiased=False) + 1e-5)], 1)
+    r = rec()
+    dW = r.alloc(2 * h, C)
+    r.gram("dWin", dev(dgp), dev(x), dW, N=2 * hp, K=C, o_sn=C, o_sk=1, n_grp=(h, hp), pro_b=L.PRO_LN, ln=(dev(g), dev(be)), stats=dev(st))
+    gg = rnd(M, 2 * hp, seed=5, scale=2)
+    gg[:, h:hp] = 0
+    gg[:, hp + h:] = 0
+    dy = rnd(M, C, seed=6)
+    dWo = r.alloc(C, h)
+    r.gram("dWout", dev(dy), dev(gg), dWo, N=C, K=h, o_sn=h, o_sk=1, pro_b=L.PRO_GATE, gate_off=hp)
+    dq = rnd(M, 3 * C, seed=7)
+    dWq = r.alloc(3 * C, C)
+    r.gram("dWqkv", dev(dq), dev(x), dWq, N=3 * C, K=C, o_sn=C, o_sk=1, pro_b=L.PRO_LN, ln=(dev(g), dev(be)), stats=dev(st))
+    # plain, operands as column slices of a wider tensor, output transposed through the strides
+    big = dev(rnd(M, 3 * C + 8, seed=8))
+    dWt = r.alloc(C, 2 * C)
+    r.gram("plain", big[:, 4:4 + 2 * C], big[:, 2 * C + 8:3 * C + 8], dWt, N=2 * C, K=C, o_sn=1, o_sk=2 * C)
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    t = F.layer_norm(x, (C,), g, be, 1e-5)
+    dreal = torch.cat([dgp[:, :h], dgp[:, hp:hp + h]], 1)
+    assert rel(dW, dreal.T @ t) < TOL
+    gate = F.gelu(gg[:, :h]) * gg[:, hp:hp + h]
+    assert rel(dWo, dy.T @ gate) < TOL
+    assert rel(dWq, dq.T @ t) < TOL
+    bd = big.double().cpu()
+    assert rel(dWt, (bd[:, 4:4 + 2 * C].T @ bd[:, 2 * C + 8:3 * C + 8]).T) < TOL
+
+
+def test_gram_split_bf16_per_sample_batches():
+    """the same kernel with per-sample operands (blockIdx.z): dW_B = dx1^T vf per image at C = 64 (engine._block backward at the deep levels)"""
+    B, HW, C = 3, 4096, 64
+    a, b = rnd(B * HW, C, seed=1), rnd(B * HW, C, seed=2)
+    r = rec()
+    out = r.alloc(B, C * C)
+    r.gram("dWB", dev(a), dev(b), out, N=C, K=C, o_sn=C, o_sk=1, o_bs=C * C, batches=B, out_elems=B * C * C)
+    r.run(r.fwd)
+    want = torch.einsum("bpi,bpj->bij", a.reshape(B, HW, C), b.reshape(B, HW, C))
+    assert rel(out.reshape(B, C, C), want) < TOL
+
+
 def test_gram_per_batch_with_norms_and_colsum():
     B, HW, C = 3, 500, 32
     qkv = rnd(B * HW, 3 * C, seed=1)

@@ -94,3 +94,15 @@ for lvl, (S, Cc, heads) in (("L2", (64, 64, 4)), ("L3", (32, 128, 8))):
     r.gram("dWqkv", qkv, x, dWq, N=3 * Cc, K=Cc, o_sn=Cc, o_sk=1, pro_b=L.PRO_LN, ln=(g1, b1), stats=st)
     r.flush_reductions("t")
     timeit(r, f"{lvl} bwd dWqkv Gram (+ reduce)", 2 * M * 3 * Cc * Cc)
+    dWo = r.alloc(Cc, h)
+    r.gram("dWout", x, gp, dWo, N=Cc, K=h, o_sn=h, o_sk=1, pro_b=L.PRO_GATE, gate_off=hp)
+    r.flush_reductions("t")
+    timeit(r, f"{lvl} bwd dWout Gram (+ reduce)", 2 * M * h * Cc)
+    dWf = r.alloc(Cc, Cc)
+    r.gram("fuse.dW", x, y, dWf, N=Cc, K=Cc, o_sn=Cc, o_sk=1)
+    r.flush_reductions("t")
+    timeit(r, f"{lvl} ups 1x1 weight gradient (C x C) (+ reduce)", 2 * M * Cc * Cc)
+    dWB = r.alloc(B, Cc * Cc)
+    r.gram("dWB", x, y, dWB, N=Cc, K=Cc, o_sn=Cc, o_sk=1, o_bs=Cc * Cc, batches=B, out_elems=B * Cc * Cc)
+    r.flush_reductions("t")
+    timeit(r, f"{lvl} bwd per-sample dW_B Gram (+ reduce)", 2 * M * Cc * Cc)

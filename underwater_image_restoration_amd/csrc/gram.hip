@@ -14,6 +14,7 @@
 #endif
 
 int uir_conv3x3_wgrad(const UirGramArgs& a, void* stream);     // csrc/conv3m.hip; -1 = not its shape
+int uir_gram_split(const UirGramArgs& a, void* stream);        // csrc/gramb.hip; -1 = not its case
 
 namespace {
 
@@ -473,6 +474,12 @@ extern "C" int uir_gram(const UirGramArgs* p, void* stream) {
   UIR_REQUIRE((long)a.M * a.lda < (1L << 30) && (long)a.M * a.ldb < (1L << 30));   // 32-bit element offsets per batch
   const bool extras = a.sq_a_off >= 0 || a.sq_b_off >= 0 || a.cs_a_off >= 0;
   UIR_REQUIRE(!extras || a.pro_b == UIR_GRAM_PRO_NONE);
+  {
+    // long pixel contractions with >= 32 columns on both sides and a narrow side (the deep levels' dW_in / dW_qkv / dW_out, the 1x1
+    // weight gradients of the up-samplers): LDS-staged split-bf16 MFMA with transposed fragment reads (csrc/gramb.hip)
+    const int rs = uir_gram_split(a, stream);
+    if (rs >= 0) return rs;
+  }
   {
     // Wide weight gradients (Linear layers of NewBigFRFNModel / AST, N and K >= UIR_TILED_GRAM_MIN, default 128): 128 x 128
     // output tiles on the LDS-tiled kernel of csrc/tiled.hip, one k split per chunk - same partial-slab contract.

@@ -712,6 +712,10 @@ class Recorder:
             nch = (M + rpc - 1) // rpc
         else:
             nch, rpc = self._chunks(M, taps * groups, batches)
+            if taps == 1 and not extras and M >= 1024 and N >= 32 and K >= 32:
+                # csrc/gramb.hip's cases (the library decides; this only shapes the chunks): whole 64-row stages per chunk
+                rpc = (rpc + 63) & ~63
+                nch = (M + rpc - 1) // rpc
         if out_elems is None:
             out_elems = out.numel()
         a = L.GramArgs()
