@@ -62,45 +62,75 @@ struct GbArgs {
   int M, rows_per_chunk;
 };
 
-// one operand's stage: SR rows x COLS columns from row0 (rows >= row_end and columns >= ncols give zeros), prologue PRO, split, LDS
+// one operand's stage: SR rows x COLS columns from row0 (rows >= row_end and columns >= ncols give zeros), prologue PRO, split, LDS.
+// NT threads, thread t owns the float4 at column 4 (t % QPR) of rows t / QPR + RPI i: its column, column mask, LayerNorm gamma / beta and the
+// swizzle term of its LDS address are the same for every i and every stage (RPI is a multiple of 4), so a stage costs per float4 the
+// prologue + split + three 8-byte LDS stores and nothing else (first written with per-element masks and per-float4 address arithmetic the
+// staging was 1 287 VALU instructions per stage and wave against 48 MFMAs: the kernel ran slower than the f32 one it replaces).
 template <int COLS, int SR, int PRO, int NT>
 struct Stager {
   static constexpr int QPR = COLS / 4;                           // float4 per row
-  static constexpr int NQ = (SR * QPR + NT - 1) / NT;
+  static constexpr int RPI = NT / QPR;                           // rows between a thread's consecutive float4
+  static constexpr int NQ = SR / RPI;
   static constexpr int PL = SR * COLS;                           // bf16 per plane
+  static_assert(NT % QPR == 0 && SR % RPI == 0 && RPI % 4 == 0, "thread -> (row, column) map");
   uint4 v[NQ], g[PRO == 2 ? NQ : 1];
   float2 st[PRO == 1 ? NQ : 1];
-  __device__ __forceinline__ void load(const float* base, int ld, int col0, int ncols, int row0, int row_end, const float* stats, int gate_off, int tid) {
+  const float* src;              // this thread's column of row 0 (clamped column)
+  const float* stats;            // + 2 * its first row
+  float4 ga, be;                 // PRO 1
+  uint32_t cm[4];                // column masks: all ones for a real column
+  int r0, lds0, ld, goff;
+  __device__ __forceinline__ void init(const float* base, int ld_, int col0, int ncols, const float* stats_, int gate_off, const float* ln_g,
+                                       const float* ln_b, int tid) {
+    r0 = tid / QPR;
+    const int cl = 4 * (tid - r0 * QPR), c = col0 + cl, cc = min(c, (ncols - 1) & ~3);   // clamped: always readable (ld >= roundup4(ncols))
+    ld = ld_; goff = gate_off;
+    src = base + cc;
+    stats = stats_;
+    lds0 = wsz<COLS>(r0, cl);
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) {
-      const int e = tid + NT * i, r = e / QPR, c = col0 + 4 * (e - r * QPR);
-      const int rr = min(row0 + r, row_end - 1), cc = min(c, (ncols - 1) & ~3);   // clamped: always readable (ld >= roundup4(ncols))
-      const float* p = base + (long)rr * ld + cc;
-      v[i] = *reinterpret_cast<const uint4*>(p);
-      if constexpr (PRO == 2) g[i] = *reinterpret_cast<const uint4*>(p + gate_off);
-      if constexpr (PRO == 1) st[i] = *reinterpret_cast<const float2*>(stats + 2L * rr);
+    for (int k = 0; k < 4; ++k) cm[k] = c + k < ncols ? 0xffffffffu : 0u;
+    if constexpr (PRO == 1) { ga = *reinterpret_cast<const float4*>(ln_g + cc); be = *reinterpret_cast<const float4*>(ln_b + cc); }
+  }
+  __device__ __forceinline__ void load(int row0, int row_end) {
+    if (row0 + SR <= row_end) {
+      const float* p = src + (long)(row0 + r0) * ld;
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        v[i] = *reinterpret_cast<const uint4*>(p + (long)i * RPI * ld);
+        if constexpr (PRO == 2) g[i] = *reinterpret_cast<const uint4*>(p + (long)i * RPI * ld + goff);
+        if constexpr (PRO == 1) st[i] = *reinterpret_cast<const float2*>(stats + 2L * (row0 + r0 + i * RPI));
+      }
+    } else {                     // the chunk's last, partial stage: clamped rows (masked when stored)
+#pragma unroll
+      for (int i = 0; i < NQ; ++i) {
+        const int rr = min(row0 + r0 + i * RPI, row_end - 1);
+        const float* p = src + (long)rr * ld;
+        v[i] = *reinterpret_cast<const uint4*>(p);
+        if constexpr (PRO == 2) g[i] = *reinterpret_cast<const uint4*>(p + goff);
+        if constexpr (PRO == 1) st[i] = *reinterpret_cast<const float2*>(stats + 2L * rr);
+      }
     }
   }
-  __device__ __forceinline__ void store(unsigned short* s, int col0, int ncols, int row0, int row_end, const float* ln_g, const float* ln_b, int tid) const {
+  __device__ __forceinline__ void store(unsigned short* s, int row0, int row_end) const {
+    const bool whole = row0 + SR <= row_end;
 #pragma unroll
     for (int i = 0; i < NQ; ++i) {
-      const int e = tid + NT * i, r = e / QPR, cl = 4 * (e - r * QPR), c = col0 + cl;
-      if ((i + 1) * NT > SR * QPR && r >= SR) continue;
-      const bool rok = row0 + r < row_end;
       float x[4] = {__uint_as_float(v[i].x), __uint_as_float(v[i].y), __uint_as_float(v[i].z), __uint_as_float(v[i].w)};
       if constexpr (PRO == 1) {
-        const int cc = min(c, (ncols - 1) & ~3);
-        const float4 ga = *reinterpret_cast<const float4*>(ln_g + cc), be = *reinterpret_cast<const float4*>(ln_b + cc);
-        x[0] = (x[0] - st[i].x) * st[i].y * ga.x + be.x; x[1] = (x[1] - st[i].x) * st[i].y * ga.y + be.y;
-        x[2] = (x[2] - st[i].x) * st[i].y * ga.z + be.z; x[3] = (x[3] - st[i].x) * st[i].y * ga.w + be.w;
+        const float mu = st[i].x, rs = st[i].y;
+        x[0] = fmaf((x[0] - mu) * rs, ga.x, be.x); x[1] = fmaf((x[1] - mu) * rs, ga.y, be.y);
+        x[2] = fmaf((x[2] - mu) * rs, ga.z, be.z); x[3] = fmaf((x[3] - mu) * rs, ga.w, be.w);
       }
       if constexpr (PRO == 2) {
         x[0] = uir_gelu(x[0]) * __uint_as_float(g[i].x); x[1] = uir_gelu(x[1]) * __uint_as_float(g[i].y);
         x[2] = uir_gelu(x[2]) * __uint_as_float(g[i].z); x[3] = uir_gelu(x[3]) * __uint_as_float(g[i].w);
       }
+      const uint32_t rm = (whole || row0 + r0 + i * RPI < row_end) ? 0xffffffffu : 0u;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) x[k] = (rok && c + k < ncols) ? x[k] : 0.f;      // columns past the operand (pads of a padded group are zeros in memory)
-      store_quad<PL>(s + wsz<COLS>(r, cl), x);
+      for (int k = 0; k < 4; ++k) x[k] = __uint_as_float(__float_as_uint(x[k]) & cm[k] & rm);
+      store_quad<PL>(s + lds0 + i * RPI * COLS, x);
     }
   }
 };
@@ -138,17 +168,19 @@ __global__ __launch_bounds__(256, 2) void uir_gramb_kernel(const GbArgs a, int q
 
   Stager<128, SR, PROP, 256> sp;
   Stager<QB, SR, PROQ, 256> sq;
+  sp.init(P, a.ldp, p0, a.np, stats, a.gate_off, a.ln_g, a.ln_b, tid);
+  sq.init(Q, a.ldq, q0, a.nq, stats, a.gate_off, a.ln_g, a.ln_b, tid);
   if (row_begin < row_end) {
-    sp.load(P, a.ldp, p0, a.np, row_begin, row_end, stats, a.gate_off, tid);
-    sq.load(Q, a.ldq, q0, a.nq, row_begin, row_end, stats, a.gate_off, tid);
+    sp.load(row_begin, row_end);
+    sq.load(row_begin, row_end);
   }
   for (int row0 = row_begin; row0 < row_end; row0 += SR) {
-    sp.store(Ps, p0, a.np, row0, row_end, a.ln_g, a.ln_b, tid);
-    sq.store(Qs, q0, a.nq, row0, row_end, a.ln_g, a.ln_b, tid);
+    sp.store(Ps, row0, row_end);
+    sq.store(Qs, row0, row_end);
     __syncthreads();
     const int nxt = row0 + SR < row_end ? row0 + SR : row0;          // next stage in flight during the MFMAs (clamped, unconditional)
-    sp.load(P, a.ldp, p0, a.np, nxt, row_end, stats, a.gate_off, tid);
-    sq.load(Q, a.ldq, q0, a.nq, nxt, row_end, stats, a.gate_off, tid);
+    sp.load(nxt, row_end);
+    sq.load(nxt, row_end);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < SR / 16; ++s) {

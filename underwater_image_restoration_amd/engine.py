@@ -671,11 +671,17 @@ class Recorder:
         self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps,
                  variant=f"uir_gemm1x1_kernel<*,{pro},{epi},*>")     # the rocprofv3 symbol family (NT and HAS_R vary per call)
 
-    def _chunks(self, M, ngroups, batches):
+    def _chunks(self, M, ngroups, batches, stage64=False):
         nch = max(1, min(M // 256, _GRAM_WGS // max(1, ngroups * batches)))
         rpc = ((M + nch - 1) // nch + 7) & ~7
+        if stage64:          # csrc/gramb.hip's cases (the library decides; this only shapes the chunks): whole 64-row stages per chunk
+            rpc = (rpc + 63) & ~63
         nch = (M + rpc - 1) // rpc
         return nch, rpc
+
+    @staticmethod
+    def gram_stage64(M, N, K, taps=1, extras=False) -> bool:
+        return taps == 1 and not extras and M >= 1024 and N >= 32 and K >= 32
 
     def gram(self, name, A, Bm, out, *, N, K, o_sn, o_sk, o_st=0, o_bs=0, batches=1, taps=1, hw=None,
              n_grp=(0, 0), k_grp=(0, 0), pro_b=0, gate_off=0, ln=None, stats=None, out_elems=None,
@@ -711,11 +717,7 @@ class Recorder:
             rpc = ((M + nch - 1) // nch + 7) & ~7
             nch = (M + rpc - 1) // rpc
         else:
-            nch, rpc = self._chunks(M, taps * groups, batches)
-            if taps == 1 and not extras and M >= 1024 and N >= 32 and K >= 32:
-                # csrc/gramb.hip's cases (the library decides; this only shapes the chunks): whole 64-row stages per chunk
-                rpc = (rpc + 63) & ~63
-                nch = (M + rpc - 1) // rpc
+            nch, rpc = self._chunks(M, taps * groups, batches, stage64=self.gram_stage64(M, N, K, taps, bool(extras)))
         if out_elems is None:
             out_elems = out.numel()
         a = L.GramArgs()
@@ -1306,7 +1308,7 @@ class Plan(Recorder):
                 self.gemm(n + ".dvf+dWB", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B, epi=L.EPI_PLAIN_DW, G=vf,
                           dw_slab=slab_ab, dw_cols=C_, dw_rows=nch_ab)
             else:
-                nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B)
+                nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B, stage64=self.gram_stage64(HW, C_, C_))
                 slab_ab = self.alloc(nch_ab * 2 * nab)
                 got = self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
                                 shared_slab=(slab_ab, 0, 2 * nab))
