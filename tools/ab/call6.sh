@@ -9,6 +9,7 @@ timeout -k 10 300 python tools/bench_deep.py 30 "Gram" > $O/bench_deep_new.txt 2
 timeout -k 10 300 python tools/bench_deep.py 30 "weight gradient" >> $O/bench_deep_new.txt 2>&1
 paste -d'\n' $O/bench_deep_old.txt $O/bench_deep_new.txt | grep -v amdgpu
 for i in 1 2 3; do
-  python tools/ab/engine_flag.py 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1 | sed 's/^/new /'
+  python tools/ab/engine_flag.py GRAM_SPLIT=False 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1 | sed 's/^/f32 grams   /'
+  python tools/ab/engine_flag.py GRAM_SPLIT=True 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1 | sed 's/^/split grams /'
 done | tee $O/ab.txt
 timeout -k 10 900 python -m pytest tests/test_hip_model.py -x -q -m gpu > $O/pytest_model.txt 2>&1; echo "pytest model rc=$?"; tail -3 $O/pytest_model.txt

@@ -135,11 +135,13 @@ struct Stager {
   }
 };
 
-// PROP / PROQ: prologue of the P / Q operand (0 none, 1 LayerNorm, 2 gate).  QB = 64: 64-row stages, waves (2 P pairs) x (2 Q tiles), each 64 x 32;
-// QB = 128: 32-row stages, each wave 64 x 64.
+// PROP / PROQ: prologue of the P / Q operand (0 none, 1 LayerNorm, 2 gate).  Waves (2 P pairs) x (2 Q halves): each 64 x 32 (QB = 64) or 64 x 64 (QB = 128).
+// 32-row stages: a stage costs one trip to memory (the next stage's loads are requested right behind the barrier, a stage's 48-96 MFMAs are far
+// shorter than that trip), so what the kernel moves is set by how many stages a CU has in flight - four workgroups of 36-48 KB at <= 128
+// registers (64-row stages on two workgroups per CU ran 3.5-8 us per stage: slower than the f32 kernel it replaces).
 template <int QB, int PROP, int PROQ>
-__global__ __launch_bounds__(256, 2) void uir_gramb_kernel(const GbArgs a, int qblocks) {
-  constexpr int SR = QB == 64 ? 64 : 32;
+__global__ __launch_bounds__(256, QB == 64 ? 4 : 3) void uir_gramb_kernel(const GbArgs a, int qblocks) {
+  constexpr int SR = 32;
   constexpr int QT = QB / 64;                                    // Q tiles per wave
   constexpr int PLP = SR * 128, PLQ = SR * QB;
   extern __shared__ float smem[];
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256, 2) void uir_gramb_kernel(const GbArgs a, int q
 
 template <int QB, int PROP, int PROQ>
 int gb_launch(const GbArgs& g, int chunks, int pblocks, int qblocks, int batches, hipStream_t st) {
-  constexpr int SR = QB == 64 ? 64 : 32;
+  constexpr int SR = 32;
   const size_t lds = (size_t)3 * SR * (128 + QB) * sizeof(unsigned short);
   hipLaunchKernelGGL((uir_gramb_kernel<QB, PROP, PROQ>), dim3(chunks, pblocks * qblocks, batches), dim3(256), lds, st, g, qblocks);
   return uir_launch_status();
@@ -253,7 +255,8 @@ int uir_gram_split(const UirGramArgs& a, void* stream) {
   if (((a.lda | a.ldb) & 3) || a.lda < n4 || a.ldb < k4 || !uir_aligned16(a.A) || !uir_aligned16(a.B) || (a.a_bs & 3) || (a.b_bs & 3)) return -1;
   if (a.pro_b == UIR_GRAM_PRO_GATE && ((a.gate_off & 3) || a.gate_off < k4 || a.ldb < a.gate_off + k4)) return -1;
   if (a.pro_b == UIR_GRAM_PRO_LN && ((a.K & 3) || !uir_aligned16(a.ln_g) || !uir_aligned16(a.ln_b) || !a.stats)) return -1;
-  if ((long)a.rows_per_chunk * a.nchunks < a.M) return -1;
+  // a chunk = whole 32-row stages (engine.Recorder._chunks shapes them so for this kernel; anything else keeps the f32 kernels' chunking)
+  if ((long)a.rows_per_chunk * a.nchunks < a.M || (a.rows_per_chunk & 31)) return -1;
   const bool swap = a.K > a.N;                 // P = the operand with more columns
   // prologue on P only as the gate (dW_out: K = h > N = C), on Q only as LayerNorm (dW_in / dW_qkv: K = C < N)
   if (a.pro_b == UIR_GRAM_PRO_GATE && !swap) return -1;

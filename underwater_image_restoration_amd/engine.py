@@ -167,6 +167,8 @@ _WGRAD3_SHAPES = ((32, 8), (32, 16), (16, 8), (8, 4))   # (K, N) pairs csrc/conv
 _WGRAD3_WGS = 512              # workgroups of the LDS-staged 3 x 3 weight-gradient kernel (two per CU)
 CONV3_SPLIT = True             # 3x3 convolutions with >= 32 channels on both sides (UpSample1, down3): forward / input gradient / weight gradient on the
                                # split-bf16 implicit-GEMM kernels of csrc/conv3b.hip; False = the nine-tap f32 MFMA paths of uir_gemm / uir_gram
+GRAM_SPLIT = True              # long 1x1 weight-gradient contractions with a narrow side on csrc/gramb.hip (split-bf16, transposed LDS reads); the library takes
+                               # them when a chunk is a whole number of its 32-row stages - False shapes the chunks for csrc/gram.hip's f32 kernels instead
 _CONV3B_WGS = 512              # workgroups of a uir_conv3x3_split_wgrad launch (two 6-wave workgroups per CU)
 _PLAIN_DW_WGS = 768            # workgroups of a GEMM with the fused per-sample Gram (EPI_PLAIN_DW): the resident set at 3 per CU
 GEMM_SLAB_ROWS = 512           # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
@@ -671,17 +673,26 @@ class Recorder:
         self._op(name, lib.uir_gemm, C.byref(a), nbytes=nb, flops=2 * rows * kreal * nreal * taps,
                  variant=f"uir_gemm1x1_kernel<*,{pro},{epi},*>")     # the rocprofv3 symbol family (NT and HAS_R vary per call)
 
-    def _chunks(self, M, ngroups, batches, stage64=False):
-        nch = max(1, min(M // 256, _GRAM_WGS // max(1, ngroups * batches)))
-        rpc = ((M + nch - 1) // nch + 7) & ~7
-        if stage64:          # csrc/gramb.hip's cases (the library decides; this only shapes the chunks): whole 64-row stages per chunk
-            rpc = (rpc + 63) & ~63
+    def _chunks(self, M, ngroups, batches, split_nk=None):
+        """(chunks, rows per chunk) of a pixel contraction.  split_nk = (N, K) for the cases csrc/gramb.hip takes (gram_split_case: the library
+        decides which kernel runs, this only shapes the chunks): its workgroups own 128 x 64 / 128 x 128 blocks, four of them fit a CU and a
+        chunk is a whole number of 32-row stages."""
+        if split_nk is not None:
+            big, small = max(split_nk), min(split_nk)
+            blocks = ((big + 127) // 128) * (1 if small <= 64 else (small + 127) // 128)
+            nch = max(1, min(M // 128, _GRAM_WGS // max(1, blocks * batches)))
+            rpc = ((M + nch - 1) // nch + 31) & ~31
+        else:
+            nch = max(1, min(M // 256, _GRAM_WGS // max(1, ngroups * batches)))
+            rpc = ((M + nch - 1) // nch + 7) & ~7
+            if not GRAM_SPLIT and rpc % 32 == 0:
+                rpc += 8                       # A/B arm: never a whole number of csrc/gramb.hip's stages, so the f32 kernels keep the launch
         nch = (M + rpc - 1) // rpc
         return nch, rpc
 
     @staticmethod
-    def gram_stage64(M, N, K, taps=1, extras=False) -> bool:
-        return taps == 1 and not extras and M >= 1024 and N >= 32 and K >= 32
+    def gram_split_case(M, N, K, taps=1, extras=False):
+        return (N, K) if (GRAM_SPLIT and taps == 1 and not extras and M >= 1024 and N >= 32 and K >= 32 and not (N >= 256 and K >= 256)) else None
 
     def gram(self, name, A, Bm, out, *, N, K, o_sn, o_sk, o_st=0, o_bs=0, batches=1, taps=1, hw=None,
              n_grp=(0, 0), k_grp=(0, 0), pro_b=0, gate_off=0, ln=None, stats=None, out_elems=None,
@@ -717,7 +728,7 @@ class Recorder:
             rpc = ((M + nch - 1) // nch + 7) & ~7
             nch = (M + rpc - 1) // rpc
         else:
-            nch, rpc = self._chunks(M, taps * groups, batches, stage64=self.gram_stage64(M, N, K, taps, bool(extras)))
+            nch, rpc = self._chunks(M, taps * groups, batches, split_nk=self.gram_split_case(M, N, K, taps, bool(extras)))
         if out_elems is None:
             out_elems = out.numel()
         a = L.GramArgs()
@@ -1308,7 +1319,7 @@ class Plan(Recorder):
                 self.gemm(n + ".dvf+dWB", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B, epi=L.EPI_PLAIN_DW, G=vf,
                           dw_slab=slab_ab, dw_cols=C_, dw_rows=nch_ab)
             else:
-                nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B, stage64=self.gram_stage64(HW, C_, C_))
+                nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B, split_nk=self.gram_split_case(HW, C_, C_))
                 slab_ab = self.alloc(nch_ab * 2 * nab)
                 got = self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
                                 shared_slab=(slab_ab, 0, 2 * nab))
