@@ -965,6 +965,23 @@ def test_patch4s2_is_unfold_and_its_adjoint(B, H, W, C):
     assert rel(chw(dx[:, :C], B, 2 * H, 2 * W), fold) < 1e-6 and float(dx[:, C:].min()) == 7.0
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 3, 5, 8), (1, 16, 16, 32), (3, 7, 9, 4)])
+def test_pixel_shuffle_16_byte_form(B, H, W, C):
+    """uir_pixel_shuffle / uir_pixel_unshuffle with 16-byte rows (C % 4 == 0: every call of the network): the 4 x 4 register-transpose
+    kernels, bit-exact against torch, into / out of a column slice of a wider buffer (the up-samplers write into the decoders' concat buffers)."""
+    x = rnd(B, 4 * C, H, W, seed=1)
+    src = dev(hwc(x))
+    dst = torch.full((B * 4 * H * W, 2 * C + 4), 7.0, device=DEV)
+    assert lib.uir_pixel_shuffle(src.data_ptr(), 4 * C, dst.data_ptr(), 2 * C + 4, C, B, H, W, C, None) == 0
+    back = torch.empty(B * H * W, 4 * C, device=DEV)
+    assert lib.uir_pixel_unshuffle(dst.data_ptr(), 2 * C + 4, C, back.data_ptr(), 4 * C, B, H, W, C, None) == 0
+    torch.cuda.synchronize()
+    ps = F.pixel_shuffle(x.float(), 2)
+    assert torch.equal(chw(dst[:, C:2 * C].cpu(), B, 2 * H, 2 * W), ps)
+    assert float((dst[:, :C] - 7).abs().max()) == 0 and float((dst[:, 2 * C:] - 7).abs().max()) == 0
+    assert torch.equal(back, src)
+
+
 def test_shuffle_family():
     B, H, W, C = 2, 3, 5, 8
     x = rnd(B, 4 * C, H, W, seed=1)

@@ -1,0 +1,10 @@
+#!/bin/bash
+# vectorized shuffles + deeper weight ring in conv3b: parity tests, conv microbench, then the step (3 runs)
+T=${1:-r05j}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$T; mkdir -p $O
+cd $R && python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_hip_kernels.py -x -q -m gpu -k "shuffle or conv3x3" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
+timeout -k 10 300 python tools/bench_conv3b.py > $O/bench_conv3b.txt 2>&1; grep "split\|wsplit" $O/bench_conv3b.txt
+for i in 1 2 3; do
+  python tools/ab/engine_flag.py CONV3_SPLIT=False GRAM_SPLIT=False 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1 | sed 's/^/r04 kernels (conv3b, gramb off) /'
+  python tools/ab/engine_flag.py 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1 | sed 's/^/now                            /'
+done | tee $O/ab.txt

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void uir_conv3b_kernel(const UirConv3bArgs 
   uint4 va[HaloLoader<TH>::NQ];
   // weight fragments: a ring of PF steps, requested PF - 1 steps ahead.  A step is 6 RT CT MFMAs (192 .. 768 cycles) and an L2 hit takes
   // ~1 000: one step ahead the short steps waited for their weights (ups_1 on 64 x 128 tiles: 88 TFLOP/s)
-  constexpr int PF = RT * CT >= 4 ? 2 : 3;
+  constexpr int PF = RT * CT >= 4 ? 2 : (CT == 1 ? 6 : 3);
   uint4 fb[PF][CT][3], fa[RT][3];
   auto load_b = [&](uint4 (&dst)[CT][3], int kc, int s) {       // step s = (tap s / 2, k sub-block s % 2) of chunk kc
     const long off = (long)(s >> 1) * tapst + kc * 32 + (s & 1) * 16;
