@@ -139,18 +139,19 @@ int uir_reduce_slab_batch(const UirReduceDesc* descs_dev, const int* first_block
  * (SpectralTransformer.py:191-198; autograd's convolution_backward for :196).  f32-accurate: every f32 operand is the exact
  * sum of three bf16 planes and six of the nine plane products are accumulated in f32 (csrc/uir_common.h).
  *
- * uir_conv3x3_wsplit  native weight W[Cout][Cin][3][3] -> bf16 planes, once per optimizer step:
- *     planes_fwd[pl][tap][cout][cin]      = plane pl of W[cout][cin][tap]          (forward:        N = Cout, K = Cin)
- *     planes_bwd[pl][8 - tap][cin][cout]  = plane pl of W[cout][cin][tap]          (input gradient: N = Cin,  K = Cout)
+ * uir_conv3x3_wsplit  native weight W[Cout][Cin][3][3] -> bf16 planes, once per optimizer step (Cout % 16 == 0, Cin % 16 == 0).  A layer with
+ *   N outputs and K inputs is stored as planes[pl][tap][K / 16][N][16] - the 32 x 16 weight fragment of one MFMA step is 1 KB contiguous:
+ *     planes_fwd (N = Cout, K = Cin):   element (tap,     n = cout, k = cin ) = plane pl of W[cout][cin][tap]
+ *     planes_bwd (N = Cin,  K = Cout):  element (8 - tap, n = cin,  k = cout) = plane pl of W[cout][cin][tap]
  *   each 3 * 9 * Cout * Cin 16-bit values; either pointer may be NULL.
- * uir_conv3x3_split   Y[p][n] = (R ? R[p][n] : 0) + sum_tap sum_k X[nbr(p, tap)][k] * Wp[tap][n][k]  over HWC pixel rows
+ * uir_conv3x3_split   Y[p][n] = (R ? R[p][n] : 0) + sum_tap sum_k X[nbr(p, tap)][k] * Wp(tap, n, k)  over HWC pixel rows
  *   p = (b * H + y) * Wd + x (zero outside the image).  H % 4 == 0, Wd % 16 == 0, N % 32 == 0, K % 32 == 0; rows 16-byte aligned.
  * uir_conv3x3_split_wgrad  slab[c][(n * K + k) * 9 + tap] = sum over the pixels p of chunk c of dY[p][n] * X[nbr(p, tap)][k]
  *   (the native weight layout per slab row; uir_reduce_slab sums the rows).  N % 64 == 0, K % 32 == 0, H % 4 == 0,
  *   Wd % 16 == 0.  `nchunks` (<= B * H/4 * Wd/16) slab rows are written, one per workgroup column. */
 typedef struct UirConv3bArgs {
   const float* X;            /* [B*H*Wd][ldx]                                                      */
-  const unsigned short* Wp;  /* bf16 planes [3][9][N][K] (uir_conv3x3_wsplit)                      */
+  const unsigned short* Wp;  /* bf16 planes [3][9][K / 16][N][16] (uir_conv3x3_wsplit)            */
   float* Y;                  /* [B*H*Wd][ldy]                                                      */
   const float* R;            /* optional residual [B*H*Wd][ldr]; may alias Y                       */
   int ldx, ldy, ldr;

@@ -318,50 +318,11 @@ def test_conv3x3_split_planes_are_an_exact_three_way_split():
     def planes(t):
         u = t.view(torch.int16)[:3 * n].to(torch.int32).cpu().reshape(3, n)
         return (u << 16).view(torch.float32).double()
-    f = planes(pf).sum(0).reshape(9, Cout, Cin)
-    b = planes(pb).sum(0).reshape(9, Cin, Cout)
+    f = planes(pf).sum(0).reshape(9, Cin // 16, Cout, 16).permute(0, 2, 1, 3).reshape(9, Cout, Cin)        # [tap][k / 16][n][16] -> [tap][n][k]
+    b = planes(pb).sum(0).reshape(9, Cout // 16, Cin, 16).permute(0, 2, 1, 3).reshape(9, Cin, Cout)
     wt = w.double().reshape(Cout, Cin, 9)
     assert torch.equal(f, wt.permute(2, 0, 1).contiguous())
     assert torch.equal(b, wt.permute(2, 1, 0).flip(0).contiguous())
-
-
-def test_conv3x3_as_patches_for_wide_layers_on_few_pixels():
-    """record_conv3x3's patch path (uir_patch3x3 + one K = 9 Cin GEMM on the native weight; engine.Recorder.conv_as_patches): forward,
-    input gradient, weight gradient written in the native [Cout][Cin][3][3] layout, bias gradient - vs torch fp64; the patch kernel is
-    F.unfold (bit-exact) and uir_patch3x3_bwd F.fold."""
-    from underwater_image_restoration_amd.model.block import record_conv3x3
-    B, H, W, Cin, Cout = 2, 12, 16, 256, 132
-    assert Recorder.conv_as_patches(B * H * W, Cin, Cout)
-    x = rnd(B, Cin, H, W, seed=1).requires_grad_(True)
-    w = (rnd(Cout, Cin, 3, 3, seed=2) * 0.05).requires_grad_(True)
-    b = rnd(Cout, seed=4).requires_grad_(True)
-    y = F.conv2d(x, w, b, padding=1)
-    dy = rnd(*y.shape, seed=3)
-    dx, dw, db = torch.autograd.grad((y * dy).sum(), (x, w, b))
-    r = Recorder(DEV, scratch_floats=16 * 1024 * 1024)
-    Wd, bd, xd = dev(w.detach()), dev(b.detach()), dev(hwc(x.detach()))
-    Y, bw = record_conv3x3(r, "c", xd, Wd, bd, Cin, Cout, (B, H, W))
-    names = [m[0] for m in r.meta[id(r.fwd)]]
-    assert "c.patches" in names
-    r.cur = r.bwd
-    dW, dB = r.alloc(Cout, Cin, 3, 3), r.alloc(Cout)
-    dX = bw(dev(hwc(dy)), dW, dB)
-    r.flush_reductions("t")
-    r.run(r.fwd)
-    r.run(r.bwd)
-    torch.cuda.synchronize()
-    assert rel(chw(Y, B, H, W), y) < TOL and rel(chw(dX, B, H, W), dx) < TOL
-    assert rel(dW, dw) < TOL and rel(dB, db) < TOL
-    # the two patch kernels alone, against unfold / fold
-    Pm = torch.empty(B * H * W, 9 * Cin, device=DEV)
-    assert lib.uir_patch3x3(xd.data_ptr(), Cin, Pm.data_ptr(), 9 * Cin, B, H, W, Cin, None) == 0
-    want = F.unfold(x.detach().float(), 3, padding=1).transpose(1, 2).reshape(B * H * W, 9 * Cin)
-    assert torch.equal(Pm.cpu(), want)
-    dP = rnd(B * H * W, 9 * Cin, seed=6).float()
-    got = torch.empty(B * H * W, Cin, device=DEV)
-    assert lib.uir_patch3x3_bwd(dP.to(DEV).data_ptr(), 9 * Cin, got.data_ptr(), Cin, B, H, W, Cin, None) == 0
-    fold = F.fold(dP.double().reshape(B, H * W, 9 * Cin).transpose(1, 2), (H, W), 3, padding=1)
-    assert rel(chw(got, B, H, W), fold) < 1e-6
 
 
 @pytest.mark.parametrize("M,K,N", [(6 * 50, 32, 32), (4 * 96, 64, 100), (4 * 128, 256, 128), (2 * 300, 512, 64)])

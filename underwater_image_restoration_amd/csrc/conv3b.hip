@@ -48,18 +48,25 @@ __device__ __forceinline__ void store_quad(unsigned short* d, const uint4& v, ui
 // ------------------------------------------------------------------------------------------------ weights -> bf16 planes
 __global__ __launch_bounds__(256) void uir_conv3b_wsplit_kernel(const float* __restrict__ W, int Cout, int Cin, unsigned short* __restrict__ pf,
                                                                 unsigned short* __restrict__ pb) {
+  // plane element (tap, n, k) of an [N][K] layer sits at ((tap * K / 16 + k / 16) * N + n) * 16 + k % 16: the 32 x 16 fragment a wave loads
+  // for one MFMA step (lane = n, 16 bytes of one k half) is 1 KB CONTIGUOUS.  With plain [tap][n][k] rows a lane's 16 bytes were the only
+  // part of its 128-byte line used per instruction and the 220 KB a workgroup walks do not live in L1: 8 x the bytes from L2 (ups_2: 27 TB/s)
   const long total = (long)Cout * Cin * 9, plane = total;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    if (pf) {                    // i = (tap * Cout + n) * Cin + k
-      const int k = (int)(i % Cin), n = (int)((i / Cin) % Cout), tap = (int)(i / ((long)Cin * Cout));
+    if (pf) {                    // N = Cout, K = Cin:  i = ((tap * Cin / 16 + kb) * Cout + n) * 16 + kl
+      const int kl = (int)(i & 15), n = (int)((i >> 4) % Cout);
+      const long r = (i >> 4) / Cout;
+      const int kb = (int)(r % (Cin / 16)), tap = (int)(r / (Cin / 16));
       uint32_t h, m, l;
-      split3(W[((long)n * Cin + k) * 9 + tap], h, m, l);
+      split3(W[((long)n * Cin + 16 * kb + kl) * 9 + tap], h, m, l);
       pf[i] = (unsigned short)(h >> 16); pf[plane + i] = (unsigned short)(m >> 16); pf[2 * plane + i] = (unsigned short)(l >> 16);
     }
-    if (pb) {                    // i = (tap' * Cin + k) * Cout + n, tap' = 8 - tap
-      const int n = (int)(i % Cout), k = (int)((i / Cout) % Cin), tap = 8 - (int)(i / ((long)Cin * Cout));
+    if (pb) {                    // N = Cin, K = Cout, tap' = 8 - tap:  i = ((tap' * Cout / 16 + kb) * Cin + n) * 16 + kl
+      const int kl = (int)(i & 15), n = (int)((i >> 4) % Cin);
+      const long r = (i >> 4) / Cin;
+      const int kb = (int)(r % (Cout / 16)), tap = 8 - (int)(r / (Cout / 16));
       uint32_t h, m, l;
-      split3(W[((long)n * Cin + k) * 9 + tap], h, m, l);
+      split3(W[((long)(16 * kb + kl) * Cin + n) * 9 + tap], h, m, l);
       pb[i] = (unsigned short)(h >> 16); pb[plane + i] = (unsigned short)(m >> 16); pb[2 * plane + i] = (unsigned short)(l >> 16);
     }
   }
@@ -140,8 +147,8 @@ __global__ __launch_bounds__(256, 2) void uir_conv3b_kernel(const UirConv3bArgs 
   }
   const unsigned short* wb[CT];                              // this lane's weight row, k sub-block h2
 #pragma unroll
-  for (int x = 0; x < CT; ++x) wb[x] = a.Wp + (long)(n0 + 32 * (CT * wc + x) + li) * a.K + 8 * h2;
-  const long tapst = (long)a.N * a.K, plst = 9 * tapst;
+  for (int x = 0; x < CT; ++x) wb[x] = a.Wp + (long)(n0 + 32 * (CT * wc + x) + li) * 16 + 8 * h2;
+  const long stepst = (long)a.N * 16, tapst = (long)a.N * a.K, plst = 9 * tapst;      // planes [3][9][K / 16][N][16]
 
   f32x16 acc[RT][CT];
 #pragma unroll
@@ -154,10 +161,10 @@ __global__ __launch_bounds__(256, 2) void uir_conv3b_kernel(const UirConv3bArgs 
   uint4 va[HaloLoader<TH>::NQ];
   // weight fragments: a ring of PF steps, requested PF - 1 steps ahead.  A step is 6 RT CT MFMAs (192 .. 768 cycles) and an L2 hit takes
   // ~1 000: one step ahead the short steps waited for their weights (ups_1 on 64 x 128 tiles: 88 TFLOP/s)
-  constexpr int PF = RT * CT >= 4 ? 2 : (CT == 1 ? 6 : 3);
+  constexpr int PF = RT * CT >= 4 ? 2 : 3;
   uint4 fb[PF][CT][3], fa[RT][3];
   auto load_b = [&](uint4 (&dst)[CT][3], int kc, int s) {       // step s = (tap s / 2, k sub-block s % 2) of chunk kc
-    const long off = (long)(s >> 1) * tapst + kc * 32 + (s & 1) * 16;
+    const long off = (long)(s >> 1) * tapst + (2 * kc + (s & 1)) * stepst;
 #pragma unroll
     for (int y = 0; y < CT; ++y)
 #pragma unroll
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(WG_THREADS, 2) void uir_conv3b_wgrad_kernel(const U
 }  // namespace
 
 extern "C" int uir_conv3x3_wsplit(const float* W, int Cout, int Cin, unsigned short* planes_fwd, unsigned short* planes_bwd, void* stream) {
-  UIR_REQUIRE(W && Cout > 0 && Cin > 0 && (planes_fwd || planes_bwd));
+  UIR_REQUIRE(W && Cout > 0 && Cin > 0 && (Cout & 15) == 0 && (Cin & 15) == 0 && (planes_fwd || planes_bwd));
   const long total = (long)Cout * Cin * 9;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(uir_conv3b_wsplit_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), W, Cout, Cin, planes_fwd, planes_bwd);
