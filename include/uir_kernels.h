@@ -423,7 +423,8 @@ int uir_dft_axis(const UirDftArgs* args, void* stream);
  *   epi  UIR_DFT_EPI_MAGPHA      out_re = |F|, out_im = atan2(Im, Re), Im := +0 at the self-conjugate bins (uir_magpha_fwd; the
  *                                transform must be the H axis of a [B][H][W][C] tensor: O = B, N = H, I = W)
  *        UIR_DFT_EPI_CABS        out_re / out_im as usual and aux_out = |out|                                    (:186)
- *        UIR_DFT_EPI_POLAR_BWD   out_re = g_mag, out_im = g_pha of uir_polar_bwd with aux0 = mag, aux1 = pha at the output element */
+ *        UIR_DFT_EPI_POLAR_BWD   out_re = g_mag, out_im = g_pha of uir_polar_bwd with aux0 = mag, aux1 = pha at the output element
+ *   pro = epi = 0 with out_im == NULL (real output): aux0, if given, is ADDED to the result (out_re = scale * Re X + aux0; aux0 may be out_re) */
 #define UIR_DFT_PRO_NONE 0
 #define UIR_DFT_PRO_POLAR 1
 #define UIR_DFT_PRO_CABS_BWD 2

@@ -851,8 +851,13 @@ def test_dft_with_fused_elementwise_neighbours(S, C):
     r.dft("magpha_bwd+h_bwd", dev(hwc(gm)), dev(hwc(gp)), gar, gai, O=B, N=H, I=W, C_=C, sign=1.0, scale=1.0,
           pro=L.DFT_PRO_MAGPHA_BWD, aux=(mag, pha))
     r.dft("w_bwd", gar, gai, dx, None, O=B * H, N=W, I=1, C_=C, sign=1.0, scale=1.0)
+    # the same transform ADDING its result to a tensor that already holds the other branch's gradient (aux0 with a real output, in place)
+    other = rnd(M, C, seed=7)
+    dx_acc = dev(other)
+    r.dft("w_bwd+sum", gar, gai, dx_acc, None, O=B * H, N=W, I=1, C_=C, sign=1.0, scale=1.0, aux=(dx_acc,))
     r.run(r.fwd)
     torch.cuda.synchronize()
+    assert rel(dx_acc, dx.double().cpu() + other) < 1e-6
     assert rel(chw(mag, B, H, W), mag_ref) < TOL
     # phase: compare as unit phasors where the magnitude is not tiny (the angle of a ~0 bin is ill-conditioned; +-pi are one point)
     pc = chw(pha, B, H, W).double().cpu()

@@ -46,6 +46,35 @@ __global__ void gather_even_kernel(const float* __restrict__ src, int lds, int s
   }
 }
 
+// 16-byte forms (C % 4 == 0, 16-byte rows, 32-bit index arithmetic): one thread per (input pixel, four channels) writes / reads float4.
+// The scatter fills the 2 x 2 block of its pixel: the value on the even position, `fill` (or zeros) on the other three.
+__global__ __launch_bounds__(256) void scatter_even4_kernel(const float* __restrict__ src, int lds, const float* __restrict__ fill,
+                                                            float* __restrict__ dst, int ldd, int dcol, int H, int Wd, int C, unsigned n) {
+  const unsigned cq_n = (unsigned)C >> 2;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += gridDim.x * 256u) {      // idx over [B][H][W][C / 4]
+    const unsigned cq = idx % cq_n, p = idx / cq_n;
+    const unsigned w = p % (unsigned)Wd, q = p / (unsigned)Wd, h = q % (unsigned)H, b = q / (unsigned)H;
+    const float4 v = *reinterpret_cast<const float4*>(src + (long)p * lds + 4 * cq);
+    const float4 f = fill ? *reinterpret_cast<const float4*>(fill + 4 * cq) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const long r0 = ((long)(b * 2 * H + 2 * h) * 2 * Wd + 2 * w) * ldd + dcol + 4 * cq;
+    const long dn = 2L * Wd * ldd;
+    *reinterpret_cast<float4*>(dst + r0) = v;
+    *reinterpret_cast<float4*>(dst + r0 + ldd) = f;
+    *reinterpret_cast<float4*>(dst + r0 + dn) = f;
+    *reinterpret_cast<float4*>(dst + r0 + dn + ldd) = f;
+  }
+}
+__global__ __launch_bounds__(256) void gather_even4_kernel(const float* __restrict__ src, int lds, int scol, float* __restrict__ dst, int ldd,
+                                                           int H, int Wd, int C, unsigned n) {
+  const unsigned cq_n = (unsigned)C >> 2;
+  for (unsigned idx = blockIdx.x * 256u + threadIdx.x; idx < n; idx += gridDim.x * 256u) {
+    const unsigned cq = idx % cq_n, p = idx / cq_n;
+    const unsigned w = p % (unsigned)Wd, q = p / (unsigned)Wd, h = q % (unsigned)H, b = q / (unsigned)H;
+    *reinterpret_cast<float4*>(dst + (long)p * ldd + 4 * cq) =
+        *reinterpret_cast<const float4*>(src + ((long)(b * 2 * H + 2 * h) * 2 * Wd + 2 * w) * lds + scol + 4 * cq);
+  }
+}
+
 __global__ void pixel_shuffle_kernel(const float* __restrict__ src, int lds, float* __restrict__ dst, int ldd, int dcol,
                                      int H, int Wd, int C, long n) {
   GRID_STRIDE(idx, n) {  // idx over dst [B][2H][2W][C]
@@ -294,12 +323,25 @@ extern "C" int uir_scatter_even(const float* src, int lds, const float* fill, fl
                                 int B, int H, int Wd, int C, void* stream) {
   UIR_REQUIRE(src && dst && B > 0 && H > 0 && Wd > 0 && C > 0 && lds >= C && ldd >= dcol + C);
   const long n = (long)B * 4 * H * Wd * C;
+  if ((C & 3) == 0 && (lds & 3) == 0 && (ldd & 3) == 0 && (dcol & 3) == 0 && uir_aligned16(src) && uir_aligned16(dst) && (!fill || uir_aligned16(fill)) &&
+      n / 16 < (1L << 31)) {
+    const unsigned n4 = (unsigned)(n / 16);
+    const unsigned blocks = (n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536;
+    hipLaunchKernelGGL(scatter_even4_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, fill, dst, ldd, dcol, H, Wd, C, n4);
+    return uir_launch_status();
+  }
   hipLaunchKernelGGL(scatter_even_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, fill, dst, ldd, dcol, H, Wd, C, n);
   return uir_launch_status();
 }
 extern "C" int uir_gather_even(const float* src, int lds, int scol, float* dst, int ldd, int B, int H, int Wd, int C, void* stream) {
   UIR_REQUIRE(src && dst && B > 0 && H > 0 && Wd > 0 && C > 0 && lds >= scol + C && ldd >= C);
   const long n = (long)B * H * Wd * C;
+  if ((C & 3) == 0 && (lds & 3) == 0 && (ldd & 3) == 0 && (scol & 3) == 0 && uir_aligned16(src) && uir_aligned16(dst) && n / 4 < (1L << 31)) {
+    const unsigned n4 = (unsigned)(n / 4);
+    const unsigned blocks = (n4 + 255) / 256 < 65536 ? (n4 + 255) / 256 : 65536;
+    hipLaunchKernelGGL(gather_even4_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, scol, dst, ldd, H, Wd, C, n4);
+    return uir_launch_status();
+  }
   hipLaunchKernelGGL(gather_even_kernel, ew_grid(n), dim3(256), 0, static_cast<hipStream_t>(stream), src, lds, scol, dst, ldd, H, Wd, C, n);
   return uir_launch_status();
 }

@@ -199,13 +199,17 @@ __global__ __launch_bounds__(256) void uir_dft2_kernel(const UirDft2Args a, int 
     for (int s = 0; s < 2 * N2; ++s) e = uir_mfma(tb[s], D[s >> 1][j + 8 * (s & 1)], e);
     const int aj = (j & 3) + 8 * (j >> 2);          // k1 of lane half 0; half 1 holds k1 + 4 ... as ROW blocks w = 0 / 1
     if (cok && EPI == UIR_DFT_EPI_NONE) {
+      // plain transform: aux0 (optional, real output only) is ADDED to the result - the up-sampler's spectral input gradient lands on the
+      // shuffle branch's without a separate accumulate pass (it may alias out_re: every element is read and written by this lane alone)
+      const float* add = (PRO == UIR_DFT_PRO_NONE && !want_im) ? a.aux0 : nullptr;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int k2 = (q & 3) + 4 * h2, p = (q >> 2) & 1, w = q >> 3;
         if (k2 < N2 && (p == 0 || want_im)) {
           const int k = aj + 4 * w + 16 * k2;
           float* dst = p ? a.out_im : a.out_re;
-          dst[line + (long)k * nstride + c] = e[q] * a.scale;
+          const long at = line + (long)k * nstride + c;
+          dst[at] = add ? fmaf(e[q], a.scale, add[at]) : e[q] * a.scale;
         }
       }
     }

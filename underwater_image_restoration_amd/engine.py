@@ -1552,6 +1552,12 @@ class Plan(Recorder):
                 gfr, gfi = self.alloc(M, C_), self.alloc(M, C_)
                 self._op(f + ".magpha_bwd", lib.uir_magpha_bwd, _ptr(mag), _ptr(pha), _ptr(gmag), _ptr(gpha), _ptr(gfr), _ptr(gfi), M * C_)
                 self.dft(f + ".dftH_bwd", gfr, gfi, gar, gai, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0)
+            if fuse_ew:
+                # the last transform adds its result to the shuffle branch's input gradient (UirDft2Args: aux0 with a real output): no dx_sum
+                # pass.  The branch (side lane: unshuffle + one convolution) is long done when the spectral chain gets here
+                self.join(pfx + ".join_bwd")
+                self.dft(f + ".dftW_bwd+dx_sum", gar, gai, dx, None, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0, aux=(dx,))
+                return dx
             dxf = self.alloc(M, C_)
             self.dft(f + ".dftW_bwd", gar, gai, dxf, None, O=B * H, N=W, I=1, C_=C_, sign=1.0, scale=1.0)
             self.join(pfx + ".join_bwd")
