@@ -23,7 +23,12 @@ extern "C" {
 /* ---------------------------------------------------------------- uir_gemm */
 enum { UIR_PRO_NONE = 0, UIR_PRO_LN = 1, UIR_PRO_GATE = 2 };
 #define UIR_GEMM_SLAB_ROWS 512   /* max workgroups (= slab rows) of the GEMM variants with fused reductions */
-enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2, UIR_EPI_GATE_BWD_DW = 3, UIR_EPI_GELU_BWD = 4, UIR_EPI_PLAIN_DW = 5 };
+enum { UIR_EPI_PLAIN = 0, UIR_EPI_GATE_BWD = 1, UIR_EPI_LEAKY_BWD = 2, UIR_EPI_GATE_BWD_DW = 3, UIR_EPI_GELU_BWD = 4, UIR_EPI_PLAIN_DW = 5, UIR_EPI_LN_BWD = 6 };
+/* UIR_EPI_LN_BWD (round 5): Y = R + LayerNorm'(X . W^T) - the backward of the channel LayerNorm in front of a 1x1 convolution as the epilogue of the
+ * contraction that produces its output gradient (dt1 / dt2 of a TransformerBlock at C = 64 / 128, SpectralTransformer.py:144-147): G = the LayerNorm's
+ * input (ldg), stats = its saved (mean, rstd) per row, ln_g = its weight, R = the residual path's gradient (optional); dw_slab rows [row tile][2 N] =
+ * dgamma | dbeta partials (at most M / 64 rows are written: zero-fill the rest once), dw_stride >= 2 N.  N = 64 or 128 (= the whole row), 4096 <= M <=
+ * 65536, K >= 64, no bias / activation / column groups; the arithmetic of uir_layernorm_bwd.  Any other shape is UIR_EINVAL. */
 /* UIR_EPI_PLAIN_DW (round 4): Y = X . W^T as PLAIN (no bias / activation / residual) and, from the same pass over X, the per-batch Gram
  *   dW[z][k][j] = sum_m X[z][m][k] * G[z][m][j]   (K <= 32 channels of X, j < dw_cols <= 32 columns of a second tensor G [batches][M][ldg])
  * as per-workgroup partials dw_slab[blockIdx.x][z * K * dw_cols + k * dw_cols + j] (summed by uir_reduce_slab).  MDTA's value path: dvf = dx1 . WB

@@ -478,6 +478,41 @@ def test_gram_split_bf16_per_sample_batches():
     assert rel(out.reshape(B, C, C), want) < TOL
 
 
+@pytest.mark.parametrize("M,C,pad", [(4096, 64, False), (8192, 128, False), (4096 + 64, 64, True), (65536, 64, True)])
+def test_gemm_with_layernorm_backward_epilogue(M, C, pad):
+    """UIR_EPI_LN_BWD (csrc/tsgemm.hip): dX = dRes + LayerNorm'(Xg . W) with dgamma / dbeta, one launch - the deep levels' dt1 (K = 3C) and dt2
+    (K = 2 hp with padded hidden groups) contractions followed by uir_layernorm_bwd (SpectralTransformer.py:144-147 under autograd) - against
+    torch fp64 autograd through F.layer_norm; 64- and 128-row tiles, a ragged last row tile."""
+    h = int(C * 2.66)
+    hp = (h + 15) // 16 * 16
+    K = 2 * hp if pad else 3 * C
+    x = rnd(M, C, seed=1, scale=2).requires_grad_(True)
+    g = (1 + 0.1 * rnd(C, seed=2)).requires_grad_(True)
+    be = (0.1 * rnd(C, seed=3)).requires_grad_(True)
+    Kr = 2 * h if pad else K
+    W = rnd(Kr, C, seed=4) * Kr ** -0.5                       # conv weight [K real][C]
+    xg = rnd(M, K, seed=5)
+    if pad:
+        xg[:, h:hp] = 0
+        xg[:, hp + h:] = 0
+    xg_real = torch.cat([xg[:, :h], xg[:, hp:hp + h]], 1) if pad else xg
+    dres = rnd(M, C, seed=6)
+    tt = F.layer_norm(x, (C,), g, be, 1e-5)
+    dx_ref, dg_ref, db_ref = torch.autograd.grad(((tt @ W.T) * xg_real).sum(), (x, g, be))
+    xd = x.detach()
+    st = torch.stack([xd.mean(1), 1 / torch.sqrt(xd.var(1, unbiased=False) + 1e-5)], 1)
+    r = rec()
+    assert Recorder.gemm_ln_bwd_ok(M, C, K)
+    dX, dgb = r.alloc(M, C), r.alloc(2 * C)
+    r.gemm_ln_bwd("dt+ln", dev(xg), dev(W), X=dev(xd), stats=dev(st), gamma=dev(g.detach()), dRes=dev(dres), dX=dX, dgamma=dgb[:C], dbeta=dgb[C:],
+                  C_=C, K=K, w_sn=1, w_sk=C, k_grp=(h, hp) if pad else (0, 0))
+    r.flush_reductions("t")
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    assert rel(dX, dx_ref + dres) < TOL
+    assert rel(dgb[:C], dg_ref) < TOL and rel(dgb[C:], db_ref) < TOL
+
+
 def test_gram_per_batch_with_norms_and_colsum():
     B, HW, C = 3, 500, 32
     qkv = rnd(B * HW, 3 * C, seed=1)

@@ -1,0 +1,9 @@
+#!/bin/bash
+T=${1:-r05n}; R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/$T; mkdir -p $O
+cd $R && python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1
+timeout -k 10 900 python -m pytest tests/test_hip_kernels.py -x -q -m gpu -k "layernorm or gemm" > $O/pytest.txt 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest.txt
+timeout -k 10 900 python -m pytest tests/test_hip_model.py -x -q -m gpu > $O/pytest_model.txt 2>&1; echo "pytest model rc=$?"; tail -3 $O/pytest_model.txt
+for i in 1 2 3; do
+  python tools/ab/engine_flag.py FUSE_LN_BWD=False 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1 | sed 's/^/separate ln_bwd /'
+  python tools/ab/engine_flag.py FUSE_LN_BWD=True 2>/dev/null | grep -o '"ms_per_step": [0-9.]*' | head -1 | sed 's/^/fused           /'
+done | tee $O/ab.txt

@@ -20,7 +20,7 @@ fp = C.c_void_p  # device pointers travel as integers
 
 # enums (mirror include/uir_kernels.h)
 PRO_NONE, PRO_LN, PRO_GATE = 0, 1, 2
-EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW, EPI_GELU_BWD, EPI_PLAIN_DW = 0, 1, 2, 3, 4, 5
+EPI_PLAIN, EPI_GATE_BWD, EPI_LEAKY_BWD, EPI_GATE_BWD_DW, EPI_GELU_BWD, EPI_PLAIN_DW, EPI_LN_BWD = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_LEAKY, ACT_GELU = 0, 1, 2
 # L1ColorLum has the same formula as L1withColor in the reference (src/Losses/losses.py:59-66 vs :67-75)
 LOSS_KINDS = {"L1": 0, "L2": 1, "charbonnier": 2, "Luminance": 3, "L1withColor": 4, "L1ColorLum": 4, "LuminanceCharbonnier": 5,

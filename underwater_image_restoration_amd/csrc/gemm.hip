@@ -809,7 +809,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
                               (a.N & 15) == 0 && a.ldg >= 2 * a.N && a.ldy >= 2 * a.N));
   if (a.epi == UIR_EPI_GATE_BWD) UIR_REQUIRE(a.G && (a.il16 || (a.ldg >= a.g_off + a.N && a.ldy >= a.g_off + a.N)) && !a.R);
   if (a.epi == UIR_EPI_LEAKY_BWD) UIR_REQUIRE(a.G && a.ldg >= a.N && !a.R);
-  UIR_REQUIRE(a.epi >= UIR_EPI_PLAIN && a.epi <= UIR_EPI_PLAIN_DW);
+  UIR_REQUIRE(a.epi >= UIR_EPI_PLAIN && a.epi <= UIR_EPI_LN_BWD);
   if (a.epi == UIR_EPI_PLAIN_DW) {
     // plain store + fused per-batch Gram against G: K <= 32, one column group, whole 128-row tiles, no bias / activation / residual
     UIR_REQUIRE(a.G && a.dw_slab && a.dw_cols > 0 && a.dw_cols <= 32 && a.ldg >= a.dw_cols && a.K <= 32 && a.N <= 96 && !a.R && !a.bias &&
@@ -848,6 +848,7 @@ extern "C" int uir_gemm(const UirGemmArgs* p, void* stream) {
     // on 64- / 128-row tiles (csrc/tsgemm.hip)
     const int rc = uir_ts_gemm(a, stream);
     if (rc >= 0) return rc;
+    UIR_REQUIRE(a.epi != UIR_EPI_LN_BWD);       // the LayerNorm-backward epilogue exists on that kernel only
   }
   const int tiles = (a.N + 31) / 32;
   hipStream_t st = static_cast<hipStream_t>(stream);

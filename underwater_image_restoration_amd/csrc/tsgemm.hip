@@ -46,7 +46,9 @@ struct TsArgs {
   int n_real;                // index-contiguous B: its rows hold n_real <= NN columns (GATE_BWD: the h real hidden channels of hp)
   const float* bias;         // [NN] or null (EPI 0)
   float slope;               // EPI 0: LeakyReLU slope applied to acc + bias (1 = none); EPI 1: the backward's slope
-  const float* G; long ldg, g_bs; int g_off;   // EPI 1: forward LeakyReLU output; EPI 2: the GDFN tensor t2 (x1 half | x2 half at g_off)
+  const float* G; long ldg, g_bs; int g_off;   // EPI 1: forward LeakyReLU output; EPI 2: the GDFN tensor t2 (x1 half | x2 half at g_off); EPI 3: LN input
+  const float* stats; const float* gamma;      // EPI 3: per-row (mean, rstd) of the LayerNorm, its weight
+  float* slab; long slab_stride;               // EPI 3: per-workgroup partials [gridDim.x][2 NN] = dgamma | dbeta
 };
 
 // row of B's k axis that holds contraction index k (A's pad columns are exact zeros: a pad k may read any finite row)
@@ -135,7 +137,10 @@ struct IcLoader {
   }
 };
 
-// EPI 0: D = leaky(acc + bias) + R;  1: LeakyReLU backward (D = G > 0 ? acc : slope acc);  2: GDFN gate backward (two outputs)
+// EPI 0: D = leaky(acc + bias) + R;  1: LeakyReLU backward (D = G > 0 ? acc : slope acc);  2: GDFN gate backward (two outputs);
+// 3: LayerNorm backward on the accumulators (the tile holds whole rows: NN == TNW) - D = R + LN'(acc) with the LayerNorm's input G, its
+//    saved statistics and weight, and the workgroup's dgamma | dbeta partial sums to one slab row (uir_layernorm_bwd's arithmetic: the
+//    deep levels' dt1 / dt2 contractions were followed by that kernel, 20 launches and 0.3 ms of the chain per step)
 template <bool BKC, int TMW, int TNW, int EPI>
 __global__ __launch_bounds__(256, 3) void uir_ts_split_kernel(const TsArgs t) {
   constexpr int RT = TMW / 64, CT = TNW / 64;              // 32-row / 32-column tiles per wave (2 x 2 waves)
@@ -222,6 +227,81 @@ __global__ __launch_bounds__(256, 3) void uir_ts_split_kernel(const TsArgs t) {
     __syncthreads();
   }
 
+  if constexpr (EPI == 3) {
+    // LayerNorm backward.  A row's NN columns live in the two waves wc = 0 / 1 of a row pair: each wave reduces its half over the LPR lanes
+    // of the row, the halves meet in LDS (one workgroup barrier per 32-row band; every wave walks the same bands)
+    float* ws = smem + wave * (32 * EW);
+    float* xr = smem + 4 * 32 * EW;                            // [band parity][wave][32 rows][2]
+    float* cred = xr + 2 * 4 * 32 * 2;                         // [wave][64 lanes][8]: column partials at the end
+    constexpr int LPR = 8 * CT, RPI = 64 / LPR, NI = 32 / RPI;
+    const int c4 = 4 * (lane % LPR), rl = lane / LPR;
+    const int col = 32 * CT * wc + c4;                         // j0 == 0: the tile is the whole row
+    const float invc = 1.0f / (float)t.NN;
+    const float4 gam = *reinterpret_cast<const float4*>(t.gamma + col);
+    float dg[4] = {0.f, 0.f, 0.f, 0.f}, db[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int a = 0; a < RT; ++a) {
+#pragma unroll
+      for (int b = 0; b < CT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ws[uir_mfma_row(r, h2) * EW + 32 * b + li] = acc[a][b][r];
+      __builtin_amdgcn_wave_barrier();
+      const int rb = i0 + 32 * RT * wr + 32 * a;
+      float4 dt[NI], xh[NI], rv[NI];
+      float rs[NI], s1[NI], s2[NI];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int rr = rl + RPI * i;
+        const int row = min(rb + rr, t.MM - 1);
+        const float4 x = *reinterpret_cast<const float4*>(t.G + (long)row * t.ldg + col);
+        const float2 st = *reinterpret_cast<const float2*>(t.stats + 2L * row);
+        rv[i] = t.R ? *reinterpret_cast<const float4*>(t.R + (long)row * t.ldr + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+        dt[i] = *reinterpret_cast<const float4*>(ws + rr * EW + c4);
+        rs[i] = st.y;
+        xh[i] = make_float4((x.x - st.x) * st.y, (x.y - st.x) * st.y, (x.z - st.x) * st.y, (x.w - st.x) * st.y);
+        const float4 gd = make_float4(dt[i].x * gam.x, dt[i].y * gam.y, dt[i].z * gam.z, dt[i].w * gam.w);
+        float p1 = (gd.x + gd.y) + (gd.z + gd.w);
+        float p2 = (gd.x * xh[i].x + gd.y * xh[i].y) + (gd.z * xh[i].z + gd.w * xh[i].w);
+#pragma unroll
+        for (int o = LPR / 2; o > 0; o >>= 1) { p1 += __shfl_xor(p1, o); p2 += __shfl_xor(p2, o); }
+        s1[i] = p1; s2[i] = p2;
+        if ((lane % LPR) == 0) { xr[(((a & 1) * 4 + wave) * 32 + rr) * 2] = p1; xr[(((a & 1) * 4 + wave) * 32 + rr) * 2 + 1] = p2; }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < NI; ++i) {
+        const int rr = rl + RPI * i, row = rb + rr;
+        const float* o = xr + (((a & 1) * 4 + (wave ^ 1)) * 32 + rr) * 2;       // the other half of the row: wave with the other wc
+        // fixed order (wc = 0 half first) so that both waves form the same sums
+        const float t1 = (wc == 0 ? s1[i] + o[0] : o[0] + s1[i]) * invc, t2 = (wc == 0 ? s2[i] + o[1] : o[1] + s2[i]) * invc;
+        const float4 gd = make_float4(dt[i].x * gam.x, dt[i].y * gam.y, dt[i].z * gam.z, dt[i].w * gam.w);
+        float4 dx = make_float4(rs[i] * (gd.x - t1 - xh[i].x * t2), rs[i] * (gd.y - t1 - xh[i].y * t2),
+                                rs[i] * (gd.z - t1 - xh[i].z * t2), rs[i] * (gd.w - t1 - xh[i].w * t2));
+        dx.x += rv[i].x; dx.y += rv[i].y; dx.z += rv[i].z; dx.w += rv[i].w;
+        if (row < t.MM) {
+          *reinterpret_cast<float4*>(t.D + (long)row * t.sd_i + col) = dx;
+          dg[0] += dt[i].x * xh[i].x; dg[1] += dt[i].y * xh[i].y; dg[2] += dt[i].z * xh[i].z; dg[3] += dt[i].w * xh[i].w;
+          db[0] += dt[i].x; db[1] += dt[i].y; db[2] += dt[i].z; db[3] += dt[i].w;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    // dgamma | dbeta of the workgroup's rows: lanes with the same column quad (RPI per wave, two waves wr) in a fixed order
+    float* cp = cred + (wave * 64 + lane) * 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { cp[k] = dg[k]; cp[4 + k] = db[k]; }
+    __syncthreads();
+    for (int e = tid; e < 2 * t.NN; e += 256) {
+      const int which = e / t.NN, c = e - which * t.NN;
+      const int wcc = c / (32 * CT), q = (c - 32 * CT * wcc) >> 2, k = c & 3;
+      float sum = 0.f;
+#pragma unroll
+      for (int wrr = 0; wrr < 2; ++wrr)
+        for (int r2 = 0; r2 < RPI; ++r2) sum += cred[((2 * wrr + wcc) * 64 + r2 * LPR + q) * 8 + 4 * which + k];
+      t.slab[(long)blockIdx.x * t.slab_stride + e] = sum;
+    }
+    return;
+  }
   // row-major epilogue through the wave's own LDS slice (the operand planes are dead behind the loop's last barrier): float4 stores
   float* D = t.D + (long)z * t.d_bs;
   const float* R = t.R ? t.R + (long)z * t.r_bs : nullptr;
@@ -291,7 +371,8 @@ template <bool BKC, int TMW, int TNW, int EPI>
 int ts_launch(const TsArgs& t, int batches, hipStream_t st) {
   const dim3 grid(((t.MM + TMW - 1) / TMW) * ((t.NN + TNW - 1) / TNW), 1, batches);
   const size_t lds_op = (size_t)3 * (TMW + TNW) * SROW * sizeof(unsigned short);
-  const size_t lds_ep = (size_t)4 * 32 * (32 * (TNW / 64) + 4) * sizeof(float);
+  size_t lds_ep = (size_t)4 * 32 * (32 * (TNW / 64) + 4) * sizeof(float);
+  if (EPI == 3) lds_ep += (size_t)(2 * 4 * 32 * 2 + 4 * 64 * 8) * sizeof(float);       // row-sum exchange + column partials
   hipLaunchKernelGGL((uir_ts_split_kernel<BKC, TMW, TNW, EPI>), grid, dim3(256), lds_op > lds_ep ? lds_op : lds_ep, st, t);
   return uir_launch_status();
 }
@@ -302,8 +383,11 @@ int ts_launch(const TsArgs& t, int batches, hipStream_t st) {
 int uir_ts_gemm(const UirGemmArgs& a, void* stream) {
   if (!uir_fused_split() || uir_mixed_mode() != 0) return -1;      // UIR_MIXED: the 16-bit kernel of csrc/tiled.hip takes these calls
   if (a.taps != 1 || a.pro != UIR_PRO_NONE || a.out_scale || a.pre_out || a.il16) return -1;
-  const int epi = a.epi == UIR_EPI_PLAIN ? 0 : a.epi == UIR_EPI_LEAKY_BWD ? 1 : a.epi == UIR_EPI_GATE_BWD ? 2 : -1;
-  if (epi < 0 || (a.act != UIR_ACT_NONE && (a.act != UIR_ACT_LEAKY || epi != 0)) || (epi != 0 && (a.bias || a.R || !a.G || a.batches != 1))) return -1;
+  const int epi = a.epi == UIR_EPI_PLAIN ? 0 : a.epi == UIR_EPI_LEAKY_BWD ? 1 : a.epi == UIR_EPI_GATE_BWD ? 2 : a.epi == UIR_EPI_LN_BWD ? 3 : -1;
+  if (epi < 0 || (a.act != UIR_ACT_NONE && (a.act != UIR_ACT_LEAKY || epi != 0)) || (epi != 0 && (a.bias || (a.R && epi != 3) || !a.G || a.batches != 1))) return -1;
+  // LayerNorm backward: the tile is the whole row
+  if (epi == 3 && ((a.N != 64 && a.N != 128) || a.n_grp_pad > 0 || !a.stats || !a.ln_g || !uir_aligned16(a.ln_g) || !a.dw_slab || a.dw_stride < 2 * a.N ||
+                   (a.ldg & 3) || a.ldg < a.N || !uir_aligned16(a.G))) return -1;
   // column groups only as the gate backward has them: one group, N = hp columns of which the first h are real
   if (a.n_grp_pad > 0 && !(epi == 2 && a.n_grp_pad == a.N && a.w_sn == 1)) return -1;
   if (epi == 2 && ((a.g_off & 3) || (a.ldg & 3) || !uir_aligned16(a.G) || a.ldg < a.g_off + a.N || a.ldy < a.g_off + a.N)) return -1;
@@ -328,7 +412,20 @@ int uir_ts_gemm(const UirGemmArgs& a, void* stream) {
   t.bias = a.bias;
   t.slope = (epi == 0 && a.act != UIR_ACT_LEAKY) ? 1.0f : a.slope;
   t.G = a.G; t.ldg = a.ldg; t.g_bs = a.g_bs; t.g_off = a.g_off;
+  t.stats = a.stats; t.gamma = a.ln_g; t.slab = a.dw_slab; t.slab_stride = a.dw_stride;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (epi == 3) {
+    // one column tile = the row; 128-row tiles while they still give two workgroups per CU.  Slab rows = row tiles (<= M / 64)
+    const bool m128 = (long)((a.M + 127) / 128) >= 512;
+    const bool bic3 = a.w_sn == 1 && (a.w_sk & 3) == 0;
+    if (!bic3 && !(a.w_sk == 1 && (a.w_sn & 3) == 0)) return -1;
+    if (a.N == 64) {
+      if (bic3) return m128 ? ts_launch<false, 128, 64, 3>(t, 1, st) : ts_launch<false, 64, 64, 3>(t, 1, st);
+      return m128 ? ts_launch<true, 128, 64, 3>(t, 1, st) : ts_launch<true, 64, 64, 3>(t, 1, st);
+    }
+    if (bic3) return m128 ? ts_launch<false, 128, 128, 3>(t, 1, st) : ts_launch<false, 64, 128, 3>(t, 1, st);
+    return m128 ? ts_launch<true, 128, 128, 3>(t, 1, st) : ts_launch<true, 64, 128, 3>(t, 1, st);
+  }
   // tile: the largest of 128 x 128, 64 x 128 / 128 x 64, 64 x 64 that still gives the chip two workgroups per CU (512): these launches
   // are latency chains of K / 32 chunks, and a second workgroup on the CU runs under the first one's barriers and load waits
   // (level 3's dt1, 16 384 x 384 -> 128: 256 workgroups of 64 x 128 lost to the f32 kernel of csrc/tiled.hip, 512 of 64 x 64 do not).

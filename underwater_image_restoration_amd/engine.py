@@ -167,6 +167,7 @@ _WGRAD3_SHAPES = ((32, 8), (32, 16), (16, 8), (8, 4))   # (K, N) pairs csrc/conv
 _WGRAD3_WGS = 512              # workgroups of the LDS-staged 3 x 3 weight-gradient kernel (two per CU)
 CONV3_SPLIT = True             # 3x3 convolutions with >= 32 channels on both sides (UpSample1, down3): forward / input gradient / weight gradient on the
                                # split-bf16 implicit-GEMM kernels of csrc/conv3b.hip; False = the nine-tap f32 MFMA paths of uir_gemm / uir_gram
+FUSE_LN_BWD = True             # deep levels (C = 64 / 128): LayerNorm backward as the epilogue of the dt1 / dt2 contraction (UIR_EPI_LN_BWD); False = uir_layernorm_bwd launches
 GRAM_SPLIT = True              # long 1x1 weight-gradient contractions with a narrow side on csrc/gramb.hip (split-bf16, transposed LDS reads); the library takes
                                # them when a chunk is a whole number of its 32-row stages - False shapes the chunks for csrc/gram.hip's f32 kernels instead
 _CONV3B_WGS = 512              # workgroups of a uir_conv3x3_split_wgrad launch (two 6-wave workgroups per CU)
@@ -641,6 +642,9 @@ class Recorder:
         if pro == L.PRO_LN:
             a.ln_g, a.ln_b = _ptr(ln[0]), _ptr(ln[1])
             a.stats = _ptr(stats)
+        if epi == L.EPI_LN_BWD:          # LayerNorm backward on the accumulators: G = the norm's input, ln = (its weight,), stats = (mean, rstd)
+            assert pro == L.PRO_NONE and G is not None and stats is not None and dw_slab is not None and N in (64, 128)
+            a.ln_g, a.stats = _ptr(ln[0]), _ptr(stats)
         a.epi, a.g_off, a.act = epi, g_off, act
         a.il16 = il16
         a.dw_cols, a.dw_rows = dw_cols, dw_rows
@@ -1082,6 +1086,25 @@ class Recorder:
             if dbu is not None:
                 self._reduce(name + ".dbu", _ptr(dbu), a.nblocks, creal, _ptr(dbias_gate), creal)
 
+    @staticmethod
+    def gemm_ln_bwd_ok(M: int, C_: int, K: int) -> bool:
+        """UIR_EPI_LN_BWD's contract (csrc/tsgemm.hip): the deep levels' dt1 / dt2 contractions."""
+        return FUSE_LN_BWD and knobs.flag("UIR_FUSED_SPLIT") and knobs.get("UIR_MIXED") == "0" and C_ in (64, 128) and 4096 <= M <= 65536 and K >= 64 and K % 4 == 0
+
+    def gemm_ln_bwd(self, name, Xg, W, *, X, stats, gamma, dRes, dX, dgamma, dbeta, C_, K, w_sn, w_sk, k_grp=(0, 0)):
+        """dX = dRes + LayerNorm'(Xg . W^T) in ONE launch (UIR_EPI_LN_BWD) + the dgamma | dbeta partial rows reduced on the bulk lane."""
+        M = Xg.shape[0]
+        slab = torch.zeros((M + 63) // 64, 2 * C_, device=self.dev, dtype=torch.float32)     # rows past the launch's row tiles stay zero
+        self.keep.append(slab)
+        self.bytes += slab.numel() * 4
+        self.gemm(name, Xg, W, dX, N=C_, K=K, w_sn=w_sn, w_sk=w_sk, k_grp=k_grp, epi=L.EPI_LN_BWD, G=X, stats=stats, ln=(gamma,), R=dRes, dw_slab=slab)
+        with self.bulk():
+            if dbeta.data_ptr() == dgamma.data_ptr() + 4 * C_:
+                self._reduce(name + ".dgb", slab.data_ptr(), slab.shape[0], 2 * C_, _ptr(dgamma), 2 * C_)
+            else:
+                self._reduce(name + ".dg", slab.data_ptr(), slab.shape[0], 2 * C_, _ptr(dgamma), C_)
+                self._reduce(name + ".db", slab.data_ptr() + 4 * C_, slab.shape[0], 2 * C_, _ptr(dbeta), C_)
+
     def ln_bwd(self, name, dT, X, stats, gamma, dRes, dX, dgamma, dbeta, *, C_):
         self._hold(dT, X, stats, gamma, dRes, dX, dgamma, dbeta)
         a = L.LnBwdArgs()
@@ -1299,12 +1322,18 @@ class Plan(Recorder):
             else:
                 self.dwconv_bwd(n + ".dgpre+dWffdw", dg, gpre, Wffdw, dgpre, Gr(f"{pfx}.ffn.conv.weight"), C_=2 * hp, creal=2 * h,
                                 dims=dims, grp=(h, hp))
-                self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
+                fuse_ln = self.gemm_ln_bwd_ok(M, C_, 2 * hp) and self.gemm_ln_bwd_ok(M, C_, 3 * C_)
+                if fuse_ln:
+                    self.gemm_ln_bwd(n + ".dt2+ln2_bwd", dgpre, Win, X=x1, stats=stats2, gamma=g2, dRes=dy, dX=dx1, dgamma=Gr(f"{pfx}.norm2.weight"),
+                                     dbeta=Gr(f"{pfx}.norm2.bias"), C_=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
+                else:
+                    self.gemm(n + ".dt2", dgpre, Win, dt, N=C_, K=2 * hp, w_sn=1, w_sk=C_, k_grp=(h, hp))
                 # released after the GEMM that shares its dgpre operand (a Gram starting beside a persistent 2-WG/CU GEMM cost it 60 %)
                 with self.bulk():
                     self.gram(n + ".dWin", dgpre, x1, Gr(f"{pfx}.ffn.project_in.weight"), N=2 * hp, K=C_, o_sn=C_, o_sk=1,
                               n_grp=(h, hp), pro_b=L.PRO_LN, ln=(g2, b2), stats=stats2)
-                self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
+                if not fuse_ln:
+                    self.ln_bwd(n + ".ln2_bwd", dt, x1, stats2, g2, dy, dx1, Gr(f"{pfx}.norm2.weight"), Gr(f"{pfx}.norm2.bias"), C_=C_)
             # MDTA
             # dWB | dWA partials side by side in one slab: a single reduction launch (before uir_attn_bwd) instead of two
             nab = B * C_ * C_
@@ -1359,8 +1388,12 @@ class Plan(Recorder):
                 return dx
             self.dwconv_bwd(n + ".dqkv_pre+dWqkvdw", dqkv, qkv_pre, Wdw, dqkv_pre, Gr(f"{a}.qkv_conv.weight"), C_=3 * C_,
                             creal=3 * C_, dims=dims)
-            self.gemm(n + ".dt1", dqkv_pre, Wqkv, dt, N=C_, K=3 * C_, w_sn=1, w_sk=C_)
-            self.ln_bwd(n + ".ln1_bwd", dt, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_)
+            if self.gemm_ln_bwd_ok(M, C_, 2 * hp) and self.gemm_ln_bwd_ok(M, C_, 3 * C_):
+                self.gemm_ln_bwd(n + ".dt1+ln1_bwd", dqkv_pre, Wqkv, X=x, stats=stats1, gamma=g1, dRes=dx1, dX=dx, dgamma=Gr(f"{pfx}.norm1.weight"),
+                                 dbeta=Gr(f"{pfx}.norm1.bias"), C_=C_, K=3 * C_, w_sn=1, w_sk=C_)
+            else:
+                self.gemm(n + ".dt1", dqkv_pre, Wqkv, dt, N=C_, K=3 * C_, w_sn=1, w_sk=C_)
+                self.ln_bwd(n + ".ln1_bwd", dt, x, stats1, g1, dx1, dx, Gr(f"{pfx}.norm1.weight"), Gr(f"{pfx}.norm1.bias"), C_=C_)
             with self.bulk():      # after the GEMM that shares its dqkv_pre operand (see dWin above)
                 self.gram(n + ".dWqkv", dqkv_pre, x, Gr(f"{a}.qkv.weight"), N=3 * C_, K=C_, o_sn=C_, o_sk=1,
                           pro_b=L.PRO_LN, ln=(g1, b1), stats=stats1)
