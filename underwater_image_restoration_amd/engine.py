@@ -167,6 +167,7 @@ _WGRAD3_SHAPES = ((32, 8), (32, 16), (16, 8), (8, 4))   # (K, N) pairs csrc/conv
 _WGRAD3_WGS = 512              # workgroups of the LDS-staged 3 x 3 weight-gradient kernel (two per CU)
 CONV3_SPLIT = True             # 3x3 convolutions with >= 32 channels on both sides (UpSample1, down3): forward / input gradient / weight gradient on the
                                # split-bf16 implicit-GEMM kernels of csrc/conv3b.hip; False = the nine-tap f32 MFMA paths of uir_gemm / uir_gram
+FUPS_PHA_SIDE_MAXROWS = 65536  # UpSample's phase MLP on the side lane beside the amplitude MLP where a level has at most this many pixels (0: never)
 FUSE_LN_BWD = True             # deep levels (C = 64 / 128): LayerNorm backward as the epilogue of the dt1 / dt2 contraction (UIR_EPI_LN_BWD); False = uir_layernorm_bwd launches
 GRAM_SPLIT = True              # long 1x1 weight-gradient contractions with a narrow side on csrc/gramb.hip (split-bf16, transposed LDS reads); the library takes
                                # them when a chunk is a whole number of its 32-row stages - False shapes the chunks for csrc/gram.hip's f32 kernels instead
@@ -1522,8 +1523,17 @@ class Plan(Recorder):
             fr, fi = self.alloc(M, C_), self.alloc(M, C_)
             self.dft(f + ".dftH", ar, ai, fr, fi, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0)
             self._op(f + ".magpha", lib.uir_magpha_fwd, _ptr(fr), _ptr(fi), _ptr(mag), _ptr(pha), B, H, W, C_)
+        # the two 1x1 MLPs are independent: on few pixels (latency-bound 10-20 us launches) the phase one runs on the side lane beside the
+        # amplitude one.  Recorded FIRST: a side launch is ordered behind everything the chain has launched when it is recorded
+        pha_side = M <= FUPS_PHA_SIDE_MAXROWS
+        if pha_side:
+            with self.side():
+                Pha, pha_bw = self._fuse(f + ".pha_fuse", pha, C_)
         Mag, amp_bw = self._fuse(f + ".amp_fuse", mag, C_)
-        Pha, pha_bw = self._fuse(f + ".pha_fuse", pha, C_)
+        if pha_side:
+            self.join(f + ".pha_fuse.join")
+        else:
+            Pha, pha_bw = self._fuse(f + ".pha_fuse", pha, C_)
         cr, ci, tr, ti = (self.alloc(M, C_) for _ in range(4))
         t = self.alloc(M, C_)
         if fuse_ew:
@@ -1575,8 +1585,14 @@ class Plan(Recorder):
                 self.dft(f + ".idftW_bwd", gtr, gti, gcr, gci, O=B * H, N=W, I=1, C_=C_, sign=-1.0, scale=1.0 / (H * W))
                 self.dft(f + ".idftH_bwd", gcr, gci, gzr, gzi, O=B, N=H, I=W, C_=C_, sign=-1.0, scale=1.0)
                 self._op(f + ".polar_bwd", lib.uir_polar_bwd, _ptr(Mag), _ptr(Pha), _ptr(gzr), _ptr(gzi), _ptr(gMag), _ptr(gPha), M * C_)
-            gmag = amp_bw(gMag)
-            gpha = pha_bw(gPha)
+            if pha_side:
+                with self.side():
+                    gpha = pha_bw(gPha)
+                gmag = amp_bw(gMag)
+                self.join(f + ".pha_fuse.join_bwd")
+            else:
+                gmag = amp_bw(gMag)
+                gpha = pha_bw(gPha)
             gar, gai = self.alloc(M, C_), self.alloc(M, C_)
             if fuse_ew:
                 self.dft(f + ".magpha_bwd+dftH_bwd", gmag, gpha, gar, gai, O=B, N=H, I=W, C_=C_, sign=1.0, scale=1.0,
