@@ -40,8 +40,8 @@ ALG_FLOPS_PER_IMAGE_256 = 90.14e9
 HBM_PEAK = 8.0e12                       # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 
 
-def cpu_baseline(image_size: int, budget_s: float = 45.0):
-    """The oracle's train step (fwd + L1 + bwd + clip + Adam) on the host cores: bounded sample."""
+def cpu_baseline(image_size: int, loss_name: str = "L1withColor", budget_s: float = 45.0):
+    """The oracle's train step (fwd + the GPU line's loss + bwd + clip + Adam) on the host cores: bounded sample."""
     from oracle import cpu_ref as O
     cores = os.cpu_count() or 1
     try:
@@ -64,7 +64,7 @@ def cpu_baseline(image_size: int, budget_s: float = 45.0):
     ref = torch.rand(B, 3, image_size, image_size, generator=g) * 2 - 1
 
     def one():
-        _, _, grads = O.loss_and_grads(P, raw, ref, "L1")
+        _, _, grads = O.loss_and_grads(P, raw, ref, loss_name)
         st.step(P, grads, 3e-4)
     t0 = time.time()
     one()                                   # warm-up (also sizes the sample)
@@ -78,7 +78,7 @@ def cpu_baseline(image_size: int, budget_s: float = 45.0):
         one()
     dt = (time.time() - t0) / n
     return {"value": B / dt, "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": f"{n} timed train steps (after 1 warm-up) of B={B} at {image_size}x{image_size}, fp32, torch CPU, {cores} threads "
+            "sample": f"{n} timed train steps (after 1 warm-up) of B={B} at {image_size}x{image_size}, {loss_name} loss, fp32, torch CPU, {cores} threads "
                       f"(BASELINE.md section 4: host RAM {ram_gb:.0f} GB -> B={B}); the oracle is the build's restatement of the "
                       f"reference's live path (dead branches not evaluated)",
             "s_per_step": dt}
@@ -184,6 +184,8 @@ def main():
                 # context only (BASELINE.md section 3 lists both ceilings): against the 6.29 TB/s a device copy reaches on this part
                 "frac_of_measured_copy_ceiling_6.29TBps": achieved / 6.29e12,
                 "traffic": traffic, "traffic_source": traffic_src, "traffic_note": traffic_note,
+                # what the counters say was really moved, against the same peak: traffic / step time / 8 TB/s
+                "frac_counter_bytes": (traffic / (ms * 1e-3) / HBM_PEAK) if traffic else None,
                 "source_sha": sha,
                 "algorithmic_bytes_per_step": alg_bytes_step,
                 "launch": "one train step = forward+backward launch lists + loss + clip/Adam",
@@ -265,7 +267,7 @@ def main():
     if rank == 0:
         print("[bench] gpu: " + json.dumps({k: out[k] for k in ("value", "ms_per_step")}), file=sys.stderr, flush=True)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(S)
+            out["cpu_baseline"] = cpu_baseline(S, args.loss)
         else:
             out["cpu_baseline"] = None
         sys.stdout.flush()

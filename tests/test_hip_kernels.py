@@ -903,6 +903,25 @@ def test_dft_with_fused_elementwise_neighbours(S, C):
     assert rel(chw(dx, B, H, W), dx_ref) < 5 * TOL
 
 
+def test_dft_polar_prologue_at_large_phases():
+    """UIR_DFT_PRO_POLAR evaluates exp(i Pha) with the hardware sine / cosine behind a fract range reduction (csrc/spectral.hip): at
+    |Pha| ~ 50 rad (8 revolutions: three bits of the f32 argument go to the integer part) the polar form -> ifft2 -> |.| of UpSample
+    (SpectralTransformer.py:183-186) still agrees with fp64 to 2e-5 of its maximum - the f32 forward's own rounding level there
+    (the kernel's tests stopped at |Pha| <= 3)."""
+    B, S, C = 1, 64, 64
+    M = B * S * S
+    Mg = rnd(B, C, S, S, seed=2) + 1.5
+    Ph = 50 * rnd(B, C, S, S, seed=3)
+    t_ref = torch.fft.ifft2(torch.complex(Mg * torch.cos(Ph), Mg * torch.sin(Ph))).abs()
+    r = rec()
+    cr, ci, tr, ti, tt = (r.alloc(M, C) for _ in range(5))
+    r.dft("polar+ih", dev(hwc(Mg)), dev(hwc(Ph)), cr, ci, O=B, N=S, I=S, C_=C, sign=1.0, scale=1.0, pro=L.DFT_PRO_POLAR)
+    r.dft("iw+cabs", cr, ci, tr, ti, O=B * S, N=S, I=1, C_=C, sign=1.0, scale=1.0 / (S * S), epi=L.DFT_EPI_CABS, aux_out=tt)
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    assert rel(chw(tt, B, S, S), t_ref) < 2e-5
+
+
 def test_spectral_elementwise_and_adjoints():
     B, H, W, C = 2, 8, 8, 32
     x = rnd(B, C, H, W, seed=1)

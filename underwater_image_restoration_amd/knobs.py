@@ -17,9 +17,11 @@ KNOBS = {
                         "operand, 6 products, f32-accurate).  2 (default) = where it is faster: full 128 x 128 tiles, >= 256 workgroups, "
                         ">= 64 k per split; 0 = never (f32 MFMA everywhere); 1 = every tiled call; 3 = only the calls the dispatchers mark",
                         "tests/test_tiled.py::test_split_bf16_mode_is_f32_accurate"),
-    "UIR_FUSED_SPLIT": ("1", "read by libuir_hip.so: 1 (default) = the tile-fused kernels of the SpectralTransformer step (uir_gdfn_fwd, uir_qkv_fwd, "
-                        "uir_attnv_fwd) run their channel contractions on split-bf16 MFMA in registers (3 bf16 planes per f32 operand, 6 products, "
-                        "f32-accurate: csrc/uir_common.h uir_mfma_split); 0 = on the f32 MFMA (the arithmetic of rounds 1-3)",
+    "UIR_FUSED_SPLIT": ("1", "read by libuir_hip.so and engine.py: 1 (default) = the SpectralTransformer step's split-bf16 kernels (3 bf16 planes per f32 "
+                        "operand, 6 products, f32-accurate: csrc/uir_common.h) - the tile-fused forwards uir_gdfn_fwd / uir_qkv_fwd / uir_attnv_fwd in "
+                        "registers, the deep levels' contractions on csrc/tsgemm.hip (uir_ts_gemm declines when 0, so every plain contraction with "
+                        "4 096 - 65 536 rows moves to csrc/gemm.hip; with it the LayerNorm-backward epilogue UIR_EPI_LN_BWD), the 3 x 3 convolutions of "
+                        "csrc/conv3b.hip and the weight-gradient Grams of csrc/gramb.hip; 0 = everything on the f32 MFMA (the arithmetic of rounds 1-3)",
                         "tests/test_hip_kernels.py::test_fused_kernels_agree_between_split_bf16_and_f32_mfma"),
     "UIR_MIXED": ("0", "read by libuir_hip.so: bf16 | fp16 = MIXED precision - every plain Linear contraction with >= 64 input channels, >= 64 outputs and "
                   ">= 256 rows (csrc/gemm.hip routes them all to csrc/tiled.hip in this mode: the Linear layers of AST / NewBigFRFNModel "

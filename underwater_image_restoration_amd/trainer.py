@@ -307,12 +307,18 @@ class ModuleTrainStep:
         # (e.g. a validation tail batch beside training plans at 92 % of the HBM).  If the existing plans are in the way - the new
         # shape would get a smaller micro-batch than an empty device allows, or none - they are dropped first (rebuilt on demand,
         # their cached decisions with them) and the shape is sized against what is then really free.
+        #  A VALIDATION shape that fits beside the training plans with a smaller micro-batch takes that micro-batch: dropping the
+        # training plans for it made every train -> val -> train transition rebuild all plans, buffers and twiddle tables, silently, each epoch.
         free = engine.device_bytes_available(dev)
         mb, best = pick(free), pick(free + self.plan_bytes())
-        if best is not None and (mb is None or mb < best):
+        if best is not None and (mb is None or (mb < best and train)):
+            held = self.plan_bytes()
             self.drop_plans()
             free = engine.device_bytes_available(dev)
             mb = pick(free)
+            if parallel.rank() == 0:
+                print(f"[uir] {type(self.model).__name__}: dropped the launch plans of other shapes ({held / 2**30:.1f} GiB) to fit {'training' if train else 'validation'} "
+                      f"batch {B} at {H}x{W} (micro-batch {mb}); they are rebuilt on demand", flush=True)
         if mb is None:
             raise RuntimeError(f"{type(self.model).__name__}(HIP): even one {H}x{W} image needs ~{self.plan_bytes_estimate(1, H, W, train) / 2**30:.1f} GiB "
                                f"of HBM for its launch plans ({free / 2**30:.1f} GiB available)")
@@ -323,7 +329,9 @@ class ModuleTrainStep:
         """Free every module's launch plans (activation buffers) and what torch's allocator caches; they are rebuilt on demand."""
         for m in self.mods:
             m._plans.clear()
-        self._mb_cache.clear()
+        # the TRAINING shapes keep their decision: the micro-batch - and with it the accumulation order of the gradients - stays the same
+        # from epoch to epoch however often validation shapes push the plans out
+        self._mb_cache = {k: v for k, v in self._mb_cache.items() if k[3]}
         torch.cuda.empty_cache()
 
     def check_memory(self, B: int, H: int, W: int) -> int:
