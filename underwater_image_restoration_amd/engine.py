@@ -169,6 +169,7 @@ CONV3_SPLIT = True             # 3x3 convolutions with >= 32 channels on both si
                                # split-bf16 implicit-GEMM kernels of csrc/conv3b.hip; False = the nine-tap f32 MFMA paths of uir_gemm / uir_gram
 FUPS_PHA_SIDE_MAXROWS = 0      # UpSample's phase MLP on the side lane beside the amplitude MLP where a level has at most this many pixels (0: never)
 FUSE_LN_BWD = True             # deep levels (C = 64 / 128): LayerNorm backward as the epilogue of the dt1 / dt2 contraction (UIR_EPI_LN_BWD); False = uir_layernorm_bwd launches
+GRAM_SLAB_CAP = True           # see Recorder._chunks
 GRAM_SPLIT = True              # long 1x1 weight-gradient contractions with a narrow side on csrc/gramb.hip (split-bf16, transposed LDS reads); the library takes
                                # them when a chunk is a whole number of its 32-row stages - False shapes the chunks for csrc/gram.hip's f32 kernels instead
 _CONV3B_WGS = 512              # workgroups of a uir_conv3x3_split_wgrad launch (two 6-wave workgroups per CU)
@@ -686,6 +687,11 @@ class Recorder:
             big, small = max(split_nk), min(split_nk)
             blocks = ((big + 127) // 128) * (1 if small <= 64 else (small + 127) // 128)
             nch = max(1, min(M // 128, _GRAM_WGS // max(1, blocks * batches)))
+            # the partial slab is written here and read by the reduction: no more of it than half the operands' own bytes (level 3: M = 16 384
+            # rows against a 704 x 128 output - 128 chunks were 46 MB of slab per Gram for 54 MB of operands, and the stage's batched reduction
+            # 123 us of the weight-gradient lane)
+            if GRAM_SLAB_CAP:
+                nch = max(1, min(nch, (M * (split_nk[0] + split_nk[1])) // (2 * split_nk[0] * split_nk[1])))
             rpc = ((M + nch - 1) // nch + 31) & ~31
         else:
             nch = max(1, min(M // 256, _GRAM_WGS // max(1, ngroups * batches)))
