@@ -309,6 +309,33 @@ typedef struct UirAttnvFwdArgs {
 int uir_attnv_fwd(const UirAttnvFwdArgs* args, void* stream);
 
 
+/* uir_attnv_bwd (round 5): the backward of uir_attnv_fwd in one pass over the pixels, C = 16 / 32, H % 8 == 0, Wd % 16 == 0
+ * (SpectralTransformer.py:100,107,110,113 under autograd):
+ *   dV[p] = dw3x3^T(dX1 . WB[b])[p] . WA[b]                                     written to dV rows (ldd)
+ *   slab_ab[w][b*C*C + i*C + j]       = partial of dWB[b][i][j] = sum_p dX1[p][i] VF[p][j]
+ *   slab_ab[w][nab + b*C*C + j*C + o] = partial of dWA[b][j][o] = sum_p du[p][j] V[p][o]      w < uir_attnv_bwd_rows(H, Wd) rows, stride slab_ab_stride >= 2 nab
+ *   slab_dw[b * rows + w][c*9 + t]    = partial of the depthwise weight gradient sum_p dvf[p - off(t)][c] U[p][c]
+ * with nab = B*C*C; uir_reduce_slab sums the rows.  Replaces the dvf GEMM (+ fused Gram), uir_dwconv_bwd_fused and the dv GEMM (+ fused Gram).
+ * Split-bf16 form only (UIR_FUSED_SPLIT=1), otherwise UIR_EINVAL. */
+typedef struct UirAttnvBwdArgs {
+  const float* dX1;    /* [B*H*W][ldx] gradient at the value path's output                         */
+  const float* WA;     /* [B][C][C]                                                               */
+  const float* WB;     /* [B][C][C]                                                               */
+  const float* Wdw;    /* kv_conv weights of the vf half [C][1][3][3]                             */
+  const float* U;      /* [B*H*W][ldu] saved by uir_attnv_fwd                                     */
+  const float* VF;     /* [B*H*W][ldf] saved by uir_attnv_fwd                                     */
+  const float* V;      /* [B*H*W][ldv] v slice of qkv                                             */
+  float* dV;           /* [B*H*W][ldd]                                                            */
+  float* slab_ab;
+  float* slab_dw;
+  long slab_ab_stride, nab;
+  int ldx, ldu, ldf, ldv, ldd;
+  int B, H, Wd;
+  int C;               /* 16 or 32                                                                */
+} UirAttnvBwdArgs;
+int uir_attnv_bwd(const UirAttnvBwdArgs* args, void* stream);
+int uir_attnv_bwd_rows(int H, int Wd);   /* host helper: slab rows per image (not a status) */
+
 /* ------------------------------------------------------------- uir_dwln_bwd */
 /* Backward of  LayerNorm -> 1x1 conv (C -> CH, no bias) -> depthwise 3x3 (no bias)  in one pass over the pixels (csrc/dwln.hip):
  *   dP = dw3x3^T(G) (kept on chip),  dX = dRes + LayerNorm'(dP . W1),  and the partial sums of all four parameter gradients.

@@ -38,7 +38,7 @@ def test_struct_layouts_match_the_compiled_library():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import gen_abi
     structs = gen_abi.parse_structs(open(os.path.join(ROOT, "include", "uir_kernels.h")).read())
-    assert len(structs) == 26 and {n for n, _ in structs} == set(L.STRUCTS)
+    assert len(structs) == 27 and {n for n, _ in structs} == set(L.STRUCTS)
     for cname, fields in structs:
         cls = L.STRUCTS[cname]
         assert [f for f, _, _ in fields] == [f[0] for f in cls._fields_], cname

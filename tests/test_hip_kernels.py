@@ -513,6 +513,42 @@ def test_gemm_with_layernorm_backward_epilogue(M, C, pad):
     assert rel(dgb[:C], dg_ref) < TOL and rel(dgb[C:], db_ref) < TOL
 
 
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 32, 32), (3, 8, 16, 16), (1, 24, 48, 32), (2, 32, 16, 16)])
+def test_attnv_bwd_fused_value_path(B, H, W, C):
+    """csrc/attnvb.hip: the backward of  u = v WA[b]^T -> vf = dw3x3(u) -> x1 = vf WB[b]^T + x  (SpectralTransformer.py:100,107,110,113) in one launch -
+    dv, the per-sample dW_A / dW_B and the depthwise weight gradient - against torch fp64 autograd; image borders inside tiles, several tiles per
+    workgroup, one and both channel halves (C = 16 / 32)."""
+    HW, M = H * W, B * H * W
+    v = rnd(M, C, seed=1).requires_grad_(True)
+    WA = (rnd(B, C, C, seed=2) * C ** -0.5).requires_grad_(True)
+    WB = (rnd(B, C, C, seed=3) * C ** -0.5).requires_grad_(True)
+    wdw = rnd(C, 1, 3, 3, seed=4).requires_grad_(True)
+    dx1 = rnd(M, C, seed=5)
+    vb = v.reshape(B, HW, C)
+    u = torch.einsum("bpo,bjo->bpj", vb, WA)                              # u[p][j] = sum_o v[p][o] WA[j][o]
+    vf = hwc(F.conv2d(chw(u.reshape(M, C), B, H, W), wdw, padding=1, groups=C))
+    x1 = torch.einsum("bpj,bij->bpi", vf.reshape(B, HW, C), WB)          # x1[p][i] = sum_j vf[p][j] WB[i][j]
+    dv_ref, dWA_ref, dWB_ref, dw_ref = torch.autograd.grad((x1.reshape(M, C) * dx1).sum(), (v, WA, WB, wdw))
+    r = rec()
+    dims = (B, H, W)
+    assert Recorder.attnv_bwd_ok(C, dims)
+    rows = lib.uir_attnv_bwd_rows(H, W)
+    nab = B * C * C
+    slab = r.alloc(rows, 2 * nab)
+    dV = r.alloc(M, 3 * C)[:, 2 * C:]                                     # the v columns of a dqkv row
+    dWdw, dWBA = r.alloc(C, 9), r.alloc(2 * nab)
+    r.attnv_bwd("vb", dev(dx1), dev(WA.detach().reshape(B, C * C)), dev(WB.detach().reshape(B, C * C)), dev(wdw.detach().reshape(C, 9)),
+                dev(u.detach().reshape(M, C)), dev(vf.detach()), dev(v.detach()), dV, slab, dWdw, C_=C, dims=dims)
+    r._reduce("dWAB.red", slab.data_ptr(), rows, 2 * nab, dWBA.data_ptr(), 2 * nab)
+    r.flush_reductions("t")
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    assert rel(dV, dv_ref) < TOL
+    assert rel(dWBA[:nab].reshape(B, C, C), dWB_ref) < TOL
+    assert rel(dWBA[nab:].reshape(B, C, C), dWA_ref) < TOL
+    assert rel(dWdw.reshape(C, 1, 3, 3), dw_ref) < TOL
+
+
 def test_gram_per_batch_with_norms_and_colsum():
     B, HW, C = 3, 500, 32
     qkv = rnd(B * HW, 3 * C, seed=1)

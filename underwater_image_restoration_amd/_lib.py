@@ -77,6 +77,12 @@ class Conv3bWgradArgs(C.Structure):
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("N", C.c_int), ("K", C.c_int), ("nchunks", C.c_int)]
 
 
+class AttnvBwdArgs(C.Structure):
+    _fields_ = [("dX1", fp), ("WA", fp), ("WB", fp), ("Wdw", fp), ("U", fp), ("VF", fp), ("V", fp), ("dV", fp), ("slab_ab", fp), ("slab_dw", fp),
+                ("slab_ab_stride", C.c_long), ("nab", C.c_long), ("ldx", C.c_int), ("ldu", C.c_int), ("ldf", C.c_int), ("ldv", C.c_int), ("ldd", C.c_int),
+                ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int)]
+
+
 class DwArgs(C.Structure):
     _fields_ = [("X", fp), ("Wt", fp), ("Y", fp), ("ldx", C.c_int), ("ldy", C.c_int),
                 ("B", C.c_int), ("H", C.c_int), ("Wd", C.c_int), ("C", C.c_int),
@@ -237,6 +243,8 @@ SIGNATURES = {
     "uir_qkv_fwd": [C.POINTER(QkvFwdArgs), fp],
     "uir_attnv_fwd": [C.POINTER(AttnvFwdArgs), fp],
     "uir_dwln_bwd": [C.POINTER(DwLnBwdArgs), fp],
+    "uir_attnv_bwd": [C.POINTER(AttnvBwdArgs), fp],
+    "uir_attnv_bwd_rows": [i32, i32],                    # host helper: returns a count, not a status
     "uir_layernorm_bwd": [C.POINTER(LnBwdArgs), fp],
     "uir_attn_fwd": [C.POINTER(AttnFwdArgs), fp],
     "uir_attn_bwd": [C.POINTER(AttnBwdArgs), fp],
@@ -324,7 +332,7 @@ SIGNATURES = {
 # C struct name -> ctypes mirror (every argument struct of include/uir_kernels.h)
 STRUCTS = {"UirGemmArgs": GemmArgs, "UirGramArgs": GramArgs, "UirConv3bArgs": Conv3bArgs, "UirConv3bWgradArgs": Conv3bWgradArgs, "UirDwArgs": DwArgs, "UirDwWgradArgs": DwWgradArgs,
            "UirDwBwdArgs": DwBwdArgs, "UirGdfnFwdArgs": GdfnFwdArgs, "UirQkvFwdArgs": QkvFwdArgs,
-           "UirAttnvFwdArgs": AttnvFwdArgs, "UirDwLnBwdArgs": DwLnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
+           "UirAttnvFwdArgs": AttnvFwdArgs, "UirAttnvBwdArgs": AttnvBwdArgs, "UirDwLnBwdArgs": DwLnBwdArgs, "UirLnBwdArgs": LnBwdArgs,
            "UirAttnFwdArgs": AttnFwdArgs, "UirAttnBwdArgs": AttnBwdArgs, "UirDftArgs": DftArgs, "UirDft2Args": Dft2Args,
            "UirAdamArgs": AdamArgs, "UirResizeImage": ResizeImage, "UirResizeArgs": ResizeArgs, "UirSsimArgs": SsimArgs,
            "UirUiqmArgs": UiqmArgs, "UirReduceDesc": ReduceDesc,

@@ -168,6 +168,7 @@ _WGRAD3_WGS = 512              # workgroups of the LDS-staged 3 x 3 weight-gradi
 CONV3_SPLIT = True             # 3x3 convolutions with >= 32 channels on both sides (UpSample1, down3): forward / input gradient / weight gradient on the
                                # split-bf16 implicit-GEMM kernels of csrc/conv3b.hip; False = the nine-tap f32 MFMA paths of uir_gemm / uir_gram
 FUPS_PHA_SIDE_MAXROWS = 0      # UpSample's phase MLP on the side lane beside the amplitude MLP where a level has at most this many pixels (0: never)
+FUSE_VALUE_BWD = True          # MDTA value path's backward at C <= 32 as ONE tile-fused launch (csrc/attnvb.hip); False = dvf GEMM + depthwise backward + dv GEMM
 FUSE_LN_BWD = True             # deep levels (C = 64 / 128): LayerNorm backward as the epilogue of the dt1 / dt2 contraction (UIR_EPI_LN_BWD); False = uir_layernorm_bwd launches
 GRAM_SLAB_CAP = True           # see Recorder._chunks
 GRAM_SPLIT = True              # long 1x1 weight-gradient contractions with a narrow side on csrc/gramb.hip (split-bf16, transposed LDS reads); the library takes
@@ -976,6 +977,30 @@ class Recorder:
         self.keep.append(a)
         self._op(name, lib.uir_attnv_fwd, C.byref(a), nbytes=rows * 4 * 5 * C_, flops=rows * (4 * C_ * C_ + 18 * C_))
 
+    @staticmethod
+    def attnv_bwd_ok(C_: int, dims) -> bool:
+        _B, H, W = dims
+        return FUSE_VALUE_BWD and knobs.flag("UIR_FUSED_SPLIT") and C_ in (16, 32) and H % 8 == 0 and W % 16 == 0
+
+    def attnv_bwd(self, name, dX1, WA, WB, Wdw, U, VF, V, dV, slab_ab, dWdw, *, C_, dims):
+        """The value path's backward in one launch (csrc/attnvb.hip): dV, the per-sample dW_B | dW_A partial rows into slab_ab
+        [uir_attnv_bwd_rows][2 B C^2] (the caller reduces them in front of uir_attn_bwd) and the depthwise weight gradient (bulk-lane reduction)."""
+        B, H, W = dims
+        rows = lib.uir_attnv_bwd_rows(H, W)
+        assert slab_ab.shape[0] == rows and slab_ab.shape[1] >= 2 * B * C_ * C_ and dWdw.numel() == C_ * 9 and dWdw.is_contiguous()
+        slab_dw = self.alloc(B * rows, C_ * 9)
+        self._hold(dX1, WA, WB, Wdw, U, VF, V, dV, slab_ab, dWdw)
+        a = L.AttnvBwdArgs()
+        a.dX1, a.WA, a.WB, a.Wdw, a.U, a.VF, a.V, a.dV = _ptr(dX1), _ptr(WA), _ptr(WB), _ptr(Wdw), _ptr(U), _ptr(VF), _ptr(V), _ptr(dV)
+        a.slab_ab, a.slab_dw, a.slab_ab_stride, a.nab = _ptr(slab_ab), _ptr(slab_dw), slab_ab.stride(0), B * C_ * C_
+        a.ldx, a.ldu, a.ldf, a.ldv, a.ldd = _ld(dX1), _ld(U), _ld(VF), _ld(V), _ld(dV)
+        a.B, a.H, a.Wd, a.C = B, H, W, C_
+        self.keep.append(a)
+        M = B * H * W
+        self._op(name, lib.uir_attnv_bwd, C.byref(a), nbytes=4 * M * 5 * C_, flops=M * (8 * C_ * C_ + 36 * C_), variant="uir_attnv_bwd")
+        with self.bulk():
+            self._reduce(name + ".dWkvdw.red", slab_dw.data_ptr(), B * rows, C_ * 9, _ptr(dWdw), C_ * 9)
+
     def dwln_bwd(self, name, G, XP, Wdw, W1, X, stats, gamma, beta, dRes, dX, dWdw, dW1, dgamma, dbeta, *, C_, dims, h=0, hp=0, ch=0,
                  nblocks=512, il=0):
         """Backward of LayerNorm -> 1x1 conv -> depthwise 3x3 in one pass (csrc/dwln.hip): dX = dRes + LN'(dw^T(G) . W1) and the four
@@ -1295,7 +1320,8 @@ class Plan(Recorder):
             dx1 = self.alloc(M, C_)
             dWBA = self.alloc(2 * B * C_ * C_)                      # dWB | dWA adjacent: one reduction writes both
             dWB, dWA = dWBA[:B * C_ * C_].view(B, C_ * C_), dWBA[B * C_ * C_:].view(B, C_ * C_)
-            dvf, du = self.alloc(M, C_), self.alloc(M, C_)
+            value_fused = FUSE_VALUE_GRAMS and C_ <= 32 and HW % 128 == 0 and self.attnv_bwd_ok(C_, dims)      # dvf / du stay on chip (csrc/attnvb.hip)
+            dvf, du = (None, None) if value_fused else (self.alloc(M, C_), self.alloc(M, C_))
             dqkv = self.alloc(M, 3 * C_)
             dqkv_pre = None if fuse_dwln else self.alloc(M, 3 * C_)
             Mqk = self.alloc(B, 4 * C_ * C_)
@@ -1349,27 +1375,36 @@ class Plan(Recorder):
             # C <= 32: each per-sample Gram rides in the epilogue of the GEMM that reads the same gradient rows (EPI_PLAIN_DW): dx1 and du are
             # read once instead of twice
             fuse_ab = FUSE_VALUE_GRAMS and C_ <= 32 and HW % 128 == 0
-            if fuse_ab:
-                nch_ab = max(1, min(_PLAIN_DW_WGS // B, HW // 128))
+            fuse_vb = fuse_ab and self.attnv_bwd_ok(C_, dims)
+            assert fuse_vb == value_fused
+            if fuse_vb:
+                # the whole value path in one pass (dvf and du never reach HBM); its slab rows have the layout of the shared slab below
+                nch_ab = lib.uir_attnv_bwd_rows(H, W)
                 slab_ab = self.alloc(nch_ab, 2 * nab)
-                self.gemm(n + ".dvf+dWB", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B, epi=L.EPI_PLAIN_DW, G=vf,
-                          dw_slab=slab_ab, dw_cols=C_, dw_rows=nch_ab)
+                self.attnv_bwd(n + ".value_bwd", dx1, WA, WB, Wkvdw_f, u, vf, v_, dqkv[:, 2 * C_:], slab_ab,
+                               Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, dims=dims)
             else:
-                nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B, split_nk=self.gram_split_case(HW, C_, C_))
-                slab_ab = self.alloc(nch_ab * 2 * nab)
-                got = self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
-                                shared_slab=(slab_ab, 0, 2 * nab))
-                assert got == nch_ab
-                self.gemm(n + ".dvf", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
-            self.dwconv_bwd(n + ".du+dWkvdw", dvf, u, Wkvdw_f, du, Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, creal=C_,
-                            dims=dims)
-            if fuse_ab:
-                self.gemm(n + ".dv+dWA", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B, epi=L.EPI_PLAIN_DW,
-                          G=v_, dw_slab=slab_ab[:, nab:], dw_cols=C_, dw_rows=nch_ab)
-            else:
-                got = self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
-                                shared_slab=(slab_ab, nab, 2 * nab))
-                assert got == nch_ab
+                if fuse_ab:
+                    nch_ab = max(1, min(_PLAIN_DW_WGS // B, HW // 128))
+                    slab_ab = self.alloc(nch_ab, 2 * nab)
+                    self.gemm(n + ".dvf+dWB", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B, epi=L.EPI_PLAIN_DW, G=vf,
+                              dw_slab=slab_ab, dw_cols=C_, dw_rows=nch_ab)
+                else:
+                    nch_ab, _ = self._chunks(HW, 1 if tn_ == 1 else ((tn_ + 1) // 2) ** 2, B, split_nk=self.gram_split_case(HW, C_, C_))
+                    slab_ab = self.alloc(nch_ab * 2 * nab)
+                    got = self.gram(n + ".dWB", dx1, vf, dWB, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
+                                    shared_slab=(slab_ab, 0, 2 * nab))
+                    assert got == nch_ab
+                    self.gemm(n + ".dvf", dx1, WB, dvf, N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
+                self.dwconv_bwd(n + ".du+dWkvdw", dvf, u, Wkvdw_f, du, Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, creal=C_,
+                                dims=dims)
+                if fuse_ab:
+                    self.gemm(n + ".dv+dWA", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B, epi=L.EPI_PLAIN_DW,
+                              G=v_, dw_slab=slab_ab[:, nab:], dw_cols=C_, dw_rows=nch_ab)
+                else:
+                    got = self.gram(n + ".dWA", du, v_, dWA, N=C_, K=C_, o_sn=C_, o_sk=1, o_bs=C_ * C_, batches=B, out_elems=nab,
+                                    shared_slab=(slab_ab, nab, 2 * nab))
+                    assert got == nch_ab
             self._reduce(n + ".dWAB.red", _ptr(slab_ab), nch_ab, 2 * nab, _ptr(dWB), 2 * nab)
             if not fuse_ab:
                 self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
