@@ -309,11 +309,11 @@ typedef struct UirAttnvFwdArgs {
 int uir_attnv_fwd(const UirAttnvFwdArgs* args, void* stream);
 
 
-/* uir_attnv_bwd (round 5): the backward of uir_attnv_fwd in one pass over the pixels, C = 16 / 32, H % 8 == 0, Wd % 16 == 0
+/* uir_attnv_bwd (round 5): the backward of uir_attnv_fwd in one pass over the pixels, C = 16 / 32 (H % 8 == 0, Wd % 16 == 0) or C = 64 (H % 8 == 0, Wd % 8 == 0)
  * (SpectralTransformer.py:100,107,110,113 under autograd):
  *   dV[p] = dw3x3^T(dX1 . WB[b])[p] . WA[b]                                     written to dV rows (ldd)
  *   slab_ab[w][b*C*C + i*C + j]       = partial of dWB[b][i][j] = sum_p dX1[p][i] VF[p][j]
- *   slab_ab[w][nab + b*C*C + j*C + o] = partial of dWA[b][j][o] = sum_p du[p][j] V[p][o]      w < uir_attnv_bwd_rows(H, Wd) rows, stride slab_ab_stride >= 2 nab
+ *   slab_ab[w][nab + b*C*C + j*C + o] = partial of dWA[b][j][o] = sum_p du[p][j] V[p][o]      w < uir_attnv_bwd_rows_c(H, Wd, C) rows, stride slab_ab_stride >= 2 nab
  *   slab_dw[b * rows + w][c*9 + t]    = partial of the depthwise weight gradient sum_p dvf[p - off(t)][c] U[p][c]
  * with nab = B*C*C; uir_reduce_slab sums the rows.  Replaces the dvf GEMM (+ fused Gram), uir_dwconv_bwd_fused and the dv GEMM (+ fused Gram).
  * Split-bf16 form only (UIR_FUSED_SPLIT=1), otherwise UIR_EINVAL. */
@@ -331,10 +331,11 @@ typedef struct UirAttnvBwdArgs {
   long slab_ab_stride, nab;
   int ldx, ldu, ldf, ldv, ldd;
   int B, H, Wd;
-  int C;               /* 16 or 32                                                                */
+  int C;               /* 16, 32 or 64                                                            */
 } UirAttnvBwdArgs;
 int uir_attnv_bwd(const UirAttnvBwdArgs* args, void* stream);
-int uir_attnv_bwd_rows(int H, int Wd);   /* host helper: slab rows per image (not a status) */
+int uir_attnv_bwd_rows(int H, int Wd);   /* host helper: slab rows per image at C <= 32 (not a status) */
+int uir_attnv_bwd_rows_c(int H, int Wd, int C);   /* host helper: slab rows per image for any supported C (not a status) */
 
 /* ------------------------------------------------------------- uir_dwln_bwd */
 /* Backward of  LayerNorm -> 1x1 conv (C -> CH, no bias) -> depthwise 3x3 (no bias)  in one pass over the pixels (csrc/dwln.hip):

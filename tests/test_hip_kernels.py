@@ -513,11 +513,12 @@ def test_gemm_with_layernorm_backward_epilogue(M, C, pad):
     assert rel(dgb[:C], dg_ref) < TOL and rel(dgb[C:], db_ref) < TOL
 
 
-@pytest.mark.parametrize("B,H,W,C", [(2, 16, 32, 32), (3, 8, 16, 16), (1, 24, 48, 32), (2, 32, 16, 16)])
+@pytest.mark.parametrize("B,H,W,C", [(2, 16, 32, 32), (3, 8, 16, 16), (1, 24, 48, 32), (2, 32, 16, 16), (2, 16, 24, 64), (1, 8, 8, 64), (1, 96, 64, 64)])
 def test_attnv_bwd_fused_value_path(B, H, W, C):
     """csrc/attnvb.hip: the backward of  u = v WA[b]^T -> vf = dw3x3(u) -> x1 = vf WB[b]^T + x  (SpectralTransformer.py:100,107,110,113) in one launch -
     dv, the per-sample dW_A / dW_B and the depthwise weight gradient - against torch fp64 autograd; image borders inside tiles, several tiles per
-    workgroup, one and both channel halves (C = 16 / 32)."""
+    workgroup, one and both channel halves (C = 16 / 32), and the two-chunk 8 x 8 form of level 2 (C = 64; 96 x 64: 96 tiles on 64 workgroups, so some slab
+    rows are accumulated over two tiles)."""
     HW, M = H * W, B * H * W
     v = rnd(M, C, seed=1).requires_grad_(True)
     WA = (rnd(B, C, C, seed=2) * C ** -0.5).requires_grad_(True)
@@ -532,7 +533,7 @@ def test_attnv_bwd_fused_value_path(B, H, W, C):
     r = rec()
     dims = (B, H, W)
     assert Recorder.attnv_bwd_ok(C, dims)
-    rows = lib.uir_attnv_bwd_rows(H, W)
+    rows = lib.uir_attnv_bwd_rows_c(H, W, C)
     nab = B * C * C
     slab = r.alloc(rows, 2 * nab)
     dV = r.alloc(M, 3 * C)[:, 2 * C:]                                     # the v columns of a dqkv row

@@ -11,7 +11,7 @@ from underwater_image_restoration_amd import engine as E        # noqa: E402
 
 def main():
     dev = torch.device("cuda", 0)
-    for name, B, S, Cc in (("L0 C=32", 16, 256, 32), ("L0 C=16", 16, 256, 16), ("L1 C=32", 16, 128, 32)):
+    for name, B, S, Cc in (("L0 C=32", 16, 256, 32), ("L0 C=16", 16, 256, 16), ("L1 C=32", 16, 128, 32), ("L2 C=64", 16, 64, 64)):
         M, HW = B * S * S, S * S
         dims = (B, S, S)
         r = E.Recorder(dev)
@@ -22,13 +22,24 @@ def main():
         wdw = torch.randn(Cc, 9, device=dev)
         nab = B * Cc * Cc
         dvf, du, dqkv, dwd = r.alloc(M, Cc), r.alloc(M, Cc), r.alloc(M, 3 * Cc), r.alloc(Cc, 9)
-        nch = max(1, min(768 // B, HW // 128))
-        slab = r.alloc(nch, 2 * nab)
-        r.gemm(name + " dvf+dWB", dx1, WB, dvf, N=Cc, K=Cc, w_sn=1, w_sk=Cc, w_bs=Cc * Cc, batches=B, epi=L.EPI_PLAIN_DW, G=vf, dw_slab=slab, dw_cols=Cc, dw_rows=nch)
-        r.dwconv_bwd(name + " du+dWkvdw", dvf, u, wdw, du, dwd, C_=Cc, creal=Cc, dims=dims)
-        r.gemm(name + " dv+dWA", du, WA, dqkv[:, 2 * Cc:], N=Cc, K=Cc, w_sn=1, w_sk=Cc, w_bs=Cc * Cc, batches=B, epi=L.EPI_PLAIN_DW, G=v_, dw_slab=slab[:, nab:], dw_cols=Cc,
-               dw_rows=nch)
-        rows = L.lib.uir_attnv_bwd_rows(S, S)
+        if Cc <= 32:
+            nch = max(1, min(768 // B, HW // 128))
+            slab = r.alloc(nch, 2 * nab)
+            r.gemm(name + " dvf+dWB", dx1, WB, dvf, N=Cc, K=Cc, w_sn=1, w_sk=Cc, w_bs=Cc * Cc, batches=B, epi=L.EPI_PLAIN_DW, G=vf, dw_slab=slab, dw_cols=Cc, dw_rows=nch)
+            r.dwconv_bwd(name + " du+dWkvdw", dvf, u, wdw, du, dwd, C_=Cc, creal=Cc, dims=dims)
+            r.gemm(name + " dv+dWA", du, WA, dqkv[:, 2 * Cc:], N=Cc, K=Cc, w_sn=1, w_sk=Cc, w_bs=Cc * Cc, batches=B, epi=L.EPI_PLAIN_DW, G=v_, dw_slab=slab[:, nab:], dw_cols=Cc,
+                   dw_rows=nch)
+        else:       # the deep levels' five launches (engine.py _block: shared slab, split-bf16 Grams)
+            tn_ = (Cc + 31) // 32
+            nch, _ = r._chunks(HW, ((tn_ + 1) // 2) ** 2, B, split_nk=r.gram_split_case(HW, Cc, Cc))
+            slab = r.alloc(nch * 2 * nab)
+            dWBA = r.alloc(2 * nab)
+            r.gram(name + " dWB", dx1, vf, dWBA[:nab].view(B, Cc * Cc), N=Cc, K=Cc, o_sn=Cc, o_sk=1, o_bs=Cc * Cc, batches=B, out_elems=nab, shared_slab=(slab, 0, 2 * nab))
+            r.gemm(name + " dvf", dx1, WB, dvf, N=Cc, K=Cc, w_sn=1, w_sk=Cc, w_bs=Cc * Cc, batches=B)
+            r.dwconv_bwd(name + " du+dWkvdw", dvf, u, wdw, du, dwd, C_=Cc, creal=Cc, dims=dims)
+            r.gram(name + " dWA", du, v_, dWBA[nab:].view(B, Cc * Cc), N=Cc, K=Cc, o_sn=Cc, o_sk=1, o_bs=Cc * Cc, batches=B, out_elems=nab, shared_slab=(slab, nab, 2 * nab))
+            r.gemm(name + " dv", du, WA, dqkv[:, 2 * Cc:], N=Cc, K=Cc, w_sn=1, w_sk=Cc, w_bs=Cc * Cc, batches=B)
+        rows = L.lib.uir_attnv_bwd_rows_c(S, S, Cc)
         slab2, dqkv2, dwd2 = r.alloc(rows, 2 * nab), r.alloc(M, 3 * Cc), r.alloc(Cc, 9)
         r.attnv_bwd(name + " fused", dx1, WA, WB, wdw, u, vf, v_, dqkv2[:, 2 * Cc:], slab2, dwd2, C_=Cc, dims=dims)
         r.flush_reductions("t")

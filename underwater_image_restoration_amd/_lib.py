@@ -245,6 +245,7 @@ SIGNATURES = {
     "uir_dwln_bwd": [C.POINTER(DwLnBwdArgs), fp],
     "uir_attnv_bwd": [C.POINTER(AttnvBwdArgs), fp],
     "uir_attnv_bwd_rows": [i32, i32],                    # host helper: returns a count, not a status
+    "uir_attnv_bwd_rows_c": [i32, i32, i32],             # the same for any supported C
     "uir_layernorm_bwd": [C.POINTER(LnBwdArgs), fp],
     "uir_attn_fwd": [C.POINTER(AttnFwdArgs), fp],
     "uir_attn_bwd": [C.POINTER(AttnBwdArgs), fp],

@@ -261,24 +261,253 @@ __global__ __launch_bounds__(256, 2) void uir_attnv_bwd_kernel(const UirAttnvBwd
   }
 }
 
+
+// ---- C = 64 (level 2): the same pass over 8 x 8 tiles, the channels of dvf / du taken 32 at a time ----
+// dx1 on tile + ring stays in registers as split A operands for both chunks; per chunk: (a) dvf chunk -> LDS, (b) the walk -> du chunk, (c) dv +=
+// du chunk . WA[chunk rows], (d) one 32 x 32 tile of dWA or dWB per wave over all 64 pixels of the tile (wave 0 / 1: dWA[chunk rows][32 w ..],
+// wave 2 / 3: dWB[32 (w - 2) ..][chunk columns]) - every Gram tile has one owner, so the slab rows are stored from the accumulators.
+struct Avb64 {
+  static constexpr int C = 64, TH = 8, TW = 8, RW = TW + 2, RH = TH + 2;
+  static constexpr int NPX1 = RW * RH;              // 100 tile + ring pixels: 4 row tiles of 32, one per wave
+  static constexpr int NI = TH * TW;                // 64 interior pixels
+  static constexpr int S1 = 40, SG = 36, SV = 68;   // LDS row strides (floats): dvf chunk on the ring / 32-channel interior rows / 64-channel interior rows
+  static constexpr int OFF_G = 128 * S1;            // du chunk
+  static constexpr int OFF_R = OFF_G + NI * SG;     // u chunk, then vf chunk
+  static constexpr int OFF_V = OFF_R + NI * SG;     // v, all channels
+  static constexpr int OFF_X = OFF_V + NI * SV;     // dx1 interior, all channels
+  static constexpr int LDS_FLOATS = OFF_X + NI * SV;
+};
+
+__global__ __launch_bounds__(256, 2) void uir_attnv_bwd64_kernel(const UirAttnvBwdArgs a, const int wps, const int tiles_x, const int tiles_img) {
+  using T = Avb64;
+  constexpr int C = T::C, TW = T::TW;
+  extern __shared__ float smem[];
+  float* T1s = smem;
+  float* Gs = smem + T::OFF_G;
+  float* Rs = smem + T::OFF_R;
+  float* Vs = smem + T::OFF_V;
+  float* Xs = smem + T::OFF_X;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 31, h2 = lane >> 5;
+  const int b = (int)blockIdx.x / wps, w = (int)blockIdx.x % wps;
+  const long img = (long)b * a.H * a.Wd;
+  const float* WA = a.WA + (long)b * C * C;
+  const float* WB = a.WB + (long)b * C * C;
+  // the walk: 16 channel pairs (cp, cp + 16 of the chunk) x 8 tile columns x 2 half heights
+  const int cp = tid & 15;
+  const int strip16 = (tid >> 6) * 4 + (((lane >> 4) & 1) << 1 | (lane >> 5));
+  const int wcol = strip16 & 7, wrow0 = (strip16 >> 3) * 4;
+  const int rt = wave & 1, nt = wave >> 1;              // (c): this wave's 32-pixel row tile and 32-column tile of dv
+  // staging maps: [64][64] tiles 16 lanes per pixel row, [64][32] chunks 8 lanes per pixel row
+  const int fj = tid & 15, fp0 = tid >> 4;
+  const int sj = tid & 7, sp0 = tid >> 3;
+  auto pix = [&](int p, int y0, int x0) { return img + (long)(y0 + p / TW) * a.Wd + x0 + p % TW; };
+
+  for (int tile = w; tile < tiles_img; tile += wps) {
+    const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+    const int y0 = ty * T::TH, x0 = tx * TW;
+    const bool first = tile == w;
+    // ---- phase 0: v and the interior of dx1 (all channels) in flight; dx1 on tile + ring as split A operands, zero outside the image ----
+    float4 tv[4], tx1[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const long m = pix(fp0 + 16 * it, y0, x0);
+      tv[it] = *reinterpret_cast<const float4*>(a.V + m * a.ldv + 4 * fj);
+      tx1[it] = *reinterpret_cast<const float4*>(a.dX1 + m * a.ldx + 4 * fj);
+    }
+    UirBf3 Ap[C / 16];
+    {
+      const int p = wave * 32 + li;
+      const int ry = p / T::RW, rx = p - ry * T::RW;
+      const int iy = y0 + ry - 1, ix = x0 + rx - 1;
+      const bool valid = p < T::NPX1 && iy >= 0 && iy < a.H && ix >= 0 && ix < a.Wd;
+      const float* xr = a.dX1 + (valid ? img + (long)iy * a.Wd + ix : img) * a.ldx + 4 * h2;
+      float4 xv[C / 8];
+#pragma unroll
+      for (int jj = 0; jj < C / 8; ++jj) xv[jj] = keep4(*reinterpret_cast<const float4*>(xr + 8 * jj), valid);
+#pragma unroll
+      for (int s = 0; s < C / 16; ++s) Ap[s] = uir_split8(xv[2 * s], xv[2 * s + 1]);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      *reinterpret_cast<float4*>(Vs + (fp0 + 16 * it) * T::SV + 4 * fj) = tv[it];
+      *reinterpret_cast<float4*>(Xs + (fp0 + 16 * it) * T::SV + 4 * fj) = tx1[it];
+    }
+    f32x16 accv;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accv[i] = 0.f;
+
+#pragma unroll 1
+    for (int c = 0; c < 2; ++c) {
+      const int c0 = 32 * c;
+      f32x2 g[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) g[t] = f32x2{0.f, 0.f};
+      float4 tu[2];
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {
+        const long m = pix(sp0 + 32 * it, y0, x0);
+        tu[it] = *reinterpret_cast<const float4*>(a.U + m * a.ldu + c0 + 4 * sj);
+      }
+      // ---- (a) dvf[p][c0 + li] = sum_i dx1[p][i] WB[i][c0 + li] on this wave's 32 ring rows ----
+      {
+        f32x16 d;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) d[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < C / 16; ++s) {
+          float xa[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) xa[t] = WB[(16 * s + 8 * (t >> 2) + 4 * h2 + (t & 3)) * C + c0 + li];
+          d = uir_mfma_split(Ap[s], uir_split8(xa), d);
+        }
+        float* dst = T1s + (wave * 32 + 4 * h2) * T::S1 + li;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) dst[((i & 3) + 8 * (i >> 2)) * T::S1] = d[i];
+      }
+#pragma unroll
+      for (int it = 0; it < 2; ++it) *reinterpret_cast<float4*>(Rs + (sp0 + 32 * it) * T::SG + 4 * sj) = tu[it];
+      lds_barrier();
+      // the vf chunk in flight during the walk
+      const float4 tf0 = *reinterpret_cast<const float4*>(a.VF + pix(sp0, y0, x0) * a.ldf + c0 + 4 * sj);
+      const float4 tf1 = *reinterpret_cast<const float4*>(a.VF + pix(sp0 + 32, y0, x0) * a.ldf + c0 + 4 * sj);
+      // ---- (b) du chunk = transposed depthwise 3x3 of the dvf chunk; g += window x centre u ----
+      {
+        f32x2 wv[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) wv[t] = f32x2{a.Wdw[(c0 + cp) * 9 + 8 - t], a.Wdw[(c0 + cp + 16) * 9 + 8 - t]};
+        const float* rp = T1s + (wrow0 * T::RW + wcol) * T::S1 + cp;
+        const float* up = Rs + (wrow0 * TW + wcol) * T::SG + cp;
+        f32x2 rw[3][3];
+#pragma unroll
+        for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+          for (int dx = 0; dx < 3; ++dx)
+            rw[rr][dx] = f32x2{rp[(rr * T::RW + dx) * T::S1], rp[(rr * T::RW + dx) * T::S1 + 16]};
+        rp += 3 * T::RW * T::S1;
+        float* gdst = Gs + (wrow0 * TW + wcol) * T::SG + cp;
+        auto step = [&](f32x2 (&p0)[3], f32x2 (&p1)[3], f32x2 (&p2)[3], bool more) {
+          const f32x2 uv = f32x2{up[0], up[16]};
+          up += TW * T::SG;
+          f32x2 t = wv[0] * p0[0];
+          t = __builtin_elementwise_fma(wv[1], p0[1], t);
+          t = __builtin_elementwise_fma(wv[2], p0[2], t);
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) g[kx] = __builtin_elementwise_fma(p0[kx], uv, g[kx]);
+          if (more) {
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) p0[dx] = f32x2{rp[dx * T::S1], rp[dx * T::S1 + 16]};
+            rp += T::RW * T::S1;
+          }
+#pragma unroll
+          for (int kx = 0; kx < 3; ++kx) {
+            t = __builtin_elementwise_fma(wv[3 + kx], p1[kx], t);
+            t = __builtin_elementwise_fma(wv[6 + kx], p2[kx], t);
+            g[3 + kx] = __builtin_elementwise_fma(p1[kx], uv, g[3 + kx]);
+            g[6 + kx] = __builtin_elementwise_fma(p2[kx], uv, g[6 + kx]);
+          }
+          gdst[0] = t.x;
+          gdst[16] = t.y;
+          gdst += TW * T::SG;
+        };
+        step(rw[0], rw[1], rw[2], true);
+        step(rw[1], rw[2], rw[0], true);
+        step(rw[2], rw[0], rw[1], true);
+        step(rw[0], rw[1], rw[2], false);
+      }
+      lds_barrier();                      // du chunk complete; u chunk dead
+      *reinterpret_cast<float4*>(Rs + sp0 * T::SG + 4 * sj) = tf0;
+      *reinterpret_cast<float4*>(Rs + (sp0 + 32) * T::SG + 4 * sj) = tf1;
+      {
+        float* rd = T1s;                  // the walk's depthwise terms [16 strips][16 cp][18] (the dvf chunk is dead), summed after the next barrier
+#pragma unroll
+        for (int t = 0; t < 9; ++t) { rd[(strip16 * 16 + cp) * 18 + t] = g[t].x; rd[(strip16 * 16 + cp) * 18 + 9 + t] = g[t].y; }
+      }
+      // ---- (c) dv[row tile rt][32 nt + li] += du chunk . WA[c0 .. c0 + 31][32 nt + li] ----
+      {
+        const float* gq = Gs + (rt * 32 + li) * T::SG + 4 * h2;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          float xc[8];
+#pragma unroll
+          for (int t = 0; t < 8; ++t) xc[t] = WA[(c0 + 16 * s + 8 * (t >> 2) + 4 * h2 + (t & 3)) * C + 32 * nt + li];
+          accv = uir_mfma_split(uir_split8(*reinterpret_cast<const float4*>(gq + 16 * s), *reinterpret_cast<const float4*>(gq + 16 * s + 8)),
+                                uir_split8(xc), accv);
+        }
+      }
+      lds_barrier();                      // vf chunk staged (v and dx1 interior since the first barrier of the tile)
+      // ---- (d) this wave's Gram tile over the 64 pixels, added to the workgroup's slab row ----
+      {
+        f32x16 gr;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) gr[i] = 0.f;
+        const float* X = wave < 2 ? Gs + li : Xs + 32 * (wave - 2) + li;
+        const float* Y = wave < 2 ? Vs + 32 * wave + li : Rs + li;
+        const int sx = wave < 2 ? T::SG : T::SV, sy = wave < 2 ? T::SV : T::SG;
+#pragma unroll 8
+        for (int s = 0; s < 32; ++s) {
+          const int p = 2 * s + h2;
+          gr = uir_mfma(X[p * sx], Y[p * sy], gr);
+        }
+        // dWA[j = chunk row][o] (waves 0, 1) or dWB[i][j = chunk column] (waves 2, 3): one owner per element, same thread on every tile
+        float* row = a.slab_ab + (long)w * a.slab_ab_stride + (long)b * C * C + (wave < 2 ? a.nab + (long)c0 * C + 32 * wave + li : (long)32 * (wave - 2) * C + c0 + li);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          float* dst = row + uir_mfma_row(i, h2) * C;
+          *dst = first ? gr[i] : *dst + gr[i];
+        }
+      }
+      {
+        const float* rd = T1s;
+        float* row = a.slab_dw + (long)blockIdx.x * (C * 9) + c0 * 9;
+        for (int e = tid; e < 32 * 9; e += 256) {
+          const int ch = e / 9, t = e - 9 * ch;
+          const int pc = ch & 15, hi = ch >> 4;
+          float sum = 0.f;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) sum += rd[(s * 16 + pc) * 18 + 9 * hi + (8 - t)];
+          row[e] = first ? sum : row[e] + sum;
+        }
+      }
+      lds_barrier();                      // before the next chunk's (a) / the next tile's staging
+    }
+    // dv rows of this wave's unit, from the accumulators
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int p = rt * 32 + (i & 3) + 8 * (i >> 2) + 4 * h2;
+      a.dV[pix(p, y0, x0) * a.ldd + 32 * nt + li] = accv[i];
+    }
+  }
+
+}
+
 }  // namespace
 
-extern "C" int uir_attnv_bwd_rows(int H, int Wd) {       // host helper: slab rows per image (= workgroups per image), not a status
+extern "C" int uir_attnv_bwd_rows(int H, int Wd) {       // host helper: slab rows per image (= workgroups per image) at C <= 32, not a status
   const int tiles = (H / 8) * (Wd / 16);
   return tiles < 32 ? tiles : 32;
+}
+extern "C" int uir_attnv_bwd_rows_c(int H, int Wd, int C) {       // the same for any supported C (C = 64: 8 x 8 tiles, up to 64 workgroups per image)
+  if (C != 64) return uir_attnv_bwd_rows(H, Wd);
+  const int tiles = (H / 8) * (Wd / 8);
+  return tiles < 64 ? tiles : 64;
 }
 
 extern "C" int uir_attnv_bwd(const UirAttnvBwdArgs* p, void* stream) {
   const UirAttnvBwdArgs& a = *p;
   UIR_REQUIRE(uir_fused_split() != 0);      // split-bf16 form only (engine.py keeps the three-launch path when the knob is 0)
   UIR_REQUIRE(a.dX1 && a.WA && a.WB && a.Wdw && a.U && a.VF && a.V && a.dV && a.slab_ab && a.slab_dw);
-  UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0 && (a.H & 7) == 0 && (a.Wd & 15) == 0 && (a.C == 16 || a.C == 32));
+  UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0 && (a.H & 7) == 0 && (a.Wd & (a.C == 64 ? 7 : 15)) == 0 && (a.C == 16 || a.C == 32 || a.C == 64));
   UIR_REQUIRE(a.ldx >= a.C && a.ldu >= a.C && a.ldf >= a.C && a.ldv >= a.C && a.ldd >= a.C);
   UIR_REQUIRE(((a.ldx | a.ldu | a.ldf | a.ldv) & 3) == 0 && uir_aligned16(a.dX1) && uir_aligned16(a.U) && uir_aligned16(a.VF) && uir_aligned16(a.V));
   UIR_REQUIRE(a.nab == (long)a.B * a.C * a.C && a.slab_ab_stride >= 2 * a.nab);
-  const int tiles_x = a.Wd / 16, tiles_img = (a.H / 8) * tiles_x;
-  const int wps = uir_attnv_bwd_rows(a.H, a.Wd);
+  const int wps = uir_attnv_bwd_rows_c(a.H, a.Wd, a.C);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (a.C == 64) {          // 8 x 8 tiles
+    const int tx8 = a.Wd / 8;
+    hipLaunchKernelGGL(uir_attnv_bwd64_kernel, dim3(a.B * wps), dim3(256), (size_t)Avb64::LDS_FLOATS * 4, st, a, wps, tx8, (a.H / 8) * tx8);
+    return uir_launch_status();
+  }
+  const int tiles_x = a.Wd / 16, tiles_img = (a.H / 8) * tiles_x;
   if (a.C == 16) hipLaunchKernelGGL(uir_attnv_bwd_kernel<16>, dim3(a.B * wps), dim3(256), (size_t)AvbTile<16>::LDS_FLOATS * 4, st, a, wps, tiles_x, tiles_img);
   else hipLaunchKernelGGL(uir_attnv_bwd_kernel<32>, dim3(a.B * wps), dim3(256), (size_t)AvbTile<32>::LDS_FLOATS * 4, st, a, wps, tiles_x, tiles_img);
   return uir_launch_status();

@@ -202,6 +202,12 @@ __global__ __launch_bounds__(256) void uir_dft2_kernel(const UirDft2Args a, int 
       // plain transform: aux0 (optional, real output only) is ADDED to the result - the up-sampler's spectral input gradient lands on the
       // shuffle branch's without a separate accumulate pass (it may alias out_re: every element is read and written by this lane alone)
       const float* add = (PRO == UIR_DFT_PRO_NONE && !want_im) ? a.aux0 : nullptr;
+      float av[16];                                  // every addend first: the loads cannot be moved across the (possibly aliasing) stores by the compiler
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int k2 = (q & 3) + 4 * h2, p = (q >> 2) & 1, w = q >> 3;
+        av[q] = (add && k2 < N2 && p == 0) ? add[line + (long)(aj + 4 * w + 16 * k2) * nstride + c] : 0.f;
+      }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int k2 = (q & 3) + 4 * h2, p = (q >> 2) & 1, w = q >> 3;
@@ -209,7 +215,7 @@ __global__ __launch_bounds__(256) void uir_dft2_kernel(const UirDft2Args a, int 
           const int k = aj + 4 * w + 16 * k2;
           float* dst = p ? a.out_im : a.out_re;
           const long at = line + (long)k * nstride + c;
-          dst[at] = add ? fmaf(e[q], a.scale, add[at]) : e[q] * a.scale;
+          dst[at] = fmaf(e[q], a.scale, av[q]);
         }
       }
     }

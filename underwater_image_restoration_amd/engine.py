@@ -169,6 +169,7 @@ CONV3_SPLIT = True             # 3x3 convolutions with >= 32 channels on both si
                                # split-bf16 implicit-GEMM kernels of csrc/conv3b.hip; False = the nine-tap f32 MFMA paths of uir_gemm / uir_gram
 FUPS_PHA_SIDE_MAXROWS = 0      # UpSample's phase MLP on the side lane beside the amplitude MLP where a level has at most this many pixels (0: never)
 FUSE_VALUE_BWD = True          # MDTA value path's backward at C <= 32 as ONE tile-fused launch (csrc/attnvb.hip); False = dvf GEMM + depthwise backward + dv GEMM
+FUSE_VALUE_BWD_64 = True       # the same at level 2 (C = 64: 8 x 8 tiles, channels in two chunks); False = two Grams + two contractions + the depthwise backward
 FUSE_LN_BWD = True             # deep levels (C = 64 / 128): LayerNorm backward as the epilogue of the dt1 / dt2 contraction (UIR_EPI_LN_BWD); False = uir_layernorm_bwd launches
 GRAM_SLAB_CAP = True           # see Recorder._chunks
 GRAM_SPLIT = True              # long 1x1 weight-gradient contractions with a narrow side on csrc/gramb.hip (split-bf16, transposed LDS reads); the library takes
@@ -980,13 +981,15 @@ class Recorder:
     @staticmethod
     def attnv_bwd_ok(C_: int, dims) -> bool:
         _B, H, W = dims
-        return FUSE_VALUE_BWD and knobs.flag("UIR_FUSED_SPLIT") and C_ in (16, 32) and H % 8 == 0 and W % 16 == 0
+        if not (FUSE_VALUE_BWD and knobs.flag("UIR_FUSED_SPLIT") and H % 8 == 0):
+            return False
+        return (C_ in (16, 32) and W % 16 == 0) or (C_ == 64 and FUSE_VALUE_BWD_64 and W % 8 == 0)
 
     def attnv_bwd(self, name, dX1, WA, WB, Wdw, U, VF, V, dV, slab_ab, dWdw, *, C_, dims):
         """The value path's backward in one launch (csrc/attnvb.hip): dV, the per-sample dW_B | dW_A partial rows into slab_ab
         [uir_attnv_bwd_rows][2 B C^2] (the caller reduces them in front of uir_attn_bwd) and the depthwise weight gradient (bulk-lane reduction)."""
         B, H, W = dims
-        rows = lib.uir_attnv_bwd_rows(H, W)
+        rows = lib.uir_attnv_bwd_rows_c(H, W, C_)
         assert slab_ab.shape[0] == rows and slab_ab.shape[1] >= 2 * B * C_ * C_ and dWdw.numel() == C_ * 9 and dWdw.is_contiguous()
         slab_dw = self.alloc(B * rows, C_ * 9)
         self._hold(dX1, WA, WB, Wdw, U, VF, V, dV, slab_ab, dWdw)
@@ -1320,7 +1323,8 @@ class Plan(Recorder):
             dx1 = self.alloc(M, C_)
             dWBA = self.alloc(2 * B * C_ * C_)                      # dWB | dWA adjacent: one reduction writes both
             dWB, dWA = dWBA[:B * C_ * C_].view(B, C_ * C_), dWBA[B * C_ * C_:].view(B, C_ * C_)
-            value_fused = FUSE_VALUE_GRAMS and C_ <= 32 and HW % 128 == 0 and self.attnv_bwd_ok(C_, dims)      # dvf / du stay on chip (csrc/attnvb.hip)
+            # dvf / du stay on chip (csrc/attnvb.hip): C <= 32 in place of the GEMMs with fused Grams, C = 64 in place of two Grams, two GEMMs and the depthwise backward
+            value_fused = self.attnv_bwd_ok(C_, dims) and (C_ == 64 or (FUSE_VALUE_GRAMS and HW % 128 == 0))
             dvf, du = (None, None) if value_fused else (self.alloc(M, C_), self.alloc(M, C_))
             dqkv = self.alloc(M, 3 * C_)
             dqkv_pre = None if fuse_dwln else self.alloc(M, 3 * C_)
@@ -1375,11 +1379,10 @@ class Plan(Recorder):
             # C <= 32: each per-sample Gram rides in the epilogue of the GEMM that reads the same gradient rows (EPI_PLAIN_DW): dx1 and du are
             # read once instead of twice
             fuse_ab = FUSE_VALUE_GRAMS and C_ <= 32 and HW % 128 == 0
-            fuse_vb = fuse_ab and self.attnv_bwd_ok(C_, dims)
-            assert fuse_vb == value_fused
+            fuse_vb = value_fused
             if fuse_vb:
                 # the whole value path in one pass (dvf and du never reach HBM); its slab rows have the layout of the shared slab below
-                nch_ab = lib.uir_attnv_bwd_rows(H, W)
+                nch_ab = lib.uir_attnv_bwd_rows_c(H, W, C_)
                 slab_ab = self.alloc(nch_ab, 2 * nab)
                 self.attnv_bwd(n + ".value_bwd", dx1, WA, WB, Wkvdw_f, u, vf, v_, dqkv[:, 2 * C_:], slab_ab,
                                Gr(f"{a}.kv_conv.weight").view(2 * C_, 9)[C_:], C_=C_, dims=dims)
@@ -1406,7 +1409,7 @@ class Plan(Recorder):
                                     shared_slab=(slab_ab, nab, 2 * nab))
                     assert got == nch_ab
             self._reduce(n + ".dWAB.red", _ptr(slab_ab), nch_ab, 2 * nab, _ptr(dWB), 2 * nab)
-            if not fuse_ab:
+            if not fuse_ab and not fuse_vb:
                 self.gemm(n + ".dv", du, WA, dqkv[:, 2 * C_:], N=C_, K=C_, w_sn=1, w_sk=C_, w_bs=C_ * C_, batches=B)
             ba = L.AttnBwdArgs()
             ba.dWA, ba.dWB, ba.G, ba.sq_q, ba.sq_k, ba.temperature = _ptr(dWA), _ptr(dWB), _ptr(Gm), _ptr(sqq), _ptr(sqk), _ptr(temp)
