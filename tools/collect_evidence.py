@@ -7,7 +7,7 @@ import sys
 tag, rd = sys.argv[1], sys.argv[2]
 src, dst = os.path.join("gpurun_out", tag), os.path.join("profiles", rd)
 os.makedirs(dst, exist_ok=True)
-for f in ("bench.json", "kernel_stats.csv", "op_breakdown.csv", "stage_timeline.csv", "chain_gaps_events.txt", "bench_conv3b.txt", "bench_deep.txt", "bench_fused.txt",
+for f in ("bench.json", "kernel_stats.csv", "op_breakdown.csv", "stage_timeline.csv", "chain_gaps_events.txt", "bench_conv3b.txt", "bench_deep.txt", "bench_fused.txt", "bench_value_bwd.txt",
           "frfnnet_bench.json", "ast_bench.json", "smoke.log"):
     p = os.path.join(src, f)
     if os.path.exists(p):
