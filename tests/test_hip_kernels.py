@@ -665,9 +665,10 @@ def test_dwconv_padded_groups():
 # ---------------------------------------------------------------- uir_gdfn
 @pytest.mark.parametrize("B,H,W,C", [(2, 16, 16, 16), (1, 19, 37, 32), (2, 8, 16, 64), (1, 11, 9, 128), (1, 1, 1, 32),
                                      (1, 40, 24, 16)])
-@pytest.mark.parametrize("store", [True, False, "il"])
+@pytest.mark.parametrize("store", [True, False, "il", "t2", "t2il"])
 def test_gdfn_fwd_fused(B, H, W, C, store):
-    """Tile-fused GDFN forward (+ norm2 + residual) vs torch fp64; ragged tiles, image edges, pad channels."""
+    """Tile-fused GDFN forward (+ norm2 + residual) vs torch fp64; ragged tiles, image edges, pad channels.  store "t2" / "t2il": only the
+    post-depthwise tensor is written (the C <= 32 train step: uir_dwln_bwd recomputes the pre-depthwise values)."""
     h = int(C * 2.66)
     hp = (h + 15) & ~15
     ldt = (2 * hp + 31) & ~31
@@ -683,12 +684,13 @@ def test_gdfn_fwd_fused(B, H, W, C, store):
     r = rec()
     M = B * H * W
     Y, st = r.alloc(M, C), r.alloc(M, 2)
-    T1 = r.alloc(M, ldt)[:, :2 * hp] if store else None
+    T1 = r.alloc(M, ldt)[:, :2 * hp] if store in (True, "il") else None
     T2 = r.alloc(M, ldt)[:, :2 * hp] if store else None
     if store:
-        T1.fill_(7.0)
         T2.fill_(7.0)
-    il = store == "il"               # t1 / t2 written in the chunk-interleaved column layout
+    if T1 is not None:
+        T1.fill_(7.0)
+    il = store in ("il", "t2il")     # t1 / t2 written in the chunk-interleaved column layout
     r.gdfn_fwd("g", dev(rows), (dev(gam), dev(bet)), dev(win), dev(wdw), dev(wout), Y, C_=C, h=h, hp=hp, dims=(B, H, W),
                T1=T1, T2=T2, stats=st, il=int(il))
     r.run(r.fwd)
@@ -698,6 +700,8 @@ def test_gdfn_fwd_fused(B, H, W, C, store):
     assert rel(st[:, 0], mean) < TOL and rel(st[:, 1], rstd) < TOL
     if store:
         for T, t in ((T1, t1), (T2, t2)):
+            if T is None:
+                continue
             tr = hwc(t)
             if il:
                 want = torch.zeros(M, 2 * hp, dtype=tr.dtype)
@@ -744,6 +748,12 @@ def test_qkv_fwd_fused(B, H, W, C):
     r.run(r.fwd)
     assert rel(Ypre, hwc(pre)) < TOL and rel(Y, hwc(out)) < TOL
     assert rel(st[:, 0], rows.mean(1)) < TOL and rel(st[:, 1], (rows.var(1, unbiased=False) + 1e-5).rsqrt()) < TOL
+    # the pre-depthwise tensor is optional (the C <= 32 train step does not keep it): same output, bit for bit
+    r2 = rec()
+    Y2 = r2.alloc(M, 3 * C)
+    r2.qkv_fwd("q", dev(rows), (dev(gam), dev(bet)), dev(wq), dev(wdw), None, Y2, C_=C, dims=(B, H, W), stats=r2.alloc(M, 2))
+    r2.run(r2.fwd)
+    assert torch.equal(Y2, Y)
 
 
 # ------------------------------------------------------------- uir_layernorm
@@ -1271,9 +1281,11 @@ def test_gemm_with_the_per_sample_gram_in_its_epilogue(B, HW, C, rows, ldz, zoff
 @pytest.mark.parametrize("B,H,W,C,split", [(2, 16, 32, 32, True), (1, 24, 16, 32, False), (2, 8, 16, 16, True), (1, 16, 16, 16, False),
                                            (1, 20, 24, 32, True), (3, 12, 40, 16, False), (1, 40, 72, 32, False),
                                            (2, 16, 32, 32, "il"), (1, 20, 24, 16, "il"), (1, 40, 72, 32, "il")])
-def test_dwln_bwd_vs_autograd(B, H, W, C, split):
+@pytest.mark.parametrize("recompute", [False, True])
+def test_dwln_bwd_vs_autograd(B, H, W, C, split, recompute):
     """The fused backward of norm -> 1x1 -> depthwise 3x3 (SpectralTransformer.py:81-82,94,144 / :122-124,147) against fp64
-    autograd: input gradient and all four parameter gradients; image sizes that are not multiples of the 8 x 16 tile included."""
+    autograd: input gradient and all four parameter gradients; image sizes that are not multiples of the 8 x 16 tile included.
+    recompute: XP = None - the kernel recomputes the depthwise input's centre values from the LayerNorm'd tile (what the train step does)."""
     il = split == "il"               # GDFN layout with the columns interleaved by chunk (UirDwLnBwdArgs.il)
     ref, o, g = _dwln_case(B, H, W, C, bool(split), seed=11)
     if il:
@@ -1282,7 +1294,7 @@ def test_dwln_bwd_vs_autograd(B, H, W, C, split):
     M = B * H * W
     dX = r.alloc(M, C)
     dWdw, dW1, dgb = r.alloc(g["chreal"], 9), r.alloc(g["chreal"], C), r.alloc(2 * C)
-    r.dwln_bwd("dwln", dev(o["G"]), dev(o["XP"]), dev(o["wdw"]), dev(o["w1"]), dev(o["X"]), dev(o["stats"]), dev(o["gam"]), dev(o["bet"]),
+    r.dwln_bwd("dwln", dev(o["G"]), None if recompute else dev(o["XP"]), dev(o["wdw"]), dev(o["w1"]), dev(o["X"]), dev(o["stats"]), dev(o["gam"]), dev(o["bet"]),
                dev(o["dRes"]), dX, dWdw, dW1, dgb[:C], dgb[C:], C_=C, dims=(B, H, W), h=g["h"], hp=g["hp"], ch=g["ch"], nblocks=5, il=int(il))
     r.run(r.fwd)
     torch.cuda.synchronize()

@@ -1,0 +1,16 @@
+"""Per-launch breakdown of the headline step with engine constants overridden: python tools/ab/flag_breakdown.py <out.csv> NAME=VALUE [...]"""
+import ast
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+torch.cuda.set_device(0)
+import bench
+import underwater_image_restoration_amd.engine as e
+out = sys.argv[1]
+for kv in sys.argv[2:]:
+    k, v = kv.split("=", 1)
+    assert hasattr(e, k), k
+    setattr(e, k, ast.literal_eval(v))
+sys.argv = ["bench.py", "--no-cpu-baseline", "--steps", "10", "--warmup", "3", "--breakdown-file", out]
+bench.main()

@@ -20,6 +20,7 @@ print(f"UIR_FUSED_SPLIT={os.environ.get('UIR_FUSED_SPLIT', '(default)')}", flush
 
 def timeit(r, label):
     if only and only not in label:
+        r.fwd = []; r.cur = r.fwd; r.meta[id(r.fwd)] = []; r.lanes[id(r.fwd)] = []; r.variants[id(r.fwd)] = []
         return
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     calls = [(fn, args) for fn, args, _ in r.fwd if fn is not None][:1]      # the kernel itself, not its slab reductions
@@ -36,7 +37,8 @@ def timeit(r, label):
     e1.record()
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1000 / reps
-    print(f"{label:34s} {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s", flush=True)
+    print(f"{label:44s} {us:8.1f} us  {nbytes / us / 1e6:6.2f} TB/s", flush=True)
+    r.fwd = []; r.cur = r.fwd; r.meta[id(r.fwd)] = []; r.lanes[id(r.fwd)] = []; r.variants[id(r.fwd)] = []      # the recorder takes the next launch
 
 
 for S, Cc in ((256, 32), (256, 16), (128, 32), (64, 64), (32, 128)):
@@ -49,11 +51,17 @@ for S, Cc in ((256, 32), (256, 16), (128, 32), (64, 64), (32, 128)):
     T1, T2 = r.alloc(M, ldg)[:, :2 * hp], r.alloc(M, ldg)[:, :2 * hp]
     r.gdfn_fwd("g", x, (g1, b1), rnd(2 * h, Cc) * .2, rnd(2 * h, 9) * .3, rnd(Cc, h) * .1, y, C_=Cc, h=h, hp=hp, dims=dims, T1=T1, T2=T2, stats=st, il=1 if Cc <= 32 else 0)
     timeit(r, f"{tag} gdfn_fwd")
+    if Cc <= 32:           # as the train step runs it: only the post-depthwise tensor is written
+        r.gdfn_fwd("g", x, (g1, b1), rnd(2 * h, Cc) * .2, rnd(2 * h, 9) * .3, rnd(Cc, h) * .1, y, C_=Cc, h=h, hp=hp, dims=dims, T1=None, T2=T2, stats=st, il=1)
+        timeit(r, f"{tag} gdfn_fwd, t2 only")
     del r, T1, T2
     r = Recorder(dev, scratch_floats=1 << 20)
     qp, q, st = r.alloc(M, 3 * Cc), r.alloc(M, 3 * Cc), r.alloc(M, 2)
     r.qkv_fwd("q", x, (g1, b1), rnd(3 * Cc, Cc) * .2, rnd(3 * Cc, 9) * .3, qp, q, C_=Cc, dims=dims, stats=st)
     timeit(r, f"{tag} qkv_fwd")
+    if Cc <= 32:
+        r.qkv_fwd("q", x, (g1, b1), rnd(3 * Cc, Cc) * .2, rnd(3 * Cc, 9) * .3, None, q, C_=Cc, dims=dims, stats=st)
+        timeit(r, f"{tag} qkv_fwd, no pre-conv output")
     del r, qp, q
     r = Recorder(dev, scratch_floats=1 << 20)
     u, vf, y = r.alloc(M, Cc), r.alloc(M, Cc), r.alloc(M, Cc)
@@ -74,4 +82,7 @@ for S, Cc in ((256, 32), (256, 16), (128, 32), (64, 64), (32, 128)):
         r.dwln_bwd("k", G, XP, rnd(chreal, 9), rnd(chreal, Cc), x, stats, g1, b1, dRes, dX, dWdw, dW1, dgb[:Cc], dgb[Cc:], C_=Cc, dims=dims,
                    h=hh, hp=hpp, ch=ch, il=1 if split else 0)     # interleaved GDFN columns, as the step runs them
         timeit(r, f"{tag} dwln_bwd {'gdfn' if split else 'qkv'}")
+        r.dwln_bwd("k", G, None, rnd(chreal, 9), rnd(chreal, Cc), x, stats, g1, b1, dRes, dX, dWdw, dW1, dgb[:Cc], dgb[Cc:], C_=Cc, dims=dims,
+                   h=hh, hp=hpp, ch=ch, il=1 if split else 0)
+        timeit(r, f"{tag} dwln_bwd {'gdfn' if split else 'qkv'}, XP recomputed")
         del r, G, XP

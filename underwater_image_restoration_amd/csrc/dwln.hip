@@ -86,7 +86,8 @@ struct DwLn {
   static constexpr int OFF_W1 = OFF_WR + 4 * 16 * 18;
   static constexpr int SWF = 20;                           // row stride of the staged depthwise taps [16 channel pairs][9 A | 9 B] (16-byte rows)
   static constexpr int OFF_WF = OFF_W1 + 32 * SW;
-  static constexpr int LDS_FLOATS = OFF_WF + 16 * SWF;
+  static constexpr int OFF_GB = OFF_WF + 16 * SWF;         // recompute mode: (gamma, beta) pairs of the LayerNorm [C][2]
+  static constexpr int LDS_FLOATS = OFF_GB + 2 * C;
   static_assert(C == 16 || C == 32, "channel count");
 };
 
@@ -104,7 +105,11 @@ struct DwLn {
   const int part = (T::NG == 4) ? 0 : (wave >> 1), n16 = 16 * gr_n + l16;                                                 \
   (void)li; (void)h2; (void)cp; (void)sx; (void)l16; (void)j16; (void)gr_k; (void)part; (void)n16
 
-template <int C, int NCH, bool SPLIT>
+// RC (a.XP == NULL): the centre pre-conv values XP = LayerNorm(x) . W1^T are RECOMPUTED per chunk from the normalised tile and the staged W1
+// chunk (f32 MFMA, one 32-channel x 32-pixel tile per wave = exactly the pixels of the wave's four walk columns), parked in the dP buffer at
+// the element the same thread overwrites with dP in the walk.  The forward then never writes the pre-depthwise tensor (96 resp. 192 floats
+// per pixel at C = 32: 43 % of uir_qkv_fwd's / uir_gdfn_fwd's bytes) and this kernel does not read it.
+template <int C, int NCH, bool SPLIT, bool RC>
 __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdArgs a) {
   using T = DwLn<C, NCH, SPLIT>;
   extern __shared__ float smem[];
@@ -115,6 +120,11 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
   float* WR = smem + T::OFF_WR;
   float* W1s = smem + T::OFF_W1;
   float* WFs = smem + T::OFF_WF;
+  float* GB = smem + T::OFF_GB;
+  if (RC && threadIdx.x < C) {                               // visible after the first tile's barriers
+    GB[2 * threadIdx.x] = a.gamma[threadIdx.x];
+    GB[2 * threadIdx.x + 1] = a.beta[threadIdx.x];
+  }
   const int tiles_x = (a.Wd + T::TW - 1) / T::TW, tiles_y = (a.H + T::TH - 1) / T::TH;
   const int ntiles = a.B * tiles_x * tiles_y;
   const int h = a.h, hp = a.hp, ch = a.ch;
@@ -258,7 +268,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     load_wf(0, t_);
     load_w1(0, t_);
     load_g(0, t_);
-    load_xp(0, cp, sx, c0);
+    if constexpr (!RC) load_xp(0, cp, sx, c0);
   }
 
   UIR_ST_DECL;
@@ -305,6 +315,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    float bv[RC ? C / 2 : 1];                                // RC: LayerNorm output of this lane's (pixel, n) slots, the B operand of the XP recompute
 
 #pragma unroll 1
     for (int ci = 0; ci < NCH; ++ci) {
@@ -335,6 +346,35 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       if (t_ / (C / 4) < 32) *reinterpret_cast<float4*>(W1s + (t_ / (C / 4)) * T::SW + 4 * (t_ % (C / 4))) = w1pre;
       lds_barrier2();
       UIR_ST(1);
+      f32x16 xd;
+      if constexpr (RC) {
+        // XP tile of this wave: D[chunk channel r][pixel q] = sum_n W1s[r][n] (xhat[n][pixel q] gamma[n] + beta[n]); MFMA column q = li is the
+        // pixel (row li >> 2, column 4 wave + (li & 3)) - the walk's pixels of this wave; k slot (step s, half h2) is n = (C / 2) h2 + s, so a lane's
+        // A values are C / 2 consecutive floats of its W1s row.  Every wave is past (c) / (d) of the previous chunk (the barrier above): Gs is free
+        const int pix = (li >> 2) * T::TW + 4 * wave + (li & 3);
+        const float* ap = W1s + li * T::SW + (C / 2) * h2;
+        const float* bp = XH + (C / 2) * h2 * T::SXT + pix;
+        const float* gb = GB + C * h2;
+        float av[C / 2];
+#pragma unroll
+        for (int j = 0; j < C / 8; ++j) {
+          const f32x4v v = *reinterpret_cast<const f32x4v*>(ap + 4 * j);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) av[4 * j + e] = v[e];
+        }
+        if (ci == 0) {                                       // the B operand is the tile's, not the chunk's: C / 2 registers across the chunk loop
+#pragma unroll
+          for (int s2 = 0; s2 < C / 2; ++s2) {
+            const float2 g2 = *reinterpret_cast<const float2*>(gb + 2 * s2);
+            bv[s2] = fmaf(bp[s2 * T::SXT], g2.x, g2.y);
+          }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xd[r] = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < C / 2; ++s2) xd = uir_mfma(av[s2], bv[s2], xd);
+        // (stored to Gs below, behind the weight reads and the next unit's loads: the MFMA chain runs under them)
+      }
       // issue order = need order (vmcnt retires in order): this chunk's 1x1 weights now (used after the walk); the next chunk's
       // G, XP and depthwise taps after the walk, when its window / tap / accumulator registers are free - they land during (c), (d)
       // (c) B operand: W1[row of k-slot 8 jj + 4 h2 + e][n = li].  k-slots 0..15 are channels i = 8 (jj & 1) + 4 h2 + e of group A,
@@ -367,6 +407,13 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
 #pragma unroll
         for (int t = 0; t < 9; ++t) wf[t] = f32x2{w18[t], w18[9 + t]};
       }
+      if constexpr (RC) {
+        const int pix = (li >> 2) * T::TW + 4 * wave + (li & 3);
+        float* xo = Gs + pix * T::SG + 4 * h2;               // registers 4 j .. 4 j + 3 = channels 8 j + 4 h2 .. + 3 of pixel q
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4v*>(xo + 8 * j) = f32x4v{xd[4 * j], xd[4 * j + 1], xd[4 * j + 2], xd[4 * j + 3]};
+        // read back in the walk by lanes of THIS wave only (LDS instructions of a wave execute in order)
+      }
       UIR_ST(2);
 
       // ---- (b) transposed depthwise 3x3 + depthwise weight-gradient terms ----
@@ -386,7 +433,8 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
         float* gdst = Gs + sx * T::SG + cp;
         auto step = [&](f32x2 (&p0)[3], f32x2 (&p1)[3], f32x2 (&p2)[3], const int y) {
           const float keep = PL ? 1.f : ((colok && y < nrows) ? 1.f : 0.f);
-          const f32x2 xc = PL ? xpv[y] : xpv[y] * (xm * keep);
+          const f32x2 xraw = RC ? f32x2{gdst[0], gdst[16]} : xpv[y];       // RC: parked where this thread's dP goes a few lines down
+          const f32x2 xc = PL ? xraw : xraw * (xm * keep);
           f32x2 t = wf[0] * p0[0];
           t = __builtin_elementwise_fma(wf[1], p0[1], t);
           t = __builtin_elementwise_fma(wf[2], p0[2], t);
@@ -419,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       if (plain) walk(std::true_type{});
       else walk(std::false_type{});
       UIR_ST(3);
-      load_xp(cn, cp, sx, last ? tn : tc);
+      if constexpr (!RC) load_xp(cn, cp, sx, last ? tn : tc);
       UIR_ST(9);
       // sum over the wave's four strips = the four lanes of a quad: two DPP adds per value (quad_perm [1,0,3,2], [2,3,0,1]); the strips
       // on lanes 16 apart needed a v_permlane16_swap + v_permlane32_swap pair with its register copies (~110 VALU per chunk instead
@@ -628,7 +676,8 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
 template <int C, int NCH, bool SPLIT>
 int dwln_launch(const UirDwLnBwdArgs& a, hipStream_t st) {
   using T = DwLn<C, NCH, SPLIT>;
-  hipLaunchKernelGGL((uir_dwln_bwd_kernel<C, NCH, SPLIT>), dim3(a.nblocks), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
+  if (a.XP) hipLaunchKernelGGL((uir_dwln_bwd_kernel<C, NCH, SPLIT, false>), dim3(a.nblocks), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
+  else hipLaunchKernelGGL((uir_dwln_bwd_kernel<C, NCH, SPLIT, true>), dim3(a.nblocks), dim3(256), (size_t)T::LDS_FLOATS * 4, st, a);
   return uir_launch_status();
 }
 
@@ -637,20 +686,20 @@ UIR_ST_EXPORT
 
 extern "C" int uir_dwln_bwd(const UirDwLnBwdArgs* p, void* stream) {
   const UirDwLnBwdArgs& a = *p;
-  UIR_REQUIRE(a.G && a.XP && a.Wdw && a.W1 && a.X && a.stats && a.gamma && a.beta && a.dRes && a.dX && a.slab);
+  UIR_REQUIRE(a.G && a.Wdw && a.W1 && a.X && a.stats && a.gamma && a.beta && a.dRes && a.dX && a.slab);
   UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0 && a.nblocks > 0 && (a.C == 16 || a.C == 32));
   UIR_REQUIRE((a.ldg & 3) == 0 && (a.ldx & 3) == 0 && uir_aligned16(a.G) && uir_aligned16(a.X) && (a.ldx >= a.C) && a.ldr >= a.C && a.ldo >= a.C);
   UIR_REQUIRE((reinterpret_cast<uintptr_t>(a.stats) & 7u) == 0);
   const bool split = a.hp > 0;
   UIR_REQUIRE(a.il == 0 || (a.il == 1 && split));
   const int chreal = split ? 2 * a.h : a.ch;
-  if (split) UIR_REQUIRE(a.h > 0 && a.hp >= a.h && (a.hp & 15) == 0 && a.ldg >= 2 * a.hp && a.ldp >= 2 * a.hp);
-  else UIR_REQUIRE(a.ch > 0 && (a.ch & 15) == 0 && a.ldg >= a.ch && a.ldp >= a.ch);
+  if (split) UIR_REQUIRE(a.h > 0 && a.hp >= a.h && (a.hp & 15) == 0 && a.ldg >= 2 * a.hp && (!a.XP || a.ldp >= 2 * a.hp));
+  else UIR_REQUIRE(a.ch > 0 && (a.ch & 15) == 0 && a.ldg >= a.ch && (!a.XP || a.ldp >= a.ch));
   UIR_REQUIRE(a.slab_stride >= (long)chreal * 9 + (long)chreal * a.C + 2 * a.C);
   // 32-bit byte offsets into G
   {
     const long rows = (long)a.B * a.H * a.Wd;
-    const long ldmax = a.ldg > a.ldp ? a.ldg : a.ldp;
+    const long ldmax = (a.XP && a.ldp > a.ldg) ? a.ldp : a.ldg;
     UIR_REQUIRE(rows * ldmax < (1L << 30) && rows * a.ldx < (1L << 30) && rows * a.ldr < (1L << 30) && rows * a.ldo < (1L << 30));
   }
   hipStream_t st = static_cast<hipStream_t>(stream);

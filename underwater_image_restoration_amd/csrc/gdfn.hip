@@ -486,7 +486,7 @@ __global__ __launch_bounds__(256, 2) void uir_gdfn_fwd_kernel(const UirGdfnFwdAr
         st4(reinterpret_cast<char*>(a.T2) + (st_off[it] + (unsigned)c0 * cbytes), v);
       }
     };
-    if (STORE) {
+    if (STORE && a.T1) {                         // T1 == NULL (uniform): the backward recomputes the pre-depthwise values (uir_dwln_bwd, XP == NULL)
 #pragma unroll
       for (int it = 0; it < T::NST; ++it) t1_store(it);
     }
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256, 2) void uir_qkv_fwd_kernel(const UirQkvFwdArgs
     const int iy = y0 + py, ix = x0 + px;
     const bool ok = p < T::NI && iy < a.H && ix < a.Wd;
     const long m = img + (long)iy * a.Wd + ix;
-    st_pre[it] = ok ? (unsigned)((m * a.ldp + 4 * j) * 4) : ~0u;
+    st_pre[it] = (ok && a.Ypre) ? (unsigned)((m * a.ldp + 4 * j) * 4) : ~0u;     // Ypre == NULL: not stored (uir_dwln_bwd recomputes it)
     st_out[it] = ok ? (unsigned)((m * a.ldq + 4 * j) * 4) : ~0u;
     st_lds[it] = ((py + 1) * T::RW + px + 1) * T::S1 + 4 * j;
   }
@@ -1351,7 +1351,7 @@ int gdfn_fwd_launch(const UirGdfnFwdArgs& a, hipStream_t st) {
   } else {
     lds += sb ? (size_t)2 * 3 * 32 * (C + 8) * 2 : (size_t)2 * 32 * (C + 4) * 4;
   }
-  if (a.T1) { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, true>), dim3(tiles), dim3(256), lds, st, a);
+  if (a.T2) { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, true>), dim3(tiles), dim3(256), lds, st, a);
               else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, true, false>), dim3(tiles), dim3(256), lds, st, a); }
   else { if (sb) hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, true>), dim3(tiles), dim3(256), lds, st, a);
          else hipLaunchKernelGGL((uir_gdfn_fwd_kernel<C, TH, TW, false, false>), dim3(tiles), dim3(256), lds, st, a); }
@@ -1364,11 +1364,11 @@ UIR_ST_EXPORT
 extern "C" int uir_gdfn_fwd(const UirGdfnFwdArgs* p, void* stream) {
   const UirGdfnFwdArgs& a = *p;
   UIR_REQUIRE(a.X && a.ln_g && a.ln_b && a.Win && a.Wdw && a.Wout && a.Y);
-  UIR_REQUIRE((a.T1 == nullptr) == (a.T2 == nullptr) && (a.il == 0 || a.il == 1));
+  UIR_REQUIRE((a.T1 == nullptr || a.T2 != nullptr) && (a.il == 0 || a.il == 1));      // T2 alone: the backward recomputes T1 (C <= 32, uir_dwln_bwd)
   UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0 && a.h > 0 && a.hp >= a.h && (a.hp & 15) == 0);
   UIR_REQUIRE(a.ldx >= a.C && (a.ldx & 3) == 0 && a.ldy >= a.C && uir_aligned16(a.X));
   UIR_REQUIRE(uir_aligned16(a.ln_g) && uir_aligned16(a.ln_b) && uir_aligned16(a.Win));
-  UIR_REQUIRE(!a.T1 || (a.ldt >= 2 * a.hp && (a.ldt & 3) == 0 && uir_aligned16(a.T1) && uir_aligned16(a.T2) &&
+  UIR_REQUIRE(!a.T2 || (a.ldt >= 2 * a.hp && (a.ldt & 3) == 0 && uir_aligned16(a.T1) && uir_aligned16(a.T2) &&
                         (long)a.B * a.H * a.Wd * a.ldt < (1L << 30)));
   UIR_REQUIRE((long)a.B * ((a.H + 7) / 8) * ((a.Wd + 7) / 8) < (1L << 30));
   hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1383,13 +1383,13 @@ extern "C" int uir_gdfn_fwd(const UirGdfnFwdArgs* p, void* stream) {
 
 extern "C" int uir_qkv_fwd(const UirQkvFwdArgs* p, void* stream) {
   const UirQkvFwdArgs& a = *p;
-  UIR_REQUIRE(a.X && a.ln_g && a.ln_b && a.Wqkv && a.Wdw && a.Ypre && a.Y);
+  UIR_REQUIRE(a.X && a.ln_g && a.ln_b && a.Wqkv && a.Wdw && a.Y);
   UIR_REQUIRE(!a.gram_slab || (a.C <= 32 && a.gram_stride >= (long)a.C * a.C + 2 * a.C));
   UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0);
   UIR_REQUIRE(a.ldx >= a.C && (a.ldx & 3) == 0 && uir_aligned16(a.X) && uir_aligned16(a.ln_g) && uir_aligned16(a.ln_b) &&
               uir_aligned16(a.Wqkv));
-  UIR_REQUIRE(a.ldp >= 3 * a.C && a.ldq >= 3 * a.C && (a.ldp & 3) == 0 && (a.ldq & 3) == 0 && uir_aligned16(a.Ypre) && uir_aligned16(a.Y));
-  UIR_REQUIRE((long)a.B * a.H * a.Wd * (a.ldp > a.ldq ? a.ldp : a.ldq) < (1L << 30));
+  UIR_REQUIRE((!a.Ypre || (a.ldp >= 3 * a.C && (a.ldp & 3) == 0 && uir_aligned16(a.Ypre))) && a.ldq >= 3 * a.C && (a.ldq & 3) == 0 && uir_aligned16(a.Y));
+  UIR_REQUIRE((long)a.B * a.H * a.Wd * ((a.Ypre && a.ldp > a.ldq) ? a.ldp : a.ldq) < (1L << 30));
   hipStream_t st = static_cast<hipStream_t>(stream);
   switch (a.C) {
     case 16: return qkv_fwd_launch<16, 12, 16>(a, st);

@@ -47,10 +47,11 @@ SCRATCH_FLOATS = 96 * 1024 * 1024  # 384 MB of slab scratch shared by every redu
 
 
 # Plan memory model: every activation / gradient buffer lives for the plan's lifetime and is linear in B*H*W
-# (measured by building plans of several shapes: 52.7-53.6 KB per pixel with the backward list, 28.8-29.2 KB forward only;
+# (measured by building plans of several shapes: 40.4-43.1 KB per pixel with the backward list, 18.7-19.3 KB forward only, the smaller plans
+# the larger figures - the estimate's 64 MB margin covers them; 52.7-53.6 / 28.8-29.2 while the C <= 32 blocks kept their pre-depthwise tensors;
 # tests/test_cpu_surface.py holds the estimate to the real Plan.bytes), plus two slab scratch areas.
-PLAN_BYTES_PER_PIXEL_TRAIN = 54_000
-PLAN_BYTES_PER_PIXEL_EVAL = 29_300
+PLAN_BYTES_PER_PIXEL_TRAIN = 41_000
+PLAN_BYTES_PER_PIXEL_EVAL = 19_000
 
 
 def plan_bytes_estimate(B: int, H: int, W: int, want_backward: bool = True) -> int:
@@ -169,6 +170,7 @@ CONV3_SPLIT = True             # 3x3 convolutions with >= 32 channels on both si
                                # split-bf16 implicit-GEMM kernels of csrc/conv3b.hip; False = the nine-tap f32 MFMA paths of uir_gemm / uir_gram
 FUPS_PHA_SIDE_MAXROWS = 0      # UpSample's phase MLP on the side lane beside the amplitude MLP where a level has at most this many pixels (0: never)
 FUSE_VALUE_BWD = True          # MDTA value path's backward at C <= 32 as ONE tile-fused launch (csrc/attnvb.hip); False = dvf GEMM + depthwise backward + dv GEMM
+RECOMPUTE_PRE = True           # C <= 32: qkv_pre / gpre (the depthwise inputs) are not written by the forward; uir_dwln_bwd recomputes its centre values (XP = NULL)
 FUSE_VALUE_BWD_64 = True       # the same at level 2 (C = 64: 8 x 8 tiles, channels in two chunks); False = two Grams + two contractions + the depthwise backward
 FUSE_LN_BWD = True             # deep levels (C = 64 / 128): LayerNorm backward as the epilogue of the dt1 / dt2 contraction (UIR_EPI_LN_BWD); False = uir_layernorm_bwd launches
 GRAM_SLAB_CAP = True           # see Recorder._chunks
@@ -915,16 +917,17 @@ class Recorder:
         a.T2 = _ptr(T2) if T2 is not None else None
         a.stats = _ptr(stats) if stats is not None else None
         a.ldx, a.ldy = _ld(X), _ld(Y)
-        a.ldt = _ld(T1) if T1 is not None else 0
+        a.ldt = _ld(T2) if T2 is not None else 0
         a.B, a.H, a.Wd = dims
         a.C, a.h, a.hp = C_, h, hp
         a.ln_eps = eps
         a.il = il
         rows = dims[0] * dims[1] * dims[2]
         assert X.shape[0] == rows and C_ in (16, 32, 64, 128) and hp % 16 == 0 and hp >= h
-        assert (T1 is None) == (T2 is None) and (T1 is None or (_ld(T1) == _ld(T2) and _ld(T1) >= 2 * hp))
+        # T2 alone: the backward recomputes the pre-depthwise tensor (C <= 32, uir_dwln_bwd with XP = None)
+        assert (T1 is None or T2 is not None) and (T2 is None or _ld(T2) >= 2 * hp) and (T1 is None or _ld(T1) == _ld(T2))
         self.keep.append(a)
-        stored = 0 if T1 is None else 16 * hp
+        stored = (8 * hp if T1 is not None else 0) + (8 * hp if T2 is not None else 0)
         self._op(name, lib.uir_gdfn_fwd, C.byref(a), nbytes=rows * (12 * C_ + stored),
                  flops=rows * (2 * C_ * 2 * hp + 18 * 2 * hp + 2 * hp * C_))
 
@@ -942,7 +945,7 @@ class Recorder:
         a.X, a.ln_g, a.ln_b, a.Wqkv, a.Wdw, a.Ypre, a.Y = (_ptr(X), _ptr(ln[0]), _ptr(ln[1]), _ptr(Wqkv), _ptr(Wdw),
                                                             _ptr(Ypre), _ptr(Y))
         a.stats = _ptr(stats) if stats is not None else None
-        a.ldx, a.ldp, a.ldq = _ld(X), _ld(Ypre), _ld(Y)
+        a.ldx, a.ldp, a.ldq = _ld(X), (_ld(Ypre) if Ypre is not None else 0), _ld(Y)       # Ypre None: not stored (uir_dwln_bwd recomputes it)
         a.B, a.H, a.Wd = dims
         a.C = C_
         a.ln_eps = eps
@@ -961,7 +964,7 @@ class Recorder:
                 for off, t, n in ((0, gram_out[0], C_ * C_), (C_ * C_, gram_out[1], C_), (C_ * C_ + C_, gram_out[2], C_)):
                     pend.append((name, base + 4 * off, tpi, stride, _ptr(t) + 4 * b * n, n))
         self.keep.append(a)
-        self._op(name, lib.uir_qkv_fwd, C.byref(a), nbytes=rows * 4 * (C_ + 6 * C_), flops=rows * (2 * C_ * 3 * C_ + 18 * 3 * C_))
+        self._op(name, lib.uir_qkv_fwd, C.byref(a), nbytes=rows * 4 * (C_ + (6 if Ypre is not None else 3) * C_), flops=rows * (2 * C_ * 3 * C_ + 18 * 3 * C_))
         if pend:
             self._reduce_batch(name + ".gram.red", pend, self.lane)
 
@@ -1015,7 +1018,7 @@ class Recorder:
         a = L.DwLnBwdArgs()
         a.G, a.XP, a.Wdw, a.W1, a.X, a.stats = _ptr(G), _ptr(XP), _ptr(Wdw), _ptr(W1), _ptr(X), _ptr(stats)
         a.gamma, a.beta, a.dRes, a.dX = _ptr(gamma), _ptr(beta), _ptr(dRes), _ptr(dX)
-        a.ldg, a.ldp, a.ldx, a.ldr, a.ldo = _ld(G), _ld(XP), _ld(X), _ld(dRes), _ld(dX)
+        a.ldg, a.ldp, a.ldx, a.ldr, a.ldo = _ld(G), (_ld(XP) if XP is not None else 0), _ld(X), _ld(dRes), _ld(dX)     # XP None: recomputed on chip
         a.B, a.H, a.Wd, a.C, a.h, a.hp, a.ch = B, H, W, C_, h, hp, ch
         a.il = il
         tiles = B * ((H + 7) // 8) * ((W + 15) // 16)
@@ -1027,7 +1030,7 @@ class Recorder:
         self.keep.append(a)
         rows = B * H * W
         cols = 2 * hp if hp else ch
-        self._op(name, lib.uir_dwln_bwd, C.byref(a), nbytes=4 * rows * (2 * cols + 3 * C_),
+        self._op(name, lib.uir_dwln_bwd, C.byref(a), nbytes=4 * rows * ((2 if XP is not None else 1) * cols + 3 * C_),
                  flops=rows * (36 * cols + 4 * cols * C_), variant="uir_dwln_bwd_kernel<*>")
         sp = slab.data_ptr()
         with self.bulk():
@@ -1263,13 +1266,15 @@ class Plan(Recorder):
         # (tools/probes/vmem/halfline: 3.5 vs 5-6.5 TB/s).  The deep levels' separate kernels keep the split layout.
         il = 1 if (C_ <= 32 and hp <= 96 and M % 128 == 0) else 0
         stats1, stats2 = self.alloc(M, 2), self.alloc(M, 2)
-        qkv_pre, qkv = self.alloc(M, 3 * C_), self.alloc(M, 3 * C_)
+        # C <= 32: the pre-depthwise tensors are not kept - uir_dwln_bwd recomputes the values it needs from the LayerNorm'd tile it holds anyway
+        recompute_pre = RECOMPUTE_PRE and C_ <= 32
+        qkv_pre, qkv = (None if recompute_pre else self.alloc(M, 3 * C_)), self.alloc(M, 3 * C_)
         gbuf = self.alloc(B * C_ * C_ + 2 * B * C_)
         Gm, sqq, sqk = gbuf[:B * C_ * C_], gbuf[B * C_ * C_:B * C_ * C_ + B * C_], gbuf[B * C_ * C_ + B * C_:]
         Pm = self.alloc(C_, C_)
         attn, WA, WB = self.alloc(B * C_ * (C_ // heads)), self.alloc(B, C_ * C_), self.alloc(B, C_ * C_)
         u, vf, x1 = self.alloc(M, C_), self.alloc(M, C_), self.alloc(M, C_)
-        gpre, g = self.alloc(M, ldg)[:, :2 * hp], self.alloc(M, ldg)[:, :2 * hp]
+        gpre, g = (None if recompute_pre else self.alloc(M, ldg)[:, :2 * hp]), self.alloc(M, ldg)[:, :2 * hp]
         y = self.alloc(M, C_) if y_out is None else y_out
         assert tuple(y.shape) == (M, C_)
         q_, k_, v_ = qkv[:, :C_], qkv[:, C_:2 * C_], qkv[:, 2 * C_:]
