@@ -586,10 +586,23 @@ def record_conv3x3(rec: Recorder, name: str, x: torch.Tensor, Wt, bias, Cin: int
             rec.conv3x3_dx_from_patches(name + ".dX", dy, Wt, dx, Cin, Cout, dims)
             return dx
         return y, backward_p
+    # plain convolutions with >= 32 channels on both sides (the samplers between the levels that the patch form above does not take): the
+    # split-bf16 implicit GEMMs of csrc/conv3b.hip, per direction where its contract holds (engine.Recorder._conv3 does the same for UpSample1)
+    plain = Kp is None and Np is None and act == L.ACT_NONE and bias is None and k_grp == (0, 0) and n_grp == (0, 0)
+    want_bw = getattr(rec, "want_backward", True)
+    split_f = plain and rec.conv3_split_ok(Cout, Cin, dims)
+    split_b = plain and want_bw and need_dx and rec.conv3_split_ok(Cin, Cout, dims)
+    split_w = plain and want_bw and rec.conv3_split_wgrad_ok(Cout, Cin, dims)
+    pf = pb = None
+    if split_f or split_b:
+        pf, pb = rec.conv3_wsplit(name + ".wsplit", Wt, Cout, Cin, want_bwd=split_b)
     Kp, Np = Kp or Cin, Np or Cout
     y = rec.alloc(M, Np)
-    rec.gemm(name, x, Wt, y, N=Np, K=Kp, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=dims[1:], k_grp=k_grp, n_grp=n_grp, bias=bias, act=act,
-             slope=slope)
+    if split_f:
+        rec.conv3_split(name, x, pf, y, N=Cout, K=Cin, dims=dims)
+    else:
+        rec.gemm(name, x, Wt, y, N=Np, K=Kp, w_sn=Cin * 9, w_sk=9, w_st=1, taps=9, hw=dims[1:], k_grp=k_grp, n_grp=n_grp, bias=bias, act=act,
+                 slope=slope)
 
     def backward(dy, dW, db):
         if act == L.ACT_LEAKY:                       # y = leaky(z): dz from the stored output
@@ -599,7 +612,10 @@ def record_conv3x3(rec: Recorder, name: str, x: torch.Tensor, Wt, bias, Cin: int
                     nbytes=12 * M * Np)
             dy = dz
         with rec.bulk():
-            rec.gram(name + ".dW", dy, x, dW, N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:], n_grp=n_grp, k_grp=k_grp)
+            if split_w:
+                rec.conv3_split_wgrad(name + ".dW", dy, x, dW, N=Cout, K=Cin, dims=dims)
+            else:
+                rec.gram(name + ".dW", dy, x, dW, N=Np, K=Kp, o_sn=Cin * 9, o_sk=9, o_st=1, taps=9, hw=dims[1:], n_grp=n_grp, k_grp=k_grp)
             if db is not None:
                 if Cout <= 256:
                     rec.colsum(name + ".db", dy, 0, Cout, db)
@@ -608,7 +624,10 @@ def record_conv3x3(rec: Recorder, name: str, x: torch.Tensor, Wt, bias, Cin: int
         if not need_dx:
             return None
         dx = rec.alloc(M, Kp)
-        rec.gemm(name + ".dX", dy, Wt, dx, N=Kp, K=Np, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=dims[1:], n_grp=k_grp, k_grp=n_grp)
+        if split_b:
+            rec.conv3_split(name + ".dX", dy, pb, dx, N=Cin, K=Cout, dims=dims)
+        else:
+            rec.gemm(name + ".dX", dy, Wt, dx, N=Kp, K=Np, w_sn=9, w_sk=Cin * 9, w_st=1, taps=9, flip=1, hw=dims[1:], n_grp=k_grp, k_grp=n_grp)
         return dx
     return y, backward
 
