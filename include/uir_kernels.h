@@ -240,8 +240,9 @@ int uir_dwconv_bwd_fused(const UirDwBwdArgs* args, void* stream);
  *   Y = X + W_out . ( gelu(dw3x3(W_in . LN(X))[:h]) * dw3x3(W_in . LN(X))[h:] )
  * One pass over the pixels instead of project_in -> conv -> gate/project_out as three kernels.
  * Replaces SpectralTransformer.py:127-130 (GDFN.forward) together with norm2 and the residual
- * add of :147-148.  T1/T2 (both or neither): the pre-/post-depthwise tensors the backward
- * kernels read, x1 half at column c, x2 half at column hp + c, pad columns c in [h, hp) zero. */
+ * add of :147-148.  T1 / T2: the pre- / post-depthwise tensors the backward kernels read (both, T2 alone, or neither): x1 half at
+ * column c, x2 half at column hp + c, pad columns c in [h, hp) zero.  T2 alone (round 5, what the C <= 32 train step passes): the
+ * pre-depthwise tensor is not kept - uir_dwln_bwd (XP = NULL) recomputes the values it needs. */
 typedef struct UirGdfnFwdArgs {
   const float* X;      /* [B*H*W][ldx] block input (also the residual), float4-aligned rows     */
   const float* ln_g;   /* norm2 gamma[C], beta[C] (16-B aligned)                                 */
@@ -250,7 +251,7 @@ typedef struct UirGdfnFwdArgs {
   const float* Wdw;    /* conv        [2h][1][3][3]                                              */
   const float* Wout;   /* project_out [C][h]                                                     */
   float* Y;            /* [B*H*W][ldy]                                                           */
-  float* T1;           /* optional [B*H*W][ldt]                                                  */
+  float* T1;           /* optional [B*H*W][ldt] (only together with T2)                          */
   float* T2;           /* optional [B*H*W][ldt]                                                  */
   float* stats;        /* optional [B*H*W][2] = (mean, rstd) of norm2 for the backward           */
   int ldx, ldy, ldt;
@@ -274,7 +275,7 @@ typedef struct UirQkvFwdArgs {
   const float* ln_b;
   const float* Wqkv;   /* qkv      [3C][C]   (16-B aligned)                                       */
   const float* Wdw;    /* qkv_conv [3C][1][3][3]                                                  */
-  float* Ypre;         /* [B*H*W][ldp] pre-depthwise                                              */
+  float* Ypre;         /* [B*H*W][ldp] pre-depthwise, or NULL: not stored (uir_dwln_bwd, XP = NULL, recomputes it) */
   float* Y;            /* [B*H*W][ldq] q | k | v                                                  */
   float* stats;        /* optional [B*H*W][2] = (mean, rstd) of norm1 for the backward            */
   int ldx, ldp, ldq;
@@ -347,7 +348,9 @@ int uir_attnv_bwd_rows_c(int H, int Wd, int C);   /* host helper: slab rows per 
  * CHreal = 2h or ch; uir_reduce_slab sums the nblocks rows.  Every workgroup writes its whole row. */
 typedef struct UirDwLnBwdArgs {
   const float* G;      /* [B*H*W][ldg] gradient of the depthwise output, float4-aligned rows                 */
-  const float* XP;     /* [B*H*W][ldp] depthwise input saved by the forward (same column layout as G)         */
+  const float* XP;     /* [B*H*W][ldp] depthwise input saved by the forward (same column layout as G), or NULL */
+                       /* (round 5): the kernel recomputes its centre values LN(X) . W1^T per 32-channel chunk  */
+                       /* (one f32 MFMA tile per wave from the tile it normalises anyway); ldp is ignored then */
   const float* Wdw;    /* [CHreal][9]                                                                       */
   const float* W1;     /* [CHreal][C]                                                                       */
   const float* X;      /* [B*H*W][ldx] LayerNorm input                                                      */
