@@ -203,9 +203,10 @@ __device__ __forceinline__ void mix_weights(const float* w, float& w1, float& w2
 }
 
 // Per-wave LDS: the head's bias table, the table-gradient accumulator, the per-query softmax statistics and the tokens' regions.
+constexpr int NACC = 4;   // table-gradient accumulators per wave (backward): see the table section of winattn_bwd_kernel
 struct WaveLds {
   float tab[TABP];
-  float tacc[TABP];
+  float tacc[NACC][TABP];
   float mx[NT], inv[NT], sp[NT];
   int regs[NT];
 };
@@ -297,7 +298,8 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_kernel(const UirWinAttnArg
   make_geo(a, win, lane, g, L.regs);
   for (int t = lane; t < TABP; t += 64) {
     L.tab[t] = t < NTAB ? a.table[t * a.heads + h] : 0.f;
-    L.tacc[t] = 0.f;
+#pragma unroll
+    for (int e = 0; e < NACC; ++e) L.tacc[e][t] = 0.f;
   }
   float w1, w2;
   mix_weights(a.w, w1, w2);
@@ -342,16 +344,26 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_kernel(const UirWinAttnArg
       d1[r] = fmaf(w1i * __expf(s1[r] - mx), d1[r] - sp, w2 * d1[r] * 2.f * r1);
     }
     {  // relative-position-bias table: entry (yi - yj + 7) * 15 + (xi - xj + 7) collects dS over the pairs with that offset.  Inside one
-       // instruction the 32 active lanes are 32 different queries against one key: distinct entries, no collision, fixed order.
+       // instruction the 32 active lanes are 32 different queries against one key: distinct entries, no collision, fixed order - so a
+       // plain read / add / write is enough, and LDS instructions of a wave execute in order.  (As ds_add_f32 the 128 adds per item
+       // held the CU's LDS pipe ~90 cycles each: 78 % busy, 39 % of the wave-cycles waiting on it - tools/pmc_winattn.sh.)  The four
+       // registers of a key row go to FOUR accumulator tables: four independent round trips per wait instead of one.
       const int yi = qt * 4 + (g.l32 >> 3), xi = g.l32 & 7;
-      float* tb = L.tacc + ((yi + 7) * RP + xi + 7 - g.half * 4);
+      const int tbo = (yi + 7) * RP + xi + 7 - g.half * 4;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         if (g.half == hh) {
 #pragma unroll
           for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) atomicAdd(&tb[-((kt * 4 + r / 4) * RP + (r % 4))], kt ? d1[r] : d0[r]);
+            for (int rq = 0; rq < 4; ++rq) {
+              float t[NACC];
+#pragma unroll
+              for (int e = 0; e < NACC; ++e) t[e] = L.tacc[e][tbo - ((kt * 4 + rq) * RP + e)];
+#pragma unroll
+              for (int e = 0; e < NACC; ++e) L.tacc[e][tbo - ((kt * 4 + rq) * RP + e)] = t[e] + (kt ? d1[4 * rq + e] : d0[4 * rq + e]);
+              phase();                                                    // the next group's reads stay behind these writes
+            }
         }
         lds_wait();
       }
@@ -376,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void winattn_bwd_kernel(const UirWinAttnArg
   lds_wait();
   {
     float* tb = a.dtable_slab + (long)win * (NTAB * a.heads);
-    for (int t = lane; t < NTAB; t += 64) tb[t * a.heads + h] = L.tacc[t];
+    for (int t = lane; t < NTAB; t += 64) tb[t * a.heads + h] = (L.tacc[0][t] + L.tacc[1][t]) + (L.tacc[2][t] + L.tacc[3][t]);
   }
 
   // ---- orientation 2: register <-> query, lane <-> key of tile kt.  dK_j = scale * sum_i dS_ij q_i,  dV_j = sum_i P_ij dO_i ----
