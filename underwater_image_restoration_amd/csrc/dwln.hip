@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-    float bv[RC ? C / 2 : 1];                                // RC: LayerNorm output of this lane's (pixel, n) slots, the B operand of the XP recompute
+    UirBf3 bvp[RC ? C / 16 : 1];                             // RC: LayerNorm output of this lane's (pixel, n) slots as bf16 planes, the B operand of the XP recompute
 
 #pragma unroll 1
     for (int ci = 0; ci < NCH; ++ci) {
@@ -349,30 +349,33 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       f32x16 xd;
       if constexpr (RC) {
         // XP tile of this wave: D[chunk channel r][pixel q] = sum_n W1s[r][n] (xhat[n][pixel q] gamma[n] + beta[n]); MFMA column q = li is the
-        // pixel (row li >> 2, column 4 wave + (li & 3)) - the walk's pixels of this wave; k slot (step s, half h2) is n = (C / 2) h2 + s, so a lane's
-        // A values are C / 2 consecutive floats of its W1s row.  Every wave is past (c) / (d) of the previous chunk (the barrier above): Gs is free
+        // pixel (row li >> 2, column 4 wave + (li & 3)) - the walk's pixels of this wave.  Every wave is past (c) / (d) of the previous chunk (the
+        // barrier above): Gs is free
         const int pix = (li >> 2) * T::TW + 4 * wave + (li & 3);
-        const float* ap = W1s + li * T::SW + (C / 2) * h2;
-        const float* bp = XH + (C / 2) * h2 * T::SXT + pix;
-        const float* gb = GB + C * h2;
-        float av[C / 2];
+        // split-bf16 (three planes per operand, six products, f32-accurate: uir_common.h): the f32 MFMA keeps the SIMD's VALU from issuing while it
+        // runs and this kernel is bound by the sum of the two; the bf16 MFMA runs beside the VALU.  k slot t of step s is n = 16 s + 8 (t / 4) +
+        // 4 h2 + t % 4 for both operands: a lane's A values of a step are two float4 of its W1s row
+        if (ci == 0) {                                       // the B operand is the tile's, not the chunk's: split once, kept across the chunk loop
 #pragma unroll
-        for (int j = 0; j < C / 8; ++j) {
-          const f32x4v v = *reinterpret_cast<const f32x4v*>(ap + 4 * j);
+          for (int s2 = 0; s2 < C / 16; ++s2) {
+            float xb[8];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) av[4 * j + e] = v[e];
-        }
-        if (ci == 0) {                                       // the B operand is the tile's, not the chunk's: C / 2 registers across the chunk loop
-#pragma unroll
-          for (int s2 = 0; s2 < C / 2; ++s2) {
-            const float2 g2 = *reinterpret_cast<const float2*>(gb + 2 * s2);
-            bv[s2] = fmaf(bp[s2 * T::SXT], g2.x, g2.y);
+            for (int t = 0; t < 8; ++t) {
+              const int n = 16 * s2 + 8 * (t >> 2) + 4 * h2 + (t & 3);
+              const float2 g2 = *reinterpret_cast<const float2*>(GB + 2 * n);
+              xb[t] = fmaf(XH[n * T::SXT + pix], g2.x, g2.y);
+            }
+            bvp[s2] = uir_split8(xb);
           }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) xd[r] = 0.f;
+        const float* ap = W1s + li * T::SW + 4 * h2;
 #pragma unroll
-        for (int s2 = 0; s2 < C / 2; ++s2) xd = uir_mfma(av[s2], bv[s2], xd);
+        for (int s2 = 0; s2 < C / 16; ++s2) {
+          const f32x4v a0 = *reinterpret_cast<const f32x4v*>(ap + 16 * s2), a1 = *reinterpret_cast<const f32x4v*>(ap + 16 * s2 + 8);
+          xd = uir_mfma_split(uir_split8(make_float4(a0[0], a0[1], a0[2], a0[3]), make_float4(a1[0], a1[1], a1[2], a1[3])), bvp[s2], xd);
+        }
         // (stored to Gs below, behind the weight reads and the next unit's loads: the MFMA chain runs under them)
       }
       // issue order = need order (vmcnt retires in order): this chunk's 1x1 weights now (used after the walk); the next chunk's
