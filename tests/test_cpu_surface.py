@@ -420,3 +420,35 @@ def test_upsampler_convolutions_take_the_split_bf16_kernels():
         assert f2["ups_1.Sups"] == "uir_gemm" and "ups_1.Sups.wsplit" not in f2
     finally:
         E.CONV3_SPLIT = old
+
+
+def test_narrow_blocks_keep_no_pre_depthwise_tensor():
+    """C <= 32 blocks (full resolution and level 1): uir_qkv_fwd / uir_gdfn_fwd get NULL for their pre-depthwise outputs and uir_dwln_bwd NULL for XP
+    (it recomputes the centre values); the deep levels (C = 64 / 128: separate depthwise backward launches) keep theirs.  engine.RECOMPUTE_PRE False
+    restores the stored tensors, and the plan's memory estimate bounds both."""
+    import ctypes as C
+    from underwater_image_restoration_amd import Models, engine as E, _lib as L
+    m = Models.init_model("SpectralTransformer")
+
+    def args_of(plan, ops, name, typ):
+        fn, a, _label = next(o for o, mm in zip(ops, plan.meta[id(ops)]) if mm[0] == name)
+        return C.cast(a[0], C.POINTER(typ)).contents
+
+    plan = E.Plan(m._ensure_flat("cpu"), 1, 128, 128)
+    for blk, narrow in (("encoders.0.0", True), ("encoders.1.0", True), ("refinement.3", True), ("encoders.2.0", False), ("encoders.3.1", False)):
+        q = args_of(plan, plan.fwd, blk + ".qkv+conv", L.QkvFwdArgs)
+        g = args_of(plan, plan.fwd, blk + ".gdfn", L.GdfnFwdArgs)
+        assert bool(q.Ypre) == (not narrow) and bool(g.T1) == (not narrow) and bool(g.T2) and bool(q.Y), blk
+        if narrow:
+            for which in (".ffn_dwln_bwd", ".qkv_dwln_bwd"):
+                d = args_of(plan, plan.bwd, blk + which, L.DwLnBwdArgs)
+                assert not d.XP and d.ldp == 0 and bool(d.G), blk + which
+    old = E.RECOMPUTE_PRE
+    try:
+        E.RECOMPUTE_PRE = False
+        plan2 = E.Plan(m._ensure_flat("cpu"), 1, 128, 128)
+        assert bool(args_of(plan2, plan2.fwd, "encoders.0.0.qkv+conv", L.QkvFwdArgs).Ypre)
+        assert bool(args_of(plan2, plan2.bwd, "encoders.0.0.qkv_dwln_bwd", L.DwLnBwdArgs).XP)
+        assert plan2.bytes > plan.bytes + 128 * 128 * 4 * 1000          # > 1000 floats per full-resolution pixel fewer are kept
+    finally:
+        E.RECOMPUTE_PRE = old
