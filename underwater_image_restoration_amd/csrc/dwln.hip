@@ -497,11 +497,21 @@ __global__ __launch_bounds__(256, 2) void uir_dwln_bwd_kernel(const UirDwLnBwdAr
       // ---- (c) dT += dP chunk . W1 chunk (row tile = wave) ----
       {
         const float* gr = Gs + (wave * 32 + li) * T::SG + 4 * h2;
+        if constexpr (RC) {
+          // split-bf16 (see the XP tile above): k slot t of step s2 is channel 16 s2 + 8 (t / 4) + 4 h2 + t % 4 = w1v[8 s2 + t]
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            const f32x4v a0 = *reinterpret_cast<const f32x4v*>(gr + 16 * s2), a1 = *reinterpret_cast<const f32x4v*>(gr + 16 * s2 + 8);
+            const float wb[8] = {w1v[8 * s2], w1v[8 * s2 + 1], w1v[8 * s2 + 2], w1v[8 * s2 + 3], w1v[8 * s2 + 4], w1v[8 * s2 + 5], w1v[8 * s2 + 6], w1v[8 * s2 + 7]};
+            acc = uir_mfma_split(uir_split8(make_float4(a0[0], a0[1], a0[2], a0[3]), make_float4(a1[0], a1[1], a1[2], a1[3])), uir_split8(wb), acc);
+          }
+        } else {
 #pragma unroll
         for (int jj = 0; jj < 4; ++jj) {
           const f32x4v v = *reinterpret_cast<const f32x4v*>(gr + 8 * jj);
 #pragma unroll
           for (int e = 0; e < 4; ++e) acc = uir_mfma(v[e], w1v[4 * jj + e], acc);
+        }
         }
       }
       UIR_ST(6);
