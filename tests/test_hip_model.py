@@ -2,6 +2,7 @@
 oracle (oracle/cpu_ref.py, fp64 and fp32) and the golden vectors recorded from the reference
 (tests/golden/*.npz).  north_star tolerance: 1e-3 relative fp32; observed errors are printed."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -744,3 +745,26 @@ def test_fused_train_step_with_the_fflmix_loss_equals_the_autograd_path():
     finally:
         perceptual._weights_sd = None
         perceptual._VggPlan._cache.clear()
+
+
+@pytest.mark.gpu
+def test_train_trajectory_with_the_split_bf16_kernels_switched_off():
+    """UIR_FUSED_SPLIT=0 (knobs.py): every contraction of the step on the f32 MFMA - the C <= 32 blocks then KEEP their pre-depthwise tensors
+    (uir_dwln_bwd with a stored XP), the value path's backward runs as three launches, the samplers' convolutions on the nine-tap kernels.  The
+    variable is read once per process: the reference trajectory of BASELINE config 1 (test_train_trajectory_cfg1_vs_reference) in a child."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_hip_model.py"), "-m", "gpu", "-x", "-q", "-k",
+                          "test_train_trajectory_cfg1_vs_reference or test_transformer_block_vs_oracle"],
+                         env=dict(os.environ, UIR_FUSED_SPLIT="0"), capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "from underwater_image_restoration_amd import Models, engine as E\n"
+            "m = Models.init_model('SpectralTransformer').to('cuda')\n"
+            "plan = E.Plan(m._ensure_flat('cuda'), 1, 64, 64)\n"
+            "names = [mm[0] for mm in plan.meta[id(plan.bwd)]]\n"
+            "assert 'encoders.0.0.value_bwd' not in names and 'encoders.0.0.dvf+dWB' in names, names[:40]\n"
+            "print('KNOB0-PLAN-OK')\n" % root)
+    o2 = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UIR_FUSED_SPLIT="0"), capture_output=True, text=True, timeout=300)
+    assert "KNOB0-PLAN-OK" in o2.stdout, o2.stdout[-2000:] + o2.stderr[-2000:]

@@ -699,6 +699,7 @@ UIR_ST_EXPORT
 
 extern "C" int uir_dwln_bwd(const UirDwLnBwdArgs* p, void* stream) {
   const UirDwLnBwdArgs& a = *p;
+  UIR_REQUIRE(a.XP || uir_fused_split() != 0);      // the recompute of XP runs on split-bf16 MFMA (UIR_FUSED_SPLIT=0: pass the stored tensor)
   UIR_REQUIRE(a.G && a.Wdw && a.W1 && a.X && a.stats && a.gamma && a.beta && a.dRes && a.dX && a.slab);
   UIR_REQUIRE(a.B > 0 && a.H > 0 && a.Wd > 0 && a.nblocks > 0 && (a.C == 16 || a.C == 32));
   UIR_REQUIRE((a.ldg & 3) == 0 && (a.ldx & 3) == 0 && uir_aligned16(a.G) && uir_aligned16(a.X) && (a.ldx >= a.C) && a.ldr >= a.C && a.ldo >= a.C);

@@ -1267,7 +1267,7 @@ class Plan(Recorder):
         il = 1 if (C_ <= 32 and hp <= 96 and M % 128 == 0) else 0
         stats1, stats2 = self.alloc(M, 2), self.alloc(M, 2)
         # C <= 32: the pre-depthwise tensors are not kept - uir_dwln_bwd recomputes the values it needs from the LayerNorm'd tile it holds anyway
-        recompute_pre = RECOMPUTE_PRE and C_ <= 32
+        recompute_pre = RECOMPUTE_PRE and C_ <= 32 and knobs.flag("UIR_FUSED_SPLIT")       # (the recompute runs on split-bf16 MFMA: knob 0 keeps the tensors)
         qkv_pre, qkv = (None if recompute_pre else self.alloc(M, 3 * C_)), self.alloc(M, 3 * C_)
         gbuf = self.alloc(B * C_ * C_ + 2 * B * C_)
         Gm, sqq, sqk = gbuf[:B * C_ * C_], gbuf[B * C_ * C_:B * C_ * C_ + B * C_], gbuf[B * C_ * C_ + B * C_:]

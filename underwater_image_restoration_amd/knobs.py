@@ -21,7 +21,9 @@ KNOBS = {
                         "operand, 6 products, f32-accurate: csrc/uir_common.h) - the tile-fused forwards uir_gdfn_fwd / uir_qkv_fwd / uir_attnv_fwd in "
                         "registers, the deep levels' contractions on csrc/tsgemm.hip (uir_ts_gemm declines when 0, so every plain contraction with "
                         "4 096 - 65 536 rows moves to csrc/gemm.hip; with it the LayerNorm-backward epilogue UIR_EPI_LN_BWD), the 3 x 3 convolutions of "
-                        "csrc/conv3b.hip and the weight-gradient Grams of csrc/gramb.hip; 0 = everything on the f32 MFMA (the arithmetic of rounds 1-3)",
+                        "csrc/conv3b.hip, the weight-gradient Grams of csrc/gramb.hip, the one-launch value-path backward of csrc/attnvb.hip and the recompute of "
+                        "the pre-depthwise values inside uir_dwln_bwd (with 0 the C <= 32 blocks keep those tensors and the value path runs as three "
+                        "launches); 0 = everything on the f32 MFMA (the arithmetic of rounds 1-3)",
                         "tests/test_hip_kernels.py::test_fused_kernels_agree_between_split_bf16_and_f32_mfma"),
     "UIR_MIXED": ("0", "read by libuir_hip.so: bf16 | fp16 = MIXED precision - every plain Linear contraction with >= 64 input channels, >= 64 outputs and "
                   ">= 256 rows (csrc/gemm.hip routes them all to csrc/tiled.hip in this mode: the Linear layers of AST / NewBigFRFNModel "
