@@ -1394,7 +1394,7 @@ def test_gemm_tall_skinny_gate_and_leaky_epilogues(C, rows):
     assert e(dmid, want) < 3e-6
 
 
-@pytest.mark.parametrize("case", ["kc", "ic", "kgrp", "batched", "residual", "ragged", "n64"])
+@pytest.mark.parametrize("case", ["kc", "ic", "kgrp", "batched", "residual", "ragged", "n64", "narrow_long"])
 def test_gemm_tall_skinny_split(case):
     """uir_gemm sends the plain contractions of the deep U-Net levels (4 096 .. 65 536 rows, K, N >= 64; SpectralTransformer.py:81-83,
     86,90,122,125 at C = 64 / 128) to uir_ts_gemm: 64- / 128-row tiles, both operands split into three bf16 planes, six products.
@@ -1442,6 +1442,12 @@ def test_gemm_tall_skinny_split(case):
     elif case == "ragged":
         M, K, N = 5000, 68, 84            # K, N multiples of 4 only
         x, w = rn(M, 72)[:, :K], rn(K, N) * K ** -0.5
+        ref = x @ w
+        args = dict(N=N, K=K, w_sn=1, w_sk=N)
+        Wd = dev(w)
+    elif case == "narrow_long":          # a module network's Linear input gradient: 131 072 tokens, 256 -> 64 (beyond the deep levels' row window)
+        M, K, N = 131072, 256, 64
+        x, w = rn(M, K), rn(K, N) * K ** -0.5
         ref = x @ w
         args = dict(N=N, K=K, w_sn=1, w_sk=N)
         Wd = dev(w)

@@ -395,7 +395,10 @@ int uir_ts_gemm(const UirGemmArgs& a, void* stream) {
   if (a.bias && !uir_aligned16(a.bias)) return -1;
   const long rows = (long)a.M * a.batches;
   // the deep levels: few rows (an under-filled chip on the panel kernel), contractions long enough to pay for the operand splits
-  if (rows < 4096 || rows > 65536 || a.M < 256 || a.K < 64 || a.N < 64 || (a.N & 3) || (a.K & 3)) return -1;
+  // ... and, on any number of rows, long contractions into fewer than 128 columns (the module networks' Linear input gradients, 512 -> 64 on 524 288
+  // tokens): csrc/tiled.hip takes N >= 128 only and the panel kernel runs them at ~60 TFLOP/s of f32 MFMA against 2.2 TB/s of operands
+  const bool narrow_long = a.N < 128 && a.K >= 256 && a.batches == 1 && rows < (1L << 22);
+  if (rows < 4096 || (rows > 65536 && !narrow_long) || a.M < 256 || a.K < 64 || a.N < 64 || (a.N & 3) || (a.K & 3)) return -1;
   const bool bkc = a.w_sk == 1 && (a.w_sn & 3) == 0, bic = a.w_sn == 1 && (a.w_sk & 3) == 0;
   if (!bkc && !bic) return -1;
   if (a.k_grp_pad > 0 && (!bic || (a.K % a.k_grp_pad) != 0)) return -1;
