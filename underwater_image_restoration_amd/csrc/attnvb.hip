@@ -1,5 +1,5 @@
 // uir_attnv_bwd: the backward of MDTA's pixel-sized tail (uir_attnv_fwd:  u = v . WA[b]^T,  vf = dw3x3(u),  x1 = vf . WB[b]^T + x;
-// SpectralTransformer.py:100,107,110,113 under autograd) in ONE pass over the pixels, C = 16 / 32:
+// SpectralTransformer.py:100,107,110,113 under autograd) in ONE pass over the pixels, C = 16 / 32 (below) and C = 64 (uir_attnv_bwd64_kernel):
 //
 //   dvf = dx1 . WB[b]        du = dw3x3^T(dvf)        dv = du . WA[b]                              the value path's input gradient
 //   dWB[b][i][j] = sum_p dx1[p][i] vf[p][j]       dWA[b][j][o] = sum_p du[p][j] v[p][o]            per-sample C x C gradients (uir_attn_bwd reads them)
@@ -15,7 +15,7 @@
 //   (c) dv = du . WA         split-bf16 MFMA, stored from the accumulators
 //   (d) the two per-sample Grams on the f32 MFMA, a quarter of the tile's pixels per wave (operands read from LDS one value per lane:
 //       lane = channel, k slot = pixel, the layout of uir_qkv_fwd's logit Gram)
-// Pixels outside the image get dvf := 0 (the zero padding of the forward convolution).  H % 8 == 0, W % 16 == 0.
+// Pixels outside the image get dvf := 0 (the zero padding of the forward convolution).  H % 8 == 0, W % 16 == 0 (C = 64: W % 8 == 0).
 #include "uir_common.h"
 #include "../../include/uir_kernels.h"
 

@@ -18,7 +18,11 @@
 //   (b) transposed depthwise 3x3 from LDS with the rotating three-row register window of uir_gdfn_fwd (packed f32 over the
 //       channel pair); the SAME window elements times the centre XP value give the 9 depthwise weight-gradient terms;
 //       dP chunk -> LDS; the weight-gradient terms are summed over the wave's four strips by shuffles, over waves through LDS
-//   (c) dT += dP chunk . W1 chunk        v_mfma_f32_32x32x2_f32, one 32-pixel row tile per wave, accumulators live across chunks
+//   (a') XP = NULL (round 5, what the train step passes): the centre XP values of the walk are RECOMPUTED - one 32-channel x 32-pixel tile
+//       per wave (its own walk pixels) = W1 chunk . LayerNorm(xhat), split-bf16 MFMA, parked in the dP buffer at the element the same thread
+//       overwrites in (b); the forward then never writes the pre-depthwise tensor
+//   (c) dT += dP chunk . W1 chunk        one 32-pixel row tile per wave, accumulators live across chunks; split-bf16 MFMA in the XP = NULL
+//       variants (an f32 MFMA does not run beside the SIMD's VALU and this kernel is bound by the sum of the two), v_mfma_f32_32x32x2_f32 otherwise
 //   (d) dW1 chunk += dP^T . (LN output)  v_mfma_f32_16x16x4_f32: each wave owns one 16 x 16 granule of the chunk's 32 x C tile and
 //       contracts over the tile's pixels, so a wave keeps 4 accumulator registers per chunk across all its tiles
 // and the tile ends with the LayerNorm backward on the dT accumulators (channel on the lane: row means by xor-shuffles).

@@ -24,7 +24,9 @@
 // relative_position_index (:302-311) is evaluated from the token coordinates: in either orientation it is (a per-lane base) +- (a
 // compile-time constant of the register), i.e. an immediate LDS offset.  Backward writes dQ / dK / dV rows and per-(window, head)
 // partials of the bias-table and mixing-weight gradients (summed in fixed order by uir_reduce_slab(_batch); the table partial is
-// accumulated with LDS float adds whose addresses are distinct inside each instruction: order fixed, bitwise run-to-run).
+// accumulated with plain LDS read / add / write sequences - the addresses are distinct inside each instruction and a wave's LDS
+// instructions execute in order - on four wave-private tables, since round 5: order fixed, bitwise run-to-run; as ds_add_f32 they held
+// the LDS pipe 78 % of the launch).
 #include "uir_common.h"
 #include "../../include/uir_kernels.h"
 
