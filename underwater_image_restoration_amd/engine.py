@@ -149,7 +149,8 @@ def twiddles(n: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
     return _TWIDDLE_CACHE[key]
 
 
-_GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per Gram launch
+_GRAM_WGS = 512                # workgroups (= partial rows x column groups) per Gram launch (1 024 until the end of round 5: the bulk lane's Grams run BESIDE the chain's
+                               # kernels, and with half the workgroups they take less from them - 31.75 -> 31.1 ms together with BULK_DEFER 30 -> 45, profiles/r05/ab_notes.md u)
 # Cross-lane ordering costs the CHAIN: every event recorded on (or waited for by) the main stream is a barrier packet between two of
 # its kernels - 6-7 us of idle queue each (rocprofv3 kernel trace, tools/trace_gaps.py: 162 such gaps = 1.05 ms of a 36.4 ms step).
 # BULK_DEFER: weight-gradient (bulk lane) launches are held back on the host until this many chain launches have passed since the
@@ -157,7 +158,7 @@ _GRAM_WGS = 1024               # workgroups (= partial rows x column groups) per
 # join reads their results, so a later release is only more of the lag the lane already has).  0 = release at once.  Only where the
 # chain still has 2 x BULK_DEFER launches to go: held work released near the end of a list is a tail behind its last chain kernel (the
 # short per-module lists of NewBigFRFNModel / AST lost 2-5 % with an unconditional hold).
-BULK_DEFER = 30
+BULK_DEFER = 45                # (30 until the end of round 5; 43 - 47 measure the same, 40 and 50 are 0.2 - 0.3 ms slower: ab_notes.md u)
 FAST_LANE_EVENTS = True        # lane-ordering events without the system-scope fence (see _LaneEvent)
 SIDE_LOW_PRIORITY = True       # side lane on the least-priority stream torch offers (on this ROCm build priority_range() is (0, -1): the
                                # default priority - no difference was ever measured, nor with the chain on a priority -1 stream)
