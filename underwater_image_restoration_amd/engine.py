@@ -180,7 +180,8 @@ GRAM_SPLIT = True              # long 1x1 weight-gradient contractions with a na
 _CONV3B_WGS = 512              # workgroups of a uir_conv3x3_split_wgrad launch (two 6-wave workgroups per CU)
 _PLAIN_DW_WGS = 768            # workgroups of a GEMM with the fused per-sample Gram (EPI_PLAIN_DW): the resident set at 3 per CU
 GEMM_SLAB_ROWS = 512           # = UIR_GEMM_SLAB_ROWS of include/uir_kernels.h (max workgroups of the GEMMs with fused reductions)
-FUSED_DW_MINROWS = 16 * 128 * 128   # depthwise backward as ONE pass (dX + dW) from this many pixels on; below, two kernels on two lanes
+FUSED_DW_MINROWS = 16 * 32 * 32     # depthwise backward as ONE pass (dX + dW) from this many pixels on (every level of the headline step since the end of round 5:
+                               # -0.17 ms, profiles/r05/ab_notes.md v; 16 * 128 * 128 before); below, two kernels on two lanes
 _DFT2_CACHE: dict = {}
 
 
