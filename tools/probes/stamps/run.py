@@ -79,8 +79,9 @@ for split in (True, False):
     G, XP = rnd(M, cols), rnd(M, cols)
     dRes, stats = rnd(M, Cc), torch.stack([rnd(M) * 0.1, 1 + 0.1 * rnd(M)], 1).contiguous()
     dX, dWdw, dW1, dgb = r.alloc(M, Cc), r.alloc(chreal, 9), r.alloc(chreal, Cc), r.alloc(2 * Cc)
-    r.dwln_bwd("k", G, XP, rnd(chreal, 9), rnd(chreal, Cc), x, stats, g1, b1, dRes, dX, dWdw, dW1, dgb[:Cc], dgb[Cc:], C_=Cc, dims=dims,
-               h=hh, hp=hpp, ch=ch)
+    # the train step's form (round 5): XP = None (centre values recomputed), the GDFN tensors chunk-interleaved; STAMPS_XP=1: the stored-XP form
+    r.dwln_bwd("k", G, XP if os.environ.get("STAMPS_XP") == "1" else None, rnd(chreal, 9), rnd(chreal, Cc), x, stats, g1, b1, dRes, dX, dWdw, dW1, dgb[:Cc], dgb[Cc:],
+               C_=Cc, dims=dims, h=hh, hp=hpp, ch=ch, il=1 if split else 0)
     _, args, _ = r.fwd[0]
     print(f"uir_dwln_bwd C={Cc} {S}x{S} {'gdfn' if split else 'qkv'} layout")
     run("libstamps_dwln.so", "uir_dwln_bwd", args, 512,
@@ -90,7 +91,8 @@ for split in (True, False):
 r = Recorder(dev, scratch_floats=1 << 20)
 y, st = r.alloc(M, Cc), r.alloc(M, 2)
 T1, T2 = r.alloc(M, ldg)[:, :2 * hp], r.alloc(M, ldg)[:, :2 * hp]
-r.gdfn_fwd("g", x, (g1, b1), rnd(2 * h, Cc) * .2, rnd(2 * h, 9) * .3, rnd(Cc, h) * .1, y, C_=Cc, h=h, hp=hp, dims=dims, T1=T1, T2=T2, stats=st)
+r.gdfn_fwd("g", x, (g1, b1), rnd(2 * h, Cc) * .2, rnd(2 * h, 9) * .3, rnd(Cc, h) * .1, y, C_=Cc, h=h, hp=hp, dims=dims,
+           T1=T1 if os.environ.get("STAMPS_XP") == "1" else None, T2=T2, stats=st, il=1)
 _, args, _ = r.fwd[0]
 print(f"uir_gdfn_fwd C={Cc} {S}x{S} (UIR_FUSED_SPLIT={os.environ.get('UIR_FUSED_SPLIT', '1')})")
 run("libstamps_gdfn.so", "uir_gdfn_fwd", args, 1024,
