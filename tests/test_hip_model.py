@@ -768,3 +768,31 @@ def test_train_trajectory_with_the_split_bf16_kernels_switched_off():
             "print('KNOB0-PLAN-OK')\n" % root)
     o2 = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, UIR_FUSED_SPLIT="0"), capture_output=True, text=True, timeout=300)
     assert "KNOB0-PLAN-OK" in o2.stdout, o2.stdout[-2000:] + o2.stderr[-2000:]
+
+
+@pytest.mark.gpu
+def test_debug_mode_refuses_a_step_beside_work_on_the_default_stream(monkeypatch):
+    """UIR_DEBUG=1 (the part a process can check): a train step launched under `torch.cuda.stream(s)` while the default
+    stream still has torch work in flight is refused; ordered behind it (`s.wait_stream(default)` does not help `query()` - the work must have
+    finished, so the test synchronises), or on the default stream, it runs and gives the step's usual result."""
+    from underwater_image_restoration_amd.trainer import TrainStep
+    monkeypatch.setenv("UIR_DEBUG", "1")
+    torch.manual_seed(3)
+    model = init_model("SpectralTransformer").to(DEV)
+    step = TrainStep(model, "L1", lr=1e-4)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    raw, ref = (torch.rand(2, 3, 32, 32, generator=g).to(DEV) for _ in range(2))
+    loss0, _ = step(raw, ref)                                   # default stream: fine
+    torch.cuda.synchronize()
+    s = torch.cuda.Stream()
+    big = torch.empty(1 << 28, device=DEV)
+    for _ in range(40):                                        # ~10 ms of fills queued on the DEFAULT stream, then the step on s
+        big.fill_(1.0)
+    with torch.cuda.stream(s):
+        with pytest.raises(RuntimeError, match="UIR_DEBUG"):
+            step(raw, ref)
+    torch.cuda.synchronize()
+    with torch.cuda.stream(s):
+        loss1, _ = step(raw, ref)                               # default stream idle: allowed on s
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss0) and torch.isfinite(loss1)

@@ -49,6 +49,11 @@ def main():
             print(f"pass {p} {tag}: chain {len(chain)} launches, busy {busy / 1e3:.3f} ms, between launches {idle / 1e3:.3f} ms "
                   f"(median gap {med:.1f} us = the event pair's own cost; {sum(1 for g_, _, _ in gaps if g_ > min_us)} gaps > {min_us} us "
                   f"= {sum(g_ for g_, _, _ in gaps if g_ > min_us) / 1e3:.3f} ms); other lanes {len(other)} launches {sum(e - s for s, e, _ in other) / 1e3:.3f} ms")
+            if other and chain:
+                # what the list's closing join waits for: the other lanes' last end against the chain's (the weight-gradient lane's tail)
+                last_c, last_o = max(e for _, e, _ in chain), max(other, key=lambda r: r[1])
+                n_after = sum(1 for s, e, _ in other if e > last_c)
+                print(f"         tail: the other lanes end {last_o[1] - last_c:+.1f} us after the chain's last launch ({n_after} launches end behind it; last: {ops[last_o[2]][2]})")
             if p == passes - 1:
                 for g_, a, b in gaps:
                     if g_ > min_us:

@@ -31,6 +31,9 @@ KNOBS = {
                   "16-bit type on the bf16 / f16 matrix pipe, f32 accumulation, f32 master weights, everything else f32 (BASELINE "
                   "configs[4]'s 'mixed fp16'); results are NOT f32-accurate and no f32 number is measured with it; any other value is refused",
                   "tests/test_tiled.py::test_mixed_mode_equals_the_rounded_operand_products"),
+    "UIR_DEBUG": ("0", "1: TrainStep / ModuleTrainStep refuse to start on a non-default stream while the device's default stream has work in flight (the checkable "
+                  "part of INTEGRATION.md section 6: torch kernels must not run beside the step's bf16-MFMA kernels); no effect on results",
+                  "tests/test_hip_model.py::test_debug_mode_refuses_a_step_beside_work_on_the_default_stream"),
     "UIR_FORCE_ALLREDUCE": ("0", "1: run the gradient all-reduce even in a world of one process (exercises the RCCL call path on a 1-GPU box)",
                             "tests/test_hip_model.py::test_rccl_allreduce_call_path_world1"),
 }
