@@ -640,6 +640,40 @@ def test_dwconv_with_fused_gelus(B, H, W, C):
     assert rel(dBu, db2) < TOL
 
 
+@pytest.mark.parametrize("B,H,W,h,hp", [(2, 16, 32, 64, 64), (1, 8, 16, 96, 96), (2, 24, 32, 84, 96), (4, 32, 32, 340, 352), (16, 64, 64, 170, 176), (3, 7, 13, 16, 16)])
+def test_dwconv_bwd_one_pass_plain_and_padded_groups(B, H, W, h, hp):
+    """uir_dwconv_bwd_fused without an activation - the depthwise 3 x 3 backward (input gradient + weight-gradient partials in one pass) the headline
+    step runs at levels 2 and 3 since round 5 (engine.FUSED_DW_MINROWS; SpectralTransformer.py:82,124 at C = 64 / 128) - against torch fp64 autograd:
+    plain channels and the padded two-group GDFN columns (pad columns: dX exactly 0, no weight row), the deep levels' own sizes (704 columns on
+    4 x 32 x 32; level 2's 16 x 64 x 64 x 352), odd image sizes."""
+    C = 2 * hp
+    dims = (B, H, W)
+    xr = rnd(B, 2 * h, H, W, seed=1).requires_grad_(True)
+    w = rnd(2 * h, 1, 3, 3, seed=2).requires_grad_(True)
+    y = F.conv2d(xr, w, padding=1, groups=2 * h)
+    dy = rnd(*y.shape, seed=3)
+    dx_ref, dw_ref = torch.autograd.grad((y * dy).sum(), (xr, w))
+
+    def padded(t):                                              # [M][2h] -> [M][2hp], x1 half at [0, h), x2 half at [hp, hp + h), pads zero
+        o = torch.zeros(B * H * W, C, dtype=torch.float64)
+        o[:, :h], o[:, hp:hp + h] = t[:, :h], t[:, h:]
+        return o
+    r = rec()
+    X, dY = dev(padded(hwc(xr.detach()))), dev(padded(hwc(dy)))
+    dX, dW = r.alloc(B * H * W, C), r.alloc(2 * h, 9)
+    dX.fill_(7.0)
+    r.dwconv_bwd("b", dY, X, dev(w.detach().reshape(2 * h, 9)), dX, dW, C_=C, creal=2 * h, dims=dims, grp=(h, hp), min_rows=0)
+    assert r.meta[id(r.fwd)][0][1] == "uir_dwconv_bwd_fused"
+    r.flush_reductions("t")
+    r.run(r.fwd)
+    torch.cuda.synchronize()
+    want = hwc(dx_ref)
+    assert rel(dX[:, :h], want[:, :h]) < TOL and rel(dX[:, hp:hp + h], want[:, h:]) < TOL
+    if hp > h:
+        assert float(dX[:, h:hp].abs().max()) == 0 and float(dX[:, hp + h:].abs().max()) == 0
+    assert rel(dW.reshape(2 * h, 1, 3, 3), dw_ref) < TOL
+
+
 def test_dwconv_padded_groups():
     B, H, W, h, hp = 2, 6, 5, 42, 44
     xr = rnd(B, 2 * h, H, W, seed=1)

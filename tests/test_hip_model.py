@@ -461,10 +461,16 @@ def test_train_trajectory_cfg1_deferred_readback():
         assert abs(float(p.detach().double().norm()) - fin[n]) <= 1e-4 * max(fin[n], 1e-6), n
 
 
-def test_full_resolution_256_vs_oracle():
+@pytest.mark.parametrize("one_pass_dw", [False, True], ids=["default", "one-pass-depthwise-backward-everywhere"])
+def test_full_resolution_256_vs_oracle(one_pass_dw, monkeypatch):
     """The resolution BENCH times (256 x 256; B = 2 so the fp64 oracle finishes in seconds): the persistent-workgroup
     loops, chunked Grams, slab rows and tap-group launches that 64 x 64 inputs never reach.  Output, L1withColor loss
-    and every live gradient against the fp64 oracle, tolerances of test_ragged_shapes_vs_oracle."""
+    and every live gradient against the fp64 oracle, tolerances of test_ragged_shapes_vs_oracle.
+    one_pass_dw: engine.FUSED_DW_MINROWS = 0 - at B = 16 (bench.py) levels 2 and 3 run their depthwise backward as ONE pass (dX + dW,
+    uir_dwconv_bwd_fused on the padded two-group GDFN columns); at B = 2 their pixel counts fall under the threshold, so the test forces it."""
+    if one_pass_dw:
+        from underwater_image_restoration_amd import engine as E
+        monkeypatch.setattr(E, "FUSED_DW_MINROWS", 0)
     B, S = 2, 256
     P64 = O.closed_form_state(torch.float64)
     n = B * 3 * S * S
@@ -473,6 +479,8 @@ def test_full_resolution_256_vs_oracle():
     loss64, out64, grads64 = O.loss_and_grads(P64, raw, ref, "L1withColor")
     fp = flat_from_state(P64)
     plan = Plan(fp, B, S, S)
+    bn = {m[0]: m[1] for m in plan.meta[id(plan.bwd)]}
+    assert (bn.get("encoders.3.0.dgpre+dWffdw") == "uir_dwconv_bwd_fused") == one_pass_dw
     kind = L.LOSS_KINDS["L1withColor"]
     out = plan.forward(raw.float().to(DEV)).clone()
     res = ops.loss_sums(out, ref.float().to(DEV), kind)
