@@ -591,6 +591,40 @@ def test_micro_batched_step_equals_full_batch():
         _fresh_step(micro_batch=3)[1](raw, ref)
 
 
+def test_headline_batch_equals_its_oracle_checked_micro_batches():
+    """bench.py's workload (B = 16 at 256 x 256) takes kernel paths its pixel counts select and no smaller batch reaches - the deep levels' tall-skinny
+    contractions with the LayerNorm-backward epilogue (16 384 rows at level 3), the one-pass depthwise backward there, the Grams' chunking, the 3 x 3
+    convolutions' tile choices - and the fp64 oracle is too slow for 16 images in a test.  The network has no cross-sample statistics, so the same step run
+    as eight micro-batches of B = 2 (the configuration test_full_resolution_256_vs_oracle holds against the oracle, gradients accumulated) must give the
+    same loss, gradient, clip norm and updated parameters: that ties every B = 16 branch to the oracle."""
+    B, S = 16, 256
+    g = torch.Generator(device="cpu").manual_seed(77)
+    raw = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
+    ref = (torch.rand(B, 3, S, S, generator=g) * 2 - 1).to(DEV)
+    model, step = _fresh_step("L1withColor")
+    l0, n0 = step(raw, ref)
+    l0, n0 = l0.clone(), n0.clone()
+    torch.cuda.synchronize()
+    fp = model.flat_params()
+    g0 = fp.grad[:fp.n_live].clone()
+    plan = model._plan_for(raw)
+    bn = {m[0]: m[1] for m in plan.meta[id(plan.bwd)]}
+    assert bn["encoders.3.0.dgpre+dWffdw"] == "uir_dwconv_bwd_fused" and "encoders.3.0.dt2+ln2_bwd" in bn      # the B = 16 branches are the ones recorded
+    model2, step2 = _fresh_step("L1withColor", micro_batch=2)
+    l1, n1 = step2(raw, ref)
+    l1, n1 = l1.clone(), n1.clone()
+    torch.cuda.synchronize()
+    g1 = step2._acc[:g0.numel()].clone()
+    plan2 = model2._plan_for(raw[:2])
+    bn2 = {m[0]: m[1] for m in plan2.meta[id(plan2.bwd)]}
+    assert "encoders.3.0.dgpre+dWffdw.dX" in bn2 and "encoders.3.0.dt2+ln2_bwd" not in bn2                        # ... and the micro-batches take the other ones
+    eg = float((g1 - g0).abs().max()) / float(g0.abs().max())
+    print(f"B = 16 vs 8 x B = 2: gradient {eg:.2e}, loss {float(l0):.8f} / {float(l1):.8f}, norm {float(n0):.6e} / {float(n1):.6e}")
+    assert eg <= 5e-5
+    assert abs(float(l1) - float(l0)) <= 2e-6 * abs(float(l0)) and abs(float(n1) - float(n0)) <= 5e-5 * abs(float(n0))
+    assert float((model2.flat_params().flat - fp.flat).abs().max()) <= 1e-4                                       # (Adam's first step ~ lr * sign(g): see the test above)
+
+
 def test_adamw_and_optimizer_state_layout():
     """--optim adamw (src/ModelTrainer.py:200-201: torch.optim.AdamW(lr), weight decay 0.01) through the fused kernel vs
     the oracle; and the checkpointed optimizer state has torch.optim.Adam.state_dict()'s layout: it loads into a real
